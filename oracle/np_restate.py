@@ -1,0 +1,259 @@
+"""Second, independent restatement of the reference semantics (numpy, vectorised over lanes).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/rs_oracle.h).  It exists so that the C
+oracle (rs_oracle.c) is not the only reading of the Rust source: tests compare the two on random
+inputs, and tests/golden/make_golden.py uses this file to generate the committed fixtures.
+
+Written array-at-a-time on purpose (the C oracle is scalar and recursive) so that a shared
+misreading is less likely.  Reference lines are cited per function.
+"""
+import numpy as np
+
+F32 = np.float32
+I32_MAX, I32_MIN = 2**31 - 1, -(2**31)
+PRUNE_THRESHOLD = -10_000_000  # cfr.rs:352
+
+
+def rust_f32_as_i64(x):
+    """Rust `f32 as i64`: trunc toward zero, saturating, NaN -> 0."""
+    x = np.asarray(x, dtype=np.float32)
+    out = np.zeros(x.shape, dtype=np.int64)
+    ok = np.isfinite(x) & (np.abs(x) < F32(2.0**63))
+    out[ok] = np.trunc(x[ok].astype(np.float64)).astype(np.int64)
+    out[(x >= F32(2.0**63))] = np.iinfo(np.int64).max
+    out[(x <= F32(-(2.0**63)))] = np.iinfo(np.int64).min
+    return out
+
+
+def rust_f32_as_i32(x):
+    """Rust `f32 as i32`."""
+    return np.clip(rust_f32_as_i64(x), I32_MIN, I32_MAX).astype(np.int32)
+
+
+def get_strategy(R):
+    """infoset.rs:83-102 over an [A, n] integer array -> [A, n] f32."""
+    R = np.asarray(R)
+    A, n = R.shape
+    Rf = R.astype(np.float32)  # `as f32` (RNE)
+    pos = R > 0
+    norm = np.zeros(n, dtype=np.float32)
+    for i in range(A):  # index order, f32 accumulation
+        norm = np.where(pos[i], norm + Rf[i], norm).astype(np.float32)
+    has = norm > 0
+    safe = np.where(has, norm, F32(1.0)).astype(np.float32)
+    sig = np.zeros((A, n), dtype=np.float32)
+    for i in range(A):
+        sig[i] = np.where(has, np.where(pos[i], Rf[i] / safe, F32(0.0)), F32(1.0) / F32(A))
+    return sig
+
+
+def get_strategy_f32(R):
+    """Extension: the same formula on float regrets."""
+    R = np.asarray(R, dtype=np.float32)
+    A, n = R.shape
+    pos = R > 0
+    norm = np.zeros(n, dtype=np.float32)
+    for i in range(A):
+        norm = np.where(pos[i], norm + R[i], norm).astype(np.float32)
+    has = norm > 0
+    safe = np.where(has, norm, F32(1.0)).astype(np.float32)
+    sig = np.zeros((A, n), dtype=np.float32)
+    for i in range(A):
+        sig[i] = np.where(has, np.where(pos[i], R[i] / safe, F32(0.0)), F32(1.0) / F32(A))
+    return sig
+
+
+def node_util(sig, U, explored=None):
+    """cfr.rs:384/:391/:588: util += utils[i] * strategy[i], sequential, no FMA."""
+    A, n = sig.shape
+    util = np.zeros(n, dtype=np.float32)
+    for i in range(A):
+        term = (U[i].astype(np.float32) * sig[i]).astype(np.float32)
+        nxt = (util + term).astype(np.float32)
+        util = nxt if explored is None else np.where(explored[i], nxt, util)
+    return util
+
+
+def update(R, S, U, reach, scale, mode="clamp", prune=False):
+    """One traverser visit for n lanes.  mode 'clamp' = cfr.rs:413-464, 'wrap' = cfr.rs:612-621.
+    R, S: [A, n] int32; U: [A, n] f32; reach: [n] f32.  Returns (util, R', S')."""
+    R = np.asarray(R, dtype=np.int32)
+    S = np.asarray(S, dtype=np.int32)
+    U = np.asarray(U, dtype=np.float32)
+    reach = np.broadcast_to(np.asarray(reach, dtype=np.float32), R.shape[1:]).astype(np.float32)
+    A, n = R.shape
+    sig = get_strategy(R)
+    explored = (R > PRUNE_THRESHOLD) if prune else np.ones((A, n), dtype=bool)
+    util = node_util(sig, U, explored)
+    k = (F32(scale) * reach).astype(np.float32)  # (scale * cfr_reach) first
+    with np.errstate(invalid="ignore", over="ignore"):
+        dR = (k * (U - util).astype(np.float32)).astype(np.float32)
+        dS = (k * sig).astype(np.float32)
+    if mode == "clamp":
+        Rn = np.clip(R.astype(np.int64) + rust_f32_as_i64(dR), I32_MIN, I32_MAX).astype(np.int32)
+        Sn = np.clip(S.astype(np.int64) + rust_f32_as_i64(dS), I32_MIN, I32_MAX).astype(np.int32)
+    elif mode == "wrap":
+        Rn = (R.astype(np.uint32) + rust_f32_as_i32(dR).astype(np.uint32)).astype(np.uint32).view(np.int32)
+        Sn = (S.astype(np.uint32) + rust_f32_as_i32(dS).astype(np.uint32)).astype(np.uint32).view(np.int32)
+    elif mode == "rmplus":
+        Rn = np.clip(R.astype(np.int64) + rust_f32_as_i64(dR), 0, I32_MAX).astype(np.int32)
+        Sn = np.clip(S.astype(np.int64) + rust_f32_as_i64(dS), I32_MIN, I32_MAX).astype(np.int32)
+    else:
+        raise ValueError(mode)
+    Rn = np.where(explored, Rn, R)
+    Sn = np.where(explored, Sn, S)
+    return util, Rn, Sn
+
+
+def round_f16(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def update_f32(R, S, U, reach, scale, rmplus=False, f16=False):
+    """Extension modes: float tables (optionally binary16 storage), f32 accumulate."""
+    R = np.asarray(R, dtype=np.float32)
+    S = np.asarray(S, dtype=np.float32)
+    U = np.asarray(U, dtype=np.float32)
+    reach = np.broadcast_to(np.asarray(reach, dtype=np.float32), R.shape[1:]).astype(np.float32)
+    sig = get_strategy_f32(R)
+    util = node_util(sig, U)
+    k = (F32(scale) * reach).astype(np.float32)
+    Rn = (R + (k * (U - util).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    Sn = (S + (k * sig).astype(np.float32)).astype(np.float32)
+    if rmplus:
+        Rn = np.where(Rn > 0, Rn, F32(0.0)).astype(np.float32)
+    if f16:
+        with np.errstate(over="ignore"):
+            Rn, Sn = round_f16(Rn), round_f16(Sn)
+    return util, Rn, Sn
+
+
+def discount_factor(tc, interval=100_000):
+    """cfr.rs:248-249: p = (tc / DISCOUNT_INTERVAL) as f32 (integer divide first); d = p/(p+1)."""
+    p = F32(tc // interval)
+    return F32(p / F32(p + F32(1.0)))
+
+
+def discount(X, d):
+    """cfr.rs:256-257: ((x as f32) * d) as i32."""
+    X = np.asarray(X, dtype=np.int32)
+    return rust_f32_as_i32((X.astype(np.float32) * F32(d)).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# public tree (tree_builder.rs + state.rs), written as plain dict/list Python
+# ---------------------------------------------------------------------------------------------------
+ALLIN_THRESHOLD, MAX_RAISES = 0.67, 2  # constants.rs:2,5
+
+
+def build_tree(stacks=(500, 500), pot=35, n_board_cards=5, bet_sizes=((0.5, 1.0),), raise_sizes=((3.0,),)):
+    """Returns (nodes, n_action_nodes); node = dict(kind, children, ...), ids in creation order."""
+    nodes = []
+    counter = [0]
+    first_round = {3: 0, 4: 1, 5: 2}[n_board_cards]  # state.rs:60-65
+
+    def new(parent, **kw):
+        nodes.append(dict(parent=parent, children=[], **kw))
+        return len(nodes) - 1
+
+    def valid_actions(st, ridx):  # state.rs:125-157
+        cur, oth = st["p"][st["cur"]], st["p"][1 - st["cur"]]
+        acts = []
+        if oth["wager"] == 0:
+            acts.append(("check", 0.0))
+        if oth["wager"] > cur["wager"]:
+            acts.append(("call", 0.0))
+            acts.append(("fold", 0.0))
+        if oth["wager"] == 0:
+            for b in bet_sizes[ridx]:
+                acts.append(("bet", b))
+                if b * float(st["pot"]) > ALLIN_THRESHOLD * float(cur["stack"]):
+                    break
+        allin = any(p["stack"] == 0 for p in st["p"])
+        if st["raises"] < MAX_RAISES and not allin and oth["wager"] > cur["wager"]:
+            for r in raise_sizes[ridx]:
+                acts.append(("raise", r))
+                if r * float(oth["wager"]) > ALLIN_THRESHOLD * float(cur["stack"]):
+                    break
+        return acts
+
+    def clone(st):
+        return dict(p=[dict(q) for q in st["p"]], pot=st["pot"], raises=st["raises"], cur=st["cur"],
+                    round=st["round"], settled=st["settled"])
+
+    def apply(st, kind, amt):  # state.rs:158-212
+        n = clone(st)
+        cur, oth = n["p"][n["cur"]], n["p"][1 - n["cur"]]
+        if kind == "bet":
+            chips = int(n["pot"] * amt)
+            if chips > int(cur["stack"] * ALLIN_THRESHOLD):
+                chips = cur["stack"]
+            cur["stack"] -= chips
+            cur["wager"] = chips
+            n["pot"] += chips
+            n["cur"] = 1 - n["cur"]
+        elif kind == "raise":
+            chips = int(oth["wager"] * amt)
+            if chips > int(cur["stack"] * ALLIN_THRESHOLD):
+                chips = cur["stack"]
+            cur["stack"] -= chips
+            cur["wager"] += chips
+            n["raises"] += 1
+            n["pot"] += chips
+            n["cur"] = 1 - n["cur"]
+        elif kind == "call":
+            diff = oth["wager"] - cur["wager"]
+            if cur["stack"] >= diff:
+                n["pot"] += diff
+                cur["stack"] -= diff
+            else:
+                n["pot"] += cur["stack"]
+                cur["stack"] = 0
+            n["settled"] = True
+        elif kind == "check":
+            if n["cur"] == 1:
+                n["settled"] = True
+            n["cur"] = 1 - n["cur"]
+        elif kind == "fold":
+            cur["folded"] = True
+            n["pot"] -= oth["wager"] - cur["wager"]
+            n["settled"] = True
+        return n
+
+    def action_nodes(parent, ridx, st):  # tree_builder.rs:67-90
+        nid = new(parent, kind="action", player=st["cur"], index=counter[0], round_idx=ridx, actions=[])
+        counter[0] += 1
+        for kind, amt in valid_actions(st, ridx):
+            nxt = apply(st, kind, amt)
+            folded = any(p["folded"] for p in nxt["p"])
+            allin = any(p["stack"] == 0 for p in nxt["p"])
+            if nxt["settled"]:
+                if nxt["round"] == 2 or allin or folded:  # is_terminal, state.rs:95-99
+                    ttype = "SHOWDOWN"
+                    if allin and nxt["round"] != 2:
+                        ttype = "ALLIN"
+                    if folded:
+                        ttype = "UNCONTESTED"
+                    child = new(nid, kind="terminal", value=nxt["pot"], ttype=ttype, last_to_act=nxt["cur"],
+                                round=nxt["round"])
+                else:
+                    street = clone(nxt)  # to_next_street, state.rs:108-124
+                    street["settled"] = False
+                    street["cur"] = 0
+                    for p in street["p"]:
+                        p["wager"] = 0
+                    street["round"] += 1
+                    child = new(nid, kind="public_chance", round=street["round"])
+                    gc = action_nodes(child, ridx + 1, street)
+                    nodes[child]["children"].append(gc)
+            else:
+                child = action_nodes(nid, ridx, nxt)
+            nodes[nid]["children"].append(child)
+            nodes[nid]["actions"].append([kind, amt])
+        return nid
+
+    st0 = dict(p=[dict(stack=stacks[0], wager=0, folded=False), dict(stack=stacks[1], wager=0, folded=False)],
+               pot=pot, raises=0, cur=0, round=first_round, settled=False)
+    root = new(-1, kind="private_chance")
+    nodes[root]["children"].append(action_nodes(root, 0, st0))
+    return nodes, counter[0]

@@ -1,0 +1,384 @@
+"""ctypes binding of the CPU oracle (oracle/rs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/rs_oracle.h).  Imported by tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg, never by ``rustsolver_amd``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librs_oracle.so")
+
+MAX_ACTIONS, MAX_ROUNDS, MAX_SIZES = 8, 3, 4
+PRIVATE_CHANCE, PUBLIC_CHANCE, ACTION, TERMINAL = 0, 1, 2, 3
+ALLIN, SHOWDOWN, UNCONTESTED = 0, 1, 2
+ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
+UPD_CLAMP_I64, UPD_WRAP_I32 = 0, 1
+LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
+CHANCE_PASS, CHANCE_ENUM = 0, 1
+T_I32, T_F32, T_F16 = 0, 1, 2
+F_F32, F_F16 = 0, 1
+PRUNE_THRESHOLD = -10000000
+
+
+class Node(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("parent", C.c_int), ("n_children", C.c_int),
+        ("children", C.c_int * MAX_ACTIONS),
+        ("index", C.c_int), ("player", C.c_uint8), ("round_idx", C.c_uint8),
+        ("action_kind", C.c_int * MAX_ACTIONS), ("action_amt", C.c_double * MAX_ACTIONS),
+        ("value", C.c_uint32), ("ttype", C.c_int), ("last_to_act", C.c_uint8), ("round", C.c_int),
+    ]
+
+
+class Tree(C.Structure):
+    _fields_ = [("nodes", C.POINTER(Node)), ("n_nodes", C.c_int), ("cap", C.c_int), ("n_action_nodes", C.c_int)]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("stack_sizes", C.c_uint32 * 2), ("starting_pot", C.c_uint32), ("n_board_cards", C.c_int),
+        ("n_rounds", C.c_int),
+        ("n_bet_sizes", C.c_int * MAX_ROUNDS), ("bet_sizes", (C.c_double * MAX_SIZES) * MAX_ROUNDS),
+        ("n_raise_sizes", C.c_int * MAX_ROUNDS), ("raise_sizes", (C.c_double * MAX_SIZES) * MAX_ROUNDS),
+    ]
+
+
+class Infoset(C.Structure):
+    _fields_ = [("regrets", C.POINTER(C.c_int32)), ("strategy_sum", C.POINTER(C.c_int32)),
+                ("fregrets", C.POINTER(C.c_float)), ("fstrategy_sum", C.POINTER(C.c_float)),
+                ("n_actions", C.c_int)]
+
+
+class Table(C.Structure):
+    _fields_ = [("rows", C.POINTER(C.POINTER(Infoset))), ("row_len", C.POINTER(C.c_size_t)),
+                ("n_rows", C.c_int), ("dtype", C.c_int)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("kind", C.c_int), ("buf", C.POINTER(C.c_float))]
+
+
+class Ctx(C.Structure):
+    _fields_ = [
+        ("tree", C.POINTER(Tree)), ("table", C.POINTER(Table)),
+        ("n_boards", C.c_uint32 * MAX_ROUNDS), ("n_clusters", C.c_uint32),
+        ("leaves", C.POINTER(Leaf)),
+        ("scale", C.c_float), ("mode", C.c_int), ("prune", C.c_int), ("rmplus", C.c_int),
+        ("chance_mode", C.c_int), ("ref_alloc", C.c_int),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/librs_oracle.so with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "librs_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    L.orc_options_default_river.argtypes = [C.POINTER(Options)]
+    L.orc_options_three_street.argtypes = [C.POINTER(Options)]
+    L.orc_tree_build.argtypes = [C.POINTER(Options), C.POINTER(Tree)]
+    L.orc_tree_build.restype = C.c_int
+    L.orc_tree_free.argtypes = [C.POINTER(Tree)]
+    L.orc_table_create.argtypes = [C.POINTER(Tree), C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.POINTER(Table)]
+    L.orc_table_create.restype = C.c_int
+    L.orc_table_free.argtypes = [C.POINTER(Table)]
+    L.orc_get_strategy.argtypes = [i32p, C.c_int, f32p]
+    L.orc_get_final_strategy.argtypes = [i32p, C.c_int, f32p]
+    L.orc_f32_as_i64.argtypes = [C.c_float]
+    L.orc_f32_as_i64.restype = C.c_int64
+    L.orc_f32_as_i32.argtypes = [C.c_float]
+    L.orc_f32_as_i32.restype = C.c_int32
+    L.orc_update_infoset.argtypes = [i32p, i32p, C.c_int, f32p, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.orc_update_infoset.restype = C.c_float
+    L.orc_node_util.argtypes = [i32p, C.c_int, f32p]
+    L.orc_node_util.restype = C.c_float
+    L.orc_discount_factor.argtypes = [C.c_size_t, C.c_size_t]
+    L.orc_discount_factor.restype = C.c_float
+    L.orc_discount_infoset.argtypes = [i32p, i32p, C.c_int, C.c_float]
+    L.orc_discount_table.argtypes = [C.POINTER(Table), C.c_float]
+    L.orc_traverse.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_float]
+    L.orc_traverse.restype = C.c_float
+    L.orc_iterate.argtypes = [C.POINTER(Ctx), C.c_int, f32p]
+    L.orc_iterate_range.argtypes = [C.POINTER(Ctx), C.c_int, C.c_size_t, C.c_size_t, f32p]
+    L.orc_train.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_size_t, C.c_size_t]
+    L.orc_get_strategy_f32.argtypes = [f32p, C.c_int, f32p]
+    L.orc_update_infoset_f32.argtypes = [f32p, f32p, C.c_int, f32p, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.orc_update_infoset_f32.restype = C.c_float
+    L.orc_node_util_f32.argtypes = [f32p, C.c_int, f32p]
+    L.orc_node_util_f32.restype = C.c_float
+    L.orc_discount_f32.argtypes = [f32p, f32p, C.c_int, C.c_float, C.c_int]
+    L.orc_round_f16.argtypes = [C.c_float]
+    L.orc_round_f16.restype = C.c_float
+    L.orc_update_infoset_rmplus.argtypes = [i32p, i32p, C.c_int, f32p, C.c_float, C.c_float]
+    L.orc_update_infoset_rmplus.restype = C.c_float
+    for nm, pt in (("i32", i32p), ("f32", f32p)):
+        getattr(L, "orc_table_set_node_" + nm).argtypes = [C.POINTER(Table), C.c_int, pt, pt]
+        getattr(L, "orc_table_get_node_" + nm).argtypes = [C.POINTER(Table), C.c_int, pt, pt]
+    L.orc_iterate_mt.argtypes = [C.POINTER(Ctx), C.c_int, f32p, C.c_int]
+    L.orc_run_iterations_mt.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_int]
+    _lib = L
+    return L
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ---- scalar wrappers (numpy in / numpy out) ------------------------------------------------------
+
+def get_strategy(regrets):
+    r = np.ascontiguousarray(regrets, dtype=np.int32)
+    out = np.zeros(len(r), dtype=np.float32)
+    lib().orc_get_strategy(_i32(r), len(r), _f32(out))
+    return out
+
+
+def get_final_strategy(ssum):
+    s = np.ascontiguousarray(ssum, dtype=np.int32)
+    out = np.zeros(len(s), dtype=np.float32)
+    lib().orc_get_final_strategy(_i32(s), len(s), _f32(out))
+    return out
+
+
+def update_infoset(regrets, ssum, utils, reach, scale=100.0, mode=UPD_CLAMP_I64, prune=False):
+    """Returns (util, new_regrets, new_strategy_sum); inputs are not modified."""
+    r = np.array(regrets, dtype=np.int32)
+    s = np.array(ssum, dtype=np.int32)
+    u = np.ascontiguousarray(utils, dtype=np.float32)
+    util = lib().orc_update_infoset(_i32(r), _i32(s), len(r), _f32(u), np.float32(reach), np.float32(scale),
+                                    mode, int(prune))
+    return np.float32(util), r, s
+
+
+def update_infoset_rmplus(regrets, ssum, utils, reach, scale=100.0):
+    r = np.array(regrets, dtype=np.int32)
+    s = np.array(ssum, dtype=np.int32)
+    u = np.ascontiguousarray(utils, dtype=np.float32)
+    util = lib().orc_update_infoset_rmplus(_i32(r), _i32(s), len(r), _f32(u), np.float32(reach), np.float32(scale))
+    return np.float32(util), r, s
+
+
+def update_infoset_f32(regrets, ssum, utils, reach, scale=100.0, rmplus=False, storage=F_F32):
+    r = np.array(regrets, dtype=np.float32)
+    s = np.array(ssum, dtype=np.float32)
+    u = np.ascontiguousarray(utils, dtype=np.float32)
+    util = lib().orc_update_infoset_f32(_f32(r), _f32(s), len(r), _f32(u), np.float32(reach), np.float32(scale),
+                                        int(rmplus), storage)
+    return np.float32(util), r, s
+
+
+def node_util(regrets, utils):
+    r = np.ascontiguousarray(regrets, dtype=np.int32)
+    u = np.ascontiguousarray(utils, dtype=np.float32)
+    return np.float32(lib().orc_node_util(_i32(r), len(r), _f32(u)))
+
+
+def discount(values_r, values_s, d):
+    r = np.array(values_r, dtype=np.int32)
+    s = np.array(values_s, dtype=np.int32)
+    lib().orc_discount_infoset(_i32(r), _i32(s), len(r), np.float32(d))
+    return r, s
+
+
+def discount_factor(tc, interval=100000):
+    return np.float32(lib().orc_discount_factor(tc, interval))
+
+
+# ---- tree ----------------------------------------------------------------------------------------
+
+def make_options(stacks=(500, 500), pot=35, n_board_cards=5, bet_sizes=((0.5, 1.0),), raise_sizes=((3.0,),)):
+    o = Options()
+    o.stack_sizes[0], o.stack_sizes[1] = stacks
+    o.starting_pot = pot
+    o.n_board_cards = n_board_cards
+    o.n_rounds = len(bet_sizes)
+    for r, (bs, rs) in enumerate(zip(bet_sizes, raise_sizes)):
+        o.n_bet_sizes[r] = len(bs)
+        for i, v in enumerate(bs):
+            o.bet_sizes[r][i] = v
+        o.n_raise_sizes[r] = len(rs)
+        for i, v in enumerate(rs):
+            o.raise_sizes[r][i] = v
+    return o
+
+
+def options_default_river():
+    o = Options()
+    lib().orc_options_default_river(C.byref(o))
+    return o
+
+
+def options_three_street():
+    o = Options()
+    lib().orc_options_three_street(C.byref(o))
+    return o
+
+
+class OracleTree:
+    def __init__(self, options):
+        self.t = Tree()
+        if lib().orc_tree_build(C.byref(options), C.byref(self.t)) != 0:
+            raise ValueError("invalid board mask")  # state.rs:64 panic
+        self.n_nodes = self.t.n_nodes
+        self.n_action_nodes = self.t.n_action_nodes
+
+    def node(self, i):
+        return self.t.nodes[i]
+
+    def as_dicts(self):
+        out = []
+        for i in range(self.n_nodes):
+            n = self.t.nodes[i]
+            d = {"id": i, "kind": n.kind, "parent": n.parent, "children": [n.children[k] for k in range(n.n_children)]}
+            if n.kind == ACTION:
+                d.update(index=n.index, player=n.player, round_idx=n.round_idx,
+                         actions=[[n.action_kind[k], n.action_amt[k]] for k in range(n.n_children)])
+            elif n.kind == TERMINAL:
+                d.update(value=n.value, ttype=n.ttype, last_to_act=n.last_to_act, round=n.round)
+            elif n.kind == PUBLIC_CHANCE:
+                d.update(round=n.round)
+            out.append(d)
+        return out
+
+    def __del__(self):
+        try:
+            lib().orc_tree_free(C.byref(self.t))
+        except Exception:
+            pass
+
+
+class OracleTable:
+    """Reference-layout table (Vec<Vec<Infoset{Box<[i32]>, Box<[i32]>}>>, infoset.rs:6,63-67)."""
+
+    def __init__(self, tree, n_boards, n_clusters, dtype=T_I32):
+        self.tree = tree
+        self.n_boards = list(n_boards) + [0] * (MAX_ROUNDS - len(n_boards))
+        self.n_clusters = n_clusters
+        self.dtype = dtype
+        self.tb = Table()
+        nb = (C.c_uint32 * MAX_ROUNDS)(*self.n_boards)
+        if lib().orc_table_create(C.byref(tree.t), nb, n_clusters, dtype, C.byref(self.tb)) != 0:
+            raise MemoryError
+        self._node_by_index = {}
+        for i in range(tree.n_nodes):
+            n = tree.node(i)
+            if n.kind == ACTION:
+                self._node_by_index[n.index] = (n.n_children, n.round_idx, n.player)
+
+    def node_shape(self, index):
+        """(n_actions, n_lanes)"""
+        a, r, _ = self._node_by_index[index]
+        return a, self.n_boards[r] * self.n_clusters
+
+    def set_node(self, index, regrets, ssum):
+        """regrets/ssum: arrays [A][n_lanes]"""
+        a, n = self.node_shape(index)
+        if self.dtype == T_I32:
+            R = np.ascontiguousarray(regrets, dtype=np.int32).reshape(a, n)
+            S = np.ascontiguousarray(ssum, dtype=np.int32).reshape(a, n)
+            lib().orc_table_set_node_i32(C.byref(self.tb), index, _i32(R), _i32(S))
+        else:
+            R = np.ascontiguousarray(regrets, dtype=np.float32).reshape(a, n)
+            S = np.ascontiguousarray(ssum, dtype=np.float32).reshape(a, n)
+            lib().orc_table_set_node_f32(C.byref(self.tb), index, _f32(R), _f32(S))
+
+    def get_node(self, index):
+        a, n = self.node_shape(index)
+        if self.dtype == T_I32:
+            R = np.zeros((a, n), dtype=np.int32)
+            S = np.zeros((a, n), dtype=np.int32)
+            lib().orc_table_get_node_i32(C.byref(self.tb), index, _i32(R), _i32(S))
+        else:
+            R = np.zeros((a, n), dtype=np.float32)
+            S = np.zeros((a, n), dtype=np.float32)
+            lib().orc_table_get_node_f32(C.byref(self.tb), index, _f32(R), _f32(S))
+        return R, S
+
+    def discount(self, d):
+        lib().orc_discount_table(C.byref(self.tb), np.float32(d))
+
+    def __del__(self):
+        try:
+            lib().orc_table_free(C.byref(self.tb))
+        except Exception:
+            pass
+
+
+class OracleSolver:
+    """Per-lane cfr.rs:481-627 recursion over an OracleTable."""
+
+    def __init__(self, tree, table, leaves, scale=10000.0, mode=UPD_WRAP_I32, prune=False, rmplus=False,
+                 chance_mode=CHANCE_ENUM, ref_alloc=False):
+        """leaves: dict tree-node-id -> (kind, float32 array over that terminal's lanes or None)"""
+        self.tree, self.table = tree, table
+        self._keep = []
+        arr = (Leaf * tree.n_nodes)()
+        for i in range(tree.n_nodes):
+            arr[i].kind = LEAF_UNCONTESTED
+            arr[i].buf = None
+        for nid, (kind, buf) in leaves.items():
+            arr[nid].kind = kind
+            if buf is not None:
+                b = np.ascontiguousarray(buf, dtype=np.float32)
+                self._keep.append(b)
+                arr[nid].buf = _f32(b)
+        self._leaves = arr
+        c = Ctx()
+        c.tree = C.pointer(tree.t)
+        c.table = C.pointer(table.tb)
+        for r in range(MAX_ROUNDS):
+            c.n_boards[r] = table.n_boards[r]
+        c.n_clusters = table.n_clusters
+        c.leaves = arr
+        c.scale = scale
+        c.mode = mode
+        c.prune = int(prune)
+        c.rmplus = int(rmplus)
+        c.chance_mode = chance_mode
+        c.ref_alloc = int(ref_alloc)
+        self.ctx = c
+
+    def set_leaves(self, leaves):
+        for nid, (kind, buf) in leaves.items():
+            self._leaves[nid].kind = kind
+            if buf is not None:
+                b = np.ascontiguousarray(buf, dtype=np.float32)
+                self._keep.append(b)
+                self._leaves[nid].buf = _f32(b)
+
+    def iterate(self, player, threads=1):
+        n = self.table.n_boards[0] * self.table.n_clusters
+        out = np.zeros(n, dtype=np.float32)
+        if threads > 1:
+            lib().orc_iterate_mt(C.byref(self.ctx), player, _f32(out), threads)
+        else:
+            lib().orc_iterate(C.byref(self.ctx), player, _f32(out))
+        return out
+
+    def run_iterations(self, iterations, threads=1):
+        lib().orc_run_iterations_mt(C.byref(self.ctx), iterations, threads)
+
+    def train(self, iterations, discount_interval=100000, discount_cap=20000000):
+        lib().orc_train(C.byref(self.ctx), iterations, discount_interval, discount_cap)

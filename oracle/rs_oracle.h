@@ -1,0 +1,209 @@
+/*
+ * rs_oracle.h -- CPU restatement of RustSolver's regret/strategy-update hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it, and there only as
+ * the checker / the timed CPU baseline.  The product (rustsolver_amd/) never links, imports
+ * or falls back to this code.
+ *
+ * PARITY UNPINNED.  The reference (kmurf1999/RustSolver, Rust nightly) cannot be compiled in
+ * this image (no rustc/cargo; undeclared `extern crate cortex_m`, removed nightly features,
+ * un-vendored rust_poker 0.1.5 -- src/solver/main.rs:1-4,13, Cargo.toml:18-26) and it holds
+ * no test, golden vector or fixture for infoset.rs / cfr.rs / tree_builder.rs / state.rs.
+ * This restatement is therefore pinned only against (i) known-answer vectors worked out by
+ * hand from the Rust semantics (tests/golden/known_answers.json), (ii) an independent numpy
+ * restatement (oracle/np_restate.py) and (iii) the tree-shape facts derivable from the
+ * reference sources (14 / 706 action nodes, the Bet1.0-Raise3-Raise3-Call = 1035 pot line).
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference
+ * repository root).
+ *
+ * Rust numeric rules restated here:
+ *   - f32 arithmetic is IEEE-754 RNE with NO fused multiply-add (compile -ffp-contract=off);
+ *   - `a * b * c` associates as `(a * b) * c`;
+ *   - `i32 as f32` rounds to nearest even;
+ *   - `f32 as i64` / `f32 as i32` truncate toward zero, SATURATE, and map NaN to 0;
+ *   - `i32 += i32` wraps in release builds (cfr.rs:616-619 has no clamp);
+ *   - `usize / usize` is an integer divide (cfr.rs:248).
+ */
+#ifndef RS_ORACLE_H
+#define RS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_ACTIONS 8
+#define ORC_MAX_ROUNDS 3
+#define ORC_MAX_SIZES 4
+
+/* ---- constants.rs:1-6 --------------------------------------------------------------- */
+#define ORC_ALLIN_THRESHOLD 0.67
+#define ORC_MAX_RAISES 2
+#define ORC_MAX_PLAYERS 2
+/* cfr.rs:352 */
+#define ORC_PRUNE_THRESHOLD (-10000000)
+/* cfr.rs:190-195 */
+#define ORC_DISCOUNT_INTERVAL 100000
+#define ORC_DISCOUNT_CAP 20000000
+
+/* ---- nodes.rs ------------------------------------------------------------------------ */
+enum { ORC_PRIVATE_CHANCE = 0, ORC_PUBLIC_CHANCE = 1, ORC_ACTION = 2, ORC_TERMINAL = 3 };
+enum { ORC_ALLIN = 0, ORC_SHOWDOWN = 1, ORC_UNCONTESTED = 2 }; /* nodes.rs:16-21 */
+enum { ORC_ACT_BET = 0, ORC_ACT_RAISE = 1, ORC_ACT_CHECK = 2, ORC_ACT_CALL = 3, ORC_ACT_FOLD = 4 }; /* action_abstraction.rs:4-10 */
+enum { ORC_FLOP = 0, ORC_TURN = 1, ORC_RIVER = 2 }; /* state.rs:6-21 */
+
+typedef struct {
+    int kind;                          /* ORC_* node kind (nodes.rs:46-52) */
+    int parent;                        /* tree.rs:22, -1 for the root */
+    int n_children;                    /* tree.rs:21 */
+    int children[ORC_MAX_ACTIONS];
+    /* ActionNode (nodes.rs:4-10) */
+    int index;                         /* action-node index, pre-order (tree_builder.rs:73,78) */
+    uint8_t player;
+    uint8_t round_idx;                 /* relative to the starting street */
+    int action_kind[ORC_MAX_ACTIONS];
+    double action_amt[ORC_MAX_ACTIONS];
+    /* TerminalNode (nodes.rs:33-39) */
+    uint32_t value;                    /* size of the pot */
+    int ttype;
+    uint8_t last_to_act;
+    /* TerminalNode.round / PublicChanceNode.round (nodes.rs:38,43) */
+    int round;
+} orc_node;
+
+typedef struct {
+    orc_node *nodes;
+    int n_nodes;
+    int cap;
+    int n_action_nodes;                /* tree_builder.rs:13 `builder.n_actions` */
+} orc_tree;
+
+/* options.rs:10-28 -- only the fields the tree builder reads */
+typedef struct {
+    uint32_t stack_sizes[2];
+    uint32_t starting_pot;
+    int n_board_cards;                 /* board_mask.count_ones(): 3 flop / 4 turn / 5 river */
+    int n_rounds;                      /* len of bet_sizes / raise_sizes */
+    int n_bet_sizes[ORC_MAX_ROUNDS];
+    double bet_sizes[ORC_MAX_ROUNDS][ORC_MAX_SIZES];
+    int n_raise_sizes[ORC_MAX_ROUNDS];
+    double raise_sizes[ORC_MAX_ROUNDS][ORC_MAX_SIZES];
+} orc_options;
+
+void orc_options_default_river(orc_options *o);   /* options.rs:52-81 as shipped (5-card board) */
+void orc_options_three_street(orc_options *o);    /* options.rs:68-77 commented vectors, minus the 2.0 river bet */
+
+int orc_tree_build(const orc_options *o, orc_tree *out);  /* tree_builder.rs:9-14 */
+void orc_tree_free(orc_tree *t);
+
+/* ---- infoset.rs ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t *regrets;                  /* Box<[i32]>  infoset.rs:65 */
+    int32_t *strategy_sum;             /* Box<[i32]>  infoset.rs:66 */
+    float *fregrets;                   /* extension dtypes only (ORC_T_F32 / ORC_T_F16) */
+    float *fstrategy_sum;
+    int n_actions;
+} orc_infoset;
+
+enum { ORC_T_I32 = 0, ORC_T_F32 = 1, ORC_T_F16 = 2 };
+
+/* Vec<Vec<Infoset>> infoset.rs:6 -- outer index ActionNode.index, inner dense lane id.
+ * With the README's [board] axis (README.md:31-54) the inner id is board*n_clusters+cluster;
+ * n_boards = 1 is the reference-as-coded shape. */
+typedef struct {
+    orc_infoset **rows;
+    size_t *row_len;
+    int n_rows;
+    int dtype;                         /* ORC_T_*; I32 is the reference */
+} orc_table;
+
+/* create_infosets (infoset.rs:8-49): cluster_size(an) is n_boards[an.round_idx]*n_clusters */
+int orc_table_create(const orc_tree *t, const uint32_t *n_boards /*[round_idx]*/, uint32_t n_clusters,
+                     int dtype, orc_table *out);
+void orc_table_free(orc_table *tb);
+
+void orc_get_strategy(const int32_t *regrets, int n, float *out);        /* infoset.rs:83-102 */
+void orc_get_final_strategy(const int32_t *ssum, int n, float *out);     /* infoset.rs:104-123 */
+
+int64_t orc_f32_as_i64(float x);   /* Rust `as i64` */
+int32_t orc_f32_as_i32(float x);   /* Rust `as i32` */
+
+/* ---- cfr.rs update blocks -------------------------------------------------------------- */
+enum {
+    ORC_UPD_CLAMP_I64 = 0,   /* mccfr traverser block cfr.rs:413-464 (scale 100.0 in the reference) */
+    ORC_UPD_WRAP_I32 = 1     /* cfr action block cfr.rs:612-621 (scale 10000.0 in the reference) */
+};
+
+/* One traverser-node visit given the child utilities (the recursion is the caller's).
+ * utils[i] is ignored for actions that are not explored (prune && regrets[i] <= -10M).
+ * Returns util (cfr.rs:466 / :623). */
+float orc_update_infoset(int32_t *regrets, int32_t *ssum, int n, const float *utils, float cfr_reach,
+                         float scale, int mode, int prune);
+
+/* Opponent / read-only visit: util = sum_i utils[i]*sigma[i] (cfr.rs:588 with :608-610). */
+float orc_node_util(const int32_t *regrets, int n, const float *utils);
+
+/* discount sweep body for one infoset (cfr.rs:248-258); d = p/(p+1), p = (tc/interval) as f32 */
+float orc_discount_factor(size_t tc, size_t interval);
+void orc_discount_infoset(int32_t *regrets, int32_t *ssum, int n, float d);
+void orc_discount_table(orc_table *tb, float d);
+
+/* ---- lane traversal (cfr.rs:481-627 run once per lane, see DESIGN.md "lane model") ----- */
+enum { ORC_LEAF_UNCONTESTED = 0, ORC_LEAF_SIGN = 1, ORC_LEAF_UTIL = 2 };
+enum { ORC_CHANCE_PASS = 0,   /* cfr.rs:306-313 (mccfr): go to child 0 */
+       ORC_CHANCE_ENUM = 1 }; /* cfr.rs:502-522 (cfr): reach *= 1/len, util = sum over deals */
+
+typedef struct {
+    int kind;            /* ORC_LEAF_*; UNCONTESTED needs no buffer */
+    const float *buf;    /* SIGN: >0 player 0 wins, <0 player 1 wins, 0 tie (cfr.rs:323-334);
+                            UTIL: value from the traverser's point of view, used verbatim */
+} orc_leaf;
+
+typedef struct {
+    const orc_tree *tree;
+    orc_table *table;
+    uint32_t n_boards[ORC_MAX_ROUNDS];  /* per round_idx */
+    uint32_t n_clusters;
+    const orc_leaf *leaves;             /* indexed by tree node id; only terminals are read */
+    float scale;
+    int mode;                           /* ORC_UPD_* */
+    int prune;
+    int rmplus;                         /* extension: floor regrets at 0 on write */
+    int chance_mode;                    /* ORC_CHANCE_* */
+    int ref_alloc;                      /* 1: allocate per visit like infoset.rs:85 / cfr.rs:372-373 (timed baseline) */
+} orc_ctx;
+
+/* one lane, one traverser, from `node_id` with lane (board b, cluster c) at that node's round */
+float orc_traverse(const orc_ctx *ctx, int node_id, int player, uint32_t b, uint32_t c, float cfr_reach);
+
+/* all root lanes for one traverser; root_util (may be NULL) gets n_boards[0]*n_clusters values */
+void orc_iterate(const orc_ctx *ctx, int player, float *root_util);
+/* same, lanes [lane_lo, lane_hi) of the root round only -- for threaded / sharded callers */
+void orc_iterate_range(const orc_ctx *ctx, int player, size_t lane_lo, size_t lane_hi, float *root_util);
+
+/* deterministic restatement of train()'s schedule (cfr.rs:188-265): per iteration both players
+ * traverse, t += 1, then the discount check `tc > threshold` (cfr.rs:239-263). */
+void orc_train(const orc_ctx *ctx, size_t iterations, size_t discount_interval, size_t discount_cap);
+
+/* ---- extension modes (north_star variants; NOT reference semantics) -------------------- */
+enum { ORC_F_F32 = 0, ORC_F_F16 = 1 };
+/* float tables: r += (scale*reach)*(u-util), s += (scale*reach)*sigma in f32; RM+ floors r at 0;
+ * F16 storage rounds every stored value to binary16 (RNE). */
+void orc_get_strategy_f32(const float *regrets, int n, float *out);
+float orc_update_infoset_f32(float *regrets, float *ssum, int n, const float *utils, float cfr_reach,
+                             float scale, int rmplus, int storage);
+float orc_node_util_f32(const float *regrets, int n, const float *utils);
+void orc_discount_f32(float *regrets, float *ssum, int n, float d, int storage);
+float orc_round_f16(float x);
+/* i32 tables with regret-matching+ (floor at 0 on write), clamp mode arithmetic */
+float orc_update_infoset_rmplus(int32_t *regrets, int32_t *ssum, int n, const float *utils,
+                                float cfr_reach, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
