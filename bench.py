@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- CFR iterations/sec of the MI355X regret/strategy-update engine + the roofline of its
+dominant kernel (the river regret-update kernel), next to the CPU restatement of the reference.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--clusters C]
+
+Workload (BASELINE.json configs[1]): the 14-action-node river tree of
+options::default_flop() (options.rs:52-81), C = 1000 clusters, A in {2,3}, i32 tables, with the board axis
+replicated to `--boards` per GPU so that one sweep streams >= 8 GB (>> the 256 MB Infinity Cache).
+One STEP = one CFR iteration = both traversers swept over every (board, cluster) lane of the tree
+(rs_iterate x 2).  `value` = board-iterations / second summed over all ranks, inputs resident in HBM.
+N > 1: boards shard across ranks (one process per GPU, no data-path collective for this river-only
+workload -- nothing is replicated), weak scaling.
+
+The oracle (oracle/) is used ONLY for the `cpu_baseline` leg.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--boards", type=int, default=9216, help="boards per GPU (9216 x 1000 lanes = 8.0 GB update traffic/iteration)")
+    ap.add_argument("--clusters", type=int, default=1000)
+    ap.add_argument("--mode", choices=["clamp", "wrap"], default="clamp",
+                    help="clamp: cfr.rs:413-464 scale 100 (the live mccfr update); wrap: cfr.rs:612-621 scale 10000")
+    ap.add_argument("--graph", type=int, default=0, help="replay each traverser sweep as one hipGraph")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed):
+    import numpy as np
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [n_clusters], [n_boards], rs.I32, device)
+    # synthetic inputs generated on the device (SURVEY.md 8(d) config 2 distributions)
+    table.fill_random(seed, (-10**6, 10**6), (0, 10**6))
+    root = tree.nodes[tree.nodes[0].children[0]]
+    sign = table.lane_buffer(root.index, 1)
+    from rustsolver_amd import _lib as L
+    L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), seed + 17, -1.0, 1.0))
+    leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes)
+              if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
+    trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=rs.CHANCE_PASS, use_graph=bool(graph))
+    table.sync()
+    return trainer
+
+
+def run_steps(trainer, k):
+    from rustsolver_amd import _lib as L
+    lib, h = L.load(), trainer._h
+    for _ in range(k):
+        L.check(lib.rs_iterate(h, 0, None))
+        L.check(lib.rs_iterate(h, 1, None))
+
+
+def cpu_baseline(n_clusters, mode, seconds):
+    """The C restatement in REFERENCE LAYOUT (boxed AoS, scalar recursion per lane, per-visit allocations,
+    infoset.rs:85 / cfr.rs:372-373), 8 threads like the reference's N_THREADS (cfr.rs:195) or all cores
+    if fewer, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import orc
+    threads = min(8, os.cpu_count() or 1)
+    boards = 64
+    rng = np.random.Generator(np.random.PCG64(1235))
+    tree = orc.OracleTree(orc.options_default_river())
+    tb = orc.OracleTable(tree, [boards], n_clusters)
+    for d in tree.as_dicts():
+        if d["kind"] == orc.ACTION:
+            a, n = tb.node_shape(d["index"])
+            tb.set_node(d["index"], rng.integers(-10**6, 10**6, size=(a, n)).astype(np.int32),
+                        rng.integers(0, 10**6, size=(a, n)).astype(np.int32))
+    sign = np.sign(rng.uniform(-1, 1, size=boards * n_clusters)).astype(np.float32)
+    leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in tree.as_dicts()
+              if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    scale, m = (100.0, orc.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, orc.UPD_WRAP_I32)
+    sol = orc.OracleSolver(tree, tb, leaves, scale=scale, mode=m, chance_mode=orc.CHANCE_PASS, ref_alloc=True)
+    t0 = time.perf_counter()
+    sol.run_iterations(1, threads)
+    t1 = time.perf_counter() - t0
+    iters = max(1, int(seconds / max(t1, 1e-6)))
+    t0 = time.perf_counter()
+    sol.run_iterations(iters, threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": boards * iters / dt, "unit": "board-iterations/s", "cores": threads, "kind": "port",
+        "host_cores": os.cpu_count(),
+        "sample": "%d iterations x %d boards x %d clusters of the same river tree, reference layout "
+                  "(boxed AoS, per-visit allocs), %d threads, %.1f s" % (iters, boards, n_clusters, threads, dt),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    if a.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (a.gpus, world, n_gpus), file=sys.stderr)
+
+    import rustsolver_amd as rs  # raises if the HIP library is missing (no fallback)
+    if rs.device_count() < 1:
+        raise RuntimeError("bench.py needs a GPU: the engine has no CPU fallback")
+    device = local_rank if world > 1 else 0
+
+    def barrier():
+        trainer.infosets.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    trainer = make_trainer(rs, a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank)
+    table = trainer.infosets
+
+    # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides -------------
+    run_steps(trainer, a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(trainer, a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: the same K steps again with every launch bracketed by HIP events on the table's
+    # stream (graph replay off so that single launches can be timed) ---------------------------------------
+    table.profile_reset()
+    table.profile_enable(True)
+    t0 = time.perf_counter()
+    run_steps(trainer, a.steps)
+    table.sync()
+    elapsed_prof = time.perf_counter() - t0
+    prof = table.profile_read()
+    table.profile_enable(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    upd = prof["update"]
+    achieved = upd["algo_bytes"] / (upd["ms"] * 1e-3) / 1e9 if upd["ms"] > 0 else 0.0
+    kernels = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
+                   "algo_GBps": (v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
+               for k, v in prof.items() if v["launches"]}
+    out = {
+        "metric": "cfr_iterations_per_sec",
+        "value": a.boards * n_gpus * a.steps / elapsed,
+        "unit": "board-iterations/s",
+        "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32", "data": "synthetic",
+        "config": {
+            "workload": "config2 river-only: 14-action-node tree of options::default_flop(), %d clusters, A in {2,3}, "
+                        "%d boards per GPU, i32 tables, %s update; 1 step = 1 CFR iteration (both traversers, all lanes)"
+                        % (a.clusters, a.boards, "cfr.rs:413-464 clamp scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap scale 10000"),
+            "n_boards_per_gpu": a.boards, "n_clusters": a.clusters, "lanes_per_gpu": a.boards * a.clusters,
+            "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
+            "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
+            "parallelism": "boards sharded x%d, no collective (nothing replicated in a river-only tree)" % n_gpus,
+        },
+        "roofline": {
+            "kernel": "rs::k_update (river regret/strategy_sum update, all action counts)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "launches": upd["launches"], "avg_launch_ms": upd["ms"] / max(1, upd["launches"]),
+            "algo_bytes_per_launch": upd["algo_bytes"] / max(1, upd["launches"]),
+            "note": "achieved = algorithmic bytes (DESIGN.md) / HIP-event duration of every update launch in a second, "
+                    "event-bracketed pass over the same K steps (ms_per_step there: %.3f)" % (elapsed_prof / a.steps * 1e3),
+        },
+        "kernels": kernels,
+        "lane_updates_per_sec": a.boards * n_gpus * a.clusters * 14 * a.steps / elapsed,
+    }
+
+    # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
+    try:
+        small = make_trainer(rs, 1, a.clusters, a.mode, 1, device, 99)
+        run_steps(small, 20)
+        small.infosets.sync()
+        t0 = time.perf_counter()
+        run_steps(small, 200)
+        small.infosets.sync()
+        dt = (time.perf_counter() - t0) / 200
+        out["single_board"] = {"us_per_iteration": dt * 1e6, "iterations_per_s": 1.0 / dt, "hip_graph": True,
+                               "launches_per_iteration": small.n_launches(0) + small.n_launches(1)}
+        small.destroy()
+    except Exception as e:  # the headline number must still be reported
+        out["single_board"] = {"error": str(e)}
+
+    if not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

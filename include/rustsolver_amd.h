@@ -1,0 +1,265 @@
+/*
+ * rustsolver_amd.h -- C ABI of the MI355X-native CFR regret/strategy-update engine.
+ *
+ * This is the drop-in boundary for RustSolver's hot path.  The reference has no FFI of its own
+ * (it is a single Rust crate); every entry point below replaces a crate-internal Rust item and
+ * cites it (paths relative to the reference repository root).  The Rust-side binding a
+ * maintainer would add is shown in INTEGRATION.md and rust/ffi.rs.
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers and sizes only; no C++/torch types;
+ *   - every call returns an int status (RS_OK = 0, negative = error); rs_last_error() gives the
+ *     text for the calling thread.  Where the reference panics (index out of bounds, invalid
+ *     board mask, ...) this library returns an error instead;
+ *   - the caller owns every host buffer; pointers named d_* are DEVICE pointers (from
+ *     rs_dmalloc or the caller's own hipMalloc on the same device);
+ *   - one rs_table lives on one GPU and owns one HIP stream; all calls on a table (and on
+ *     solvers built on it) are enqueued on that stream in call order.  Calls that return
+ *     host data synchronise the stream; the others are asynchronous;
+ *   - thread-safe across different tables, not for concurrent calls on the same table;
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point fails
+ *     with RS_ERR_HIP.
+ *
+ * Data layout in HBM: per action node two arrays  regrets[A][pitch]  and
+ * strategy_sum[A][pitch]; the fast axis is the LANE  lane = board * n_clusters + cluster  of
+ * that node's round, pitch = rs_table_lane_pitch() >= n_boards*n_clusters (multiple of 64).
+ * Every per-lane device vector passed through this ABI (utilities, reach, strategies) uses
+ * the same pitch:  float buf[pitch]  or  float buf[A][pitch].
+ */
+#ifndef RUSTSOLVER_AMD_H
+#define RUSTSOLVER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ABI_VERSION 1
+#define RS_MAX_ACTIONS 8
+#define RS_MAX_ROUNDS 3
+#define RS_MAX_SIZES 4
+#define RS_MAX_PLAYERS 2
+
+typedef struct rs_table rs_table;
+typedef struct rs_tree rs_tree;
+typedef struct rs_solver rs_solver;
+typedef struct rs_comm rs_comm;
+
+/* ---- status ------------------------------------------------------------------------------ */
+enum {
+    RS_OK = 0,
+    RS_ERR_INVALID = -1,     /* bad argument (NULL, negative size, mismatched shapes) */
+    RS_ERR_OOB = -2,         /* node / board / cluster index out of bounds (Rust: index panic) */
+    RS_ERR_OOM = -3,         /* host or device allocation failed */
+    RS_ERR_HIP = -4,         /* HIP runtime error or no usable GPU */
+    RS_ERR_UNSUPPORTED = -5, /* combination not implemented (e.g. prune on float tables) */
+    RS_ERR_COMM = -6         /* RCCL error */
+};
+const char *rs_last_error(void);
+int rs_abi_version(void);
+int rs_device_count(int *out);
+
+/* ---- public tree: tree.rs, nodes.rs, tree_builder.rs, state.rs, options.rs ------------------
+ * The tree stays on the host.  Either adopt the tree the Rust side already built
+ * (rs_tree_from_nodes) or let this library rebuild it from Options (rs_tree_build reproduces
+ * build_game_tree, tree_builder.rs:9-143, including the pre-order ActionNode.index numbering
+ * and the valid_actions child order Check, Call, Fold, Bet.., Raise.., state.rs:125-157). */
+enum { RS_NODE_PRIVATE_CHANCE = 0, RS_NODE_PUBLIC_CHANCE = 1, RS_NODE_ACTION = 2, RS_NODE_TERMINAL = 3 }; /* nodes.rs:46-52 */
+enum { RS_TERM_ALLIN = 0, RS_TERM_SHOWDOWN = 1, RS_TERM_UNCONTESTED = 2 };                                /* nodes.rs:16-21 */
+enum { RS_ACT_BET = 0, RS_ACT_RAISE = 1, RS_ACT_CHECK = 2, RS_ACT_CALL = 3, RS_ACT_FOLD = 4 };            /* action_abstraction.rs:4-10 */
+
+typedef struct rs_tree_node {
+    int32_t kind;                       /* RS_NODE_* */
+    int32_t parent;                     /* -1 for the root (tree.rs:22) */
+    int32_t n_children;
+    int32_t children[RS_MAX_ACTIONS];   /* tree.rs:21, child i = action i */
+    int32_t index;                      /* ActionNode.index (nodes.rs:7), -1 otherwise */
+    uint8_t player;                     /* ActionNode.player (nodes.rs:8) */
+    uint8_t round_idx;                  /* ActionNode.round_idx (nodes.rs:9), relative to the first street */
+    int32_t action_kind[RS_MAX_ACTIONS];/* ActionNode.actions (nodes.rs:6) */
+    double action_amt[RS_MAX_ACTIONS];
+    uint32_t value;                     /* TerminalNode.value = pot (nodes.rs:34) */
+    int32_t ttype;                      /* TerminalNode.ttype (nodes.rs:35) */
+    uint8_t last_to_act;                /* TerminalNode.last_to_act (nodes.rs:36) */
+    int32_t round;                      /* TerminalNode.round / PublicChanceNode.round: 0 flop, 1 turn, 2 river */
+} rs_tree_node;
+
+typedef struct rs_options {             /* options.rs:10-28, the fields build_game_tree reads */
+    uint32_t stack_sizes[RS_MAX_PLAYERS];
+    uint32_t starting_pot;
+    int32_t n_board_cards;              /* board_mask.count_ones(): 3 / 4 / 5 (state.rs:60-65) */
+    int32_t n_rounds;                   /* action_abstraction.bet_sizes.len() */
+    int32_t n_bet_sizes[RS_MAX_ROUNDS];
+    double bet_sizes[RS_MAX_ROUNDS][RS_MAX_SIZES];
+    int32_t n_raise_sizes[RS_MAX_ROUNDS];
+    double raise_sizes[RS_MAX_ROUNDS][RS_MAX_SIZES];
+} rs_options;
+
+int rs_options_default(rs_options *out);                                   /* options::default_flop(), options.rs:52-81 */
+int rs_tree_build(const rs_options *options, rs_tree **out);               /* build_game_tree, tree_builder.rs:9 */
+int rs_tree_from_nodes(const rs_tree_node *nodes, int n_nodes, rs_tree **out); /* adopt a Tree<GameTreeNode> (tree.rs:14-17) */
+void rs_tree_destroy(rs_tree *tree);
+int rs_tree_n_nodes(const rs_tree *tree);
+int rs_tree_n_action_nodes(const rs_tree *tree);                           /* the `n_actions` of tree_builder.rs:13 */
+int rs_tree_get_node(const rs_tree *tree, int node_id, rs_tree_node *out); /* Tree::get_node, tree.rs:57 */
+
+/* ---- info-set table: infoset.rs ---------------------------------------------------------- */
+enum { RS_I32 = 0,   /* reference: Box<[i32]> regrets / strategy_sum (infoset.rs:63-67) */
+       RS_F32 = 1,   /* extension: f32 tables */
+       RS_F16 = 2 }; /* extension: binary16 tables, f32 arithmetic */
+
+typedef struct rs_node_desc {           /* one row of InfosetTable = Vec<Vec<Infoset>> (infoset.rs:6) */
+    uint32_t n_actions;                 /* node.children.len() (infoset.rs:33) */
+    uint32_t n_clusters;                /* card_abs[round_idx].get_size(player) (infoset.rs:28-32) */
+    uint32_t n_boards;                  /* README.md:31-54 [board] axis; 1 = the reference as coded */
+    uint8_t player;
+    uint8_t round_idx;
+} rs_node_desc;
+
+/* order of `nodes` = ActionNode.index.  Zero-initialised like Infoset::init (infoset.rs:76-81). */
+int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int device, rs_table **out);
+/* create_infosets(n_actions, tree, card_abs) (infoset.rs:8-49): sizes from the tree, the per-round
+ * cluster counts n_clusters[round_idx][player] and board counts n_boards[round_idx]. */
+int rs_create_infosets(const rs_tree *tree, const uint32_t n_clusters[RS_MAX_ROUNDS][RS_MAX_PLAYERS],
+                       const uint32_t n_boards[RS_MAX_ROUNDS], int dtype, int device, rs_table **out);
+void rs_table_destroy(rs_table *table);
+
+int rs_table_n_nodes(const rs_table *table);
+int rs_table_node_desc(const rs_table *table, int node, rs_node_desc *out);
+int rs_table_dtype(const rs_table *table);
+int rs_table_device(const rs_table *table);
+size_t rs_table_lane_pitch(const rs_table *table, int node);  /* elements; 0 on error */
+size_t rs_table_cells(const rs_table *table);                 /* sum over nodes of n_actions * pitch */
+size_t rs_table_cell_offset(const rs_table *table, int node); /* element offset of a node's [A][pitch] block */
+size_t rs_table_bytes(const rs_table *table);                 /* device bytes of both arrays */
+
+/* Host <-> device copies.  Element type on the host: int32_t for RS_I32, float for RS_F32 and
+ * RS_F16 (converted with round-to-nearest-even).  Either pointer may be NULL to skip that array.
+ * Per (node, board): host layout [A][n_clusters].  Per node: host layout [A][n_boards*n_clusters]. */
+int rs_table_upload(rs_table *table, int node, int board, const void *regrets, const void *strategy_sum);
+int rs_table_download(rs_table *table, int node, int board, void *regrets, void *strategy_sum);
+int rs_table_upload_node(rs_table *table, int node, const void *regrets, const void *strategy_sum);
+int rs_table_download_node(rs_table *table, int node, void *regrets, void *strategy_sum);
+
+/* get-infoset: `&self.infosets[an.index][cluster_idx]` (cfr.rs:375) with its two pub fields
+ * (infoset.rs:65-66); out arrays of n_actions elements (host type as above). */
+int rs_get_infoset(rs_table *table, int node, int board, int cluster, void *regrets, void *strategy_sum);
+int rs_set_infoset(rs_table *table, int node, int board, int cluster, const void *regrets, const void *strategy_sum);
+int rs_get_strategy(rs_table *table, int node, int board, int cluster, float *out);       /* Infoset::get_strategy, infoset.rs:83-102 */
+int rs_get_final_strategy(rs_table *table, int node, int board, int cluster, float *out); /* Infoset::get_final_strategy, infoset.rs:104-123 */
+
+/* Synthetic fill on the device (bench / tests): cell value = lo + hash(seed, array, node, action,
+ * lane) mod (hi - lo + 1), a pure function mirrored in rustsolver_amd/synth.py. */
+int rs_table_fill_random(rs_table *table, uint64_t seed, int64_t regret_lo, int64_t regret_hi, int64_t ssum_lo,
+                         int64_t ssum_hi);
+/* dst[i] = lo + (hi - lo) * u(seed, i), u in [0,1) from the same hash; i < n */
+int rs_fill_uniform_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi);
+
+/* ---- device memory helpers (for hosts without their own HIP binding) ------------------------ */
+int rs_dmalloc(rs_table *table, size_t bytes, void **d_out);
+int rs_dfree(rs_table *table, void *d_ptr);
+int rs_h2d(rs_table *table, void *d_dst, const void *src, size_t bytes);
+int rs_d2h(rs_table *table, void *dst, const void *d_src, size_t bytes);
+int rs_dmemset(rs_table *table, void *d_dst, int byte, size_t bytes);
+int rs_sync(rs_table *table);
+void *rs_stream(rs_table *table);   /* the table's hipStream_t */
+
+/* ---- bulk kernels on one action node ---------------------------------------------------------- */
+enum {
+    RS_UPD_CLAMP_I64 = 0,       /* mccfr traverser block, cfr.rs:413-464: i64 add, clamp to i32 (reference scale 100.0) */
+    RS_UPD_WRAP_I32 = 1,        /* cfr action block, cfr.rs:612-621: saturating `as i32`, wrapping += (reference scale 10000.0) */
+    RS_UPD_ARITH_MASK = 0xff,
+    RS_UPD_RMPLUS = 0x100,      /* extension: regrets floored at 0 on write (regret matching+) */
+    RS_UPD_PRUNE = 0x200        /* cfr.rs:352,:379-386,:419-441: skip actions with regret <= -10 000 000 */
+};
+
+/* bulk get_strategy over every lane of a node (infoset.rs:83-102): d_strategy[A][pitch] */
+int rs_regret_match_node(rs_table *table, int node, float *d_strategy);
+/* bulk get_final_strategy (infoset.rs:104-123): d_strategy[A][pitch] */
+int rs_final_strategy_node(rs_table *table, int node, float *d_strategy);
+/* every node: d_out[rs_table_cells()] with node blocks at rs_table_cell_offset() (calc_br's reader, cfr.rs:669-672) */
+int rs_final_strategy_all(rs_table *table, float *d_out);
+
+/* One traverser visit of every lane of `node` (cfr.rs:370-466 / :571-623):
+ *   sigma = get_strategy(); util = sum_a utils[a]*sigma[a]; regrets / strategy_sum updated with
+ *   (scale*reach)*(utils[a]-util) and (scale*reach)*sigma[a] in the arithmetic of `mode`.
+ * d_action_utils[A][pitch], d_reach[pitch] (NULL = 1.0 for every lane), d_node_util[pitch] (NULL = discard). */
+int rs_update_node(rs_table *table, int node, const float *d_action_utils, const float *d_reach, float scale, int mode,
+                   float *d_node_util);
+/* opponent / read-only visit: util = sum_a utils[a]*sigma[a] (cfr.rs:574,:588,:608-610), no table write */
+int rs_node_util(rs_table *table, int node, const float *d_action_utils, float *d_node_util);
+/* opponent reach: d_child_reach[A][pitch] = sigma[a] * d_reach (cfr.rs:585; NULL reach = 1.0) */
+int rs_child_reach(rs_table *table, int node, const float *d_reach, float *d_child_reach);
+
+/* discount sweep, cfr.rs:250-261: x = ((x as f32) * d) as i32 for every regret and strategy_sum */
+int rs_discount(rs_table *table, float d);
+/* cfr.rs:248-249: p = (tc / interval) as f32; d = p / (p + 1.0) */
+float rs_discount_factor(uint64_t tc, uint64_t interval);
+
+/* ---- iterate: MCCFRTrainer (cfr.rs) ------------------------------------------------------------
+ * Lane model: lane (board b, cluster c) is one scalar cfr() traversal (cfr.rs:481-627)
+ * in which get_cluster() (cfr.rs:564-568) returns c for either player and evaluate() is replaced by
+ * the leaf inputs below.  The host walks the public tree once to build a launch plan (per tree
+ * depth: opponent-reach kernels top-down, node-util / update kernels bottom-up) and replays it. */
+enum { RS_LEAF_UNCONTESTED = 0, /* +-pot from TerminalNode.last_to_act (cfr.rs:316-322); no buffer */
+       RS_LEAF_SIGN = 1,        /* d_buf[pitch] = sign(score[0]-score[1]) of evaluate() (cfr.rs:323-347): value = +-pot / 0 */
+       RS_LEAF_UTIL = 2 };      /* d_buf[pitch] = utility from the traverser's point of view, used verbatim */
+enum { RS_CHANCE_PASS = 0,      /* mccfr: PublicChance goes to child 0 (cfr.rs:306-309); needs equal board counts */
+       RS_CHANCE_ENUM = 1 };    /* cfr: reach *= 1/len, util = sum over the len = n_boards[r+1]/n_boards[r] deals (cfr.rs:502-522) */
+
+typedef struct rs_leaf_desc {
+    int32_t kind;
+    const float *d_buf;
+} rs_leaf_desc;
+
+typedef struct rs_solver_params {
+    float scale;            /* 100.0 (cfr.rs:424) or 10000.0 (cfr.rs:617) */
+    int32_t mode;           /* RS_UPD_* */
+    int32_t chance_mode;    /* RS_CHANCE_* */
+    int32_t use_graph;      /* 1: replay each traverser's plan as one hipGraph launch */
+} rs_solver_params;
+
+/* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
+ * pass the same array twice unless RS_LEAF_UTIL buffers differ per traverser. */
+int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
+                     const rs_solver_params *params, rs_solver **out);   /* MCCFRTrainer::init, cfr.rs:159-184 */
+void rs_solver_destroy(rs_solver *solver);
+/* one traverser sweep over every lane: `self.cfr(0, player, hand, 1f32, ..)` (cfr.rs:217) for all lanes.
+ * d_root_util[pitch of the root round] (NULL = discard) receives the value returned at node 0. */
+int rs_iterate(rs_solver *solver, int traverser, float *d_root_util);
+/* MCCFRTrainer::train (cfr.rs:188-265), deterministic: per iteration both traversers sweep, t += 1, then
+ * the discount check `t > threshold` (d = p/(p+1), p = t/interval) until t > discount_cap. */
+int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap);
+size_t rs_solver_workspace_bytes(const rs_solver *solver);
+int rs_solver_n_launches(const rs_solver *solver, int traverser);
+
+/* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
+enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,
+       RS_K_COUNT = 6 };
+typedef struct rs_profile {
+    uint64_t launches[RS_K_COUNT];
+    double ms[RS_K_COUNT];              /* sum of HIP-event durations on the table's stream */
+    double algo_bytes[RS_K_COUNT];      /* sum of algorithmic bytes of those launches */
+} rs_profile;
+int rs_profile_enable(rs_table *table, int on); /* on: bracket every launch with hipEvents (adds host work) */
+int rs_profile_read(rs_table *table, rs_profile *out); /* synchronises, then accumulates pending events */
+int rs_profile_reset(rs_table *table);
+
+/* ---- multi-GPU: boards shard across GPUs, one process per GPU -------------------------
+ * Replicated tables (rounds whose boards are not sharded) accumulate rank-local deltas; one RCCL
+ * all-reduce (sum) over xGMI brings every rank to the same values. */
+#define RS_COMM_ID_BYTES 128
+int rs_comm_unique_id(void *id_out /* RS_COMM_ID_BYTES */);   /* rank 0; ship the bytes to the other ranks */
+int rs_comm_create(rs_table *table, const void *id, int rank, int n_ranks, rs_comm **out);
+void rs_comm_destroy(rs_comm *comm);
+/* snapshot the replicated rounds (bit r of round_mask) before a local iteration ... */
+int rs_replicated_begin(rs_table *table, uint32_t round_mask);
+/* ... then x = snapshot + allreduce_sum(x - snapshot) for regrets and strategy_sum of those rounds */
+int rs_allreduce_replicated(rs_table *table, rs_comm *comm, uint32_t round_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTSOLVER_AMD_H */

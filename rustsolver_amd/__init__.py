@@ -1,0 +1,22 @@
+"""rustsolver_amd -- MI355X-native CFR regret / strategy-update engine behind RustSolver's solver API.
+
+The product is the HIP shared library (csrc/, built by `python -m rustsolver_amd.build`) and its
+C ABI (include/rustsolver_amd.h).  This package is the ctypes host mirror used by tests and bench.py.
+Importing it fails loudly if the library has not been built; there is no CPU fallback.
+"""
+from . import _lib
+from ._lib import (ACT_BET, ACT_CALL, ACT_CHECK, ACT_FOLD, ACT_RAISE, CHANCE_ENUM, CHANCE_PASS, F16, F32, I32,
+                   LEAF_SIGN, LEAF_UNCONTESTED, LEAF_UTIL, NODE_ACTION, NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE,
+                   NODE_TERMINAL, TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED, UPD_CLAMP_I64, UPD_PRUNE, UPD_RMPLUS,
+                   UPD_WRAP_I32, RsError)
+
+_lib.load()  # ImportError if librustsolver_amd.so is missing
+
+from .solver import (DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
+                     build_game_tree, create_infosets, default_flop, device_count, discount_factor,
+                     three_street_options, tree_from_nodes)
+from . import synth  # noqa: E402
+
+__all__ = ["Options", "default_flop", "three_street_options", "build_game_tree", "tree_from_nodes", "create_infosets",
+           "InfosetTable", "Infoset", "GameTree", "MCCFRTrainer", "DeviceBuffer", "device_count", "discount_factor",
+           "synth", "RsError"]

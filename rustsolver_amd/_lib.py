@@ -1,0 +1,154 @@
+"""ctypes declarations for include/rustsolver_amd.h (the C ABI).  No torch, no CPU fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "librustsolver_amd.so")
+
+MAX_ACTIONS, MAX_ROUNDS, MAX_SIZES, MAX_PLAYERS = 8, 3, 4, 2
+COMM_ID_BYTES = 128
+
+OK, ERR_INVALID, ERR_OOB, ERR_OOM, ERR_HIP, ERR_UNSUPPORTED, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE, NODE_ACTION, NODE_TERMINAL = 0, 1, 2, 3
+TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED = 0, 1, 2
+ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
+I32, F32, F16 = 0, 1, 2
+UPD_CLAMP_I64, UPD_WRAP_I32, UPD_RMPLUS, UPD_PRUNE = 0, 1, 0x100, 0x200
+LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
+CHANCE_PASS, CHANCE_ENUM = 0, 1
+K_UPDATE, K_NODE_UTIL, K_REACH, K_CHANCE, K_DISCOUNT, K_STRATEGY, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+
+
+class TreeNode(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("parent", C.c_int32), ("n_children", C.c_int32),
+        ("children", C.c_int32 * MAX_ACTIONS),
+        ("index", C.c_int32), ("player", C.c_uint8), ("round_idx", C.c_uint8),
+        ("action_kind", C.c_int32 * MAX_ACTIONS), ("action_amt", C.c_double * MAX_ACTIONS),
+        ("value", C.c_uint32), ("ttype", C.c_int32), ("last_to_act", C.c_uint8), ("round", C.c_int32),
+    ]
+
+
+class OptionsC(C.Structure):
+    _fields_ = [
+        ("stack_sizes", C.c_uint32 * MAX_PLAYERS), ("starting_pot", C.c_uint32), ("n_board_cards", C.c_int32),
+        ("n_rounds", C.c_int32),
+        ("n_bet_sizes", C.c_int32 * MAX_ROUNDS), ("bet_sizes", (C.c_double * MAX_SIZES) * MAX_ROUNDS),
+        ("n_raise_sizes", C.c_int32 * MAX_ROUNDS), ("raise_sizes", (C.c_double * MAX_SIZES) * MAX_ROUNDS),
+    ]
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [("n_actions", C.c_uint32), ("n_clusters", C.c_uint32), ("n_boards", C.c_uint32),
+                ("player", C.c_uint8), ("round_idx", C.c_uint8)]
+
+
+class LeafDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d_buf", C.c_void_p)]
+
+
+class SolverParams(C.Structure):
+    _fields_ = [("scale", C.c_float), ("mode", C.c_int32), ("chance_mode", C.c_int32), ("use_graph", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * K_COUNT), ("ms", C.c_double * K_COUNT), ("algo_bytes", C.c_double * K_COUNT)]
+
+
+# every symbol the header declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "rs_last_error": (C.c_char_p, []),
+    "rs_abi_version": (C.c_int, []),
+    "rs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rs_options_default": (C.c_int, [C.POINTER(OptionsC)]),
+    "rs_tree_build": (C.c_int, [C.POINTER(OptionsC), _PP]),
+    "rs_tree_from_nodes": (C.c_int, [C.POINTER(TreeNode), C.c_int, _PP]),
+    "rs_tree_destroy": (None, [_P]),
+    "rs_tree_n_nodes": (C.c_int, [_P]),
+    "rs_tree_n_action_nodes": (C.c_int, [_P]),
+    "rs_tree_get_node": (C.c_int, [_P, C.c_int, C.POINTER(TreeNode)]),
+    "rs_table_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int, C.c_int, C.c_int, _PP]),
+    "rs_create_infosets": (C.c_int, [_P, C.POINTER((C.c_uint32 * MAX_PLAYERS) * MAX_ROUNDS), C.POINTER(C.c_uint32 * MAX_ROUNDS),
+                                     C.c_int, C.c_int, _PP]),
+    "rs_table_destroy": (None, [_P]),
+    "rs_table_n_nodes": (C.c_int, [_P]),
+    "rs_table_node_desc": (C.c_int, [_P, C.c_int, C.POINTER(NodeDesc)]),
+    "rs_table_dtype": (C.c_int, [_P]),
+    "rs_table_device": (C.c_int, [_P]),
+    "rs_table_lane_pitch": (C.c_size_t, [_P, C.c_int]),
+    "rs_table_cells": (C.c_size_t, [_P]),
+    "rs_table_cell_offset": (C.c_size_t, [_P, C.c_int]),
+    "rs_table_bytes": (C.c_size_t, [_P]),
+    "rs_table_upload": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "rs_table_download": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "rs_table_upload_node": (C.c_int, [_P, C.c_int, _P, _P]),
+    "rs_table_download_node": (C.c_int, [_P, C.c_int, _P, _P]),
+    "rs_get_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rs_set_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rs_get_strategy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rs_get_final_strategy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rs_table_fill_random": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "rs_fill_uniform_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_float, C.c_float]),
+    "rs_dmalloc": (C.c_int, [_P, C.c_size_t, _PP]),
+    "rs_dfree": (C.c_int, [_P, _P]),
+    "rs_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rs_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rs_dmemset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "rs_sync": (C.c_int, [_P]),
+    "rs_stream": (C.c_void_p, [_P]),
+    "rs_regret_match_node": (C.c_int, [_P, C.c_int, _P]),
+    "rs_final_strategy_node": (C.c_int, [_P, C.c_int, _P]),
+    "rs_final_strategy_all": (C.c_int, [_P, _P]),
+    "rs_update_node": (C.c_int, [_P, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
+    "rs_node_util": (C.c_int, [_P, C.c_int, _P, _P]),
+    "rs_child_reach": (C.c_int, [_P, C.c_int, _P, _P]),
+    "rs_discount": (C.c_int, [_P, C.c_float]),
+    "rs_discount_factor": (C.c_float, [C.c_uint64, C.c_uint64]),
+    "rs_solver_create": (C.c_int, [_P, _P, C.POINTER(LeafDesc), C.POINTER(LeafDesc), C.POINTER(SolverParams), _PP]),
+    "rs_solver_destroy": (None, [_P]),
+    "rs_iterate": (C.c_int, [_P, C.c_int, _P]),
+    "rs_train": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
+    "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
+    "rs_profile_enable": (C.c_int, [_P, C.c_int]),
+    "rs_profile_read": (C.c_int, [_P, C.POINTER(Profile)]),
+    "rs_profile_reset": (C.c_int, [_P]),
+    "rs_comm_unique_id": (C.c_int, [_P]),
+    "rs_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, _PP]),
+    "rs_comm_destroy": (None, [_P]),
+    "rs_replicated_begin": (C.c_int, [_P, C.c_uint32]),
+    "rs_allreduce_replicated": (C.c_int, [_P, _P, C.c_uint32]),
+}
+
+_lib = None
+
+
+class RsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rustsolver_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Loads librustsolver_amd.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("rustsolver_amd: %s is missing -- build it with `python -m rustsolver_amd.build` "
+                          "(hipcc, gfx950). There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise RsError(rc, load().rs_last_error().decode("utf-8", "replace"))
+    return rc

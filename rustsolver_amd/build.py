@@ -1,0 +1,51 @@
+"""Builds librustsolver_amd.so in-tree with hipcc for gfx950 (MI355X).
+
+    python -m rustsolver_amd.build [--force]
+
+-ffp-contract=off is part of the numerical contract (the Rust reference never fuses a*b+c);
+do not remove it.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "librustsolver_amd.so")
+SOURCES = ["rs_kernels.hip", "rs_table.cpp", "rs_tree.cpp", "rs_solver.cpp", "rs_comm.cpp"]
+HEADERS = [os.path.join(CSRC, "rs_internal.hpp"), os.path.join(ROOT, "include", "rustsolver_amd.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(HERE, "_build", src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + HEADERS):
+            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(SO, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

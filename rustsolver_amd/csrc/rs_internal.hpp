@@ -1,0 +1,146 @@
+// rs_internal.hpp -- structures shared by the host side (rs_table.cpp, rs_solver.cpp) and the
+// HIP kernels (rs_kernels.hip).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rustsolver_amd.h"
+
+namespace rs {
+
+constexpr int kLanePad = 64;      // lane pitch granularity (elements): keeps every row 256-B aligned
+constexpr int kVec = 4;           // lanes per thread: one 16-B access per f32/i32 row
+constexpr int kBlock = 256;       // threads per workgroup (4 waves of 64)
+constexpr int32_t kPruneThreshold = -10000000;  // cfr.rs:352
+
+// ---- job descriptors (device-visible, plain data) --------------------------------------------
+
+// where the utility of one action comes from
+enum ChildKind : int32_t {
+    CH_BUF = 0,    // u = buf[lane]                      child action/chance node util, or RS_LEAF_UTIL
+    CH_CONST = 1,  // u = value                          UNCONTESTED terminal (cfr.rs:316-322)
+    CH_SIGN = 2,   // u = sign-compare(buf[lane]) * pot  SHOWDOWN / ALLIN terminal (cfr.rs:323-347)
+};
+
+struct ChildSrc {
+    const float *buf;
+    float value;      // CH_CONST: the utility; CH_SIGN: the pot as f32
+    int32_t kind;     // ChildKind; for CH_SIGN bit 8 set = traverser is player 1 (flip the comparison)
+};
+
+// One action node visit over all lanes.  Used by the update, node-util and reach kernels.
+struct NodeJob {
+    void *regrets;            // [A][pitch] table element type
+    void *ssum;               // [A][pitch]
+    ChildSrc child[RS_MAX_ACTIONS];
+    const float *reach;       // [pitch] or nullptr
+    float reach_const;        // used when reach == nullptr
+    float *out_util;          // [pitch] or nullptr
+    float *out_reach[RS_MAX_ACTIONS];  // reach kernel: per child [pitch] or nullptr (not needed)
+    uint32_t n_vec;           // pitch / kVec
+    uint32_t pitch;           // elements
+    float scale;
+    int32_t n_actions;
+};
+
+// chance node: expand (top-down) / reduce (bottom-up) between a parent round and a child round
+struct ChanceJob {
+    const float *src;   // expand: parent reach [pitch_parent] or nullptr (const); reduce: child util [pitch_child]
+    float *dst;         // expand: child reach [pitch_child]; reduce: parent util [pitch_parent]
+    float src_const;    // expand with src == nullptr
+    float inv;          // expand: 1/len multiplier (cfr.rs:510)
+    uint32_t fan;       // deals per parent board
+    uint32_t n_clusters;
+    uint32_t n_parent_lanes;  // n_boards_parent * n_clusters
+};
+
+// ---- kernel launchers (rs_kernels.hip) ----------------------------------------------------------
+struct KernelCfg {
+    int dtype;       // RS_I32 / RS_F32 / RS_F16
+    int mode;        // RS_UPD_* bits (update only)
+};
+
+hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+                         KernelCfg cfg, hipStream_t stream);
+hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+                            KernelCfg cfg, hipStream_t stream);
+hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+                        KernelCfg cfg, hipStream_t stream);
+hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec,
+                              int n_actions, KernelCfg cfg, hipStream_t stream);
+hipError_t launch_strategy(const void *src /*[A][pitch]*/, float *dst, uint32_t pitch, int n_actions, int dtype,
+                           hipStream_t stream);
+hipError_t launch_chance_expand(const ChanceJob &job, hipStream_t stream);
+hipError_t launch_chance_reduce(const ChanceJob &job, hipStream_t stream);
+hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream);
+hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
+                              hipStream_t stream);
+hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream);
+hipError_t launch_convert_f32_to_f16(const float *src, void *dst, size_t n, hipStream_t stream);
+hipError_t launch_convert_f16_to_f32(const void *src, float *dst, size_t n, hipStream_t stream);
+hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
+hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
+
+// ---- host-side objects ----------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+inline size_t elem_size(int dtype) { return dtype == RS_F16 ? 2 : 4; }
+inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+struct Profile {
+    bool on = false;
+    struct Pending {
+        hipEvent_t a, b;
+        int kind;
+        double bytes;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    rs_profile acc{};
+};
+
+}  // namespace rs
+
+struct rs_tree {
+    std::vector<rs_tree_node> nodes;
+    int n_action_nodes = 0;
+};
+
+struct rs_table {
+    int device = 0;
+    int dtype = RS_I32;
+    hipStream_t stream = nullptr;
+    std::vector<rs_node_desc> nodes;
+    std::vector<size_t> pitch;        // per node, elements
+    std::vector<size_t> cell_off;     // per node, element offset of its [A][pitch] block
+    size_t n_cells = 0;
+    void *d_regrets = nullptr;        // n_cells elements
+    void *d_ssum = nullptr;
+    void *d_snap_regrets = nullptr;   // replicated-round snapshots (multi-GPU), lazily allocated, compact
+    void *d_snap_ssum = nullptr;
+    uint32_t rep_mask = 0;            // rounds covered by the snapshot
+    std::vector<int> rep_nodes;       // replicated node indices
+    std::vector<size_t> rep_off;      // element offset of each of them inside the compact snapshot
+    size_t rep_cells = 0;
+    void *h_stage = nullptr;          // pinned staging for small synchronous copies
+    size_t h_stage_bytes = 0;
+    rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
+    rs::Profile prof;
+
+    void *regrets_ptr(int node) const { return (char *)d_regrets + cell_off[node] * rs::elem_size(dtype); }
+    void *ssum_ptr(int node) const { return (char *)d_ssum + cell_off[node] * rs::elem_size(dtype); }
+};
+
+namespace rs {
+// profiling hooks used around launches
+void prof_begin(rs_table *t, int kind, double bytes);
+void prof_end(rs_table *t);
+double algo_bytes_update(const rs_table *t, int node, int n_buf_children, bool has_reach, bool has_out);
+}  // namespace rs

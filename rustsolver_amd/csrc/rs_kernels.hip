@@ -1,0 +1,587 @@
+// rs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for RustSolver's regret /
+// strategy-sum update path.  Everything here is HBM-bound elementwise work over the LANE axis
+// (lane = board * n_clusters + cluster): each thread owns kVec = 4 consecutive lanes, so every
+// table / utility row is touched with one 16-byte access per thread (1 KiB per wave
+// instruction), all rows of a node are issued up front, and nothing is re-read.  No MFMA, no
+// LDS: there is no reuse between lanes to stage.
+//
+// Numerics follow the Rust reference bit for bit in RS_I32 mode (rules listed in DESIGN.md):
+// no FMA contraction, sequential f32 sums in action order, RNE i32->f32, saturating
+// NaN->0 f32->int casts, i64-add-then-clamp (cfr.rs:445-461) or wrapping i32 add (cfr.rs:616-619).
+#include "rs_internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- Rust casts ---------------------------------------------------------------------------------
+// `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  |x| >= 2^32 saturates the
+// sum whatever r is, so x is first limited to +-2^32 (exact in f32) and the rest is exact i64 work.
+__device__ __forceinline__ int32_t add_clamp_i64(int32_t r, float x) {
+    if (x != x) x = 0.0f;                                  // NaN -> 0
+    x = fminf(fmaxf(x, -4294967296.0f), 4294967296.0f);
+    long long sum = (long long)r + (long long)x;            // trunc toward zero
+    sum = sum > 2147483647LL ? 2147483647LL : sum;
+    sum = sum < -2147483648LL ? -2147483648LL : sum;
+    return (int32_t)sum;
+}
+
+// `f32 as i32`: truncate, saturate, NaN -> 0 (cfr.rs:256-257, :617, :619)
+__device__ __forceinline__ int32_t f32_as_i32(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int32_t)x;
+}
+
+__device__ __forceinline__ int32_t add_wrap_i32(int32_t r, float x) {
+    return (int32_t)((uint32_t)r + (uint32_t)f32_as_i32(x));
+}
+
+// ---- row access: 4 consecutive lanes of one [pitch] row, as the compute type ---------------------
+template <int DT> struct Row;
+template <> struct Row<RS_I32> {
+    using val = int32_t;
+    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
+        i32x4 x = __builtin_nontemporal_load((const i32x4 *)((const int32_t *)base + row_off) + v);
+        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
+        i32x4 x = {in[0], in[1], in[2], in[3]};
+        __builtin_nontemporal_store(x, (i32x4 *)((int32_t *)base + row_off) + v);
+    }
+};
+template <> struct Row<RS_F32> {
+    using val = float;
+    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
+        f32x4 x = __builtin_nontemporal_load((const f32x4 *)((const float *)base + row_off) + v);
+        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
+        f32x4 x = {in[0], in[1], in[2], in[3]};
+        __builtin_nontemporal_store(x, (f32x4 *)((float *)base + row_off) + v);
+    }
+};
+template <> struct Row<RS_F16> {
+    using val = float;  // binary16 in HBM, f32 in registers
+    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
+        f16x4 x = __builtin_nontemporal_load((const f16x4 *)((const _Float16 *)base + row_off) + v);
+        out[0] = (float)x.x; out[1] = (float)x.y; out[2] = (float)x.z; out[3] = (float)x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
+        f16x4 x = {(_Float16)in[0], (_Float16)in[1], (_Float16)in[2], (_Float16)in[3]};  // RNE
+        __builtin_nontemporal_store(x, (f16x4 *)((_Float16 *)base + row_off) + v);
+    }
+};
+
+__device__ __forceinline__ void load_f32_row(const float *base, uint32_t v, float (&out)[kVec]) {
+    f32x4 x = __builtin_nontemporal_load((const f32x4 *)base + v);
+    out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+}
+__device__ __forceinline__ void store_f32_row(float *base, uint32_t v, const float (&in)[kVec]) {
+    f32x4 x = {in[0], in[1], in[2], in[3]};
+    __builtin_nontemporal_store(x, (f32x4 *)base + v);
+}
+
+// utility of one action for 4 lanes (cfr.rs:314-348 for terminals, child buffers otherwise)
+__device__ __forceinline__ void load_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
+    const int kind = c.kind & 0xff;  // wave-uniform
+    if (kind == CH_CONST) {
+#pragma unroll
+        for (int j = 0; j < kVec; j++) out[j] = c.value;
+        return;
+    }
+    load_f32_row(c.buf, v, out);
+    if (kind == CH_SIGN) {
+        const bool p1 = (c.kind & 0x100) != 0;
+        const float pot = c.value;
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            const float s = out[j];
+            const bool wins = p1 ? (s < 0.0f) : (s > 0.0f);  // scores[player] > scores[1-player]
+            out[j] = (s == 0.0f) ? 0.0f : (wins ? pot : -pot);
+        }
+    }
+}
+
+// ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
+template <int A, typename V>
+__device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {
+    float norm = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++)
+        if (r[a] > (V)0) norm += (float)r[a];
+    const float uni = 1.0f / (float)A;
+#pragma unroll
+    for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
+}
+
+// ---- the traverser visit for one lane --------------------------------------------------------------
+// I32: cfr.rs:413-464 (ARITH = RS_UPD_CLAMP_I64) or cfr.rs:612-621 (RS_UPD_WRAP_I32)
+template <int A, int ARITH>
+__device__ __forceinline__ float visit_i32(int32_t (&r)[A], int32_t (&s)[A], const float (&u)[A], float reach, float scale,
+                                           bool rmplus, bool prune) {
+    float sig[A];
+    regret_match<A, int32_t>(r, sig);
+    bool ex[A];
+    float util = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        ex[a] = !prune || (r[a] > kPruneThreshold);  // cfr.rs:380
+        if (ex[a]) util += u[a] * sig[a];            // cfr.rs:384 / :588
+    }
+    const bool active = !(reach != reach);           // NaN reach marks a lane whose subtree was pruned above
+    const float k = scale * reach;                   // (100.0 * cfr_reach) first
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        if (ex[a] && active) {
+            const float dr = k * (u[a] - util);
+            const float ds = k * sig[a];
+            if (ARITH == RS_UPD_CLAMP_I64) {
+                int32_t nr = add_clamp_i64(r[a], dr);
+                if (rmplus && nr < 0) nr = 0;
+                r[a] = nr;
+                s[a] = add_clamp_i64(s[a], ds);
+            } else {
+                r[a] = add_wrap_i32(r[a], dr);
+                s[a] = add_wrap_i32(s[a], ds);
+            }
+        }
+    }
+    return util;
+}
+
+// float tables (extension): r += (scale*reach)*(u-util); s += (scale*reach)*sigma
+template <int A>
+__device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const float (&u)[A], float reach, float scale,
+                                           bool rmplus) {
+    float sig[A];
+    regret_match<A, float>(r, sig);
+    float util = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) util += u[a] * sig[a];
+    const float k = scale * reach;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        float nr = r[a] + k * (u[a] - util);
+        if (rmplus && !(nr > 0.0f)) nr = 0.0f;
+        r[a] = nr;
+        s[a] = s[a] + k * sig[a];
+    }
+    return util;
+}
+
+// =====================================================================================================
+// update kernel: one traverser visit of every lane of the node(s) in `jobs` (blockIdx.y = job)
+// algorithmic bytes per lane: A*(4 regret + 4 ssum + 4 util) + 4 reach read, A*(4+4) + 4 written = 20A+8
+// =====================================================================================================
+template <int A, int DT, int ARITH>
+__global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ jobs, int flags) {
+    const NodeJob &job = jobs[blockIdx.y];
+    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    const bool rmplus = (flags & RS_UPD_RMPLUS) != 0, prune = (flags & RS_UPD_PRUNE) != 0;
+    using R = Row<DT>;
+    using V = typename R::val;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
+        V r[A][kVec], s[A][kVec];
+        float u[A][kVec], reach[kVec];
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(job.ssum, a * pitch, v, s[a]);
+#pragma unroll
+        for (int a = 0; a < A; a++) load_child(job.child[a], v, u[a]);
+        if (job.reach) load_f32_row(job.reach, v, reach);
+        else {
+#pragma unroll
+            for (int j = 0; j < kVec; j++) reach[j] = job.reach_const;
+        }
+        float util[kVec];
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            V rl[A], sl[A];
+            float ul[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) { rl[a] = r[a][j]; sl[a] = s[a][j]; ul[a] = u[a][j]; }
+            if constexpr (DT == RS_I32) util[j] = visit_i32<A, ARITH>(rl, sl, ul, reach[j], job.scale, rmplus, prune);
+            else util[j] = visit_f32<A>(rl, sl, ul, reach[j], job.scale, rmplus);
+#pragma unroll
+            for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < A; a++) R::store(job.regrets, a * pitch, v, r[a]);
+#pragma unroll
+        for (int a = 0; a < A; a++) R::store(job.ssum, a * pitch, v, s[a]);
+        if (job.out_util) store_f32_row(job.out_util, v, util);
+    }
+}
+
+// opponent / read-only visit: util = sum_a u[a]*sigma[a] (cfr.rs:574,:588).  8A+4 bytes per lane.
+template <int A, int DT>
+__global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict__ jobs) {
+    const NodeJob &job = jobs[blockIdx.y];
+    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    using R = Row<DT>;
+    using V = typename R::val;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
+        V r[A][kVec];
+        float u[A][kVec];
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+#pragma unroll
+        for (int a = 0; a < A; a++) load_child(job.child[a], v, u[a]);
+        float util[kVec];
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            V rl[A];
+            float sig[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) rl[a] = r[a][j];
+            regret_match<A, V>(rl, sig);
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < A; a++) acc += u[a][j] * sig[a];
+            util[j] = acc;
+        }
+        store_f32_row(job.out_util, v, util);
+    }
+}
+
+// opponent reach, top-down: out_reach[a] = sigma[a] * reach (cfr.rs:585) for the children that need it
+template <int A, int DT>
+__global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jobs) {
+    const NodeJob &job = jobs[blockIdx.y];
+    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    using R = Row<DT>;
+    using V = typename R::val;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
+        V r[A][kVec];
+        float reach[kVec], out[A][kVec];
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        if (job.reach) load_f32_row(job.reach, v, reach);
+        else {
+#pragma unroll
+            for (int j = 0; j < kVec; j++) reach[j] = job.reach_const;
+        }
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            V rl[A];
+            float sig[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) rl[a] = r[a][j];
+            regret_match<A, V>(rl, sig);
+#pragma unroll
+            for (int a = 0; a < A; a++) out[a][j] = sig[a] * reach[j];
+        }
+#pragma unroll
+        for (int a = 0; a < A; a++)
+            if (job.out_reach[a]) store_f32_row(job.out_reach[a], v, out[a]);
+    }
+}
+
+// traverser node in prune mode, top-down: children of unexplored actions get a NaN reach (= lane inactive
+// in that subtree, the reference never recurses there: cfr.rs:379-386); explored ones inherit reach.
+template <int A>
+__global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restrict__ jobs) {
+    const NodeJob &job = jobs[blockIdx.y];
+    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    using R = Row<RS_I32>;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
+        int32_t r[A][kVec];
+        float reach[kVec];
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        if (job.reach) load_f32_row(job.reach, v, reach);
+        else {
+#pragma unroll
+            for (int j = 0; j < kVec; j++) reach[j] = job.reach_const;
+        }
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            if (!job.out_reach[a]) continue;
+            float out[kVec];
+#pragma unroll
+            for (int j = 0; j < kVec; j++) out[j] = (r[a][j] > kPruneThreshold) ? reach[j] : __builtin_nanf("");
+            store_f32_row(job.out_reach[a], v, out);
+        }
+    }
+}
+
+// bulk get_strategy / get_final_strategy over a node: src[A][pitch] -> dst[A][pitch] f32
+template <int A, int DT>
+__global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ src, float *__restrict__ dst, uint32_t pitch) {
+    const uint32_t n_vec = pitch / kVec;
+    using R = Row<DT>;
+    using V = typename R::val;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
+        V r[A][kVec];
+        float out[A][kVec];
+#pragma unroll
+        for (int a = 0; a < A; a++) R::load(src, a * pitch, v, r[a]);
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            V rl[A];
+            float sig[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) rl[a] = r[a][j];
+            regret_match<A, V>(rl, sig);
+#pragma unroll
+            for (int a = 0; a < A; a++) out[a][j] = sig[a];
+        }
+#pragma unroll
+        for (int a = 0; a < A; a++) store_f32_row(dst + (size_t)a * pitch, v, out[a]);
+    }
+}
+
+// ---- public chance nodes (cfr.rs:502-522) ----------------------------------------------------------------
+// top-down: child_cfr_reach = cfr_reach * (1.0 / len) for each of the `fan` deals of a parent board
+__global__ __launch_bounds__(kBlock) void k_chance_expand(ChanceJob job) {
+    const uint32_t C = job.n_clusters, fan = job.fan;
+    const size_t n_child = (size_t)job.n_parent_lanes * fan;
+    for (size_t l = (size_t)blockIdx.x * kBlock + threadIdx.x; l < n_child; l += (size_t)gridDim.x * kBlock) {
+        const uint32_t bc = (uint32_t)(l / C), c = (uint32_t)(l % C);
+        const uint32_t bp = bc / fan;
+        const float rp = job.src ? job.src[(size_t)bp * C + c] : job.src_const;
+        job.dst[l] = rp * job.inv;
+    }
+}
+// bottom-up: util = 0 + u_0 + u_1 + ... in deal order (util.store(util.load() + u), cfr.rs:519)
+__global__ __launch_bounds__(kBlock) void k_chance_reduce(ChanceJob job) {
+    const uint32_t C = job.n_clusters, fan = job.fan;
+    for (size_t l = (size_t)blockIdx.x * kBlock + threadIdx.x; l < job.n_parent_lanes; l += (size_t)gridDim.x * kBlock) {
+        const uint32_t b = (uint32_t)(l / C), c = (uint32_t)(l % C);
+        float acc = 0.0f;
+        for (uint32_t d = 0; d < fan; d++) acc = acc + job.src[((size_t)b * fan + d) * C + c];
+        job.dst[l] = acc;
+    }
+}
+
+// ---- discount sweep (cfr.rs:250-261): 16 bytes per cell (2 arrays, read + write) ------------------------------
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets, void *__restrict__ ssum, size_t n_vec,
+                                                     float d) {
+    using R = Row<DT>;
+    using V = typename R::val;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * kBlock) {
+        constexpr size_t esize = (DT == RS_F16) ? 2 : 4;
+        char *rb = (char *)regrets + v * kVec * esize;   // 64-bit offsets: a table can exceed 2^32 cells
+        char *sb = (char *)ssum + v * kVec * esize;
+        V r[kVec], s[kVec];
+        R::load(rb, 0, 0, r);
+        R::load(sb, 0, 0, s);
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            if constexpr (DT == RS_I32) {
+                r[j] = f32_as_i32((float)r[j] * d);   // cfr.rs:256
+                s[j] = f32_as_i32((float)s[j] * d);   // cfr.rs:257
+            } else {
+                r[j] = r[j] * d;
+                s[j] = s[j] * d;
+            }
+        }
+        R::store(rb, 0, 0, r);
+        R::store(sb, 0, 0, s);
+    }
+}
+
+// ---- synthetic fills (bench / tests); mirrored in rustsolver_amd/synth.py ------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_fill_random(void *__restrict__ dst, size_t n, uint64_t seed, int64_t lo,
+                                                        uint64_t span) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const uint64_t h = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+        const int64_t val = lo + (int64_t)(h % span);
+        if constexpr (DT == RS_I32) ((int32_t *)dst)[i] = (int32_t)val;
+        else if constexpr (DT == RS_F32) ((float *)dst)[i] = (float)val;
+        else ((_Float16 *)dst)[i] = (_Float16)(float)val;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_fill_uniform(float *__restrict__ dst, size_t n, uint64_t seed, float lo,
+                                                         float width) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const uint64_t h = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+        const float u = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-08f;  // 24 bits * 2^-24 -> [0,1)
+        dst[i] = lo + width * u;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_f32_to_f16(const float *__restrict__ src, _Float16 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = (_Float16)src[i];
+}
+__global__ __launch_bounds__(kBlock) void k_f16_to_f32(const _Float16 *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = (float)src[i];
+}
+
+// replicated-round deltas for the multi-GPU all-reduce: x -= snap / x += snap (wrapping for i32)
+template <int DT, int SIGN>
+__global__ __launch_bounds__(kBlock) void k_delta(void *__restrict__ x, const void *__restrict__ snap, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (DT == RS_I32) {
+            uint32_t a = ((uint32_t *)x)[i], b = ((const uint32_t *)snap)[i];
+            ((uint32_t *)x)[i] = SIGN > 0 ? a + b : a - b;
+        } else {
+            float a = ((float *)x)[i], b = ((const float *)snap)[i];
+            ((float *)x)[i] = SIGN > 0 ? a + b : a - b;
+        }
+    }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+static inline uint32_t grid_for(size_t n_threads_needed) {
+    // memory-bound streaming: enough workgroups to fill 256 CUs x 8, grid-stride beyond that
+    size_t blocks = (n_threads_needed + kBlock - 1) / kBlock;
+    const size_t cap = 256 * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+#define RS_DISPATCH_A(A_, MACRO)                                   \
+    switch (A_) {                                                  \
+    case 1: MACRO(1); break;                                       \
+    case 2: MACRO(2); break;                                       \
+    case 3: MACRO(3); break;                                       \
+    case 4: MACRO(4); break;                                       \
+    case 5: MACRO(5); break;                                       \
+    case 6: MACRO(6); break;                                       \
+    case 7: MACRO(7); break;                                       \
+    case 8: MACRO(8); break;                                       \
+    default: return hipErrorInvalidValue;                          \
+    }
+
+hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+                         KernelCfg cfg, hipStream_t stream) {
+    dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
+    const int arith = cfg.mode & RS_UPD_ARITH_MASK, flags = cfg.mode & ~RS_UPD_ARITH_MASK;
+#define RS_UPD(A_)                                                                                               \
+    if (cfg.dtype == RS_I32 && arith == RS_UPD_CLAMP_I64)                                                        \
+        hipLaunchKernelGGL((k_update<A_, RS_I32, RS_UPD_CLAMP_I64>), grid, block, 0, stream, d_jobs, flags);     \
+    else if (cfg.dtype == RS_I32)                                                                                \
+        hipLaunchKernelGGL((k_update<A_, RS_I32, RS_UPD_WRAP_I32>), grid, block, 0, stream, d_jobs, flags);      \
+    else if (cfg.dtype == RS_F32)                                                                                \
+        hipLaunchKernelGGL((k_update<A_, RS_F32, 0>), grid, block, 0, stream, d_jobs, flags);                    \
+    else                                                                                                         \
+        hipLaunchKernelGGL((k_update<A_, RS_F16, 0>), grid, block, 0, stream, d_jobs, flags)
+    RS_DISPATCH_A(n_actions, RS_UPD)
+#undef RS_UPD
+    return hipGetLastError();
+}
+
+hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+                            KernelCfg cfg, hipStream_t stream) {
+    dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
+#define RS_NU(A_)                                                                                  \
+    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_node_util<A_, RS_I32>), grid, block, 0, stream, d_jobs); \
+    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_node_util<A_, RS_F32>), grid, block, 0, stream, d_jobs); \
+    else hipLaunchKernelGGL((k_node_util<A_, RS_F16>), grid, block, 0, stream, d_jobs)
+    RS_DISPATCH_A(n_actions, RS_NU)
+#undef RS_NU
+    return hipGetLastError();
+}
+
+hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+                        KernelCfg cfg, hipStream_t stream) {
+    dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
+#define RS_RE(A_)                                                                              \
+    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_reach<A_, RS_I32>), grid, block, 0, stream, d_jobs); \
+    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_reach<A_, RS_F32>), grid, block, 0, stream, d_jobs); \
+    else hipLaunchKernelGGL((k_reach<A_, RS_F16>), grid, block, 0, stream, d_jobs)
+    RS_DISPATCH_A(n_actions, RS_RE)
+#undef RS_RE
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+                              KernelCfg cfg, hipStream_t stream) {
+    if (cfg.dtype != RS_I32) return hipErrorInvalidValue;
+    dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
+#define RS_PR(A_) hipLaunchKernelGGL((k_prune_reach<A_>), grid, block, 0, stream, d_jobs)
+    RS_DISPATCH_A(n_actions, RS_PR)
+#undef RS_PR
+    return hipGetLastError();
+}
+
+hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, int n_actions, int dtype, hipStream_t stream) {
+    dim3 grid(grid_for(pitch / kVec)), block(kBlock);
+#define RS_ST(A_)                                                                                     \
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_strategy<A_, RS_I32>), grid, block, 0, stream, src, dst, pitch); \
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_strategy<A_, RS_F32>), grid, block, 0, stream, src, dst, pitch); \
+    else hipLaunchKernelGGL((k_strategy<A_, RS_F16>), grid, block, 0, stream, src, dst, pitch)
+    RS_DISPATCH_A(n_actions, RS_ST)
+#undef RS_ST
+    return hipGetLastError();
+}
+
+hipError_t launch_chance_expand(const ChanceJob &job, hipStream_t stream) {
+    dim3 grid(grid_for((size_t)job.n_parent_lanes * job.fan)), block(kBlock);
+    hipLaunchKernelGGL(k_chance_expand, grid, block, 0, stream, job);
+    return hipGetLastError();
+}
+hipError_t launch_chance_reduce(const ChanceJob &job, hipStream_t stream) {
+    dim3 grid(grid_for(job.n_parent_lanes)), block(kBlock);
+    hipLaunchKernelGGL(k_chance_reduce, grid, block, 0, stream, job);
+    return hipGetLastError();
+}
+
+hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream) {
+    const size_t n_vec = n_cells / kVec;
+    dim3 grid(grid_for(n_vec)), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_discount<RS_I32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_discount<RS_F32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
+    else hipLaunchKernelGGL((k_discount<RS_F16>), grid, block, 0, stream, regrets, ssum, n_vec, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
+                              hipStream_t stream) {
+    const uint64_t span = (uint64_t)(hi - lo) + 1;
+    dim3 grid(grid_for(n_cells)), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_fill_random<RS_I32>), grid, block, 0, stream, dst, n_cells, seed, lo, span);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_fill_random<RS_F32>), grid, block, 0, stream, dst, n_cells, seed, lo, span);
+    else hipLaunchKernelGGL((k_fill_random<RS_F16>), grid, block, 0, stream, dst, n_cells, seed, lo, span);
+    return hipGetLastError();
+}
+hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    hipLaunchKernelGGL(k_fill_uniform, grid, block, 0, stream, dst, n, seed, lo, hi - lo);
+    return hipGetLastError();
+}
+hipError_t launch_convert_f32_to_f16(const float *src, void *dst, size_t n, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    hipLaunchKernelGGL(k_f32_to_f16, grid, block, 0, stream, src, (_Float16 *)dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_convert_f16_to_f32(const void *src, float *dst, size_t n, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    hipLaunchKernelGGL(k_f16_to_f32, grid, block, 0, stream, (const _Float16 *)src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_delta<RS_I32, -1>), grid, block, 0, stream, x, snap, n);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_delta<RS_F32, -1>), grid, block, 0, stream, x, snap, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_delta<RS_I32, +1>), grid, block, 0, stream, x, snap, n);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_delta<RS_F32, +1>), grid, block, 0, stream, x, snap, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace rs

@@ -1,0 +1,538 @@
+// rs_solver.cpp -- the host-side traversal scheduler: MCCFRTrainer (cfr.rs:146-297) for the
+// batched lane model.  The branchy public-tree walk happens ONCE, here on the host, and yields a
+// static launch plan per traverser:
+//   top-down, by tree depth   : opponent nodes write reach[child] = sigma[a]*reach (cfr.rs:585),
+//                               ENUM chance nodes expand reach * 1/len to the child round's boards
+//   bottom-up, by tree depth  : opponent nodes write util = sum sigma*u (cfr.rs:588), traverser nodes
+//                               run the regret / strategy_sum update (cfr.rs:612-621 or :413-464),
+//                               ENUM chance nodes sum their deals (cfr.rs:519)
+// Nodes of one depth, kernel kind and action count share one launch (blockIdx.y = node).  Terminal
+// children cost no launch and no buffer: their utility is a constant or a sign lookup folded into
+// the consuming kernel.  rs_iterate replays the plan (optionally as one hipGraph).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <new>
+
+#include "rs_internal.hpp"
+
+using namespace rs;
+
+namespace {
+
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE };
+
+struct Launch {
+    int kind;
+    int n_actions = 0;
+    int first_job = 0, n_jobs = 0;
+    uint32_t max_n_vec = 0;
+    ChanceJob chance{};
+    double bytes = 0.0;
+};
+
+struct ReachSrc {
+    const float *ptr = nullptr;
+    float cst = 1.0f;
+    bool valid = false;
+};
+
+struct Plan {
+    std::vector<NodeJob> jobs;
+    NodeJob *d_jobs = nullptr;
+    std::vector<Launch> launches;
+    size_t arena_bytes = 0;
+    const float *root_util = nullptr;   // inside the arena
+    size_t root_lanes = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+};
+
+}  // namespace
+
+struct rs_solver {
+    rs_table *table = nullptr;
+    rs_tree tree;
+    rs_solver_params params{};
+    std::vector<rs_leaf_desc> leaves[2];
+    Plan plan[2];
+    char *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    uint32_t n_boards[RS_MAX_ROUNDS] = {0, 0, 0};
+    uint32_t n_clusters = 0;
+    size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
+    int n_rounds = 0;
+};
+
+namespace {
+
+#define RS_HIP(call, what)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return rs::hip_fail(e_, what); \
+    } while (0)
+
+// ---- geometry / validation ------------------------------------------------------------------------------
+int derive_geometry(rs_solver *s) {
+    const rs_table *t = s->table;
+    const rs_tree &tr = s->tree;
+    if (int(t->nodes.size()) != tr.n_action_nodes)
+        return fail(RS_ERR_INVALID, "rs_solver_create: table has " + std::to_string(t->nodes.size()) +
+                                        " rows but the tree has " + std::to_string(tr.n_action_nodes) + " action nodes");
+    bool seen[RS_MAX_ROUNDS] = {false, false, false};
+    for (const rs_tree_node &nd : tr.nodes) {
+        if (nd.kind != RS_NODE_ACTION) continue;
+        const rs_node_desc &d = t->nodes[nd.index];
+        if (d.n_actions != uint32_t(nd.n_children) || d.player != nd.player || d.round_idx != nd.round_idx)
+            return fail(RS_ERR_INVALID, "rs_solver_create: table row " + std::to_string(nd.index) + " does not match the tree");
+        const int r = nd.round_idx;
+        if (!seen[r]) {
+            seen[r] = true;
+            s->n_boards[r] = d.n_boards;
+            s->pitch[r] = t->pitch[nd.index];
+            if (s->n_clusters == 0) s->n_clusters = d.n_clusters;
+            s->n_rounds = std::max(s->n_rounds, r + 1);
+        }
+        // lane model: lane (b, c) addresses row c of BOTH players' tables on every street
+        if (d.n_boards != s->n_boards[r] || d.n_clusters != s->n_clusters)
+            return fail(RS_ERR_UNSUPPORTED,
+                        "rs_solver_create: the lane model needs one cluster count for both players and all rounds, and one "
+                        "board count per round (node " + std::to_string(nd.index) + ")");
+    }
+    for (int r = 0; r < s->n_rounds; ++r)
+        if (!seen[r]) return fail(RS_ERR_INVALID, "rs_solver_create: no action node in round " + std::to_string(r));
+    for (int r = 1; r < s->n_rounds; ++r) {
+        if (s->n_boards[r] % s->n_boards[r - 1] != 0)
+            return fail(RS_ERR_INVALID, "rs_solver_create: n_boards of a round must be a multiple of the previous round's");
+        if (s->params.chance_mode == RS_CHANCE_PASS && s->n_boards[r] != s->n_boards[r - 1])
+            return fail(RS_ERR_INVALID, "rs_solver_create: RS_CHANCE_PASS needs the same board count on every round");
+    }
+    return RS_OK;
+}
+
+struct Builder {
+    rs_solver *s;
+    int p;  // traverser
+    Plan &plan;
+    const std::vector<rs_tree_node> &nodes;
+    std::vector<int> depth, lane_round;
+    std::vector<char> has_own;
+    std::vector<ReachSrc> reach;      // reach source feeding each node
+    std::vector<size_t> util_off;     // arena offset of a node's util buffer (+1; 0 = none)
+    std::vector<size_t> reach_off;    // arena offset of a node's own reach buffer (+1; 0 = alias / const)
+    size_t arena = 0;
+    int max_depth = 0;
+
+    Builder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
+
+    size_t alloc(int round) {
+        const size_t off = arena;
+        arena += round_up(s->pitch[round] * sizeof(float), 256);
+        return off + 1;
+    }
+    float *aptr(size_t off1) const { return reinterpret_cast<float *>(s->d_arena + (off1 - 1)); }
+
+    void annotate(int id, int d, int round) {
+        depth[id] = d;
+        max_depth = std::max(max_depth, d);
+        const rs_tree_node &nd = nodes[id];
+        if (nd.kind == RS_NODE_ACTION) round = nd.round_idx;
+        lane_round[id] = round;
+        bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+        for (int k = 0; k < nd.n_children; ++k) {
+            const int c = nd.children[k];
+            // the child of a public chance node lives on the next round's boards
+            annotate(c, d + 1, nd.kind == RS_NODE_PUBLIC_CHANCE ? round + 1 : round);
+            own = own || has_own[c];
+        }
+        has_own[id] = own;
+    }
+
+    bool chance_enum(const rs_tree_node &nd) const {
+        return nd.kind == RS_NODE_PUBLIC_CHANCE && s->params.chance_mode == RS_CHANCE_ENUM;
+    }
+
+    // pass 1: decide which buffers exist (offsets only; the arena is allocated afterwards)
+    void layout(int id) {
+        const rs_tree_node &nd = nodes[id];
+        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
+        if (nd.kind == RS_NODE_ACTION || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);
+        for (int k = 0; k < nd.n_children; ++k) {
+            const int c = nd.children[k];
+            if (nodes[c].kind != RS_NODE_TERMINAL && has_own[c]) {
+                const bool opp = nd.kind == RS_NODE_ACTION && nd.player != p;
+                const bool own_prune = nd.kind == RS_NODE_ACTION && nd.player == p && prune;
+                if (opp || own_prune) reach_off[c] = alloc(lane_round[c]);
+                // ENUM chance: a buffer only if the incoming reach is itself a buffer (decided in pass 2)
+            }
+            layout(c);
+        }
+    }
+
+    ChildSrc child_source(int c) const {
+        const rs_tree_node &cn = nodes[c];
+        switch (cn.kind) {
+        case RS_NODE_ACTION: return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
+        case RS_NODE_PRIVATE_CHANCE: return child_source(cn.children[0]);
+        case RS_NODE_PUBLIC_CHANCE:
+            if (chance_enum(cn)) return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
+            return child_source(cn.children[0]);  // cfr.rs:306-309
+        default: break;
+        }
+        const float pot = float(cn.value);  // `tn.value as f32`
+        if (cn.ttype == RS_TERM_UNCONTESTED)  // cfr.rs:316-322
+            return ChildSrc{nullptr, (p == cn.last_to_act) ? -1.0f * pot : 1.0f * pot, CH_CONST};
+        const rs_leaf_desc &lf = s->leaves[p][c];
+        if (lf.kind == RS_LEAF_UTIL) return ChildSrc{lf.d_buf, 0.0f, CH_BUF};
+        return ChildSrc{lf.d_buf, pot, CH_SIGN | (p == 1 ? 0x100 : 0)};  // cfr.rs:323-347
+    }
+
+    void node_job(int id, NodeJob &job) const {
+        const rs_tree_node &nd = nodes[id];
+        const rs_table *t = s->table;
+        std::memset(&job, 0, sizeof(job));
+        job.regrets = t->regrets_ptr(nd.index);
+        job.ssum = t->ssum_ptr(nd.index);
+        job.pitch = uint32_t(t->pitch[nd.index]);
+        job.n_vec = job.pitch / kVec;
+        job.n_actions = nd.n_children;
+        job.scale = s->params.scale;
+        job.reach = reach[id].ptr;
+        job.reach_const = reach[id].cst;
+    }
+
+    double lanes(int id) const { return double(s->n_boards[lane_round[id]]) * s->n_clusters; }
+
+    int build() {
+        const size_t n = nodes.size();
+        depth.assign(n, 0);
+        lane_round.assign(n, 0);
+        has_own.assign(n, 0);
+        reach.assign(n, ReachSrc{});
+        util_off.assign(n, 0);
+        reach_off.assign(n, 0);
+        annotate(0, 0, 0);
+        layout(0);
+        // ENUM chance children: need their own reach buffer when the chance node's reach is a buffer.
+        // Resolve top-down in id order (parents have smaller ids than children).
+        std::vector<char> reach_is_buf(n, 0);
+        for (size_t id = 0; id < n; ++id) {
+            const rs_tree_node &nd = nodes[id];
+            for (int k = 0; k < nd.n_children; ++k) {
+                const int c = nd.children[k];
+                if (nodes[c].kind == RS_NODE_TERMINAL || !has_own[c]) continue;
+                if (reach_off[c]) reach_is_buf[c] = 1;
+                else if (chance_enum(nd)) {
+                    if (reach_is_buf[id]) {
+                        reach_off[c] = alloc(lane_round[c]);
+                        reach_is_buf[c] = 1;
+                    }
+                } else reach_is_buf[c] = reach_is_buf[id];
+            }
+        }
+        plan.arena_bytes = arena;
+        return RS_OK;
+    }
+
+    // pass 2 (after the arena exists): emit jobs and launches
+    int emit() {
+        const size_t n = nodes.size();
+        const rs_table *t = s->table;
+        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
+        const double es = double(elem_size(t->dtype));
+        std::vector<std::vector<int>> by_depth(max_depth + 1);
+        for (size_t id = 0; id < n; ++id) by_depth[depth[id]].push_back(int(id));
+
+        reach[0] = ReachSrc{nullptr, 1.0f, true};  // self.cfr(0, player, hand, 1f32, ..), cfr.rs:217
+        // ---- top-down ------------------------------------------------------------------------------
+        for (int d = 0; d <= max_depth; ++d) {
+            std::map<int, std::vector<int>> reach_groups, prune_groups;  // by n_actions
+            for (int id : by_depth[d]) {
+                const rs_tree_node &nd = nodes[id];
+                if (nd.kind == RS_NODE_TERMINAL) continue;
+                const bool opp = nd.kind == RS_NODE_ACTION && nd.player != p;
+                const bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+                bool any_child_buf = false;
+                for (int k = 0; k < nd.n_children; ++k) {
+                    const int c = nd.children[k];
+                    if (nodes[c].kind == RS_NODE_TERMINAL || !has_own[c]) continue;
+                    if (reach_off[c]) {
+                        reach[c] = ReachSrc{aptr(reach_off[c]), 0.0f, true};
+                        any_child_buf = true;
+                    } else if (chance_enum(nd)) {
+                        // constant incoming reach: fold cfr_reach * (1.0 / len) on the host (same f32 ops)
+                        const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
+                        reach[c] = ReachSrc{nullptr, reach[id].cst * (1.0f / float(fan)), true};
+                    } else reach[c] = reach[id];  // own node (cfr.rs:580) or pass-through chance
+                }
+                if (!any_child_buf) continue;
+                if (opp) reach_groups[nd.n_children].push_back(id);
+                else if (own && prune) prune_groups[nd.n_children].push_back(id);
+                else if (chance_enum(nd)) {
+                    const int c = nd.children[0];
+                    Launch L;
+                    L.kind = L_EXPAND;
+                    const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
+                    L.chance = ChanceJob{reach[id].ptr, aptr(reach_off[c]), reach[id].cst, 1.0f / float(fan), fan, s->n_clusters,
+                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)};
+                    L.bytes = lanes(c) * 4.0 + lanes(id) * 4.0;
+                    plan.launches.push_back(L);
+                }
+            }
+            for (int which = 0; which < 2; ++which) {
+                for (auto &g : (which == 0 ? reach_groups : prune_groups)) {
+                    Launch L;
+                    L.kind = which == 0 ? L_REACH : L_PRUNE_REACH;
+                    L.n_actions = g.first;
+                    L.first_job = int(plan.jobs.size());
+                    for (int id : g.second) {
+                        NodeJob job;
+                        node_job(id, job);
+                        const rs_tree_node &nd = nodes[id];
+                        int n_out = 0;
+                        for (int k = 0; k < nd.n_children; ++k) {
+                            const int c = nd.children[k];
+                            if (nodes[c].kind != RS_NODE_TERMINAL && has_own[c] && reach_off[c]) {
+                                job.out_reach[k] = aptr(reach_off[c]);
+                                ++n_out;
+                            }
+                        }
+                        L.max_n_vec = std::max(L.max_n_vec, job.n_vec);
+                        L.bytes += lanes(id) * (nd.n_children * es + (job.reach ? 4.0 : 0.0) + 4.0 * n_out);
+                        plan.jobs.push_back(job);
+                    }
+                    L.n_jobs = int(plan.jobs.size()) - L.first_job;
+                    plan.launches.push_back(L);
+                }
+            }
+        }
+        // ---- bottom-up -----------------------------------------------------------------------------
+        for (int d = max_depth; d >= 0; --d) {
+            std::map<int, std::vector<int>> upd_groups, util_groups;
+            for (int id : by_depth[d]) {
+                const rs_tree_node &nd = nodes[id];
+                if (nd.kind == RS_NODE_ACTION) (nd.player == p ? upd_groups : util_groups)[nd.n_children].push_back(id);
+                else if (chance_enum(nd)) {
+                    const int c = nd.children[0];
+                    const ChildSrc src = child_source(c);
+                    if (src.kind != CH_BUF) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: chance node above a terminal");
+                    Launch L;
+                    L.kind = L_REDUCE;
+                    const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
+                    L.chance = ChanceJob{src.buf, aptr(util_off[id]), 0.0f, 0.0f, fan, s->n_clusters,
+                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)};
+                    L.bytes = lanes(c) * 4.0 + lanes(id) * 4.0;
+                    plan.launches.push_back(L);
+                }
+            }
+            for (int which = 0; which < 2; ++which) {
+                for (auto &g : (which == 0 ? upd_groups : util_groups)) {
+                    Launch L;
+                    L.kind = which == 0 ? L_UPDATE : L_NODE_UTIL;
+                    L.n_actions = g.first;
+                    L.first_job = int(plan.jobs.size());
+                    for (int id : g.second) {
+                        NodeJob job;
+                        node_job(id, job);
+                        const rs_tree_node &nd = nodes[id];
+                        int n_buf = 0;
+                        for (int k = 0; k < nd.n_children; ++k) {
+                            job.child[k] = child_source(nd.children[k]);
+                            if ((job.child[k].kind & 0xff) != CH_CONST) ++n_buf;
+                        }
+                        job.out_util = aptr(util_off[id]);
+                        if (which == 0 && !reach[id].valid) return fail(RS_ERR_INVALID, "rs_solver_create: internal: no reach for a traverser node");
+                        L.max_n_vec = std::max(L.max_n_vec, job.n_vec);
+                        if (which == 0) L.bytes += lanes(id) * (nd.n_children * 4.0 * es + 4.0 * n_buf + (job.reach ? 4.0 : 0.0) + 4.0);
+                        else L.bytes += lanes(id) * (nd.n_children * es + 4.0 * n_buf + 4.0);
+                        plan.jobs.push_back(job);
+                    }
+                    L.n_jobs = int(plan.jobs.size()) - L.first_job;
+                    plan.launches.push_back(L);
+                }
+            }
+        }
+        // value returned at node 0
+        const ChildSrc root = child_source(0);
+        if (root.kind != CH_BUF) return fail(RS_ERR_INVALID, "rs_solver_create: the root has no action node below it");
+        plan.root_util = root.buf;
+        plan.root_lanes = s->pitch[0];
+        return RS_OK;
+    }
+};
+
+int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
+    rs_table *t = s->table;
+    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE};
+    prof_begin(t, prof_kind[L.kind], L.bytes);
+    hipError_t e = hipSuccess;
+    const NodeJob *jobs = plan.d_jobs + L.first_job;
+    const KernelCfg cfg{t->dtype, s->params.mode};
+    switch (L.kind) {
+    case L_REACH: e = launch_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_PRUNE_REACH: e = launch_prune_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_EXPAND: e = launch_chance_expand(L.chance, t->stream); break;
+    case L_UPDATE: e = launch_update(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_REDUCE: e = launch_chance_reduce(L.chance, t->stream); break;
+    }
+    prof_end(t);
+    RS_HIP(e, "plan launch");
+    return RS_OK;
+}
+
+int run_plan(rs_solver *s, int p) {
+    Plan &plan = s->plan[p];
+    rs_table *t = s->table;
+    if (s->params.use_graph && !t->prof.on) {
+        if (!plan.graph_exec) {
+            RS_HIP(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            int rc = RS_OK;
+            for (const Launch &L : plan.launches)
+                if ((rc = run_launch(s, plan, L)) != RS_OK) break;
+            hipError_t e = hipStreamEndCapture(t->stream, &plan.graph);
+            if (rc != RS_OK) return rc;
+            RS_HIP(e, "hipStreamEndCapture");
+            RS_HIP(hipGraphInstantiate(&plan.graph_exec, plan.graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        }
+        RS_HIP(hipGraphLaunch(plan.graph_exec, t->stream), "hipGraphLaunch");
+        return RS_OK;
+    }
+    for (const Launch &L : plan.launches)
+        if (int rc = run_launch(s, plan, L)) return rc;
+    return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
+                     const rs_solver_params *params, rs_solver **out) {
+    if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
+        return fail(RS_ERR_INVALID, "rs_solver_create: NULL argument");
+    const int arith = params->mode & RS_UPD_ARITH_MASK;
+    if (arith != RS_UPD_CLAMP_I64 && arith != RS_UPD_WRAP_I32) return fail(RS_ERR_INVALID, "rs_solver_create: bad update mode");
+    if ((params->mode & RS_UPD_PRUNE) && table->dtype != RS_I32)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: RS_UPD_PRUNE needs an RS_I32 table");
+    if ((params->mode & RS_UPD_RMPLUS) && table->dtype == RS_I32 && arith != RS_UPD_CLAMP_I64)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: RS_UPD_RMPLUS on i32 tables uses the clamp arithmetic");
+    if (params->chance_mode != RS_CHANCE_PASS && params->chance_mode != RS_CHANCE_ENUM)
+        return fail(RS_ERR_INVALID, "rs_solver_create: bad chance mode");
+    if (tree->nodes.empty() || tree->nodes[0].kind != RS_NODE_PRIVATE_CHANCE)
+        return fail(RS_ERR_INVALID, "rs_solver_create: node 0 must be the private chance root (tree_builder.rs:60-66)");
+
+    rs_solver *s = new (std::nothrow) rs_solver();
+    if (!s) return fail(RS_ERR_OOM, "rs_solver_create: out of host memory");
+    s->table = table;
+    s->tree = *tree;
+    s->params = *params;
+    const size_t n = tree->nodes.size();
+    s->leaves[0].assign(leaves_p0, leaves_p0 + n);
+    s->leaves[1].assign(leaves_p1, leaves_p1 + n);
+    int rc = derive_geometry(s);
+    for (size_t i = 0; rc == RS_OK && i < n; ++i) {
+        const rs_tree_node &nd = tree->nodes[i];
+        if (nd.kind != RS_NODE_TERMINAL || nd.ttype == RS_TERM_UNCONTESTED) continue;
+        for (int p = 0; p < 2; ++p) {
+            const rs_leaf_desc &lf = s->leaves[p][i];
+            if ((lf.kind != RS_LEAF_SIGN && lf.kind != RS_LEAF_UTIL) || !lf.d_buf)
+                rc = fail(RS_ERR_INVALID, "rs_solver_create: terminal " + std::to_string(i) +
+                                              " is a showdown / all-in and needs an RS_LEAF_SIGN or RS_LEAF_UTIL buffer");
+        }
+    }
+    if (rc != RS_OK) {
+        delete s;
+        return rc;
+    }
+    hipError_t e = hipSetDevice(table->device);
+    if (e != hipSuccess) {
+        delete s;
+        return hip_fail(e, "hipSetDevice");
+    }
+    Builder b0(s, 0), b1(s, 1);
+    if ((rc = b0.build()) != RS_OK || (rc = b1.build()) != RS_OK) {
+        delete s;
+        return rc;
+    }
+    s->arena_bytes = std::max(s->plan[0].arena_bytes, s->plan[1].arena_bytes);
+    if ((e = hipMalloc((void **)&s->d_arena, std::max<size_t>(s->arena_bytes, 256))) != hipSuccess) {
+        rc = hip_fail(e, "rs_solver_create: workspace hipMalloc");
+        delete s;
+        return rc;
+    }
+    // padding lanes are read by the vector kernels: keep them finite
+    (void)hipMemsetAsync(s->d_arena, 0, std::max<size_t>(s->arena_bytes, 256), table->stream);
+    if ((rc = b0.emit()) != RS_OK || (rc = b1.emit()) != RS_OK) {
+        rs_solver_destroy(s);
+        return rc;
+    }
+    for (int p = 0; p < 2; ++p) {
+        Plan &pl = s->plan[p];
+        const size_t bytes = std::max<size_t>(pl.jobs.size(), 1) * sizeof(NodeJob);
+        if ((e = hipMalloc((void **)&pl.d_jobs, bytes)) != hipSuccess ||
+            (e = hipMemcpyAsync(pl.d_jobs, pl.jobs.data(), pl.jobs.size() * sizeof(NodeJob), hipMemcpyHostToDevice,
+                                table->stream)) != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: job upload");
+            rs_solver_destroy(s);
+            return rc;
+        }
+    }
+    if ((e = hipStreamSynchronize(table->stream)) != hipSuccess) {
+        rc = hip_fail(e, "rs_solver_create: sync");
+        rs_solver_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return RS_OK;
+}
+
+void rs_solver_destroy(rs_solver *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->table->device);
+    (void)hipStreamSynchronize(s->table->stream);
+    for (int p = 0; p < 2; ++p) {
+        if (s->plan[p].graph_exec) (void)hipGraphExecDestroy(s->plan[p].graph_exec);
+        if (s->plan[p].graph) (void)hipGraphDestroy(s->plan[p].graph);
+        if (s->plan[p].d_jobs) (void)hipFree(s->plan[p].d_jobs);
+    }
+    if (s->d_arena) (void)hipFree(s->d_arena);
+    delete s;
+}
+
+int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
+    if (!s) return fail(RS_ERR_INVALID, "rs_iterate: solver is NULL");
+    if (traverser != 0 && traverser != 1) return fail(RS_ERR_INVALID, "rs_iterate: traverser must be 0 or 1");
+    RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+    if (int rc = run_plan(s, traverser)) return rc;
+    if (d_root_util)
+        RS_HIP(hipMemcpyAsync(d_root_util, s->plan[traverser].root_util, s->plan[traverser].root_lanes * sizeof(float),
+                              hipMemcpyDeviceToDevice, s->table->stream),
+               "rs_iterate: root util copy");
+    return RS_OK;
+}
+
+int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap) {
+    if (!s) return fail(RS_ERR_INVALID, "rs_train: solver is NULL");
+    if (discount_interval == 0) return fail(RS_ERR_INVALID, "rs_train: discount_interval must be > 0");
+    uint64_t t = 0, threshold = discount_interval;
+    while (t < iterations) {                       // cfr.rs:207
+        for (int player = 0; player < 2; ++player)  // cfr.rs:216-224
+            if (int rc = rs_iterate(s, player, nullptr)) return rc;
+        t += 1;                                     // cfr.rs:226
+        if (t > discount_cap) continue;             // cfr.rs:240-242
+        if (t > threshold) {                        // cfr.rs:243
+            if (int rc = rs_discount(s->table, rs_discount_factor(t, discount_interval))) return rc;  // cfr.rs:248-261
+            threshold = t + discount_interval;      // cfr.rs:262
+        }
+    }
+    return RS_OK;
+}
+
+size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes : 0; }
+int rs_solver_n_launches(const rs_solver *s, int traverser) {
+    if (!s || traverser < 0 || traverser > 1) return RS_ERR_INVALID;
+    return int(s->plan[traverser].launches.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,585 @@
+// rs_table.cpp -- the info-set table in HBM and the per-node entry points of the C ABI.
+// Replaces `InfosetTable = Vec<Vec<Infoset>>` (infoset.rs:6,63-67) with two SoA device arrays
+// per action node, regrets[A][pitch] and strategy_sum[A][pitch], lane-major.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "rs_internal.hpp"
+
+namespace rs {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? RS_ERR_OOM : RS_ERR_HIP;
+}
+
+#define RS_HIP(call, what)                                  \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return rs::hip_fail(e_, what); \
+    } while (0)
+
+// ---- profiling ------------------------------------------------------------------------------------
+static hipEvent_t prof_event(rs_table *t) {
+    if (!t->prof.pool.empty()) {
+        hipEvent_t e = t->prof.pool.back();
+        t->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(rs_table *t, int kind, double bytes) {
+    if (!t->prof.on) return;
+    Profile::Pending p{prof_event(t), prof_event(t), kind, bytes};
+    (void)hipEventRecord(p.a, t->stream);
+    t->prof.pending.push_back(p);
+}
+void prof_end(rs_table *t) {
+    if (!t->prof.on) return;
+    (void)hipEventRecord(t->prof.pending.back().b, t->stream);
+}
+static void prof_collect(rs_table *t) {
+    for (Profile::Pending &p : t->prof.pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            t->prof.acc.launches[p.kind] += 1;
+            t->prof.acc.ms[p.kind] += ms;
+            t->prof.acc.algo_bytes[p.kind] += p.bytes;
+        }
+        t->prof.pool.push_back(p.a);
+        t->prof.pool.push_back(p.b);
+    }
+    t->prof.pending.clear();
+}
+
+// algorithmic bytes of one traverser visit of a node: table rows are read and written,
+// utilities / reach / node util count only when they are real buffers
+double algo_bytes_update(const rs_table *t, int node, int n_buf_children, bool has_reach, bool has_out) {
+    const double lanes = double(t->nodes[node].n_boards) * t->nodes[node].n_clusters;
+    const double es = double(elem_size(t->dtype));
+    const double A = t->nodes[node].n_actions;
+    return lanes * (A * 4.0 * es + 4.0 * n_buf_children + (has_reach ? 4.0 : 0.0) + (has_out ? 4.0 : 0.0));
+}
+
+static int check_node(const rs_table *t, int node, const char *fn) {
+    if (!t) return fail(RS_ERR_INVALID, std::string(fn) + ": table is NULL");
+    if (node < 0 || node >= int(t->nodes.size()))
+        return fail(RS_ERR_OOB, std::string(fn) + ": node index " + std::to_string(node) + " out of bounds (len " +
+                                    std::to_string(t->nodes.size()) + ")");
+    return RS_OK;
+}
+
+static int ensure_stage(rs_table *t, size_t bytes) {
+    if (t->h_stage_bytes >= bytes) return RS_OK;
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    t->h_stage = nullptr;
+    t->h_stage_bytes = 0;
+    RS_HIP(hipHostMalloc(&t->h_stage, bytes, hipHostMallocDefault), "hipHostMalloc(stage)");
+    t->h_stage_bytes = bytes;
+    return RS_OK;
+}
+
+// host f32 <-> binary16 (RNE), used only by the upload / download paths of RS_F16 tables
+static uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+static float f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+// copy a strided block between host [rows][row_len] (host element) and device rows at
+// base + (r*row_stride + col0) elements.  dir: 0 = upload, 1 = download.
+static int copy_rows(rs_table *t, void *d_base, size_t row_stride, size_t col0, void *host, size_t rows, size_t row_len,
+                     int dir) {
+    const size_t es = elem_size(t->dtype);
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    if (t->dtype != RS_F16) {
+        char *d = (char *)d_base + col0 * es;
+        if (dir == 0)
+            RS_HIP(hipMemcpy2DAsync(d, row_stride * es, host, row_len * es, row_len * es, rows, hipMemcpyHostToDevice,
+                                    t->stream),
+                   "hipMemcpy2DAsync(upload)");
+        else
+            RS_HIP(hipMemcpy2DAsync(host, row_len * es, d, row_stride * es, row_len * es, rows, hipMemcpyDeviceToHost,
+                                    t->stream),
+                   "hipMemcpy2DAsync(download)");
+        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+        return RS_OK;
+    }
+    // F16: convert on the host through a temporary
+    std::vector<uint16_t> tmp(rows * row_len);
+    char *d = (char *)d_base + col0 * 2;
+    if (dir == 0) {
+        const float *h = (const float *)host;
+        for (size_t i = 0; i < rows * row_len; ++i) tmp[i] = f32_to_f16_bits(h[i]);
+        RS_HIP(hipMemcpy2DAsync(d, row_stride * 2, tmp.data(), row_len * 2, row_len * 2, rows, hipMemcpyHostToDevice,
+                                t->stream),
+               "hipMemcpy2DAsync(upload f16)");
+        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    } else {
+        RS_HIP(hipMemcpy2DAsync(tmp.data(), row_len * 2, d, row_stride * 2, row_len * 2, rows, hipMemcpyDeviceToHost,
+                                t->stream),
+               "hipMemcpy2DAsync(download f16)");
+        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+        float *h = (float *)host;
+        for (size_t i = 0; i < rows * row_len; ++i) h[i] = f16_bits_to_f32(tmp[i]);
+    }
+    return RS_OK;
+}
+
+}  // namespace rs
+
+using namespace rs;
+
+extern "C" {
+
+const char *rs_last_error(void) { return g_last_error.c_str(); }
+int rs_abi_version(void) { return RS_ABI_VERSION; }
+
+int rs_device_count(int *out) {
+    if (!out) return fail(RS_ERR_INVALID, "rs_device_count: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *out = n;
+    return RS_OK;
+}
+
+// ---- create / destroy --------------------------------------------------------------------------------
+int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int device, rs_table **out) {
+    if (!nodes || !out || n_nodes <= 0) return fail(RS_ERR_INVALID, "rs_table_create: bad argument");
+    if (dtype != RS_I32 && dtype != RS_F32 && dtype != RS_F16) return fail(RS_ERR_INVALID, "rs_table_create: bad dtype");
+    for (int i = 0; i < n_nodes; ++i) {
+        const rs_node_desc &nd = nodes[i];
+        if (nd.n_actions < 1 || nd.n_actions > RS_MAX_ACTIONS || nd.n_clusters < 1 || nd.n_boards < 1 || nd.player > 1 ||
+            nd.round_idx >= RS_MAX_ROUNDS)
+            return fail(RS_ERR_INVALID, "rs_table_create: bad descriptor for node " + std::to_string(i));
+        if (size_t(nd.n_boards) * nd.n_clusters * nd.n_actions > (size_t(1) << 31))
+            return fail(RS_ERR_UNSUPPORTED, "rs_table_create: a node exceeds 2^31 cells; shard the board axis");
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(RS_ERR_HIP, std::string("rs_table_create: no usable HIP device (") +
+                                    (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                                    "); this library has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(RS_ERR_INVALID, "rs_table_create: bad device ordinal");
+    RS_HIP(hipSetDevice(device), "hipSetDevice");
+
+    rs_table *t = new (std::nothrow) rs_table();
+    if (!t) return fail(RS_ERR_OOM, "rs_table_create: out of host memory");
+    t->device = device;
+    t->dtype = dtype;
+    t->nodes.assign(nodes, nodes + n_nodes);
+    t->pitch.resize(n_nodes);
+    t->cell_off.resize(n_nodes);
+    size_t off = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        t->pitch[i] = round_up(size_t(nodes[i].n_boards) * nodes[i].n_clusters, kLanePad);
+        t->cell_off[i] = off;
+        off += t->pitch[i] * nodes[i].n_actions;
+    }
+    t->n_cells = off;
+    const size_t bytes = off * elem_size(dtype);
+    hipError_t er;
+    if ((er = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (er = hipMalloc(&t->d_regrets, bytes)) != hipSuccess || (er = hipMalloc(&t->d_ssum, bytes)) != hipSuccess ||
+        (er = hipMemsetAsync(t->d_regrets, 0, bytes, t->stream)) != hipSuccess ||   // Infoset::init zero fill
+        (er = hipMemsetAsync(t->d_ssum, 0, bytes, t->stream)) != hipSuccess ||
+        (er = hipStreamSynchronize(t->stream)) != hipSuccess) {
+        int rc = hip_fail(er, "rs_table_create: device allocation");
+        rs_table_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return RS_OK;
+}
+
+int rs_create_infosets(const rs_tree *tree, const uint32_t n_clusters[RS_MAX_ROUNDS][RS_MAX_PLAYERS],
+                       const uint32_t n_boards[RS_MAX_ROUNDS], int dtype, int device, rs_table **out) {
+    if (!tree || !n_clusters || !n_boards || !out) return fail(RS_ERR_INVALID, "rs_create_infosets: NULL argument");
+    std::vector<rs_node_desc> descs(tree->n_action_nodes);
+    // create_infosets_rec (infoset.rs:20-49): one row per Action node, addressed by an.index
+    for (const rs_tree_node &nd : tree->nodes) {
+        if (nd.kind != RS_NODE_ACTION) continue;
+        rs_node_desc d{};
+        d.n_actions = uint32_t(nd.n_children);                  // node.children.len(), infoset.rs:33
+        d.n_clusters = n_clusters[nd.round_idx][nd.player];     // card_abs[round_idx].get_size(player), infoset.rs:28-32
+        d.n_boards = n_boards[nd.round_idx];
+        d.player = nd.player;
+        d.round_idx = nd.round_idx;
+        descs[nd.index] = d;
+    }
+    return rs_table_create(descs.data(), int(descs.size()), dtype, device, out);
+}
+
+void rs_table_destroy(rs_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    for (Profile::Pending &p : t->prof.pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (hipEvent_t e : t->prof.pool) (void)hipEventDestroy(e);
+    if (t->d_regrets) (void)hipFree(t->d_regrets);
+    if (t->d_ssum) (void)hipFree(t->d_ssum);
+    if (t->d_snap_regrets) (void)hipFree(t->d_snap_regrets);
+    if (t->d_snap_ssum) (void)hipFree(t->d_snap_ssum);
+    if (t->d_job) (void)hipFree(t->d_job);
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+// ---- introspection ---------------------------------------------------------------------------------------
+int rs_table_n_nodes(const rs_table *t) { return t ? int(t->nodes.size()) : RS_ERR_INVALID; }
+int rs_table_dtype(const rs_table *t) { return t ? t->dtype : RS_ERR_INVALID; }
+int rs_table_device(const rs_table *t) { return t ? t->device : RS_ERR_INVALID; }
+int rs_table_node_desc(const rs_table *t, int node, rs_node_desc *out) {
+    if (int rc = check_node(t, node, "rs_table_node_desc")) return rc;
+    if (!out) return fail(RS_ERR_INVALID, "rs_table_node_desc: out is NULL");
+    *out = t->nodes[node];
+    return RS_OK;
+}
+size_t rs_table_lane_pitch(const rs_table *t, int node) {
+    if (check_node(t, node, "rs_table_lane_pitch")) return 0;
+    return t->pitch[node];
+}
+size_t rs_table_cells(const rs_table *t) { return t ? t->n_cells : 0; }
+size_t rs_table_cell_offset(const rs_table *t, int node) {
+    if (check_node(t, node, "rs_table_cell_offset")) return 0;
+    return t->cell_off[node];
+}
+size_t rs_table_bytes(const rs_table *t) { return t ? 2 * t->n_cells * elem_size(t->dtype) : 0; }
+void *rs_stream(rs_table *t) { return t ? (void *)t->stream : nullptr; }
+
+// ---- host <-> device ------------------------------------------------------------------------------------------
+static int board_copy(rs_table *t, int node, int board, void *regrets, void *ssum, int dir, const char *fn) {
+    if (int rc = check_node(t, node, fn)) return rc;
+    const rs_node_desc &nd = t->nodes[node];
+    if (board < 0 || uint32_t(board) >= nd.n_boards) return fail(RS_ERR_OOB, std::string(fn) + ": board out of bounds");
+    const size_t col0 = size_t(board) * nd.n_clusters;
+    if (regrets)
+        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], col0, regrets, nd.n_actions, nd.n_clusters, dir)) return rc;
+    if (ssum)
+        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], col0, ssum, nd.n_actions, nd.n_clusters, dir)) return rc;
+    return RS_OK;
+}
+int rs_table_upload(rs_table *t, int node, int board, const void *regrets, const void *ssum) {
+    return board_copy(t, node, board, (void *)regrets, (void *)ssum, 0, "rs_table_upload");
+}
+int rs_table_download(rs_table *t, int node, int board, void *regrets, void *ssum) {
+    return board_copy(t, node, board, regrets, ssum, 1, "rs_table_download");
+}
+static int node_copy(rs_table *t, int node, void *regrets, void *ssum, int dir, const char *fn) {
+    if (int rc = check_node(t, node, fn)) return rc;
+    const rs_node_desc &nd = t->nodes[node];
+    const size_t lanes = size_t(nd.n_boards) * nd.n_clusters;
+    if (regrets)
+        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], 0, regrets, nd.n_actions, lanes, dir)) return rc;
+    if (ssum)
+        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], 0, ssum, nd.n_actions, lanes, dir)) return rc;
+    return RS_OK;
+}
+int rs_table_upload_node(rs_table *t, int node, const void *regrets, const void *ssum) {
+    return node_copy(t, node, (void *)regrets, (void *)ssum, 0, "rs_table_upload_node");
+}
+int rs_table_download_node(rs_table *t, int node, void *regrets, void *ssum) {
+    return node_copy(t, node, regrets, ssum, 1, "rs_table_download_node");
+}
+
+// get-infoset: &self.infosets[an.index][cluster_idx] (cfr.rs:375)
+static int infoset_copy(rs_table *t, int node, int board, int cluster, void *regrets, void *ssum, int dir, const char *fn) {
+    if (int rc = check_node(t, node, fn)) return rc;
+    const rs_node_desc &nd = t->nodes[node];
+    if (board < 0 || uint32_t(board) >= nd.n_boards || cluster < 0 || uint32_t(cluster) >= nd.n_clusters)
+        return fail(RS_ERR_OOB, std::string(fn) + ": index out of bounds: the len is " + std::to_string(nd.n_clusters) +
+                                    " but the index is " + std::to_string(cluster));
+    const size_t col0 = size_t(board) * nd.n_clusters + size_t(cluster);
+    if (regrets)
+        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], col0, regrets, nd.n_actions, 1, dir)) return rc;
+    if (ssum)
+        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], col0, ssum, nd.n_actions, 1, dir)) return rc;
+    return RS_OK;
+}
+int rs_get_infoset(rs_table *t, int node, int board, int cluster, void *regrets, void *ssum) {
+    return infoset_copy(t, node, board, cluster, regrets, ssum, 1, "rs_get_infoset");
+}
+int rs_set_infoset(rs_table *t, int node, int board, int cluster, const void *regrets, const void *ssum) {
+    return infoset_copy(t, node, board, cluster, (void *)regrets, (void *)ssum, 0, "rs_set_infoset");
+}
+
+// Infoset::get_strategy / get_final_strategy for ONE info set: the device kernel computes the whole
+// 64-lane group that contains the lane (so the numbers come from the same code as the bulk path).
+static int single_strategy(rs_table *t, int node, int board, int cluster, float *out, bool final_, const char *fn) {
+    if (int rc = check_node(t, node, fn)) return rc;
+    if (!out) return fail(RS_ERR_INVALID, std::string(fn) + ": out is NULL");
+    const rs_node_desc &nd = t->nodes[node];
+    if (board < 0 || uint32_t(board) >= nd.n_boards || cluster < 0 || uint32_t(cluster) >= nd.n_clusters)
+        return fail(RS_ERR_OOB, std::string(fn) + ": index out of bounds");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const size_t lane = size_t(board) * nd.n_clusters + size_t(cluster);
+    const size_t g0 = lane / kLanePad * kLanePad;  // 64-lane aligned group
+    const size_t es = elem_size(t->dtype);
+    // gather the group's A rows into a compact [A][64] block, run the kernel with pitch 64
+    void *d_in = nullptr;
+    float *d_out = nullptr;
+    RS_HIP(hipMalloc(&d_in, nd.n_actions * kLanePad * es), "hipMalloc");
+    if (hipMalloc((void **)&d_out, nd.n_actions * kLanePad * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(RS_ERR_OOM, std::string(fn) + ": hipMalloc failed");
+    }
+    const char *src = (const char *)(final_ ? t->ssum_ptr(node) : t->regrets_ptr(node)) + g0 * es;
+    hipError_t e = hipMemcpy2DAsync(d_in, kLanePad * es, src, t->pitch[node] * es, kLanePad * es, nd.n_actions,
+                                    hipMemcpyDeviceToDevice, t->stream);
+    if (e == hipSuccess) e = launch_strategy(d_in, d_out, kLanePad, int(nd.n_actions), t->dtype, t->stream);
+    std::vector<float> host(nd.n_actions * kLanePad);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, fn);
+    for (uint32_t a = 0; a < nd.n_actions; ++a) out[a] = host[a * kLanePad + (lane - g0)];
+    return RS_OK;
+}
+int rs_get_strategy(rs_table *t, int node, int board, int cluster, float *out) {
+    return single_strategy(t, node, board, cluster, out, false, "rs_get_strategy");
+}
+int rs_get_final_strategy(rs_table *t, int node, int board, int cluster, float *out) {
+    return single_strategy(t, node, board, cluster, out, true, "rs_get_final_strategy");
+}
+
+// ---- synthetic fills ---------------------------------------------------------------------------------------------
+int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_table_fill_random: table is NULL");
+    if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random: empty range");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(launch_fill_random(t->d_regrets, t->n_cells, seed, rlo, rhi, t->dtype, t->stream), "fill_random(regrets)");
+    RS_HIP(launch_fill_random(t->d_ssum, t->n_cells, seed ^ 0x5353554Dull /* "SSUM" */, slo, shi, t->dtype, t->stream),
+           "fill_random(ssum)");
+    return RS_OK;
+}
+int rs_fill_uniform_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, float lo, float hi) {
+    if (!t || !d_dst) return fail(RS_ERR_INVALID, "rs_fill_uniform_f32: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(launch_fill_uniform(d_dst, n, seed, lo, hi, t->stream), "fill_uniform");
+    return RS_OK;
+}
+
+// ---- device memory helpers ------------------------------------------------------------------------------------------
+int rs_dmalloc(rs_table *t, size_t bytes, void **d_out) {
+    if (!t || !d_out) return fail(RS_ERR_INVALID, "rs_dmalloc: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipMalloc(d_out, bytes ? bytes : 1), "hipMalloc");
+    return RS_OK;
+}
+int rs_dfree(rs_table *t, void *d_ptr) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_dfree: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    RS_HIP(hipFree(d_ptr), "hipFree");
+    return RS_OK;
+}
+int rs_h2d(rs_table *t, void *d_dst, const void *src, size_t bytes) {
+    if (!t || !d_dst || !src) return fail(RS_ERR_INVALID, "rs_h2d: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, t->stream), "hipMemcpyAsync(h2d)");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    return RS_OK;
+}
+int rs_d2h(rs_table *t, void *dst, const void *d_src, size_t bytes) {
+    if (!t || !dst || !d_src) return fail(RS_ERR_INVALID, "rs_d2h: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, t->stream), "hipMemcpyAsync(d2h)");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    return RS_OK;
+}
+int rs_dmemset(rs_table *t, void *d_dst, int byte, size_t bytes) {
+    if (!t || !d_dst) return fail(RS_ERR_INVALID, "rs_dmemset: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipMemsetAsync(d_dst, byte, bytes, t->stream), "hipMemsetAsync");
+    return RS_OK;
+}
+int rs_sync(rs_table *t) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_sync: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    return RS_OK;
+}
+
+// ---- bulk kernels on one node -------------------------------------------------------------------------------------------
+static int stage_job(rs_table *t, const NodeJob &job) {
+    if (!t->d_job) RS_HIP(hipMalloc((void **)&t->d_job, sizeof(NodeJob)), "hipMalloc(job slot)");
+    // stream-ordered: the previous kernel that read the slot has finished before this copy runs
+    RS_HIP(hipMemcpyAsync(t->d_job, &job, sizeof(NodeJob), hipMemcpyHostToDevice, t->stream), "hipMemcpyAsync(job)");
+    return RS_OK;
+}
+
+static void base_job(const rs_table *t, int node, NodeJob &job) {
+    std::memset(&job, 0, sizeof(job));
+    job.regrets = t->regrets_ptr(node);
+    job.ssum = t->ssum_ptr(node);
+    job.pitch = uint32_t(t->pitch[node]);
+    job.n_vec = uint32_t(t->pitch[node] / kVec);
+    job.n_actions = int32_t(t->nodes[node].n_actions);
+    job.reach_const = 1.0f;
+}
+
+int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
+    if (int rc = check_node(t, node, "rs_regret_match_node")) return rc;
+    if (!d_strategy) return fail(RS_ERR_INVALID, "rs_regret_match_node: d_strategy is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const rs_node_desc &nd = t->nodes[node];
+    prof_begin(t, RS_K_STRATEGY, double(nd.n_boards) * nd.n_clusters * nd.n_actions * (elem_size(t->dtype) + 4.0));
+    hipError_t e = launch_strategy(t->regrets_ptr(node), d_strategy, uint32_t(t->pitch[node]), int(nd.n_actions), t->dtype, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_strategy");
+    return RS_OK;
+}
+int rs_final_strategy_node(rs_table *t, int node, float *d_strategy) {
+    if (int rc = check_node(t, node, "rs_final_strategy_node")) return rc;
+    if (!d_strategy) return fail(RS_ERR_INVALID, "rs_final_strategy_node: d_strategy is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const rs_node_desc &nd = t->nodes[node];
+    prof_begin(t, RS_K_STRATEGY, double(nd.n_boards) * nd.n_clusters * nd.n_actions * (elem_size(t->dtype) + 4.0));
+    hipError_t e = launch_strategy(t->ssum_ptr(node), d_strategy, uint32_t(t->pitch[node]), int(nd.n_actions), t->dtype, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_strategy");
+    return RS_OK;
+}
+int rs_final_strategy_all(rs_table *t, float *d_out) {
+    if (!t || !d_out) return fail(RS_ERR_INVALID, "rs_final_strategy_all: NULL argument");
+    for (int n = 0; n < int(t->nodes.size()); ++n)
+        if (int rc = rs_final_strategy_node(t, n, d_out + t->cell_off[n])) return rc;
+    return RS_OK;
+}
+
+static int check_mode(const rs_table *t, int mode, const char *fn) {
+    const int arith = mode & RS_UPD_ARITH_MASK;
+    if (arith != RS_UPD_CLAMP_I64 && arith != RS_UPD_WRAP_I32) return fail(RS_ERR_INVALID, std::string(fn) + ": bad update mode");
+    if (mode & ~(RS_UPD_ARITH_MASK | RS_UPD_RMPLUS | RS_UPD_PRUNE)) return fail(RS_ERR_INVALID, std::string(fn) + ": unknown mode flag");
+    if ((mode & RS_UPD_PRUNE) && t->dtype != RS_I32)
+        return fail(RS_ERR_UNSUPPORTED, std::string(fn) + ": RS_UPD_PRUNE needs an RS_I32 table (threshold is an i32 regret, cfr.rs:352)");
+    if ((mode & RS_UPD_RMPLUS) && t->dtype == RS_I32 && arith != RS_UPD_CLAMP_I64)
+        return fail(RS_ERR_UNSUPPORTED, std::string(fn) + ": RS_UPD_RMPLUS on i32 tables uses the clamp arithmetic");
+    return RS_OK;
+}
+
+int rs_update_node(rs_table *t, int node, const float *d_action_utils, const float *d_reach, float scale, int mode,
+                   float *d_node_util) {
+    if (int rc = check_node(t, node, "rs_update_node")) return rc;
+    if (!d_action_utils) return fail(RS_ERR_INVALID, "rs_update_node: d_action_utils is NULL");
+    if (int rc = check_mode(t, mode, "rs_update_node")) return rc;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    NodeJob job;
+    base_job(t, node, job);
+    for (int a = 0; a < job.n_actions; ++a) job.child[a] = ChildSrc{d_action_utils + size_t(a) * job.pitch, 0.0f, CH_BUF};
+    job.reach = d_reach;
+    job.out_util = d_node_util;
+    job.scale = scale;
+    if (int rc = stage_job(t, job)) return rc;
+    prof_begin(t, RS_K_UPDATE, algo_bytes_update(t, node, job.n_actions, d_reach != nullptr, d_node_util != nullptr));
+    hipError_t e = launch_update(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, mode}, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_update");
+    return RS_OK;
+}
+
+int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_node_util) {
+    if (int rc = check_node(t, node, "rs_node_util")) return rc;
+    if (!d_action_utils || !d_node_util) return fail(RS_ERR_INVALID, "rs_node_util: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    NodeJob job;
+    base_job(t, node, job);
+    for (int a = 0; a < job.n_actions; ++a) job.child[a] = ChildSrc{d_action_utils + size_t(a) * job.pitch, 0.0f, CH_BUF};
+    job.out_util = d_node_util;
+    if (int rc = stage_job(t, job)) return rc;
+    const rs_node_desc &nd = t->nodes[node];
+    prof_begin(t, RS_K_NODE_UTIL, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + 4.0));
+    hipError_t e = launch_node_util(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_node_util");
+    return RS_OK;
+}
+
+int rs_child_reach(rs_table *t, int node, const float *d_reach, float *d_child_reach) {
+    if (int rc = check_node(t, node, "rs_child_reach")) return rc;
+    if (!d_child_reach) return fail(RS_ERR_INVALID, "rs_child_reach: d_child_reach is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    NodeJob job;
+    base_job(t, node, job);
+    job.reach = d_reach;
+    for (int a = 0; a < job.n_actions; ++a) job.out_reach[a] = d_child_reach + size_t(a) * job.pitch;
+    if (int rc = stage_job(t, job)) return rc;
+    const rs_node_desc &nd = t->nodes[node];
+    prof_begin(t, RS_K_REACH, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + (d_reach ? 4.0 : 0.0)));
+    hipError_t e = launch_reach(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_reach");
+    return RS_OK;
+}
+
+float rs_discount_factor(uint64_t tc, uint64_t interval) {  // cfr.rs:248-249
+    if (interval == 0) return 0.0f;
+    const float p = float(tc / interval);
+    return p / (p + 1.0f);
+}
+
+int rs_discount(rs_table *t, float d) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_discount: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    prof_begin(t, RS_K_DISCOUNT, double(t->n_cells) * 4.0 * elem_size(t->dtype));
+    hipError_t e = launch_discount(t->d_regrets, t->d_ssum, t->n_cells, d, t->dtype, t->stream);
+    prof_end(t);
+    RS_HIP(e, "k_discount");
+    return RS_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------------------------------------
+int rs_profile_enable(rs_table *t, int on) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_profile_enable: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    prof_collect(t);
+    t->prof.on = on != 0;
+    return RS_OK;
+}
+int rs_profile_read(rs_table *t, rs_profile *out) {
+    if (!t || !out) return fail(RS_ERR_INVALID, "rs_profile_read: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    prof_collect(t);
+    *out = t->prof.acc;
+    return RS_OK;
+}
+int rs_profile_reset(rs_table *t) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_profile_reset: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    prof_collect(t);
+    std::memset(&t->prof.acc, 0, sizeof(t->prof.acc));
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+"""Host-side mirror of the reference solver's surface (src/solver) on top of the C ABI.
+
+Names follow the Rust items they stand for so that tests read like tests of the reference:
+
+    Options / default_flop()          options.rs:10-28, :52-81
+    build_game_tree(options)          tree_builder.rs:9   -> (n_actions, tree)
+    create_infosets(n_actions, tree, card_abs)   infoset.rs:8   -> InfosetTable
+    table[an.index][cluster_idx]      cfr.rs:375 (get-infoset) -> Infoset view
+    Infoset.get_strategy() / .get_final_strategy()   infoset.rs:83 / :104
+    MCCFRTrainer.init(options, ...) / .train(iterations)   cfr.rs:159 / :188
+
+All compute runs in the HIP library; this file only marshals numpy arrays through ctypes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Options:
+    """options.rs:10-28 (the fields build_game_tree reads)."""
+
+    def __init__(self, stack_sizes=(500, 500), starting_pot=35, n_board_cards=5, bet_sizes=((0.5, 1.0),),
+                 raise_sizes=((3.0,),)):
+        self.stack_sizes = tuple(stack_sizes)
+        self.starting_pot = starting_pot
+        self.n_board_cards = n_board_cards  # board_mask.count_ones()
+        self.bet_sizes = [list(b) for b in bet_sizes]
+        self.raise_sizes = [list(r) for r in raise_sizes]
+
+    def to_c(self):
+        o = L.OptionsC()
+        o.stack_sizes[0], o.stack_sizes[1] = self.stack_sizes
+        o.starting_pot = self.starting_pot
+        o.n_board_cards = self.n_board_cards
+        o.n_rounds = len(self.bet_sizes)
+        for r, (bs, rs) in enumerate(zip(self.bet_sizes, self.raise_sizes)):
+            o.n_bet_sizes[r] = len(bs)
+            for i, v in enumerate(bs):
+                o.bet_sizes[r][i] = v
+            o.n_raise_sizes[r] = len(rs)
+            for i, v in enumerate(rs):
+                o.raise_sizes[r][i] = v
+        return o
+
+
+def default_flop():
+    """options::default_flop() (options.rs:52-81): despite the name, a 5-card (river) board."""
+    o = L.OptionsC()
+    L.check(L.load().rs_options_default(C.byref(o)))
+    return Options((o.stack_sizes[0], o.stack_sizes[1]), o.starting_pot, o.n_board_cards,
+                   [[o.bet_sizes[r][i] for i in range(o.n_bet_sizes[r])] for r in range(o.n_rounds)],
+                   [[o.raise_sizes[r][i] for i in range(o.n_raise_sizes[r])] for r in range(o.n_rounds)])
+
+
+def three_street_options():
+    """options.rs:68-77 commented vectors (minus the 2.0 river bet) from a 3-card board."""
+    return Options(n_board_cards=3, bet_sizes=((0.5, 1.0),) * 3, raise_sizes=((3.0,),) * 3)
+
+
+class GameTree:
+    """Tree<GameTreeNode> (tree.rs:14-17), host resident."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib = L.load()
+        self.n_nodes = lib.rs_tree_n_nodes(handle)
+        self.n_action_nodes = lib.rs_tree_n_action_nodes(handle)
+        self._nodes = None
+
+    def get_node(self, idx):
+        nd = L.TreeNode()
+        L.check(L.load().rs_tree_get_node(self._h, idx, C.byref(nd)))
+        return nd
+
+    @property
+    def nodes(self):
+        if self._nodes is None:
+            self._nodes = [self.get_node(i) for i in range(self.n_nodes)]
+        return self._nodes
+
+    def action_nodes(self):
+        """ActionNodes ordered by .index"""
+        out = [None] * self.n_action_nodes
+        for nd in self.nodes:
+            if nd.kind == L.NODE_ACTION:
+                out[nd.index] = nd
+        return out
+
+    def __del__(self):
+        try:
+            L.load().rs_tree_destroy(self._h)
+        except Exception:
+            pass
+
+
+def build_game_tree(options):
+    """tree_builder.rs:9 -> (n_actions, tree)."""
+    h = C.c_void_p()
+    oc = options.to_c()
+    L.check(L.load().rs_tree_build(C.byref(oc), C.byref(h)))
+    t = GameTree(h)
+    return t.n_action_nodes, t
+
+
+def tree_from_nodes(nodes):
+    arr = (L.TreeNode * len(nodes))(*nodes)
+    h = C.c_void_p()
+    L.check(L.load().rs_tree_from_nodes(arr, len(nodes), C.byref(h)))
+    return GameTree(h)
+
+
+class DeviceBuffer:
+    """A device allocation owned through the table's stream (rs_dmalloc / rs_dfree)."""
+
+    def __init__(self, table, nbytes):
+        self.table = table
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        L.check(L.load().rs_dmalloc(table._h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, table, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(table, arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        L.check(L.load().rs_h2d(self.table._h, self.ptr, _vp(arr), arr.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(L.load().rs_d2h(self.table._h, _vp(out), self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        L.check(L.load().rs_dmemset(self.table._h, self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            L.load().rs_dfree(self.table._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Infoset:
+    """View of one info set: `&self.infosets[an.index][cluster_idx]` (cfr.rs:375, infoset.rs:63-67)."""
+
+    def __init__(self, table, node, board, cluster):
+        self._t, self._n, self._b, self._c = table, node, board, cluster
+        self._a = table.node_desc(node).n_actions
+        self._np = np.int32 if table.dtype == L.I32 else np.float32
+
+    def _get(self):
+        r = np.empty(self._a, dtype=self._np)
+        s = np.empty(self._a, dtype=self._np)
+        rc = L.load().rs_get_infoset(self._t._h, self._n, self._b, self._c, _vp(r), _vp(s))
+        if rc == L.ERR_OOB:
+            raise IndexError(L.load().rs_last_error().decode())
+        L.check(rc)
+        return r, s
+
+    @property
+    def regrets(self):
+        return self._get()[0]
+
+    @property
+    def strategy_sum(self):
+        return self._get()[1]
+
+    def set(self, regrets=None, strategy_sum=None):
+        r = None if regrets is None else np.ascontiguousarray(regrets, dtype=self._np)
+        s = None if strategy_sum is None else np.ascontiguousarray(strategy_sum, dtype=self._np)
+        rc = L.load().rs_set_infoset(self._t._h, self._n, self._b, self._c, None if r is None else _vp(r),
+                                     None if s is None else _vp(s))
+        if rc == L.ERR_OOB:
+            raise IndexError(L.load().rs_last_error().decode())
+        L.check(rc)
+
+    def _strategy(self, fn):
+        out = np.empty(self._a, dtype=np.float32)
+        rc = fn(self._t._h, self._n, self._b, self._c, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc == L.ERR_OOB:
+            raise IndexError(L.load().rs_last_error().decode())
+        L.check(rc)
+        return out
+
+    def get_strategy(self):
+        """infoset.rs:83-102"""
+        return self._strategy(L.load().rs_get_strategy)
+
+    def get_final_strategy(self):
+        """infoset.rs:104-123"""
+        return self._strategy(L.load().rs_get_final_strategy)
+
+
+class _Row:
+    def __init__(self, table, node):
+        self._t, self._n = table, node
+
+    def __len__(self):
+        d = self._t.node_desc(self._n)
+        return d.n_boards * d.n_clusters
+
+    def __getitem__(self, key):
+        """row[cluster_idx] (board 0) or row[board, cluster_idx]"""
+        d = self._t.node_desc(self._n)
+        board, cluster = key if isinstance(key, tuple) else (0, key)
+        if not (0 <= cluster < d.n_clusters and 0 <= board < d.n_boards):
+            raise IndexError("index out of bounds: the len is %d but the index is %d" % (d.n_clusters, cluster))
+        return Infoset(self._t, self._n, board, cluster)
+
+
+class InfosetTable:
+    """`InfosetTable = Vec<Vec<Infoset>>` (infoset.rs:6), resident in HBM."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib = L.load()
+        self.n_nodes = lib.rs_table_n_nodes(handle)
+        self.dtype = lib.rs_table_dtype(handle)
+        self.np_dtype = np.int32 if self.dtype == L.I32 else np.float32
+        self._descs = {}
+
+    @classmethod
+    def create(cls, descs, dtype=L.I32, device=0):
+        """descs: list of (n_actions, n_clusters, n_boards, player, round_idx) in ActionNode.index order"""
+        arr = (L.NodeDesc * len(descs))()
+        for i, (a, c, b, p, r) in enumerate(descs):
+            arr[i].n_actions, arr[i].n_clusters, arr[i].n_boards, arr[i].player, arr[i].round_idx = a, c, b, p, r
+        h = C.c_void_p()
+        L.check(L.load().rs_table_create(arr, len(descs), dtype, device, C.byref(h)))
+        return cls(h)
+
+    def __len__(self):
+        return self.n_nodes
+
+    def __getitem__(self, node):
+        if not 0 <= node < self.n_nodes:
+            raise IndexError("index out of bounds: the len is %d but the index is %d" % (self.n_nodes, node))
+        return _Row(self, node)
+
+    def node_desc(self, node):
+        if node not in self._descs:
+            d = L.NodeDesc()
+            L.check(L.load().rs_table_node_desc(self._h, node, C.byref(d)))
+            self._descs[node] = d
+        return self._descs[node]
+
+    def lanes(self, node):
+        d = self.node_desc(node)
+        return d.n_boards * d.n_clusters
+
+    def pitch(self, node):
+        return L.load().rs_table_lane_pitch(self._h, node)
+
+    @property
+    def cells(self):
+        return L.load().rs_table_cells(self._h)
+
+    def cell_offset(self, node):
+        return L.load().rs_table_cell_offset(self._h, node)
+
+    @property
+    def nbytes(self):
+        return L.load().rs_table_bytes(self._h)
+
+    # ---- bulk host <-> device -------------------------------------------------------------------
+    def upload_node(self, node, regrets=None, strategy_sum=None):
+        """arrays [A][n_boards*n_clusters]"""
+        r = None if regrets is None else np.ascontiguousarray(regrets, dtype=self.np_dtype)
+        s = None if strategy_sum is None else np.ascontiguousarray(strategy_sum, dtype=self.np_dtype)
+        L.check(L.load().rs_table_upload_node(self._h, node, None if r is None else _vp(r), None if s is None else _vp(s)))
+
+    def download_node(self, node):
+        a, n = self.node_desc(node).n_actions, self.lanes(node)
+        r = np.empty((a, n), dtype=self.np_dtype)
+        s = np.empty((a, n), dtype=self.np_dtype)
+        L.check(L.load().rs_table_download_node(self._h, node, _vp(r), _vp(s)))
+        return r, s
+
+    def upload(self, node, board, regrets=None, strategy_sum=None):
+        r = None if regrets is None else np.ascontiguousarray(regrets, dtype=self.np_dtype)
+        s = None if strategy_sum is None else np.ascontiguousarray(strategy_sum, dtype=self.np_dtype)
+        L.check(L.load().rs_table_upload(self._h, node, board, None if r is None else _vp(r), None if s is None else _vp(s)))
+
+    def download(self, node, board):
+        d = self.node_desc(node)
+        r = np.empty((d.n_actions, d.n_clusters), dtype=self.np_dtype)
+        s = np.empty((d.n_actions, d.n_clusters), dtype=self.np_dtype)
+        L.check(L.load().rs_table_download(self._h, node, board, _vp(r), _vp(s)))
+        return r, s
+
+    def fill_random(self, seed, regret_range=(-10**6, 10**6), ssum_range=(0, 10**6)):
+        L.check(L.load().rs_table_fill_random(self._h, seed, regret_range[0], regret_range[1], ssum_range[0], ssum_range[1]))
+
+    # ---- device vectors ----------------------------------------------------------------------------
+    def lane_buffer(self, node, rows=1, data=None):
+        """float32 device buffer [rows][pitch]; `data` = numpy [rows][lanes] (padded on upload)"""
+        pitch = self.pitch(node)
+        buf = DeviceBuffer(self, rows * pitch * 4)
+        if data is None:
+            buf.zero()
+        else:
+            host = np.zeros((rows, pitch), dtype=np.float32)
+            host[:, : self.lanes(node)] = np.asarray(data, dtype=np.float32).reshape(rows, -1)
+            buf.upload(host)
+        return buf
+
+    def read_lane_buffer(self, buf, node, rows=1):
+        pitch = self.pitch(node)
+        return buf.download(np.float32, rows * pitch).reshape(rows, pitch)[:, : self.lanes(node)]
+
+    # ---- bulk kernels ---------------------------------------------------------------------------------
+    def regret_match_node(self, node):
+        """bulk get_strategy (infoset.rs:83-102) -> [A][lanes]"""
+        a = self.node_desc(node).n_actions
+        out = self.lane_buffer(node, a)
+        L.check(L.load().rs_regret_match_node(self._h, node, out.ptr))
+        return self.read_lane_buffer(out, node, a)
+
+    def final_strategy_node(self, node):
+        a = self.node_desc(node).n_actions
+        out = self.lane_buffer(node, a)
+        L.check(L.load().rs_final_strategy_node(self._h, node, out.ptr))
+        return self.read_lane_buffer(out, node, a)
+
+    def final_strategy_all(self):
+        out = DeviceBuffer(self, self.cells * 4)
+        L.check(L.load().rs_final_strategy_all(self._h, out.ptr))
+        flat = out.download(np.float32, self.cells)
+        res = []
+        for n in range(self.n_nodes):
+            a, p = self.node_desc(n).n_actions, self.pitch(n)
+            off = self.cell_offset(n)
+            res.append(flat[off: off + a * p].reshape(a, p)[:, : self.lanes(n)])
+        return res
+
+    def update_node(self, node, action_utils, reach=None, scale=100.0, mode=L.UPD_CLAMP_I64):
+        """One traverser visit of every lane (cfr.rs:370-466 / :571-623).  Returns node util [lanes]."""
+        a = self.node_desc(node).n_actions
+        u = self.lane_buffer(node, a, action_utils)
+        r = None if reach is None else self.lane_buffer(node, 1, reach)
+        out = self.lane_buffer(node, 1)
+        L.check(L.load().rs_update_node(self._h, node, u.ptr, None if r is None else r.ptr, scale, mode, out.ptr))
+        return self.read_lane_buffer(out, node)[0]
+
+    def node_util(self, node, action_utils):
+        a = self.node_desc(node).n_actions
+        u = self.lane_buffer(node, a, action_utils)
+        out = self.lane_buffer(node, 1)
+        L.check(L.load().rs_node_util(self._h, node, u.ptr, out.ptr))
+        return self.read_lane_buffer(out, node)[0]
+
+    def child_reach(self, node, reach=None):
+        a = self.node_desc(node).n_actions
+        r = None if reach is None else self.lane_buffer(node, 1, reach)
+        out = self.lane_buffer(node, a)
+        L.check(L.load().rs_child_reach(self._h, node, None if r is None else r.ptr, out.ptr))
+        return self.read_lane_buffer(out, node, a)
+
+    def discount(self, d):
+        """cfr.rs:250-261"""
+        L.check(L.load().rs_discount(self._h, float(d)))
+
+    def sync(self):
+        L.check(L.load().rs_sync(self._h))
+
+    # ---- profiling ------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        L.check(L.load().rs_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        L.check(L.load().rs_profile_reset(self._h))
+
+    def profile_read(self):
+        p = L.Profile()
+        L.check(L.load().rs_profile_read(self._h, C.byref(p)))
+        names = ["update", "node_util", "reach", "chance", "discount", "strategy"]
+        return {n: dict(launches=int(p.launches[i]), ms=float(p.ms[i]), algo_bytes=float(p.algo_bytes[i]))
+                for i, n in enumerate(names)}
+
+    def destroy(self):
+        if self._h:
+            L.load().rs_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def create_infosets(n_actions, tree, card_abs, n_boards=(1, 1, 1), dtype=L.I32, device=0):
+    """infoset.rs:8.  `card_abs[round_idx]` stands for CardAbstraction::get_size: either an int (same for
+    both players) or a (size_p0, size_p1) pair.  n_boards[round_idx] is the README's [board] axis."""
+    if n_actions != tree.n_action_nodes:
+        raise ValueError("n_actions does not match the tree")
+    nc = ((C.c_uint32 * L.MAX_PLAYERS) * L.MAX_ROUNDS)()
+    nb = (C.c_uint32 * L.MAX_ROUNDS)()
+    for r in range(L.MAX_ROUNDS):
+        sz = card_abs[r] if r < len(card_abs) else card_abs[-1]
+        sz = (sz, sz) if isinstance(sz, int) else tuple(sz)
+        nc[r][0], nc[r][1] = sz
+        nb[r] = n_boards[r] if r < len(n_boards) else n_boards[-1]
+    h = C.c_void_p()
+    L.check(L.load().rs_create_infosets(tree._h, C.byref(nc), C.byref(nb), dtype, device, C.byref(h)))
+    return InfosetTable(h)
+
+
+class MCCFRTrainer:
+    """cfr.rs:146-297 for the batched lane model."""
+
+    DISCOUNT_INTERVAL = 100_000   # cfr.rs:193
+    DISCOUNT_CAP = 20_000_000     # cfr.rs:194
+
+    def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
+                 use_graph=False, leaves_p1=None):
+        """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal"""
+        self.game_tree, self.infosets = tree, infosets
+        self._keep = [leaves, leaves_p1]
+        arrs = []
+        for lv in (leaves, leaves if leaves_p1 is None else leaves_p1):
+            arr = (L.LeafDesc * tree.n_nodes)()
+            for nid, (kind, buf) in lv.items():
+                arr[nid].kind = kind
+                arr[nid].d_buf = buf.ptr
+            arrs.append(arr)
+        p = L.SolverParams(scale, mode, chance_mode, int(use_graph))
+        h = C.c_void_p()
+        L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
+        self._h = h
+        self.workspace_bytes = L.load().rs_solver_workspace_bytes(h)
+
+    @classmethod
+    def init(cls, options, card_abs, n_boards=(1, 1, 1), leaf_sign=None, dtype=L.I32, device=0, **kw):
+        """MCCFRTrainer::init (cfr.rs:159-184): tree, table, plan.  leaf_sign: numpy [lanes of the last round]
+        = sign(score0 - score1) per lane, shared by every showdown / all-in terminal of that round."""
+        n_actions, tree = build_game_tree(options)
+        infosets = create_infosets(n_actions, tree, card_abs, n_boards, dtype, device)
+        leaves = {}
+        bufs = {}
+        for i, nd in enumerate(tree.nodes):
+            if nd.kind == L.NODE_TERMINAL and nd.ttype != L.TERM_UNCONTESTED:
+                parent = tree.nodes[nd.parent]
+                r = parent.round_idx
+                if r not in bufs:
+                    sign = leaf_sign[r] if isinstance(leaf_sign, dict) else leaf_sign
+                    bufs[r] = infosets.lane_buffer(parent.index, 1, sign)
+                leaves[i] = (L.LEAF_SIGN, bufs[r])
+        return cls(tree, infosets, leaves, **kw)
+
+    def n_launches(self, player):
+        return L.load().rs_solver_n_launches(self._h, player)
+
+    def iterate(self, player, want_root_util=False):
+        """`self.cfr(0, player, hand, 1f32, ..)` for every lane (cfr.rs:217)"""
+        root = self.game_tree.nodes[self.game_tree.nodes[0].children[0]]
+        if not want_root_util:
+            L.check(L.load().rs_iterate(self._h, player, None))
+            return None
+        out = self.infosets.lane_buffer(root.index, 1)
+        L.check(L.load().rs_iterate(self._h, player, out.ptr))
+        return self.infosets.read_lane_buffer(out, root.index)[0]
+
+    def train(self, iterations, discount_interval=None, discount_cap=None):
+        """cfr.rs:188"""
+        L.check(L.load().rs_train(self._h, iterations, discount_interval or self.DISCOUNT_INTERVAL,
+                                  discount_cap or self.DISCOUNT_CAP))
+        self.infosets.sync()
+
+    def destroy(self):
+        if self._h:
+            L.load().rs_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def discount_factor(tc, interval=MCCFRTrainer.DISCOUNT_INTERVAL):
+    """cfr.rs:248-249"""
+    return np.float32(L.load().rs_discount_factor(tc, interval))
+
+
+def device_count():
+    n = C.c_int()
+    rc = L.load().rs_device_count(C.byref(n))
+    return n.value if rc == L.OK else 0

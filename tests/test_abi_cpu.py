@@ -1,0 +1,140 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rustsolver_amd.h declares (no compute
+calls), and the host-side logic that needs no GPU (the public-tree builder) matches the oracle."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rustsolver_amd as rs
+from oracle import np_restate as npr
+from oracle import orc
+from rustsolver_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rustsolver_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = header_functions()
+    assert len(names) >= 50
+    lib = C.CDLL(L.SO_PATH)
+    for n in names:
+        assert hasattr(lib, n), "librustsolver_amd.so does not export %s" % n
+    assert sorted(L.SYMBOLS) == names, set(L.SYMBOLS) ^ set(names)
+    assert lib.rs_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if rs.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    n, tree = rs.build_game_tree(rs.default_flop())
+    with pytest.raises(rs.RsError) as e:
+        rs.create_infosets(n, tree, [8])
+    assert e.value.code == L.ERR_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rustsolver_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "rs_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def _same_tree(tree, otree):
+    assert (tree.n_nodes, tree.n_action_nodes) == (otree.n_nodes, otree.n_action_nodes)
+    for nd, d in zip(tree.nodes, otree.as_dicts()):
+        assert (nd.kind, nd.parent, [nd.children[k] for k in range(nd.n_children)]) == (d["kind"], d["parent"], d["children"])
+        if nd.kind == L.NODE_ACTION:
+            assert (nd.index, nd.player, nd.round_idx) == (d["index"], d["player"], d["round_idx"])
+            assert [[nd.action_kind[k], nd.action_amt[k]] for k in range(nd.n_children)] == d["actions"]
+        elif nd.kind == L.NODE_TERMINAL:
+            assert (nd.value, nd.ttype, nd.last_to_act, nd.round) == (d["value"], d["ttype"], d["last_to_act"], d["round"])
+        elif nd.kind == L.NODE_PUBLIC_CHANCE:
+            assert nd.round == d["round"]
+
+
+def test_default_tree_matches_oracle_and_golden(golden_dir):
+    n, tree = rs.build_game_tree(rs.default_flop())        # tree_builder.rs:9 on options.rs:52-81
+    assert n == 14 and tree.n_nodes == 40
+    _same_tree(tree, orc.OracleTree(orc.options_default_river()))
+    fx = json.load(open(os.path.join(golden_dir, "tree_river.json")))
+    acts = {L.ACT_BET: "bet", L.ACT_RAISE: "raise", L.ACT_CHECK: "check", L.ACT_CALL: "call", L.ACT_FOLD: "fold"}
+    for nd, g in zip(tree.nodes, fx["nodes"]):
+        if g["kind"] == "action":
+            assert [[acts[nd.action_kind[k]], nd.action_amt[k]] for k in range(nd.n_children)] == g["actions"]
+            assert nd.index == g["index"] and nd.player == g["player"]
+        if g["kind"] == "terminal":
+            assert nd.value == g["value"] and nd.last_to_act == g["last_to_act"]
+
+
+def test_three_street_tree_matches_oracle_and_golden(golden_dir):
+    n, tree = rs.build_game_tree(rs.three_street_options())
+    assert (n, tree.n_nodes) == (706, 1864)
+    _same_tree(tree, orc.OracleTree(orc.options_three_street()))
+    fx = json.load(open(os.path.join(golden_dir, "tree_three_street.json")))
+    assert [[nd.index, nd.player, nd.round_idx, nd.n_children] for nd in tree.nodes if nd.kind == L.NODE_ACTION] == fx["action_nodes"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_options_trees_match_oracle(seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nb = int(rng.integers(3, 6))
+    rounds = 6 - nb
+    bets = [sorted(rng.choice([0.25, 0.33, 0.5, 0.75, 1.0, 1.5, 2.0], size=int(rng.integers(1, 4)), replace=False).tolist())
+            for _ in range(rounds)]
+    raises = [sorted(rng.choice([2.0, 2.5, 3.0, 4.0], size=int(rng.integers(1, 3)), replace=False).tolist()) for _ in range(rounds)]
+    stacks = (int(rng.integers(20, 2000)), int(rng.integers(20, 2000)))
+    pot = int(rng.integers(2, 300))
+    n, tree = rs.build_game_tree(rs.Options(stacks, pot, nb, bets, raises))
+    otree = orc.OracleTree(orc.make_options(stacks, pot, nb, bets, raises))
+    _same_tree(tree, otree)
+    pn, pcount = npr.build_tree(stacks, pot, nb, bets, raises)
+    assert pcount == n and len(pn) == tree.n_nodes
+
+
+def test_tree_errors_instead_of_panics():
+    with pytest.raises(rs.RsError) as e:                      # state.rs:64 panic!("invalid board mask")
+        rs.build_game_tree(rs.Options(n_board_cards=2))
+    assert "invalid board mask" in str(e.value)
+    with pytest.raises(rs.RsError) as e:                      # bet_sizes[round_idx] index panic on the turn
+        rs.build_game_tree(rs.Options(n_board_cards=3, bet_sizes=((0.5,),), raise_sizes=((3.0,),)))
+    assert e.value.code == L.ERR_OOB
+
+
+def test_tree_from_nodes_roundtrip_and_validation():
+    _, tree = rs.build_game_tree(rs.default_flop())
+    t2 = rs.tree_from_nodes(tree.nodes)
+    assert (t2.n_nodes, t2.n_action_nodes) == (40, 14)
+    for a, b in zip(tree.nodes, t2.nodes):
+        assert bytes(a) == bytes(b)
+    bad = [L.TreeNode.from_buffer_copy(bytes(n)) for n in tree.nodes]
+    bad[1].children[0] = 99
+    with pytest.raises(rs.RsError):
+        rs.tree_from_nodes(bad)
+    bad = [L.TreeNode.from_buffer_copy(bytes(n)) for n in tree.nodes]
+    bad[1].index = 5                                           # duplicate ActionNode.index
+    with pytest.raises(rs.RsError):
+        rs.tree_from_nodes(bad)
+
+
+def test_discount_factor_matches_reference_rule():
+    for tc in (0, 99999, 100000, 100001, 250000, 1999999, 20000000, 2**40):
+        assert rs.discount_factor(tc).view(np.uint32) == orc.discount_factor(tc).view(np.uint32)
+        assert rs.discount_factor(tc).view(np.uint32) == npr.discount_factor(tc).view(np.uint32)
+
+
+def test_synth_mirror_is_deterministic():
+    a = rs.synth.fill_values(7, np.arange(1000), -10**6, 10**6)
+    b = rs.synth.fill_values(7, np.arange(1000), -10**6, 10**6)
+    assert (a == b).all() and a.min() >= -10**6 and a.max() <= 10**6 and len(set(a.tolist())) > 900
+    u = rs.synth.uniform_f32(3, 1000, -1.0, 1.0)
+    assert u.dtype == np.float32 and (u >= -1).all() and (u < 1).all()

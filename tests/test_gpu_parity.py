@@ -1,0 +1,455 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the committed golden
+fixtures.  Bar: BIT-EXACT for RS_I32 tables (regrets, strategy_sum, and every f32 strategy / utility the
+reference would compute); RS_F32 / RS_F16 extension modes are also compared bit for bit (same IEEE f32
+operations, no FMA contraction) with a documented fallback tolerance of 1e-5 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustsolver_amd as rs
+from oracle import orc
+from rustsolver_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).reshape(-1).view(np.uint32)
+
+
+def f32(b):
+    return np.array(b, dtype=np.uint32).view(np.float32)
+
+
+def assert_bits(a, b, what=""):
+    a, b = bits(a), bits(b)
+    bad = np.nonzero(a != b)[0]
+    assert bad.size == 0, "%s: %d/%d f32 values differ, first at %d: %08x vs %08x" % (what, bad.size, a.size, bad[0], a[bad[0]], b[bad[0]])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if rs.device_count() < 1:
+        pytest.fail("no HIP device visible: GPU parity tests need a real MI355X (there is no CPU fallback)")
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "known_answers.json")))
+
+
+@pytest.fixture(scope="module")
+def rand(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "random_cases.json")))
+
+
+def one_node_table(A, C, dtype=rs.I32, n_boards=1):
+    return rs.InfosetTable.create([(A, C, n_boards, 0, 0)], dtype)
+
+
+# ---- golden vectors through the ABI -------------------------------------------------------------------
+
+def test_known_answers_update_and_strategy(known):
+    # infoset.rs:83-102 + cfr.rs:413-464, scale 100, one info set per lane
+    for A in (2, 3):
+        kas = [k for k in known["update"] if len(k["regrets"]) == A]
+        n = len(kas)
+        t = one_node_table(A, n)
+        R = np.array([k["regrets"] for k in kas], dtype=np.int32).T
+        S = np.array([k["ssum"] for k in kas], dtype=np.int32).T
+        U = np.array([k["utils"] for k in kas], dtype=np.float32).T
+        reach = np.array([k["reach"] for k in kas], dtype=np.float32)
+        t.upload_node(0, R, S)
+        sig = t.regret_match_node(0)
+        for i, k in enumerate(kas):
+            assert bits(sig[:, i]).tolist() == k["strategy_bits"]
+            assert bits(t[0][i].get_strategy()).tolist() == k["strategy_bits"]      # Infoset::get_strategy
+            assert t[0][i].regrets.tolist() == k["regrets"]                          # get-infoset
+        util = t.update_node(0, U, reach, 100.0, rs.UPD_CLAMP_I64)
+        r, s = t.download_node(0)
+        for i, k in enumerate(kas):
+            assert bits(util[i])[0] == k["util_bits"]
+            assert r[:, i].tolist() == k["new_regrets"] and s[:, i].tolist() == k["new_ssum"]
+
+
+def test_known_answers_discount(known):
+    x = np.array(known["discount_in"], dtype=np.int32)
+    for da in known["discount"]:
+        t = one_node_table(1, len(x))
+        t.upload_node(0, x[None, :], x[None, :])
+        d = rs.discount_factor(da["tc"])
+        assert bits(d)[0] == da["d_bits"]
+        t.discount(d)                                        # cfr.rs:250-261
+        r, s = t.download_node(0)
+        assert r[0].tolist() == da["out"] and s[0].tolist() == da["out"]
+
+
+def test_golden_random_update_cases(rand):
+    for c in rand["update"]:
+        A, n = c["A"], c["n"]
+        R = np.array(c["regrets"], dtype=np.int32).reshape(A, n)
+        S = np.array(c["ssum"], dtype=np.int32).reshape(A, n)
+        U, reach = f32(c["utils_bits"]).reshape(A, n), f32(c["reach_bits"])
+        mode = (rs.UPD_CLAMP_I64 if c["mode"] == "clamp" else rs.UPD_WRAP_I32) | (rs.UPD_PRUNE if c["prune"] else 0)
+        t = one_node_table(A, n)
+        t.upload_node(0, R, S)
+        assert_bits(t.regret_match_node(0), f32(c["strategy_bits"]), "strategy")
+        util = t.update_node(0, U, reach, c["scale"], mode)
+        r, s = t.download_node(0)
+        tag = "A=%d %s prune=%s" % (A, c["mode"], c["prune"])
+        assert_bits(util, f32(c["util_bits"]), tag)
+        assert (r.reshape(-1) == np.array(c["new_regrets"], dtype=np.int32)).all(), tag
+        assert (s.reshape(-1) == np.array(c["new_ssum"], dtype=np.int32)).all(), tag
+
+
+def test_golden_random_discount_cases(rand):
+    for c in rand["discount"]:
+        x = np.array(c["x"], dtype=np.int32)
+        t = one_node_table(1, len(x))
+        t.upload_node(0, x[None, :], x[None, :])
+        t.discount(f32([c["d_bits"]])[0])
+        r, s = t.download_node(0)
+        assert r[0].tolist() == c["out"] and s[0].tolist() == c["out"]
+
+
+def test_golden_extension_cases(rand):
+    for c in rand["extension"]:
+        A, n = c["A"], c["n"]
+        t = one_node_table(A, n, rs.F16 if c["f16"] else rs.F32)
+        R, S = f32(c["regrets_bits"]).reshape(A, n), f32(c["ssum_bits"]).reshape(A, n)
+        t.upload_node(0, R, S)
+        r0, s0 = t.download_node(0)
+        assert_bits(r0, R, "upload roundtrip"), assert_bits(s0, S, "upload roundtrip")
+        mode = rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if c["rmplus"] else 0)
+        util = t.update_node(0, f32(c["utils_bits"]).reshape(A, n), f32(c["reach_bits"]), c["scale"], mode)
+        r, s = t.download_node(0)
+        assert_bits(util, f32(c["util_bits"]), "util")                           # tolerance if this ever fails: 1e-5 rel
+        assert_bits(r, f32(c["new_regrets_bits"]), "regrets")
+        assert_bits(s, f32(c["new_ssum_bits"]), "ssum")
+
+
+# ---- per-node kernels vs the oracle on seeded inputs ------------------------------------------------------
+
+@pytest.mark.parametrize("A", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("C,B", [(1, 1), (5, 3), (169, 1), (1000, 2), (1081, 1)])
+def test_update_node_vs_oracle(A, C, B):
+    rng = np.random.Generator(np.random.PCG64(1000 * A + C + B))
+    n = C * B
+    R = rng.integers(-10**6, 10**6, size=(A, n)).astype(np.int32)
+    S = rng.integers(0, 10**6, size=(A, n)).astype(np.int32)
+    sat = rng.random(n) < 0.02                                                    # >= 1% saturating lanes
+    R[:, sat] = rng.integers(2_100_000_000, 2_147_483_647, size=(A, int(sat.sum()))) * rng.choice([-1, 1], size=(A, int(sat.sum())))
+    S[:, sat] = 2_147_483_000
+    U = rng.uniform(-1035, 1035, size=(A, n)).astype(np.float32)
+    reach = rng.uniform(0, 1, size=n).astype(np.float32)
+    for mode_o, mode_g, scale in ((orc.UPD_CLAMP_I64, rs.UPD_CLAMP_I64, 100.0), (orc.UPD_WRAP_I32, rs.UPD_WRAP_I32, 10000.0)):
+        for prune in (False, True):
+            t = one_node_table(A, C, rs.I32, B)
+            t.upload_node(0, R, S)
+            util = t.update_node(0, U, reach, scale, mode_g | (rs.UPD_PRUNE if prune else 0))
+            r, s = t.download_node(0)
+            want_u = np.zeros(n, dtype=np.float32)
+            for k in range(n):
+                want_u[k], rk, sk = orc.update_infoset(R[:, k], S[:, k], U[:, k], reach[k], scale, mode_o, prune)
+                assert (r[:, k] == rk).all() and (s[:, k] == sk).all(), (A, C, B, mode_o, prune, k)
+            assert_bits(util, want_u, "util")
+            # read-only kernels on the updated table
+            nu = t.node_util(0, U)
+            cr = t.child_reach(0, reach)
+            fs = t.final_strategy_node(0)
+            for k in range(0, n, max(1, n // 97)):
+                assert bits(nu[k])[0] == bits(orc.node_util(r[:, k], U[:, k]))[0]
+                sig = orc.get_strategy(r[:, k])
+                assert_bits(cr[:, k], (sig * reach[k]).astype(np.float32), "child reach")       # cfr.rs:585
+                assert_bits(fs[:, k], orc.get_final_strategy(s[:, k]), "final strategy")        # infoset.rs:104-123
+            t.destroy()
+
+
+def test_rmplus_i32_vs_oracle():
+    rng = np.random.Generator(np.random.PCG64(5))
+    A, n = 3, 300
+    R = rng.integers(-10**5, 10**5, size=(A, n)).astype(np.int32)
+    S = rng.integers(0, 10**6, size=(A, n)).astype(np.int32)
+    U = rng.uniform(-100, 100, size=(A, n)).astype(np.float32)
+    reach = rng.uniform(0, 1, size=n).astype(np.float32)
+    t = one_node_table(A, n)
+    t.upload_node(0, R, S)
+    util = t.update_node(0, U, reach, 100.0, rs.UPD_CLAMP_I64 | rs.UPD_RMPLUS)
+    r, s = t.download_node(0)
+    assert (r >= 0).all()
+    for k in range(n):
+        wu, rk, sk = orc.update_infoset_rmplus(R[:, k], S[:, k], U[:, k], reach[k], 100.0)
+        assert bits(util[k])[0] == bits(wu)[0] and (r[:, k] == rk).all() and (s[:, k] == sk).all()
+
+
+def test_null_reach_means_one_and_per_board_copies():
+    rng = np.random.Generator(np.random.PCG64(6))
+    A, C, B = 3, 37, 4
+    t = one_node_table(A, C, rs.I32, B)
+    for b in range(B):
+        t.upload(0, b, rng.integers(-1000, 1000, size=(A, C)).astype(np.int32), rng.integers(0, 1000, size=(A, C)).astype(np.int32))
+    R, S = t.download_node(0)
+    for b in range(B):
+        r, s = t.download(0, b)
+        assert (r == R[:, b * C:(b + 1) * C]).all() and (s == S[:, b * C:(b + 1) * C]).all()
+    U = rng.uniform(-35, 35, size=(A, B * C)).astype(np.float32)
+    util = t.update_node(0, U, None, 100.0, rs.UPD_CLAMP_I64)
+    r, s = t.download_node(0)
+    for k in range(B * C):
+        wu, rk, sk = orc.update_infoset(R[:, k], S[:, k], U[:, k], 1.0, 100.0, orc.UPD_CLAMP_I64)
+        assert bits(util[k])[0] == bits(wu)[0] and (r[:, k] == rk).all() and (s[:, k] == sk).all()
+    inf = t[0][2, 5]
+    assert (inf.regrets == r[:, 2 * C + 5]).all() and (inf.strategy_sum == s[:, 2 * C + 5]).all()
+    inf.set([1, 2, 3], [4, 5, 6])
+    assert t[0][2, 5].regrets.tolist() == [1, 2, 3] and t[0][2, 5].strategy_sum.tolist() == [4, 5, 6]
+    assert_bits(t[0][2, 5].get_final_strategy(), orc.get_final_strategy([4, 5, 6]))
+
+
+def test_zero_init_and_fill_mirror():
+    t = one_node_table(3, 130, rs.I32, 2)
+    r, s = t.download_node(0)
+    assert not r.any() and not s.any()                        # Infoset::init (infoset.rs:76-81)
+    assert_bits(t.regret_match_node(0), np.full((3, 260), np.float32(1.0) / np.float32(3.0)))
+    t.fill_random(77, (-10**6, 10**6), (0, 10**6))
+    r, s = t.download_node(0)
+    assert (r == rs.synth.table_node_values(t, 0, 77, -10**6, 10**6)).all()
+    assert (s == rs.synth.table_node_values(t, 0, 77, 0, 10**6, ssum=True)).all()
+    buf = t.lane_buffer(0, 1)
+    L.check(L.load().rs_fill_uniform_f32(t._h, buf.ptr, t.pitch(0), 5, -1.0, 1.0))
+    assert_bits(buf.download(np.float32, t.pitch(0)), rs.synth.uniform_f32(5, t.pitch(0), -1.0, 1.0))
+
+
+def test_errors_instead_of_panics():
+    t = one_node_table(3, 10)
+    with pytest.raises(IndexError):
+        t[1]
+    with pytest.raises(IndexError):
+        t[0][10].regrets
+    with pytest.raises(rs.RsError) as e:
+        L.check(L.load().rs_get_infoset(t._h, 0, 0, 10, None, None))
+    assert e.value.code == L.ERR_OOB
+    with pytest.raises(rs.RsError) as e:
+        t.update_node(0, np.zeros((3, 10), np.float32), None, 100.0, 7)
+    assert e.value.code == L.ERR_INVALID
+    tf = one_node_table(3, 10, rs.F32)
+    with pytest.raises(rs.RsError) as e:
+        tf.update_node(0, np.zeros((3, 10), np.float32), None, 100.0, rs.UPD_PRUNE)
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(rs.RsError):
+        rs.InfosetTable.create([(9, 10, 1, 0, 0)])           # more than RS_MAX_ACTIONS
+
+
+# ---- rs_iterate / rs_train vs the oracle's per-lane recursion ---------------------------------------------------
+
+def setup_pair(options_rs, options_orc, n_boards, C, seed, dtype=rs.I32, odtype=orc.T_I32, regret_scale=10**6):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_actions, tree = rs.build_game_tree(options_rs)
+    table = rs.create_infosets(n_actions, tree, [C], n_boards, dtype)
+    otree = orc.OracleTree(options_orc)
+    otab = orc.OracleTable(otree, n_boards, C, odtype)
+    for nd in tree.action_nodes():
+        a, lanes = nd.n_children, table.lanes(nd.index)
+        if dtype == rs.I32:
+            R = rng.integers(-regret_scale, regret_scale, size=(a, lanes)).astype(np.int32)
+            S = rng.integers(0, regret_scale, size=(a, lanes)).astype(np.int32)
+            if regret_scale >= 10**6:                                        # prune + saturation lanes
+                R[0, ::11] = -10_000_001
+                R[a - 1, ::13] = 2_147_000_000
+        else:
+            R = rng.uniform(-1000, 1000, size=(a, lanes)).astype(np.float32)
+            S = rng.uniform(0, 1000, size=(a, lanes)).astype(np.float32)
+            if dtype == rs.F16:
+                R, S = R.astype(np.float16).astype(np.float32), S.astype(np.float16).astype(np.float32)
+        table.upload_node(nd.index, R, S)
+        otab.set_node(nd.index, R, S)
+    # one sign vector per round (lanes of that round), shared by its showdown / all-in terminals
+    signs, leaves_g, leaves_o = {}, {}, {}
+    for i, nd in enumerate(tree.nodes):
+        if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+            parent = tree.nodes[nd.parent]
+            r = parent.round_idx
+            if r not in signs:
+                sv = rng.integers(-1, 2, size=n_boards[r] * C).astype(np.float32)
+                signs[r] = (sv, table.lane_buffer(parent.index, 1, sv))
+            leaves_g[i] = (rs.LEAF_SIGN, signs[r][1])
+            leaves_o[i] = (orc.LEAF_SIGN, signs[r][0])
+    return tree, table, otree, otab, leaves_g, leaves_o
+
+
+def compare_tables(tree, table, otab, exact=True):
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        if r.dtype == np.int32:
+            assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+        else:
+            assert_bits(r, ro, "regrets node %d" % nd.index)
+            assert_bits(s, so, "ssum node %d" % nd.index)
+
+
+@pytest.mark.parametrize("C,B", [(5, 1), (250, 3), (1081, 1), (1000, 2)])
+@pytest.mark.parametrize("mode", ["clamp", "wrap", "clamp+prune"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_iterate_river_tree_vs_oracle(C, B, mode, graph):
+    if graph and (C, B) not in ((250, 3), (1081, 1)):
+        pytest.skip("graph replay covered on two shapes")
+    tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [B], C, C * 7 + B)
+    prune = "prune" in mode
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if mode == "wrap" else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), chance_mode=rs.CHANCE_PASS,
+                         use_graph=graph)
+    osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, prune=prune, chance_mode=orc.CHANCE_PASS)
+    for it in range(3):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player, threads=4)
+            assert_bits(got, want, "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+
+
+@pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([1, 1, 1], "enum"), ([2, 2, 2], "pass"), ([1, 3, 3], "enum")])
+def test_iterate_three_street_tree_vs_oracle(boards, chance):
+    C = 9
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), boards, C, 42)
+    cm_g, cm_o = (rs.CHANCE_ENUM, orc.CHANCE_ENUM) if chance == "enum" else (rs.CHANCE_PASS, orc.CHANCE_PASS)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=cm_g)
+    osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=cm_o)
+    for it in range(2):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player, threads=4)
+            assert_bits(got, want, "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32+rmplus", "i32+rmplus"])
+def test_iterate_extension_dtypes_vs_oracle(dtype):
+    rmplus = "rmplus" in dtype
+    dt_g, dt_o = {"f32": (rs.F32, orc.T_F32), "f16": (rs.F16, orc.T_F16), "i32": (rs.I32, orc.T_I32)}[dtype.split("+")[0]]
+    tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [2], 100, 9, dt_g, dt_o, 10**5)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=1.0 if dt_g != rs.I32 else 100.0,
+                         mode=rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if rmplus else 0), chance_mode=rs.CHANCE_PASS)
+    osol = orc.OracleSolver(otree, otab, lo, scale=1.0 if dt_g != rs.I32 else 100.0, mode=orc.UPD_CLAMP_I64, rmplus=rmplus,
+                            chance_mode=orc.CHANCE_PASS)
+    for it in range(3):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util")
+    compare_tables(tree, table, otab)
+
+
+def test_train_with_discount_schedule_vs_oracle():
+    # cfr.rs:188-265 with a short interval so that several discount ticks happen
+    tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [1], 64, 3)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, use_graph=True)
+    osol = orc.OracleSolver(otree, otab, lo, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+    tr.train(11, discount_interval=3, discount_cap=9)
+    osol.train(11, discount_interval=3, discount_cap=9)
+    compare_tables(tree, table, otab)
+    fs = table.final_strategy_all()
+    for nd in tree.action_nodes():
+        _, so = otab.get_node(nd.index)
+        for k in range(0, so.shape[1], 7):
+            assert_bits(fs[nd.index][:, k], orc.get_final_strategy(so[:, k]), "final strategy")
+
+
+def test_leaf_util_buffers_per_traverser():
+    """RS_LEAF_UTIL: utilities given verbatim, a different buffer per traverser"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    C, B = 33, 2
+    tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [B], C, 12)
+    root = tree.nodes[tree.nodes[0].children[0]]
+    lg0, lg1, lo0, lo1 = {}, {}, {}, {}
+    for i in lg:
+        u0 = rng.uniform(-500, 500, size=B * C).astype(np.float32)
+        u1 = rng.uniform(-500, 500, size=B * C).astype(np.float32)
+        lg0[i] = (rs.LEAF_UTIL, table.lane_buffer(root.index, 1, u0))
+        lg1[i] = (rs.LEAF_UTIL, table.lane_buffer(root.index, 1, u1))
+        lo0[i], lo1[i] = (orc.LEAF_UTIL, u0), (orc.LEAF_UTIL, u1)
+    tr = rs.MCCFRTrainer(tree, table, lg0, leaves_p1=lg1, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS)
+    os0 = orc.OracleSolver(otree, otab, lo0, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+    os1 = orc.OracleSolver(otree, otab, lo1, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+    for it in range(2):
+        assert_bits(tr.iterate(0, True), os0.iterate(0), "p0")
+        assert_bits(tr.iterate(1, True), os1.iterate(1), "p1")
+    compare_tables(tree, table, otab)
+
+
+def test_solver_rejects_mismatched_inputs():
+    n, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n, tree, [(8, 9)], [1])          # different cluster counts per player
+    sign = table.lane_buffer(0, 1)
+    leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    with pytest.raises(rs.RsError) as e:
+        rs.MCCFRTrainer(tree, table, leaves)
+    assert e.value.code == L.ERR_UNSUPPORTED
+    table2 = rs.create_infosets(n, tree, [8], [1])
+    with pytest.raises(rs.RsError) as e:
+        rs.MCCFRTrainer(tree, table2, {})                        # showdown terminals without a leaf buffer
+    assert e.value.code == L.ERR_INVALID
+
+
+# ---- full BASELINE size: size-independent property (lanes are independent => any sampled board must match) ----------
+
+def test_full_size_config2_sampled_boards_match_oracle():
+    B, C, seed = 9216, 1000, 1235
+    n, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n, tree, [C], [B])
+    table.fill_random(seed, (-10**6, 10**6), (0, 10**6))
+    root = tree.nodes[tree.nodes[0].children[0]]
+    sign = table.lane_buffer(root.index, 1)
+    L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), seed + 17, -1.0, 1.0))
+    leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    tr = rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS)
+    sample = [0, 4607, 9215]
+    sign_host = rs.synth.uniform_f32(seed + 17, table.pitch(root.index), -1.0, 1.0)
+    otree = orc.OracleTree(orc.options_default_river())
+    otab = orc.OracleTable(otree, [len(sample)], C)
+    for nd in tree.action_nodes():
+        R = rs.synth.table_node_values(table, nd.index, seed, -10**6, 10**6)
+        S = rs.synth.table_node_values(table, nd.index, seed, 0, 10**6, ssum=True)
+        cols = np.concatenate([np.arange(b * C, (b + 1) * C) for b in sample])
+        otab.set_node(nd.index, R[:, cols].astype(np.int32), S[:, cols].astype(np.int32))
+    sgn = np.concatenate([sign_host[b * C:(b + 1) * C] for b in sample])
+    lo = {d["id"]: (orc.LEAF_SIGN, sgn) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    osol = orc.OracleSolver(otree, otab, lo, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+    for it in range(2):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player, threads=4)
+            assert_bits(np.concatenate([got[b * C:(b + 1) * C] for b in sample]), want, "root util")
+    for nd in tree.action_nodes():
+        ro, so = otab.get_node(nd.index)
+        for j, b in enumerate(sample):
+            r, s = table.download(nd.index, b)
+            assert (r == ro[:, j * C:(j + 1) * C]).all() and (s == so[:, j * C:(j + 1) * C]).all()
+    # discount at full size: sampled boards again
+    d = rs.discount_factor(300001)
+    table.discount(d)
+    otab.discount(d)
+    for nd in tree.action_nodes():
+        ro, so = otab.get_node(nd.index)
+        r, s = table.download(nd.index, sample[1])
+        assert (r == ro[:, C:2 * C]).all() and (s == so[:, C:2 * C]).all()
+
+
+# ---- multi-GPU primitive on one rank ------------------------------------------------------------------------------------
+
+def test_allreduce_replicated_single_rank_is_identity():
+    import ctypes as C
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [1, 2, 2], 6, 8)
+    lib = L.load()
+    ident = (C.c_char * L.COMM_ID_BYTES)()
+    L.check(lib.rs_comm_unique_id(ident))
+    comm = C.c_void_p()
+    L.check(lib.rs_comm_create(table._h, ident, 0, 1, C.byref(comm)))
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM)
+    osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=orc.CHANCE_ENUM)
+    L.check(lib.rs_replicated_begin(table._h, 0b001))
+    tr.iterate(0), tr.iterate(1)
+    L.check(lib.rs_allreduce_replicated(table._h, comm, 0b001))
+    table.sync()
+    osol.iterate(0), osol.iterate(1)
+    compare_tables(tree, table, otab)
+    lib.rs_comm_destroy(comm)
