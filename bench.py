@@ -104,6 +104,21 @@ def cpu_baseline(n_clusters, mode, seconds):
     }
 
 
+def pmc_traffic(a):
+    """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
+    this exact workload; PMC counters cannot be read from inside the process."""
+    import glob
+    if (a.boards, a.clusters, a.mode) != (9216, 1000, "clamp"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,9 +204,10 @@ def main():
             "kernel": "rs::k_update (river regret/strategy_sum update, all action counts)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(a),
             "launches": upd["launches"], "avg_launch_ms": upd["ms"] / max(1, upd["launches"]),
             "algo_bytes_per_launch": upd["algo_bytes"] / max(1, upd["launches"]),
+            "traffic_source": "profiles/r*_roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
             "note": "achieved = algorithmic bytes (DESIGN.md) / HIP-event duration of every update launch in a second, "
                     "event-bracketed pass over the same K steps (ms_per_step there: %.3f)" % (elapsed_prof / a.steps * 1e3),
         },

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 output (gpurun_out/prof/{trace,pmc_fetch,pmc_write}) into the committed summaries.
+
+    python profiles/summarize_rocprof.py gpurun_out/prof profiles/r01
+
+Writes <prefix>_kernel_stats.csv (rocprofv3 --stats as-is), <prefix>_summary.md and
+<prefix>_roofline_traffic.json (read back by bench.py for `roofline.traffic`).
+
+Only dispatches with >= 1M work-items are summarised as "full-size": bench.py also times a
+single-board trainer whose ~5 us launches would otherwise dominate the --stats averages.
+PMC handling follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate passes,
+are in KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is
+doubled before being compared with byte counts.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+FULL = 1 << 20
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+stats = one("trace/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, prefix + "_kernel_stats.csv")
+
+lines = ["# rocprofv3 summary (%s)" % os.path.basename(prefix), ""]
+bench = one("trace_bench.json")
+if bench:
+    try:
+        b = json.loads(open(bench).read().strip().splitlines()[-1])
+        lines += ["bench.py under rocprofv3 --kernel-trace --stats: value = %.4g %s, ms_per_step = %.3f, "
+                  "roofline.achieved = %.1f GB/s (HIP events, avg update launch %.1f us)"
+                  % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["avg_launch_ms"] * 1e3), ""]
+    except Exception as e:  # noqa
+        lines += ["(bench json unreadable: %s)" % e, ""]
+
+trace = one("trace/*/*_kernel_trace.csv")
+per_kernel = collections.defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace)):
+        g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::")):
+            per_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    lines += ["## full-size dispatches (>= 1M work-items), kernel trace", "",
+              "| kernel | dispatches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
+    for k, v in sorted(per_kernel.items(), key=lambda kv: -sum(kv[1])):
+        lines.append("| `%s` | %d | %.1f | %.1f | %.1f | %.2f |" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, sum(v) / 1e6))
+    upd = [d for k, v in per_kernel.items() if "k_update" in k for d in v]
+    if upd:
+        lines += ["", "all `k_update` full-size dispatches: %d, average %.1f us" % (len(upd), sum(upd) / len(upd) / 1e3), ""]
+
+traffic = {}
+for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = one(name + "/*/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and "rs::" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    traffic[counter] = agg
+if traffic:
+    lines += ["## HBM traffic from PMC (separate passes; KiB; FETCH_SIZE doubled per the gfx950 correction)", "",
+              "| kernel | dispatches | FETCH_SIZE avg KiB (raw) | read bytes (x2 x1024) | WRITE_SIZE avg KiB | write bytes | total bytes / dispatch |",
+              "|---|---|---|---|---|---|---|"]
+    tot_upd, n_upd = 0.0, 0
+    for k in sorted(set(traffic.get("FETCH_SIZE", {})) | set(traffic.get("WRITE_SIZE", {}))):
+        fv, wv = traffic.get("FETCH_SIZE", {}).get(k, []), traffic.get("WRITE_SIZE", {}).get(k, [])
+        fa = sum(fv) / len(fv) if fv else 0.0
+        wa = sum(wv) / len(wv) if wv else 0.0
+        total = fa * 2 * 1024 + wa * 1024
+        lines.append("| `%s` | %d | %.0f | %.4g | %.0f | %.4g | %.4g |" % (k, max(len(fv), len(wv)), fa, fa * 2048, wa, wa * 1024, total))
+        if "k_update" in k:
+            tot_upd += total * max(len(fv), len(wv))
+            n_upd += max(len(fv), len(wv))
+    if n_upd:
+        per_launch = tot_upd / n_upd
+        lines += ["", "`k_update`: PMC HBM bytes per dispatch (dispatch-weighted) = %.4g" % per_launch]
+        json.dump({"kernel": "rs::k_update", "hbm_bytes_per_launch": per_launch, "dispatches": n_upd,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB x1024",
+                   "workload": "bench.py default (9216 boards x 1000 clusters, clamp)"},
+                  open(prefix + "_roofline_traffic.json", "w"), indent=1)
+open(prefix + "_summary.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
