@@ -37,12 +37,14 @@ def parse():
     ap.add_argument("--mode", choices=["clamp", "wrap"], default="clamp",
                     help="clamp: cfr.rs:413-464 scale 100 (the live mccfr update); wrap: cfr.rs:612-621 scale 10000")
     ap.add_argument("--graph", type=int, default=0, help="replay each traverser sweep as one hipGraph")
+    ap.add_argument("--fuse", type=int, default=1,
+                    help="1: one tree-specialised (hipRTC) kernel per traverser sweep; 0: level-by-level node kernels")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed):
+def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1):
     import numpy as np
     n_actions, tree = rs.build_game_tree(rs.default_flop())
     table = rs.create_infosets(n_actions, tree, [n_clusters], [n_boards], rs.I32, device)
@@ -55,7 +57,8 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed):
     leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes)
               if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
     scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
-    trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=rs.CHANCE_PASS, use_graph=bool(graph))
+    trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=rs.CHANCE_PASS, use_graph=bool(graph),
+                              fuse_subtrees=int(fuse))
     table.sync()
     return trainer
 
@@ -104,13 +107,13 @@ def cpu_baseline(n_clusters, mode, seconds):
     }
 
 
-def pmc_traffic(a):
+def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
     import glob
     if (a.boards, a.clusters, a.mode) != (9216, 1000, "clamp"):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_traffic_%s.json" % kernel)))
     if not files:
         return None
     try:
@@ -146,7 +149,7 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    trainer = make_trainer(rs, a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank)
+    trainer = make_trainer(rs, a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse)
     table = trainer.infosets
 
     # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides -------------
@@ -178,11 +181,48 @@ def main():
             dist.destroy_process_group()
         return
 
-    upd = prof["update"]
+    dom_name = "tree" if prof["tree"]["launches"] else "update"
+    upd = prof[dom_name]
     achieved = upd["algo_bytes"] / (upd["ms"] * 1e-3) / 1e9 if upd["ms"] > 0 else 0.0
     kernels = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
                    "algo_GBps": (v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                for k, v in prof.items() if v["launches"]}
+
+    # ---- the per-node river regret-update kernel on its own (20A+8 bytes per lane, all inputs
+    # buffers): rs_update_node on the root node (A = 3), HIP-event timed ---------------------------------------
+    upd_node = None
+    try:
+        import numpy as np  # noqa: F401
+        from rustsolver_amd import _lib as L
+        lib = L.load()
+        ubuf = table.lane_buffer(0, 3)
+        rbuf = table.lane_buffer(0, 1)
+        obuf = table.lane_buffer(0, 1)
+        L.check(lib.rs_fill_uniform_f32(table._h, ubuf.ptr, 3 * table.pitch(0), 5, -1035.0, 1035.0))
+        L.check(lib.rs_fill_uniform_f32(table._h, rbuf.ptr, table.pitch(0), 6, 0.0, 1.0))
+        mode_flag = rs.UPD_CLAMP_I64 if a.mode == "clamp" else rs.UPD_WRAP_I32
+        scale = 100.0 if a.mode == "clamp" else 10000.0
+        for _ in range(3):
+            L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
+        table.profile_reset()
+        table.profile_enable(True)
+        for _ in range(20):
+            L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
+        pu = table.profile_read()["update"]
+        table.profile_enable(False)
+        gbs = pu["algo_bytes"] / (pu["ms"] * 1e-3) / 1e9
+        upd_node = {"kernel": "rs::k_update<3> via rs_update_node (20A+8 = 68 B per lane, all inputs buffers)",
+                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "launches": pu["launches"], "avg_launch_ms": pu["ms"] / max(1, pu["launches"]),
+                    "algo_bytes_per_launch": pu["algo_bytes"] / max(1, pu["launches"])}
+        for b in (ubuf, rbuf, obuf):
+            b.free()
+    except Exception as e:
+        upd_node = {"error": str(e)}
+
+    dom_kernel = ("rs_tree_kernel (tree-specialised, hipRTC: regret matching, reach, utilities and the regret / strategy_sum "
+                  "update of all 14 river nodes in one launch per traverser)") if dom_name == "tree" else \
+                 "rs::k_update (river regret/strategy_sum update, all action counts)"
     out = {
         "metric": "cfr_iterations_per_sec",
         "value": a.boards * n_gpus * a.steps / elapsed,
@@ -198,26 +238,28 @@ def main():
             "n_boards_per_gpu": a.boards, "n_clusters": a.clusters, "lanes_per_gpu": a.boards * a.clusters,
             "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
             "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
+            "fused_subtrees": int(a.fuse),
             "parallelism": "boards sharded x%d, no collective (nothing replicated in a river-only tree)" % n_gpus,
         },
         "roofline": {
-            "kernel": "rs::k_update (river regret/strategy_sum update, all action counts)",
+            "kernel": dom_kernel,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(a),
+            "traffic": pmc_traffic(a, dom_name),
+            "traffic_source": "profiles/r*_roofline_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % dom_name,
             "launches": upd["launches"], "avg_launch_ms": upd["ms"] / max(1, upd["launches"]),
             "algo_bytes_per_launch": upd["algo_bytes"] / max(1, upd["launches"]),
-            "traffic_source": "profiles/r*_roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-            "note": "achieved = algorithmic bytes (DESIGN.md) / HIP-event duration of every update launch in a second, "
+            "note": "achieved = algorithmic bytes (DESIGN.md) / HIP-event duration of every launch of this kernel in a second, "
                     "event-bracketed pass over the same K steps (ms_per_step there: %.3f)" % (elapsed_prof / a.steps * 1e3),
         },
+        "roofline_update_node": upd_node,
         "kernels": kernels,
         "lane_updates_per_sec": a.boards * n_gpus * a.clusters * 14 * a.steps / elapsed,
     }
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:
-        small = make_trainer(rs, 1, a.clusters, a.mode, 1, device, 99)
+        small = make_trainer(rs, 1, a.clusters, a.mode, 1, device, 99, a.fuse)
         run_steps(small, 20)
         small.infosets.sync()
         t0 = time.perf_counter()

@@ -219,6 +219,10 @@ typedef struct rs_solver_params {
     int32_t mode;           /* RS_UPD_* */
     int32_t chance_mode;    /* RS_CHANCE_* */
     int32_t use_graph;      /* 1: replay each traverser's plan as one hipGraph launch */
+    int32_t fuse_subtrees;  /* 1: every chance-free subtree is walked by ONE tree-specialised straight-line kernel per
+                               traverser, generated from the tree and compiled at create time with hipRTC: utilities and
+                               reaches stay in registers, only table rows and leaf rows touch HBM.  0: level-by-level node
+                               kernels.  Results are bit-identical either way. */
 } rs_solver_params;
 
 /* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
@@ -233,11 +237,14 @@ int rs_iterate(rs_solver *solver, int traverser, float *d_root_util);
  * the discount check `t > threshold` (d = p/(p+1), p = t/interval) until t > discount_cap. */
 int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap);
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
+int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
+/* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
+int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int *n_kernels);
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
 enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,
-       RS_K_COUNT = 6 };
+       RS_K_TREE = 6, RS_K_COUNT = 7 };
 typedef struct rs_profile {
     uint64_t launches[RS_K_COUNT];
     double ms[RS_K_COUNT];              /* sum of HIP-event durations on the table's stream */

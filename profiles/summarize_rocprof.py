@@ -49,7 +49,7 @@ per_kernel = collections.defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace)):
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::")):
+        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_kernel")):
             per_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     lines += ["## full-size dispatches (>= 1M work-items), kernel trace", "",
               "| kernel | dispatches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
@@ -66,29 +66,31 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and "rs::" in r["Kernel_Name"]:
+        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and ("rs::" in r["Kernel_Name"] or "rs_tree_kernel" in r["Kernel_Name"]):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     traffic[counter] = agg
 if traffic:
     lines += ["## HBM traffic from PMC (separate passes; KiB; FETCH_SIZE doubled per the gfx950 correction)", "",
               "| kernel | dispatches | FETCH_SIZE avg KiB (raw) | read bytes (x2 x1024) | WRITE_SIZE avg KiB | write bytes | total bytes / dispatch |",
               "|---|---|---|---|---|---|---|"]
-    tot_upd, n_upd = 0.0, 0
+    fam = {"update": [0.0, 0], "tree": [0.0, 0]}
     for k in sorted(set(traffic.get("FETCH_SIZE", {})) | set(traffic.get("WRITE_SIZE", {}))):
         fv, wv = traffic.get("FETCH_SIZE", {}).get(k, []), traffic.get("WRITE_SIZE", {}).get(k, [])
         fa = sum(fv) / len(fv) if fv else 0.0
         wa = sum(wv) / len(wv) if wv else 0.0
         total = fa * 2 * 1024 + wa * 1024
         lines.append("| `%s` | %d | %.0f | %.4g | %.0f | %.4g | %.4g |" % (k, max(len(fv), len(wv)), fa, fa * 2048, wa, wa * 1024, total))
-        if "k_update" in k:
-            tot_upd += total * max(len(fv), len(wv))
-            n_upd += max(len(fv), len(wv))
-    if n_upd:
-        per_launch = tot_upd / n_upd
-        lines += ["", "`k_update`: PMC HBM bytes per dispatch (dispatch-weighted) = %.4g" % per_launch]
-        json.dump({"kernel": "rs::k_update", "hbm_bytes_per_launch": per_launch, "dispatches": n_upd,
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB x1024",
-                   "workload": "bench.py default (9216 boards x 1000 clusters, clamp)"},
-                  open(prefix + "_roofline_traffic.json", "w"), indent=1)
+        for name in fam:
+            if ("k_" + name in k) or (name == "tree" and "rs_tree_kernel" in k):
+                fam[name][0] += total * max(len(fv), len(wv))
+                fam[name][1] += max(len(fv), len(wv))
+    for name, (tot, n) in fam.items():
+        if n:
+            per_launch = tot / n
+            lines += ["", "`k_%s`: PMC HBM bytes per dispatch (dispatch-weighted) = %.4g" % (name, per_launch)]
+            json.dump({"kernel": "rs::k_" + name, "hbm_bytes_per_launch": per_launch, "dispatches": n,
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB x1024",
+                       "workload": "bench.py default (9216 boards x 1000 clusters, clamp)"},
+                      open(prefix + "_roofline_traffic_%s.json" % name, "w"), indent=1)
 open(prefix + "_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

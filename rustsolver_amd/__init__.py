@@ -4,16 +4,22 @@ The product is the HIP shared library (csrc/, built by `python -m rustsolver_amd
 C ABI (include/rustsolver_amd.h).  This package is the ctypes host mirror used by tests and bench.py.
 Importing it fails loudly if the library has not been built; there is no CPU fallback.
 """
-from . import _lib
+import sys as _sys
+
+# `python -m rustsolver_amd.build` must be able to run while the .so is missing or stale
+_BUILDING = "rustsolver_amd.build" in getattr(_sys, "orig_argv", [])
+
+from . import _lib  # noqa: E402
 from ._lib import (ACT_BET, ACT_CALL, ACT_CHECK, ACT_FOLD, ACT_RAISE, CHANCE_ENUM, CHANCE_PASS, F16, F32, I32,
                    LEAF_SIGN, LEAF_UNCONTESTED, LEAF_UTIL, NODE_ACTION, NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE,
                    NODE_TERMINAL, TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED, UPD_CLAMP_I64, UPD_PRUNE, UPD_RMPLUS,
                    UPD_WRAP_I32, RsError)
 
-_lib.load()  # ImportError if librustsolver_amd.so is missing
+if not _BUILDING:
+    _lib.load()  # ImportError if librustsolver_amd.so is missing
 
 from .solver import (DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
-                     build_game_tree, create_infosets, default_flop, device_count, discount_factor,
+                     build_game_tree, create_infosets, default_flop, device_count, discount_factor, jit_check_tree,
                      three_street_options, tree_from_nodes)
 from . import synth  # noqa: E402
 

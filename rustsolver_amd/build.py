@@ -13,11 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librustsolver_amd.so")
-SOURCES = ["rs_kernels.hip", "rs_table.cpp", "rs_tree.cpp", "rs_solver.cpp", "rs_comm.cpp"]
-HEADERS = [os.path.join(CSRC, "rs_internal.hpp"), os.path.join(ROOT, "include", "rustsolver_amd.h")]
+SOURCES = ["rs_kernels.hip", "rs_table.cpp", "rs_tree.cpp", "rs_solver.cpp", "rs_comm.cpp", "rs_jit.cpp"]
+HEADERS = [os.path.join(CSRC, "rs_internal.hpp"), os.path.join(CSRC, "rs_device.hpp"), os.path.join(ROOT, "include", "rustsolver_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + os.path.join(HERE, "_build")]
 
 
 def _stale(target, deps):
@@ -27,14 +27,28 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _embed_device_source():
+    """rs_device.hpp as a C++ raw string literal (rs_device_src.inc) for the hipRTC kernels of rs_jit.cpp"""
+    src = os.path.join(CSRC, "rs_device.hpp")
+    inc = os.path.join(HERE, "_build", "rs_device_src.inc")
+    text = open(src).read().replace("#pragma once\n", "")
+    assert ')RSDEV"' not in text
+    body = 'R"RSDEV(' + text + ')RSDEV"\n'
+    if not os.path.exists(inc) or open(inc).read() != body:
+        with open(inc, "w") as f:
+            f.write(body)
+    return inc
+
+
 def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    _embed_device_source()
     objs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(HERE, "_build", src + ".o")
         objs.append(obj)
-        if force or _stale(obj, [sp] + HEADERS):
+        if force or _stale(obj, [sp] + HEADERS + [os.path.join(HERE, "_build", "rs_device_src.inc")]):
             cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

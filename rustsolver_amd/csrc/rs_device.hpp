@@ -1,0 +1,221 @@
+// rs_device.hpp -- the hand-written per-lane device code shared by the static kernels (rs_kernels.hip)
+// and the tree-specialised kernels compiled at run time with hipRTC (rs_jit.cpp).  Self-contained on
+// purpose: no includes, only builtin types, so the same text compiles under hipcc and hipRTC.
+//
+// Numerics (bit-exact contract with the Rust reference in RS_I32 mode): no FMA
+// contraction, sequential f32 sums in action order from +0.0, RNE i32->f32, correctly rounded
+// division, saturating NaN->0 float->int casts, i64-add-then-clamp (cfr.rs:445-461) or wrapping
+// i32 add (cfr.rs:616-619).
+#pragma once
+#pragma clang fp contract(off)
+
+namespace rs {
+
+#ifndef RS_DEVICE_CONSTS
+#define RS_DEVICE_CONSTS
+constexpr int kVecD = 4;                       // lanes per thread
+constexpr int kPruneThresholdD = -10000000;    // cfr.rs:352
+constexpr int kDT_I32 = 0, kDT_F32 = 1, kDT_F16 = 2;      // == RS_I32 / RS_F32 / RS_F16
+constexpr int kARITH_CLAMP = 0, kARITH_WRAP = 1;           // == RS_UPD_CLAMP_I64 / RS_UPD_WRAP_I32
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Every table / utility pointer reaches the kernels through a job descriptor in memory, so the compiler cannot
+// know its address space and would emit flat_load / flat_store (which also tick lgkmcnt and return out of
+// order).  All of them are hipMalloc'ed global memory: say so, and get global_load_dwordx4 / global_store_dwordx4.
+#define RS_GLOBAL __attribute__((address_space(1)))
+#ifdef RS_AB_FLAT
+template <typename T> __device__ __forceinline__ const T *as_global(const void *p) { return (const T *)p; }
+template <typename T> __device__ __forceinline__ T *as_global(void *p) { return (T *)p; }
+#else
+template <typename T> __device__ __forceinline__ const RS_GLOBAL T *as_global(const void *p) {
+    return (const RS_GLOBAL T *)(unsigned long long)p;
+}
+template <typename T> __device__ __forceinline__ RS_GLOBAL T *as_global(void *p) { return (RS_GLOBAL T *)(unsigned long long)p; }
+#endif
+
+// ---- Rust casts ---------------------------------------------------------------------------------
+// `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  |x| >= 2^32 saturates the
+// sum whatever r is, so x is first limited to +-2^32 (exact in f32) and the rest is exact i64 work.
+__device__ __forceinline__ int add_clamp_i64(int r, float x) {
+    if (x != x) x = 0.0f;                                  // NaN -> 0
+    x = fminf(fmaxf(x, -4294967296.0f), 4294967296.0f);
+    long long sum = (long long)r + (long long)x;            // trunc toward zero
+    sum = sum > 2147483647LL ? 2147483647LL : sum;
+    sum = sum < -2147483648LL ? -2147483648LL : sum;
+    return (int)sum;
+}
+
+// `f32 as i32`: truncate, saturate, NaN -> 0 (cfr.rs:256-257, :617, :619)
+__device__ __forceinline__ int f32_as_i32(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
+
+__device__ __forceinline__ int add_wrap_i32(int r, float x) {
+    return (int)((unsigned)r + (unsigned)f32_as_i32(x));
+}
+
+// ---- row access: 4 consecutive lanes of one [pitch] row, as the compute type ---------------------
+template <int DT> struct Row;
+template <> struct Row<kDT_I32> {
+    using val = int;
+    static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+        i32x4 x = __builtin_nontemporal_load(as_global<i32x4>((const int *)base + row_off) + v);
+        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+        i32x4 x = {in[0], in[1], in[2], in[3]};
+        __builtin_nontemporal_store(x, as_global<i32x4>((int *)base + row_off) + v);
+    }
+};
+template <> struct Row<kDT_F32> {
+    using val = float;
+    static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+        f32x4 x = __builtin_nontemporal_load(as_global<f32x4>((const float *)base + row_off) + v);
+        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+        f32x4 x = {in[0], in[1], in[2], in[3]};
+        __builtin_nontemporal_store(x, as_global<f32x4>((float *)base + row_off) + v);
+    }
+};
+template <> struct Row<kDT_F16> {
+    using val = float;  // binary16 in HBM, f32 in registers
+    static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+        f16x4 x = __builtin_nontemporal_load(as_global<f16x4>((const _Float16 *)base + row_off) + v);
+        out[0] = (float)x.x; out[1] = (float)x.y; out[2] = (float)x.z; out[3] = (float)x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+        f16x4 x = {(_Float16)in[0], (_Float16)in[1], (_Float16)in[2], (_Float16)in[3]};  // RNE
+        __builtin_nontemporal_store(x, as_global<f16x4>((_Float16 *)base + row_off) + v);
+    }
+};
+
+__device__ __forceinline__ void load_f32_row(const float *base, unsigned v, float (&out)[kVecD]) {
+    f32x4 x = __builtin_nontemporal_load(as_global<f32x4>(base) + v);
+    out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+}
+__device__ __forceinline__ void store_f32_row(float *base, unsigned v, const float (&in)[kVecD]) {
+    f32x4 x = {in[0], in[1], in[2], in[3]};
+    __builtin_nontemporal_store(x, as_global<f32x4>(base) + v);
+}
+
+// showdown / all-in leaf from a sign row: compare as evaluate() scores (cfr.rs:323-334); p1 flips the view
+__device__ __forceinline__ void sign_to_util(float (&x)[kVecD], bool p1, float pot) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        const float s = x[j];
+        const bool wins = p1 ? (s < 0.0f) : (s > 0.0f);
+        x[j] = (s == 0.0f) ? 0.0f : (wins ? pot : -pot);
+    }
+}
+
+// ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
+template <int A, typename V>
+__device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {
+    float norm = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++)
+        if (r[a] > (V)0) norm += (float)r[a];
+    const float uni = 1.0f / (float)A;
+#pragma unroll
+    for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
+}
+
+// ---- the traverser visit for one lane --------------------------------------------------------------
+// I32: cfr.rs:413-464 (ARITH = kARITH_CLAMP) or cfr.rs:612-621 (kARITH_WRAP)
+template <int A, int ARITH>
+__device__ __forceinline__ float visit_i32(int (&r)[A], int (&s)[A], const float (&u)[A], float reach, float scale,
+                                           bool rmplus, bool prune) {
+    float sig[A];
+    regret_match<A, int>(r, sig);
+    bool ex[A];
+    float util = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        ex[a] = !prune || (r[a] > kPruneThresholdD);  // cfr.rs:380
+        if (ex[a]) util += u[a] * sig[a];            // cfr.rs:384 / :588
+    }
+    const bool active = !(reach != reach);           // NaN reach marks a lane whose subtree was pruned above
+    const float k = scale * reach;                   // (100.0 * cfr_reach) first
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        if (ex[a] && active) {
+            const float dr = k * (u[a] - util);
+            const float ds = k * sig[a];
+            if (ARITH == kARITH_CLAMP) {
+                int nr = add_clamp_i64(r[a], dr);
+                if (rmplus && nr < 0) nr = 0;
+                r[a] = nr;
+                s[a] = add_clamp_i64(s[a], ds);
+            } else {
+                r[a] = add_wrap_i32(r[a], dr);
+                s[a] = add_wrap_i32(s[a], ds);
+            }
+        }
+    }
+    return util;
+}
+
+// float tables (extension): r += (scale*reach)*(u-util); s += (scale*reach)*sigma
+template <int A>
+__device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const float (&u)[A], float reach, float scale,
+                                           bool rmplus) {
+    float sig[A];
+    regret_match<A, float>(r, sig);
+    float util = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) util += u[a] * sig[a];
+    const float k = scale * reach;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        float nr = r[a] + k * (u[a] - util);
+        if (rmplus && !(nr > 0.0f)) nr = 0.0f;
+        r[a] = nr;
+        s[a] = s[a] + k * sig[a];
+    }
+    return util;
+}
+
+// ---- 4-lane wrappers used by the tree-specialised (hipRTC) kernels ------------------------------------------
+template <int A, int DT>
+__device__ __forceinline__ void lanes_regret_match(const typename Row<DT>::val (&r)[A][kVecD], float (&sig)[A][kVecD]) {
+    using V = typename Row<DT>::val;
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        V rl[A];
+        float sg[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) rl[a] = r[a][j];
+        regret_match<A, V>(rl, sg);
+#pragma unroll
+        for (int a = 0; a < A; a++) sig[a][j] = sg[a];
+    }
+}
+
+// one traverser visit of 4 lanes: updates r / s in place, writes the node utility to dest
+template <int A, int DT, int ARITH>
+__device__ __forceinline__ void lanes_visit(typename Row<DT>::val (&r)[A][kVecD], typename Row<DT>::val (&s)[A][kVecD],
+                                            const float (&u)[A][kVecD], const float (&reach)[kVecD], float scale, bool rmplus,
+                                            float (&dest)[kVecD]) {
+    using V = typename Row<DT>::val;
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        V rl[A], sl[A];
+        float ul[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) { rl[a] = r[a][j]; sl[a] = s[a][j]; ul[a] = u[a][j]; }
+        if constexpr (DT == kDT_I32) dest[j] = visit_i32<A, ARITH>(rl, sl, ul, reach[j], scale, rmplus, false);
+        else dest[j] = visit_f32<A>(rl, sl, ul, reach[j], scale, rmplus);
+#pragma unroll
+        for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
+    }
+}
+
+}  // namespace rs

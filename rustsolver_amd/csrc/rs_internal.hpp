@@ -86,6 +86,23 @@ hipError_t launch_convert_f16_to_f32(const void *src, float *dst, size_t n, hipS
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
 
+// ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
+struct JitSubtree {
+    std::string source;
+    std::vector<int> node_ids;     // tree node id of every action node, in the order the kernel indexes reg[] / ssm[]
+    std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
+    std::vector<int> const_terms;  // terminal ids in the order of cval[]
+    int max_actions = 0;
+    size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_cval = 0, off_reach_const = 0, off_scale = 0,
+           off_n_vec = 0, off_pitch = 0, args_size = 0;
+};
+void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
+                      const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, JitSubtree &out);
+bool jit_available();
+int jit_get_kernel(const std::string &source, int device, hipFunction_t *fn);
+int jit_compile_only(const std::string &source);
+const char *jit_device_source();
+
 // ---- host-side objects ----------------------------------------------------------------------------
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);

@@ -8,171 +8,47 @@
 // Numerics follow the Rust reference bit for bit in RS_I32 mode (rules listed in DESIGN.md):
 // no FMA contraction, sequential f32 sums in action order, RNE i32->f32, saturating
 // NaN->0 f32->int casts, i64-add-then-clamp (cfr.rs:445-461) or wrapping i32 add (cfr.rs:616-619).
+#include <cstdlib>
+
 #include "rs_internal.hpp"
+#include "rs_device.hpp"
 
 #pragma clang fp contract(off)
 
 namespace rs {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+static_assert(kVec == kVecD && kPruneThreshold == kPruneThresholdD, "device constants");
+static_assert(RS_I32 == kDT_I32 && RS_F32 == kDT_F32 && RS_F16 == kDT_F16 && RS_UPD_CLAMP_I64 == kARITH_CLAMP && RS_UPD_WRAP_I32 == kARITH_WRAP, "enum values");
 
-// ---- Rust casts ---------------------------------------------------------------------------------
-// `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  |x| >= 2^32 saturates the
-// sum whatever r is, so x is first limited to +-2^32 (exact in f32) and the rest is exact i64 work.
-__device__ __forceinline__ int32_t add_clamp_i64(int32_t r, float x) {
-    if (x != x) x = 0.0f;                                  // NaN -> 0
-    x = fminf(fmaxf(x, -4294967296.0f), 4294967296.0f);
-    long long sum = (long long)r + (long long)x;            // trunc toward zero
-    sum = sum > 2147483647LL ? 2147483647LL : sum;
-    sum = sum < -2147483648LL ? -2147483648LL : sum;
-    return (int32_t)sum;
+#ifdef RS_AB_REFJOB
+#define RS_JOB_DECL(T) const T &job = jobs[blockIdx.y];
+#else
+#define RS_JOB_DECL(T) const T job = jobs[blockIdx.y];   // by value, before any store: one-time scalar loads into SGPRs
+#endif
+
+// utility of one action for 4 lanes (cfr.rs:314-348 for terminals, child buffers otherwise), in two phases so
+// that the loads of all children are in flight together: issue_child only issues the row load (no use of the
+// data, hence no s_waitcnt in its branch); finish_child turns the raw row into the utility.
+__device__ __forceinline__ void issue_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
+#ifdef RS_AB_LOADCHILD
+    (void)c; (void)v; (void)out;
+#else
+    if ((c.kind & 0xff) != CH_CONST) load_f32_row(c.buf, v, out);   // wave-uniform branch
+#endif
 }
-
-// `f32 as i32`: truncate, saturate, NaN -> 0 (cfr.rs:256-257, :617, :619)
-__device__ __forceinline__ int32_t f32_as_i32(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return -2147483647 - 1;
-    return (int32_t)x;
-}
-
-__device__ __forceinline__ int32_t add_wrap_i32(int32_t r, float x) {
-    return (int32_t)((uint32_t)r + (uint32_t)f32_as_i32(x));
-}
-
-// ---- row access: 4 consecutive lanes of one [pitch] row, as the compute type ---------------------
-template <int DT> struct Row;
-template <> struct Row<RS_I32> {
-    using val = int32_t;
-    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
-        i32x4 x = __builtin_nontemporal_load((const i32x4 *)((const int32_t *)base + row_off) + v);
-        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
-    }
-    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
-        i32x4 x = {in[0], in[1], in[2], in[3]};
-        __builtin_nontemporal_store(x, (i32x4 *)((int32_t *)base + row_off) + v);
-    }
-};
-template <> struct Row<RS_F32> {
-    using val = float;
-    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
-        f32x4 x = __builtin_nontemporal_load((const f32x4 *)((const float *)base + row_off) + v);
-        out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
-    }
-    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
-        f32x4 x = {in[0], in[1], in[2], in[3]};
-        __builtin_nontemporal_store(x, (f32x4 *)((float *)base + row_off) + v);
-    }
-};
-template <> struct Row<RS_F16> {
-    using val = float;  // binary16 in HBM, f32 in registers
-    static __device__ __forceinline__ void load(const void *base, uint32_t row_off, uint32_t v, val (&out)[kVec]) {
-        f16x4 x = __builtin_nontemporal_load((const f16x4 *)((const _Float16 *)base + row_off) + v);
-        out[0] = (float)x.x; out[1] = (float)x.y; out[2] = (float)x.z; out[3] = (float)x.w;
-    }
-    static __device__ __forceinline__ void store(void *base, uint32_t row_off, uint32_t v, const val (&in)[kVec]) {
-        f16x4 x = {(_Float16)in[0], (_Float16)in[1], (_Float16)in[2], (_Float16)in[3]};  // RNE
-        __builtin_nontemporal_store(x, (f16x4 *)((_Float16 *)base + row_off) + v);
-    }
-};
-
-__device__ __forceinline__ void load_f32_row(const float *base, uint32_t v, float (&out)[kVec]) {
-    f32x4 x = __builtin_nontemporal_load((const f32x4 *)base + v);
-    out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
-}
-__device__ __forceinline__ void store_f32_row(float *base, uint32_t v, const float (&in)[kVec]) {
-    f32x4 x = {in[0], in[1], in[2], in[3]};
-    __builtin_nontemporal_store(x, (f32x4 *)base + v);
-}
-
-// utility of one action for 4 lanes (cfr.rs:314-348 for terminals, child buffers otherwise)
-__device__ __forceinline__ void load_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
-    const int kind = c.kind & 0xff;  // wave-uniform
+__device__ __forceinline__ void finish_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
+#ifdef RS_AB_LOADCHILD
+    if ((c.kind & 0xff) != CH_CONST) load_f32_row(c.buf, v, out);
+#else
+    (void)v;
+#endif
+    const int kind = c.kind & 0xff;
     if (kind == CH_CONST) {
 #pragma unroll
         for (int j = 0; j < kVec; j++) out[j] = c.value;
-        return;
+    } else if (kind == CH_SIGN) {
+        sign_to_util(out, (c.kind & 0x100) != 0, c.value);
     }
-    load_f32_row(c.buf, v, out);
-    if (kind == CH_SIGN) {
-        const bool p1 = (c.kind & 0x100) != 0;
-        const float pot = c.value;
-#pragma unroll
-        for (int j = 0; j < kVec; j++) {
-            const float s = out[j];
-            const bool wins = p1 ? (s < 0.0f) : (s > 0.0f);  // scores[player] > scores[1-player]
-            out[j] = (s == 0.0f) ? 0.0f : (wins ? pot : -pot);
-        }
-    }
-}
-
-// ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
-template <int A, typename V>
-__device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {
-    float norm = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; a++)
-        if (r[a] > (V)0) norm += (float)r[a];
-    const float uni = 1.0f / (float)A;
-#pragma unroll
-    for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
-}
-
-// ---- the traverser visit for one lane --------------------------------------------------------------
-// I32: cfr.rs:413-464 (ARITH = RS_UPD_CLAMP_I64) or cfr.rs:612-621 (RS_UPD_WRAP_I32)
-template <int A, int ARITH>
-__device__ __forceinline__ float visit_i32(int32_t (&r)[A], int32_t (&s)[A], const float (&u)[A], float reach, float scale,
-                                           bool rmplus, bool prune) {
-    float sig[A];
-    regret_match<A, int32_t>(r, sig);
-    bool ex[A];
-    float util = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; a++) {
-        ex[a] = !prune || (r[a] > kPruneThreshold);  // cfr.rs:380
-        if (ex[a]) util += u[a] * sig[a];            // cfr.rs:384 / :588
-    }
-    const bool active = !(reach != reach);           // NaN reach marks a lane whose subtree was pruned above
-    const float k = scale * reach;                   // (100.0 * cfr_reach) first
-#pragma unroll
-    for (int a = 0; a < A; a++) {
-        if (ex[a] && active) {
-            const float dr = k * (u[a] - util);
-            const float ds = k * sig[a];
-            if (ARITH == RS_UPD_CLAMP_I64) {
-                int32_t nr = add_clamp_i64(r[a], dr);
-                if (rmplus && nr < 0) nr = 0;
-                r[a] = nr;
-                s[a] = add_clamp_i64(s[a], ds);
-            } else {
-                r[a] = add_wrap_i32(r[a], dr);
-                s[a] = add_wrap_i32(s[a], ds);
-            }
-        }
-    }
-    return util;
-}
-
-// float tables (extension): r += (scale*reach)*(u-util); s += (scale*reach)*sigma
-template <int A>
-__device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const float (&u)[A], float reach, float scale,
-                                           bool rmplus) {
-    float sig[A];
-    regret_match<A, float>(r, sig);
-    float util = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; a++) util += u[a] * sig[a];
-    const float k = scale * reach;
-#pragma unroll
-    for (int a = 0; a < A; a++) {
-        float nr = r[a] + k * (u[a] - util);
-        if (rmplus && !(nr > 0.0f)) nr = 0.0f;
-        r[a] = nr;
-        s[a] = s[a] + k * sig[a];
-    }
-    return util;
 }
 
 // =====================================================================================================
@@ -181,7 +57,7 @@ __device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const f
 // =====================================================================================================
 template <int A, int DT, int ARITH>
 __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ jobs, int flags) {
-    const NodeJob &job = jobs[blockIdx.y];
+    RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     const bool rmplus = (flags & RS_UPD_RMPLUS) != 0, prune = (flags & RS_UPD_PRUNE) != 0;
     using R = Row<DT>;
@@ -194,12 +70,14 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
 #pragma unroll
         for (int a = 0; a < A; a++) R::load(job.ssum, a * pitch, v, s[a]);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_child(job.child[a], v, u[a]);
+        for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
         else {
 #pragma unroll
             for (int j = 0; j < kVec; j++) reach[j] = job.reach_const;
         }
+#pragma unroll
+        for (int a = 0; a < A; a++) finish_child(job.child[a], v, u[a]);
         float util[kVec];
 #pragma unroll
         for (int j = 0; j < kVec; j++) {
@@ -223,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
 // opponent / read-only visit: util = sum_a u[a]*sigma[a] (cfr.rs:574,:588).  8A+4 bytes per lane.
 template <int A, int DT>
 __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict__ jobs) {
-    const NodeJob &job = jobs[blockIdx.y];
+    RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     using R = Row<DT>;
     using V = typename R::val;
@@ -233,7 +111,9 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
 #pragma unroll
         for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_child(job.child[a], v, u[a]);
+        for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
+#pragma unroll
+        for (int a = 0; a < A; a++) finish_child(job.child[a], v, u[a]);
         float util[kVec];
 #pragma unroll
         for (int j = 0; j < kVec; j++) {
@@ -254,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
 // opponent reach, top-down: out_reach[a] = sigma[a] * reach (cfr.rs:585) for the children that need it
 template <int A, int DT>
 __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jobs) {
-    const NodeJob &job = jobs[blockIdx.y];
+    RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     using R = Row<DT>;
     using V = typename R::val;
@@ -288,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
 // in that subtree, the reference never recurses there: cfr.rs:379-386); explored ones inherit reach.
 template <int A>
 __global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restrict__ jobs) {
-    const NodeJob &job = jobs[blockIdx.y];
+    RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     using R = Row<RS_I32>;
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
@@ -337,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ sr
         for (int a = 0; a < A; a++) store_f32_row(dst + (size_t)a * pitch, v, out[a]);
     }
 }
+
 
 // ---- public chance nodes (cfr.rs:502-522) ----------------------------------------------------------------
 // top-down: child_cfr_reach = cfr_reach * (1.0 / len) for each of the `fan` deals of a parent board
@@ -513,6 +394,7 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs
 #undef RS_PR
     return hipGetLastError();
 }
+
 
 hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, int n_actions, int dtype, hipStream_t stream) {
     dim3 grid(grid_for(pitch / kVec)), block(kBlock);

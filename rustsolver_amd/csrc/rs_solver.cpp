@@ -20,7 +20,7 @@ using namespace rs;
 
 namespace {
 
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE };
 
 struct Launch {
     int kind;
@@ -37,7 +37,19 @@ struct ReachSrc {
     bool valid = false;
 };
 
+// one launch of a tree-specialised (hipRTC) kernel: blockIdx.y indexes the argument blobs
+struct JitLaunch {
+    hipFunction_t fn = nullptr;
+    std::vector<unsigned char> blob;   // n_jobs * stride bytes, layout = JArgs of the generated source
+    size_t stride = 0;
+    int n_jobs = 0;
+    uint32_t max_n_vec = 0;
+    unsigned char *d_blob = nullptr;
+    double bytes = 0.0;
+};
+
 struct Plan {
+    std::vector<JitLaunch> jit;
     std::vector<NodeJob> jobs;
     NodeJob *d_jobs = nullptr;
     std::vector<Launch> launches;
@@ -116,12 +128,13 @@ struct Builder {
     Plan &plan;
     const std::vector<rs_tree_node> &nodes;
     std::vector<int> depth, lane_round;
-    std::vector<char> has_own;
+    std::vector<char> has_own, closed, fused_root, inside;
     std::vector<ReachSrc> reach;      // reach source feeding each node
     std::vector<size_t> util_off;     // arena offset of a node's util buffer (+1; 0 = none)
     std::vector<size_t> reach_off;    // arena offset of a node's own reach buffer (+1; 0 = alias / const)
     size_t arena = 0;
     int max_depth = 0;
+    std::map<const float *, int> leaf_ids;   // leaf buffer -> id, so that kernels see the sharing pattern, not pointers
 
     Builder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
 
@@ -139,13 +152,34 @@ struct Builder {
         if (nd.kind == RS_NODE_ACTION) round = nd.round_idx;
         lane_round[id] = round;
         bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+        bool cl = nd.kind != RS_NODE_PUBLIC_CHANCE && nd.kind != RS_NODE_PRIVATE_CHANCE;
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
             // the child of a public chance node lives on the next round's boards
             annotate(c, d + 1, nd.kind == RS_NODE_PUBLIC_CHANCE ? round + 1 : round);
             own = own || has_own[c];
+            cl = cl && closed[c];
         }
         has_own[id] = own;
+        closed[id] = cl;   // no chance node at or below: one lane geometry, fusable into a single kernel
+    }
+
+    // ---- fused subtrees: every topmost chance-free subtree becomes ONE tree-specialised kernel ---------------------
+    void mark_inside(int id) {
+        for (int k = 0; k < nodes[id].n_children; ++k) {
+            inside[nodes[id].children[k]] = 1;
+            mark_inside(nodes[id].children[k]);
+        }
+    }
+    void mark_fused(int id) {
+        const rs_tree_node &nd = nodes[id];
+        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;   // prune keeps the level plan (NaN-reach bookkeeping)
+        if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && closed[id]) {
+            fused_root[id] = 1;
+            mark_inside(id);
+            return;
+        }
+        for (int k = 0; k < nd.n_children; ++k) mark_fused(nd.children[k]);
     }
 
     bool chance_enum(const rs_tree_node &nd) const {
@@ -157,6 +191,7 @@ struct Builder {
         const rs_tree_node &nd = nodes[id];
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
         if (nd.kind == RS_NODE_ACTION || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);
+        if (fused_root[id]) return;   // everything below lives in registers / LDS of k_subtree
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
             if (nodes[c].kind != RS_NODE_TERMINAL && has_own[c]) {
@@ -208,16 +243,21 @@ struct Builder {
         depth.assign(n, 0);
         lane_round.assign(n, 0);
         has_own.assign(n, 0);
+        closed.assign(n, 0);
+        fused_root.assign(n, 0);
+        inside.assign(n, 0);
         reach.assign(n, ReachSrc{});
         util_off.assign(n, 0);
         reach_off.assign(n, 0);
         annotate(0, 0, 0);
+        mark_fused(0);
         layout(0);
         // ENUM chance children: need their own reach buffer when the chance node's reach is a buffer.
         // Resolve top-down in id order (parents have smaller ids than children).
         std::vector<char> reach_is_buf(n, 0);
         for (size_t id = 0; id < n; ++id) {
             const rs_tree_node &nd = nodes[id];
+            if (fused_root[id] || inside[id]) continue;
             for (int k = 0; k < nd.n_children; ++k) {
                 const int c = nd.children[k];
                 if (nodes[c].kind == RS_NODE_TERMINAL || !has_own[c]) continue;
@@ -249,7 +289,7 @@ struct Builder {
             std::map<int, std::vector<int>> reach_groups, prune_groups;  // by n_actions
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
-                if (nd.kind == RS_NODE_TERMINAL) continue;
+                if (nd.kind == RS_NODE_TERMINAL || fused_root[id] || inside[id]) continue;
                 const bool opp = nd.kind == RS_NODE_ACTION && nd.player != p;
                 const bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
                 bool any_child_buf = false;
@@ -309,8 +349,14 @@ struct Builder {
         // ---- bottom-up -----------------------------------------------------------------------------
         for (int d = max_depth; d >= 0; --d) {
             std::map<int, std::vector<int>> upd_groups, util_groups;
+            std::vector<int> sub_roots;
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
+                if (inside[id]) continue;
+                if (fused_root[id]) {
+                    sub_roots.push_back(id);
+                    continue;
+                }
                 if (nd.kind == RS_NODE_ACTION) (nd.player == p ? upd_groups : util_groups)[nd.n_children].push_back(id);
                 else if (chance_enum(nd)) {
                     const int c = nd.children[0];
@@ -322,6 +368,71 @@ struct Builder {
                     L.chance = ChanceJob{src.buf, aptr(util_off[id]), 0.0f, 0.0f, fan, s->n_clusters,
                                          uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)};
                     L.bytes = lanes(c) * 4.0 + lanes(id) * 4.0;
+                    plan.launches.push_back(L);
+                }
+            }
+            if (!sub_roots.empty()) {
+                // tree-specialised kernels: subtrees of one shape share a kernel and a launch (blockIdx.y = subtree)
+                std::map<hipFunction_t, int> by_fn;
+                for (int id : sub_roots) {
+                    if (has_own[id] && !reach[id].valid) return fail(RS_ERR_INVALID, "rs_solver_create: internal: no reach for a fused subtree");
+                    std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
+                    for (size_t t2 = 0; t2 < n; ++t2) {
+                        const rs_tree_node &tn = nodes[t2];
+                        if (tn.kind != RS_NODE_TERMINAL || tn.ttype == RS_TERM_UNCONTESTED) continue;
+                        const rs_leaf_desc &lf = s->leaves[p][t2];
+                        auto it = leaf_ids.find(lf.d_buf);
+                        if (it == leaf_ids.end()) it = leaf_ids.emplace(lf.d_buf, int(leaf_ids.size())).first;
+                        leaf_buf[t2] = it->second;
+                        leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
+                    }
+                    JitSubtree js;
+                    jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK, js);
+                    hipFunction_t fn = nullptr;
+                    if (int rc = jit_get_kernel(js.source, t->device, &fn)) return rc;
+                    auto bi = by_fn.find(fn);
+                    if (bi == by_fn.end()) {
+                        bi = by_fn.emplace(fn, int(plan.jit.size())).first;
+                        plan.jit.emplace_back();
+                        plan.jit.back().fn = fn;
+                        plan.jit.back().stride = js.args_size;
+                    }
+                    JitLaunch &JL = plan.jit[bi->second];
+                    const size_t base = JL.blob.size();
+                    JL.blob.resize(base + js.args_size, 0);
+                    unsigned char *a = JL.blob.data() + base;
+                    auto put_ptr = [&](size_t off, const void *ptr) { std::memcpy(a + off, &ptr, 8); };
+                    auto put_f32 = [&](size_t off, float f) { std::memcpy(a + off, &f, 4); };
+                    auto put_u32 = [&](size_t off, uint32_t u) { std::memcpy(a + off, &u, 4); };
+                    double bytes = 0.0;
+                    for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                        const rs_tree_node &an = nodes[js.node_ids[k]];
+                        put_ptr(js.off_reg + 8 * k, t->regrets_ptr(an.index));
+                        put_ptr(js.off_ssm + 8 * k, t->ssum_ptr(an.index));
+                        bytes += lanes(js.node_ids[k]) * an.n_children * es * (an.player == p ? 4.0 : 1.0);
+                    }
+                    for (size_t k = 0; k < js.leaf_terms.size(); ++k) put_ptr(js.off_leaf + 8 * k, s->leaves[p][js.leaf_terms[k]].d_buf);
+                    for (size_t k = 0; k < js.const_terms.size(); ++k) {
+                        const rs_tree_node &tn = nodes[js.const_terms[k]];
+                        const float pot = float(tn.value);   // `tn.value as f32`
+                        put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
+                    }
+                    put_ptr(js.off_reach, reach[id].ptr);
+                    put_ptr(js.off_out, aptr(util_off[id]));
+                    put_f32(js.off_reach_const, reach[id].cst);
+                    put_f32(js.off_scale, s->params.scale);
+                    const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / kVec);
+                    put_u32(js.off_n_vec, n_vec);
+                    put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
+                    JL.n_jobs += 1;
+                    JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
+                    JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
+                }
+                for (auto &kv : by_fn) {
+                    Launch L;
+                    L.kind = L_TREE;
+                    L.first_job = kv.second;
+                    L.bytes = plan.jit[kv.second].bytes;
                     plan.launches.push_back(L);
                 }
             }
@@ -363,7 +474,7 @@ struct Builder {
 
 int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     rs_table *t = s->table;
-    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE};
+    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE};
     prof_begin(t, prof_kind[L.kind], L.bytes);
     hipError_t e = hipSuccess;
     const NodeJob *jobs = plan.d_jobs + L.first_job;
@@ -375,6 +486,16 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     case L_UPDATE: e = launch_update(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
     case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
     case L_REDUCE: e = launch_chance_reduce(L.chance, t->stream); break;
+    case L_TREE: {
+        const JitLaunch &JL = plan.jit[L.first_job];
+        size_t blocks = (size_t(JL.max_n_vec) + kBlock - 1) / kBlock;
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 16);
+        const void *d_blob = JL.d_blob;
+        int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
+        void *params[] = {&d_blob, &flags};
+        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, kBlock, 1, 1, 0, t->stream, params, nullptr);
+        break;
+    }
     }
     prof_end(t);
     RS_HIP(e, "plan launch");
@@ -419,6 +540,9 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
         return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: RS_UPD_RMPLUS on i32 tables uses the clamp arithmetic");
     if (params->chance_mode != RS_CHANCE_PASS && params->chance_mode != RS_CHANCE_ENUM)
         return fail(RS_ERR_INVALID, "rs_solver_create: bad chance mode");
+    if (params->fuse_subtrees < 0 || params->fuse_subtrees > 1) return fail(RS_ERR_INVALID, "rs_solver_create: fuse_subtrees must be 0 or 1");
+    if (params->fuse_subtrees && !jit_available())
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: fuse_subtrees needs libhiprtc.so (tree-specialised kernels); pass 0 for the level plan");
     if (tree->nodes.empty() || tree->nodes[0].kind != RS_NODE_PRIVATE_CHANCE)
         return fail(RS_ERR_INVALID, "rs_solver_create: node 0 must be the private chance root (tree_builder.rs:60-66)");
 
@@ -470,8 +594,20 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
     for (int p = 0; p < 2; ++p) {
         Plan &pl = s->plan[p];
         const size_t bytes = std::max<size_t>(pl.jobs.size(), 1) * sizeof(NodeJob);
-        if ((e = hipMalloc((void **)&pl.d_jobs, bytes)) != hipSuccess ||
-            (e = hipMemcpyAsync(pl.d_jobs, pl.jobs.data(), pl.jobs.size() * sizeof(NodeJob), hipMemcpyHostToDevice,
+        if ((e = hipMalloc((void **)&pl.d_jobs, bytes)) != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: job allocation");
+            rs_solver_destroy(s);
+            return rc;
+        }
+        for (JitLaunch &JL : pl.jit) {
+            if ((e = hipMalloc((void **)&JL.d_blob, JL.blob.size())) != hipSuccess ||
+                (e = hipMemcpyAsync(JL.d_blob, JL.blob.data(), JL.blob.size(), hipMemcpyHostToDevice, table->stream)) != hipSuccess) {
+                rc = hip_fail(e, "rs_solver_create: tree-kernel argument upload");
+                rs_solver_destroy(s);
+                return rc;
+            }
+        }
+        if ((e = hipMemcpyAsync(pl.d_jobs, pl.jobs.data(), pl.jobs.size() * sizeof(NodeJob), hipMemcpyHostToDevice,
                                 table->stream)) != hipSuccess) {
             rc = hip_fail(e, "rs_solver_create: job upload");
             rs_solver_destroy(s);
@@ -495,6 +631,8 @@ void rs_solver_destroy(rs_solver *s) {
         if (s->plan[p].graph_exec) (void)hipGraphExecDestroy(s->plan[p].graph_exec);
         if (s->plan[p].graph) (void)hipGraphDestroy(s->plan[p].graph);
         if (s->plan[p].d_jobs) (void)hipFree(s->plan[p].d_jobs);
+        for (JitLaunch &JL : s->plan[p].jit)
+            if (JL.d_blob) (void)hipFree(JL.d_blob);
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
     delete s;
@@ -530,6 +668,48 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
 }
 
 size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes : 0; }
+
+int rs_jit_available(void) { return jit_available() ? 1 : 0; }
+
+// Generates and compiles (no GPU needed) the tree-specialised kernel of every chance-free subtree of `tree`, for
+// both traversers, assuming one shared sign buffer per round.  *n_kernels = distinct kernels.
+int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int *n_kernels) {
+    if (!tree || tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_jit_check_tree: bad tree");
+    const std::vector<rs_tree_node> &nodes = tree->nodes;
+    const size_t n = nodes.size();
+    std::map<std::string, int> seen;
+    for (int p = 0; p < 2; ++p) {
+        std::vector<char> has_own(n, 0), closed(n, 0);
+        std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
+        for (size_t i = n; i-- > 0;) {   // children have larger ids than parents
+            const rs_tree_node &nd = nodes[i];
+            bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+            bool cl = nd.kind != RS_NODE_PUBLIC_CHANCE && nd.kind != RS_NODE_PRIVATE_CHANCE;
+            for (int k = 0; k < nd.n_children; ++k) {
+                own = own || has_own[nd.children[k]];
+                cl = cl && closed[nd.children[k]];
+            }
+            has_own[i] = own;
+            closed[i] = cl;
+            if (nd.kind == RS_NODE_TERMINAL && nd.ttype != RS_TERM_UNCONTESTED) {
+                leaf_buf[i] = nd.round;
+                leaf_flags[i] = 1;
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const rs_tree_node &nd = nodes[i];
+            if (nd.kind != RS_NODE_ACTION || !closed[i]) continue;
+            if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
+            JitSubtree js;
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, js);
+            if (seen.count(js.source)) continue;
+            seen[js.source] = 1;
+            if (int rc = jit_compile_only(js.source)) return rc;
+        }
+    }
+    if (n_kernels) *n_kernels = int(seen.size());
+    return RS_OK;
+}
 int rs_solver_n_launches(const rs_solver *s, int traverser) {
     if (!s || traverser < 0 || traverser > 1) return RS_ERR_INVALID;
     return int(s->plan[traverser].launches.size());

@@ -12,6 +12,7 @@ Names follow the Rust items they stand for so that tests read like tests of the 
 All compute runs in the HIP library; this file only marshals numpy arrays through ctypes.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -236,6 +237,7 @@ class InfosetTable:
         self.dtype = lib.rs_table_dtype(handle)
         self.np_dtype = np.int32 if self.dtype == L.I32 else np.float32
         self._descs = {}
+        self._solvers = weakref.WeakSet()   # solvers built on this table must be destroyed before it
 
     @classmethod
     def create(cls, descs, dtype=L.I32, device=0):
@@ -391,12 +393,14 @@ class InfosetTable:
     def profile_read(self):
         p = L.Profile()
         L.check(L.load().rs_profile_read(self._h, C.byref(p)))
-        names = ["update", "node_util", "reach", "chance", "discount", "strategy"]
+        names = ["update", "node_util", "reach", "chance", "discount", "strategy", "tree"]
         return {n: dict(launches=int(p.launches[i]), ms=float(p.ms[i]), algo_bytes=float(p.algo_bytes[i]))
                 for i, n in enumerate(names)}
 
     def destroy(self):
         if self._h:
+            for sv in list(self._solvers):
+                sv.destroy()
             L.load().rs_table_destroy(self._h)
             self._h = None
 
@@ -431,7 +435,7 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=True):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal"""
         self.game_tree, self.infosets = tree, infosets
         self._keep = [leaves, leaves_p1]
@@ -442,10 +446,11 @@ class MCCFRTrainer:
                 arr[nid].kind = kind
                 arr[nid].d_buf = buf.ptr
             arrs.append(arr)
-        p = L.SolverParams(scale, mode, chance_mode, int(use_graph))
+        p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees))
         h = C.c_void_p()
         L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
         self._h = h
+        infosets._solvers.add(self)
         self.workspace_bytes = L.load().rs_solver_workspace_bytes(h)
 
     @classmethod
@@ -495,6 +500,13 @@ class MCCFRTrainer:
             self.destroy()
         except Exception:
             pass
+
+
+def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64):
+    """compile (no GPU needed) every tree-specialised kernel of `tree`; returns the number of distinct kernels"""
+    n = C.c_int()
+    L.check(L.load().rs_jit_check_tree(tree._h, dtype, mode, C.byref(n)))
+    return n.value
 
 
 def discount_factor(tc, interval=MCCFRTrainer.DISCOUNT_INTERVAL):

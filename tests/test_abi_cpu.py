@@ -138,3 +138,15 @@ def test_synth_mirror_is_deterministic():
     assert (a == b).all() and a.min() >= -10**6 and a.max() <= 10**6 and len(set(a.tolist())) > 900
     u = rs.synth.uniform_f32(3, 1000, -1.0, 1.0)
     assert u.dtype == np.float32 and (u >= -1).all() and (u < 1).all()
+
+
+def test_tree_specialised_kernels_compile_without_a_gpu():
+    """hipRTC cross-compiles gfx950 here: every generated kernel of the default trees must build"""
+    from rustsolver_amd import _lib as L2
+    if not L2.load().rs_jit_available():
+        pytest.skip("libhiprtc.so not present")
+    _, tree = rs.build_game_tree(rs.default_flop())
+    assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64) == 2          # one kernel per traverser
+    assert rs.jit_check_tree(tree, rs.F16, rs.UPD_CLAMP_I64) == 2
+    _, tree3 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5,), (1.0,)), raise_sizes=((3.0,), (3.0,))))
+    assert rs.jit_check_tree(tree3, rs.I32, rs.UPD_WRAP_I32) >= 2

@@ -292,14 +292,17 @@ def compare_tables(tree, table, otab, exact=True):
 @pytest.mark.parametrize("C,B", [(5, 1), (250, 3), (1081, 1), (1000, 2)])
 @pytest.mark.parametrize("mode", ["clamp", "wrap", "clamp+prune"])
 @pytest.mark.parametrize("graph", [False, True])
-def test_iterate_river_tree_vs_oracle(C, B, mode, graph):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_iterate_river_tree_vs_oracle(C, B, mode, graph, fuse):
     if graph and (C, B) not in ((250, 3), (1081, 1)):
         pytest.skip("graph replay covered on two shapes")
     tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [B], C, C * 7 + B)
     prune = "prune" in mode
     scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if mode == "wrap" else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), chance_mode=rs.CHANCE_PASS,
-                         use_graph=graph)
+                         use_graph=graph, fuse_subtrees=fuse)
+    # fused: the whole river tree is ONE tree-specialised launch per traverser (prune falls back to the level plan)
+    assert tr.n_launches(0) == (1 if fuse and not prune else (10 if prune else 8))
     osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, prune=prune, chance_mode=orc.CHANCE_PASS)
     for it in range(3):
         for player in (0, 1):
@@ -310,11 +313,12 @@ def test_iterate_river_tree_vs_oracle(C, B, mode, graph):
 
 
 @pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([1, 1, 1], "enum"), ([2, 2, 2], "pass"), ([1, 3, 3], "enum")])
-def test_iterate_three_street_tree_vs_oracle(boards, chance):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_iterate_three_street_tree_vs_oracle(boards, chance, fuse):
     C = 9
     tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), boards, C, 42)
     cm_g, cm_o = (rs.CHANCE_ENUM, orc.CHANCE_ENUM) if chance == "enum" else (rs.CHANCE_PASS, orc.CHANCE_PASS)
-    tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=cm_g)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=cm_g, fuse_subtrees=fuse)
     osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=cm_o)
     for it in range(2):
         for player in (0, 1):
@@ -325,12 +329,13 @@ def test_iterate_three_street_tree_vs_oracle(boards, chance):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16", "f32+rmplus", "i32+rmplus"])
-def test_iterate_extension_dtypes_vs_oracle(dtype):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_iterate_extension_dtypes_vs_oracle(dtype, fuse):
     rmplus = "rmplus" in dtype
     dt_g, dt_o = {"f32": (rs.F32, orc.T_F32), "f16": (rs.F16, orc.T_F16), "i32": (rs.I32, orc.T_I32)}[dtype.split("+")[0]]
     tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [2], 100, 9, dt_g, dt_o, 10**5)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=1.0 if dt_g != rs.I32 else 100.0,
-                         mode=rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if rmplus else 0), chance_mode=rs.CHANCE_PASS)
+                         mode=rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if rmplus else 0), chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse)
     osol = orc.OracleSolver(otree, otab, lo, scale=1.0 if dt_g != rs.I32 else 100.0, mode=orc.UPD_CLAMP_I64, rmplus=rmplus,
                             chance_mode=orc.CHANCE_PASS)
     for it in range(3):
@@ -392,7 +397,8 @@ def test_solver_rejects_mismatched_inputs():
 
 # ---- full BASELINE size: size-independent property (lanes are independent => any sampled board must match) ----------
 
-def test_full_size_config2_sampled_boards_match_oracle():
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_full_size_config2_sampled_boards_match_oracle(fuse):
     B, C, seed = 9216, 1000, 1235
     n, tree = rs.build_game_tree(rs.default_flop())
     table = rs.create_infosets(n, tree, [C], [B])
@@ -401,7 +407,7 @@ def test_full_size_config2_sampled_boards_match_oracle():
     sign = table.lane_buffer(root.index, 1)
     L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), seed + 17, -1.0, 1.0))
     leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
-    tr = rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS)
+    tr = rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse)
     sample = [0, 4607, 9215]
     sign_host = rs.synth.uniform_f32(seed + 17, table.pitch(root.index), -1.0, 1.0)
     otree = orc.OracleTree(orc.options_default_river())

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""In-process, interleaved A/B of tree-kernel code-generation variants (cdna guide rule 24: perf deltas come
+from interleaved rounds in ONE process).  Variants are selected through the RS_JIT_* environment variables that
+rs_jit.cpp reads at solver creation; all trainers share one table, so every variant streams the same bytes.
+
+    python tools/ab_tree_kernel.py "RS_JIT_DISTANCE=0" "RS_JIT_DISTANCE=5" "RS_JIT_DISTANCE=8" --rounds 7
+"""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustsolver_amd as rs  # noqa: E402
+from rustsolver_amd import _lib as L  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("variants", nargs="+", help='each: "KEY=VAL KEY=VAL" (empty string = defaults); FUSE=0 selects the level plan')
+ap.add_argument("--boards", type=int, default=9216)
+ap.add_argument("--clusters", type=int, default=1000)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--steps", type=int, default=10)
+a = ap.parse_args()
+
+n_actions, tree = rs.build_game_tree(rs.default_flop())
+table = rs.create_infosets(n_actions, tree, [a.clusters], [a.boards])
+table.fill_random(1235, (-10**6, 10**6), (0, 10**6))
+root = tree.nodes[tree.nodes[0].children[0]]
+sign = table.lane_buffer(root.index, 1)
+L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), 99, -1.0, 1.0))
+leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+trainers = []
+for v in a.variants:
+    env = dict(kv.split("=") for kv in v.split()) if v.strip() else {}
+    for k in list(os.environ):
+        if k.startswith("RS_JIT_") and k != "RS_JIT_CACHE":
+            del os.environ[k]
+    fuse = int(env.pop("FUSE", "1"))
+    os.environ.update(env)
+    trainers.append(rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse))
+lib = L.load()
+
+
+def run(tr, k):
+    for _ in range(k):
+        L.check(lib.rs_iterate(tr._h, 0, None))
+        L.check(lib.rs_iterate(tr._h, 1, None))
+    table.sync()
+
+
+for tr in trainers:
+    run(tr, 3)
+times = [[] for _ in trainers]
+for r in range(a.rounds):
+    for i, tr in enumerate(trainers):
+        t0 = time.perf_counter()
+        run(tr, a.steps)
+        times[i].append((time.perf_counter() - t0) / a.steps * 1e3)
+for v, ts in zip(a.variants, times):
+    print("%-40s median %.3f ms  min %.3f  max %.3f   (%s)" % (v or "<default>", statistics.median(ts), min(ts), max(ts),
+                                                            " ".join("%.3f" % t for t in ts)))
