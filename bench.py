@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--boards", type=int, default=9216, help="boards per GPU (9216 x 1000 lanes = 8.0 GB update traffic/iteration)")
     ap.add_argument("--clusters", type=int, default=1000)
     ap.add_argument("--mode", choices=["clamp", "wrap"], default="clamp",
