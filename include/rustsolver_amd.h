@@ -206,6 +206,10 @@ float rs_discount_factor(uint64_t tc, uint64_t interval);
 enum { RS_LEAF_UNCONTESTED = 0, /* +-pot from TerminalNode.last_to_act (cfr.rs:316-322); no buffer */
        RS_LEAF_SIGN = 1,        /* d_buf[pitch] = sign(score[0]-score[1]) of evaluate() (cfr.rs:323-347): value = +-pot / 0 */
        RS_LEAF_UTIL = 2 };      /* d_buf[pitch] = utility from the traverser's point of view, used verbatim */
+enum { RS_OPP_FULL = 0,         /* cfr(): every opponent action is recursed, reach * sigma[i], util = sum (cfr.rs:576-589) */
+       RS_OPP_SAMPLE = 1 };     /* mccfr(): ONE opponent action sampled from sigma with rand's WeightedIndex (cfr.rs:467-476);
+                                   the random bits are a counter hash of (sweep seed, ActionNode.index, lane), the sweep seed
+                                   advances by one on every rs_iterate call (sample_seed, call index) */
 enum { RS_CHANCE_PASS = 0,      /* mccfr: PublicChance goes to child 0 (cfr.rs:306-309); needs equal board counts */
        RS_CHANCE_ENUM = 1 };    /* cfr: reach *= 1/len, util = sum over the len = n_boards[r+1]/n_boards[r] deals (cfr.rs:502-522) */
 
@@ -223,6 +227,8 @@ typedef struct rs_solver_params {
                                traverser, generated from the tree and compiled at create time with hipRTC: utilities and
                                reaches stay in registers, only table rows and leaf rows touch HBM.  0: level-by-level node
                                kernels.  Results are bit-identical either way. */
+    int32_t opp_mode;       /* RS_OPP_* */
+    uint64_t sample_seed;   /* RS_OPP_SAMPLE: base seed of the sweep-seed sequence */
 } rs_solver_params;
 
 /* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
@@ -239,7 +245,7 @@ int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval,
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
-int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int *n_kernels);
+int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */

@@ -257,3 +257,44 @@ def build_tree(stacks=(500, 500), pot=35, n_board_cards=5, bet_sizes=((0.5, 1.0)
     root = new(-1, kind="private_chance")
     nodes[root]["children"].append(action_nodes(root, 0, st0))
     return nodes, counter[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# opponent sampling (cfr.rs:467-476): rand 0.7 WeightedIndex over supplied bits, second opinion
+# ---------------------------------------------------------------------------------------------------
+def splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def sample_bits(seed, node_index, lanes):
+    lanes = np.asarray(lanes, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        k = np.uint64(seed) ^ (np.uint64(node_index + 1) * np.uint64(0xD1B54A32D192ED03)) ^ (lanes * np.uint64(0x9E3779B97F4A7C15))
+    return (splitmix64(k) >> np.uint64(32)).astype(np.uint32)
+
+
+def sweep_seed(base_seed, call_index):
+    with np.errstate(over="ignore"):
+        return int(splitmix64(np.uint64(base_seed) + np.uint64(call_index) * np.uint64(0x632BE59BD9B4E019)))
+
+
+def weighted_index(W, bits):
+    """W: [A, n] f32 weights, bits: [n] uint32 -> [n] sampled indices (rand 0.7.3 WeightedIndex + UniformFloat<f32>)"""
+    W = np.asarray(W, dtype=np.float32)
+    A, n = W.shape
+    total = W[0].copy()
+    cum = []
+    for i in range(1, A):
+        cum.append(total.copy())
+        total = (total + W[i]).astype(np.float32)
+    u01 = ((np.asarray(bits, dtype=np.uint32) >> np.uint32(9)).astype(np.float32) * F32(2.0 ** -23)).astype(np.float32)
+    chosen = ((u01 * total).astype(np.float32) + F32(0.0)).astype(np.float32)
+    idx = np.zeros(n, dtype=np.int64)
+    for i, c in enumerate(cum):
+        idx = np.where(c <= chosen, i + 1, idx)
+    return idx

@@ -19,6 +19,7 @@ ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
 UPD_CLAMP_I64, UPD_WRAP_I32 = 0, 1
 LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
 CHANCE_PASS, CHANCE_ENUM = 0, 1
+OPP_FULL, OPP_SAMPLE = 0, 1
 T_I32, T_F32, T_F16 = 0, 1, 2
 F_F32, F_F16 = 0, 1
 PRUNE_THRESHOLD = -10000000
@@ -68,7 +69,7 @@ class Ctx(C.Structure):
         ("n_boards", C.c_uint32 * MAX_ROUNDS), ("n_clusters", C.c_uint32),
         ("leaves", C.POINTER(Leaf)),
         ("scale", C.c_float), ("mode", C.c_int), ("prune", C.c_int), ("rmplus", C.c_int),
-        ("chance_mode", C.c_int), ("ref_alloc", C.c_int),
+        ("chance_mode", C.c_int), ("opp_mode", C.c_int), ("sample_seed", C.c_uint64), ("ref_alloc", C.c_int),
     ]
 
 
@@ -132,6 +133,14 @@ def lib():
     for nm, pt in (("i32", i32p), ("f32", f32p)):
         getattr(L, "orc_table_set_node_" + nm).argtypes = [C.POINTER(Table), C.c_int, pt, pt]
         getattr(L, "orc_table_get_node_" + nm).argtypes = [C.POINTER(Table), C.c_int, pt, pt]
+    L.orc_splitmix64.argtypes = [C.c_uint64]
+    L.orc_splitmix64.restype = C.c_uint64
+    L.orc_sample_bits.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    L.orc_sample_bits.restype = C.c_uint32
+    L.orc_weighted_index.argtypes = [f32p, C.c_int, C.c_uint32]
+    L.orc_weighted_index.restype = C.c_int
+    L.orc_sweep_seed.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_sweep_seed.restype = C.c_uint64
     L.orc_iterate_mt.argtypes = [C.POINTER(Ctx), C.c_int, f32p, C.c_int]
     L.orc_run_iterations_mt.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_int]
     _lib = L
@@ -330,7 +339,7 @@ class OracleSolver:
     """Per-lane cfr.rs:481-627 recursion over an OracleTable."""
 
     def __init__(self, tree, table, leaves, scale=10000.0, mode=UPD_WRAP_I32, prune=False, rmplus=False,
-                 chance_mode=CHANCE_ENUM, ref_alloc=False):
+                 chance_mode=CHANCE_ENUM, ref_alloc=False, opp_mode=OPP_FULL, base_seed=0):
         """leaves: dict tree-node-id -> (kind, float32 array over that terminal's lanes or None)"""
         self.tree, self.table = tree, table
         self._keep = []
@@ -357,8 +366,12 @@ class OracleSolver:
         c.prune = int(prune)
         c.rmplus = int(rmplus)
         c.chance_mode = chance_mode
+        c.opp_mode = opp_mode
+        c.sample_seed = 0
         c.ref_alloc = int(ref_alloc)
         self.ctx = c
+        self.base_seed = base_seed
+        self.calls = 0          # mirrors the GPU solver: sweep k uses orc_sweep_seed(base_seed, k)
 
     def set_leaves(self, leaves):
         for nid, (kind, buf) in leaves.items():
@@ -368,7 +381,9 @@ class OracleSolver:
                 self._keep.append(b)
                 self._leaves[nid].buf = _f32(b)
 
-    def iterate(self, player, threads=1):
+    def iterate(self, player, threads=1, seed=None):
+        self.ctx.sample_seed = lib().orc_sweep_seed(self.base_seed, self.calls) if seed is None else seed
+        self.calls += 1
         n = self.table.n_boards[0] * self.table.n_clusters
         out = np.zeros(n, dtype=np.float32)
         if threads > 1:

@@ -616,6 +616,39 @@ float orc_update_infoset_rmplus(int32_t *regrets, int32_t *ssum, int n, const fl
  * lane traversal: cfr.rs:481-627 (and the terminal block :314-348) run once per lane
  * ==================================================================================== */
 
+/* ---- opponent sampling (restated rand 0.7 WeightedIndex over supplied bits, see rs_oracle.h) -------------- */
+uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+uint32_t orc_sample_bits(uint64_t seed, uint32_t node_index, uint64_t lane) {
+    uint64_t h = orc_splitmix64(seed ^ ((uint64_t)(node_index + 1u) * 0xD1B54A32D192ED03ull) ^ (lane * 0x9E3779B97F4A7C15ull));
+    return (uint32_t)(h >> 32);
+}
+
+uint64_t orc_sweep_seed(uint64_t base_seed, uint64_t call_index) {
+    return orc_splitmix64(base_seed + call_index * 0x632BE59BD9B4E019ull);
+}
+
+int orc_weighted_index(const float *weights, int n, uint32_t bits) {
+    float cumulative[ORC_MAX_ACTIONS];
+    float total_weight = weights[0];          /* WeightedIndex::new: first weight seeds the total */
+    float u01, chosen;
+    int i, idx = 0;
+    for (i = 1; i < n; i++) {
+        cumulative[i - 1] = total_weight;     /* weights.push(total_weight.clone()) */
+        total_weight += weights[i];
+    }
+    u01 = (float)(bits >> 9) * 1.1920928955078125e-07f;   /* (value1_2 - 1.0) with 23 random mantissa bits */
+    chosen = u01 * total_weight + 0.0f;                     /* value0_1 * scale + low */
+    for (i = 0; i < n - 1; i++)               /* binary_search_by(|w| if *w <= chosen {Less} else {Greater}).unwrap_err() */
+        if (cumulative[i] <= chosen) idx = i + 1;
+    return idx;
+}
+
 static uint32_t child_round_idx(const orc_tree *t, const orc_node *chance) {
     return t->nodes[chance->children[0]].round_idx;
 }
@@ -703,6 +736,10 @@ float orc_traverse(const orc_ctx *ctx, int node_id, int player, uint32_t b, uint
                                               ctx->scale, ctx->rmplus,
                                               ctx->table->dtype == ORC_T_F16 ? ORC_F_F16 : ORC_F_F32);
             }
+        } else if (ctx->opp_mode == ORC_OPP_SAMPLE) {
+            /* cfr.rs:467-476: sample one action from the strategy, recurse with cfr_reach * strategy[a_idx] */
+            int a_idx = orc_weighted_index(strategy, n_actions, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, cluster_idx));
+            util = orc_traverse(ctx, nd->children[a_idx], player, b, c, cfr_reach * strategy[a_idx]);
         } else {
             for (i = 0; i < n_actions; i++) {
                 utils[i] = orc_traverse(ctx, nd->children[i], player, b, c, strategy[i] * cfr_reach); /* cfr.rs:583-586 */

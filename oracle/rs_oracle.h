@@ -154,6 +154,8 @@ void orc_discount_table(orc_table *tb, float d);
 
 /* ---- lane traversal (cfr.rs:481-627 run once per lane, see DESIGN.md "lane model") ----- */
 enum { ORC_LEAF_UNCONTESTED = 0, ORC_LEAF_SIGN = 1, ORC_LEAF_UTIL = 2 };
+enum { ORC_OPP_FULL = 0,     /* cfr.rs:576-589: every opponent action recursed, reach * sigma[i], util = sum */
+       ORC_OPP_SAMPLE = 1 }; /* cfr.rs:467-476: ONE action sampled from sigma (WeightedIndex), reach * sigma[a], util = child's */
 enum { ORC_CHANCE_PASS = 0,   /* cfr.rs:306-313 (mccfr): go to child 0 */
        ORC_CHANCE_ENUM = 1 }; /* cfr.rs:502-522 (cfr): reach *= 1/len, util = sum over deals */
 
@@ -174,8 +176,24 @@ typedef struct {
     int prune;
     int rmplus;                         /* extension: floor regrets at 0 on write */
     int chance_mode;                    /* ORC_CHANCE_* */
+    int opp_mode;                       /* ORC_OPP_* */
+    uint64_t sample_seed;               /* ORC_OPP_SAMPLE: seed of this sweep's counter-based random bits */
     int ref_alloc;                      /* 1: allocate per visit like infoset.rs:85 / cfr.rs:372-373 (timed baseline) */
 } orc_ctx;
+
+/* ---- opponent sampling (cfr.rs:467-476) --------------------------------------------------------
+ * The reference draws from rand 0.7 (`WeightedIndex::new(&strategy)`, `dist.sample(rng)`, SmallRng seeded from
+ * thread_rng: not reproducible, cfr.rs:197,204).  rand is a crates.io dependency absent from the reference tree
+ * (Cargo.toml:23 `rand = "0.7"`); its published algorithm is restated here on a SUPPLIED raw u32:
+ *   WeightedIndex::new : cumulative[i] = w0 + .. + wi for i < n-1 (f32, sequential), total = sum of all
+ *   UniformFloat<f32>  : u01 = (bits >> 9) * 2^-23 ; chosen = u01 * total + 0.0   (scale == total for low = 0)
+ *   sample             : index = number of cumulative[i] <= chosen
+ * The raw bits come from a counter-based hash of (sweep seed, ActionNode.index, lane) so that the GPU and
+ * this oracle draw the same numbers. */
+uint64_t orc_splitmix64(uint64_t x);
+uint32_t orc_sample_bits(uint64_t seed, uint32_t node_index, uint64_t lane);
+int orc_weighted_index(const float *weights, int n, uint32_t bits);
+uint64_t orc_sweep_seed(uint64_t base_seed, uint64_t call_index);   /* seed of the k-th rs_iterate call */
 
 /* one lane, one traverser, from `node_id` with lane (board b, cluster c) at that node's round */
 float orc_traverse(const orc_ctx *ctx, int node_id, int player, uint32_t b, uint32_t c, float cfr_reach);

@@ -26,7 +26,7 @@ pub struct rs_node_desc { pub n_actions: u32, pub n_clusters: u32, pub n_boards:
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_leaf_desc { pub kind: i32, pub d_buf: *const f32 }
 #[repr(C)] #[derive(Clone, Copy)]
-pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32 }
+pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32, pub opp_mode: i32, pub sample_seed: u64 }
 
 pub const RS_I32: c_int = 0;
 pub const RS_UPD_CLAMP_I64: c_int = 0;   // cfr.rs:413-464

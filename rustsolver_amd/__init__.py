@@ -11,7 +11,7 @@ _BUILDING = "rustsolver_amd.build" in getattr(_sys, "orig_argv", [])
 
 from . import _lib  # noqa: E402
 from ._lib import (ACT_BET, ACT_CALL, ACT_CHECK, ACT_FOLD, ACT_RAISE, CHANCE_ENUM, CHANCE_PASS, F16, F32, I32,
-                   LEAF_SIGN, LEAF_UNCONTESTED, LEAF_UTIL, NODE_ACTION, NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE,
+                   LEAF_SIGN, LEAF_UNCONTESTED, LEAF_UTIL, OPP_FULL, OPP_SAMPLE, NODE_ACTION, NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE,
                    NODE_TERMINAL, TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED, UPD_CLAMP_I64, UPD_PRUNE, UPD_RMPLUS,
                    UPD_WRAP_I32, RsError)
 

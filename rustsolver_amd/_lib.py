@@ -16,6 +16,7 @@ I32, F32, F16 = 0, 1, 2
 UPD_CLAMP_I64, UPD_WRAP_I32, UPD_RMPLUS, UPD_PRUNE = 0, 1, 0x100, 0x200
 LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
 CHANCE_PASS, CHANCE_ENUM = 0, 1
+OPP_FULL, OPP_SAMPLE = 0, 1
 K_UPDATE, K_NODE_UTIL, K_REACH, K_CHANCE, K_DISCOUNT, K_STRATEGY, K_TREE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -49,7 +50,7 @@ class LeafDesc(C.Structure):
 
 class SolverParams(C.Structure):
     _fields_ = [("scale", C.c_float), ("mode", C.c_int32), ("chance_mode", C.c_int32), ("use_graph", C.c_int32),
-                ("fuse_subtrees", C.c_int32)]
+                ("fuse_subtrees", C.c_int32), ("opp_mode", C.c_int32), ("sample_seed", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -114,7 +115,7 @@ SYMBOLS = {
     "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
     "rs_jit_available": (C.c_int, []),
-    "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rs_profile_enable": (C.c_int, [_P, C.c_int]),
     "rs_profile_read": (C.c_int, [_P, C.POINTER(Profile)]),
     "rs_profile_reset": (C.c_int, [_P]),

@@ -172,15 +172,67 @@ __device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const f
     float util = 0.0f;
 #pragma unroll
     for (int a = 0; a < A; a++) util += u[a] * sig[a];
+    const bool active = !(reach != reach);   // NaN reach: lane not reached in sampled-opponent mode
     const float k = scale * reach;
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        float nr = r[a] + k * (u[a] - util);
-        if (rmplus && !(nr > 0.0f)) nr = 0.0f;
-        r[a] = nr;
-        s[a] = s[a] + k * sig[a];
+        if (active) {
+            float nr = r[a] + k * (u[a] - util);
+            if (rmplus && !(nr > 0.0f)) nr = 0.0f;
+            r[a] = nr;
+            s[a] = s[a] + k * sig[a];
+        }
     }
     return util;
+}
+
+// ---- opponent sampling: mccfr's `WeightedIndex::new(&strategy)` + `dist.sample(rng)` (cfr.rs:471-472) ------------
+// rand 0.7 restated over supplied raw bits (the reference's SmallRng is seeded from thread_rng and is not
+// reproducible): cumulative[i] = w0+..+wi (f32, sequential), total = sum; u01 = (bits >> 9) * 2^-23;
+// chosen = u01 * total + 0; index = number of cumulative[i] <= chosen.  The bits are a counter-based hash of
+// (sweep seed, ActionNode.index, lane), identical on the GPU and in the CPU oracle.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ unsigned sample_bits(unsigned long long seed, unsigned node_index, unsigned long long lane) {
+    const unsigned long long h =
+        splitmix64(seed ^ ((unsigned long long)(node_index + 1u) * 0xD1B54A32D192ED03ull) ^ (lane * 0x9E3779B97F4A7C15ull));
+    return (unsigned)(h >> 32);
+}
+__device__ __forceinline__ unsigned long long sweep_seed(unsigned long long base_seed, unsigned long long call_index) {
+    return splitmix64(base_seed + call_index * 0x632BE59BD9B4E019ull);
+}
+template <int A>
+__device__ __forceinline__ int weighted_index(const float (&w)[A], unsigned bits) {
+    float cumulative[A];
+    float total = w[0];
+#pragma unroll
+    for (int i = 1; i < A; i++) {
+        cumulative[i - 1] = total;
+        total += w[i];
+    }
+    const float u01 = (float)(bits >> 9) * 1.1920928955078125e-07f;
+    const float chosen = u01 * total + 0.0f;
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < A - 1; i++)
+        if (cumulative[i] <= chosen) idx = i + 1;
+    return idx;
+}
+// sampled action of 4 lanes of one opponent node
+template <int A>
+__device__ __forceinline__ void lanes_sample(const float (&sig)[A][kVecD], unsigned long long seed, unsigned node_index,
+                                             unsigned v, int (&a_s)[kVecD]) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        float w[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) w[a] = sig[a][j];
+        a_s[j] = weighted_index<A>(w, sample_bits(seed, node_index, (unsigned long long)v * kVecD + j));
+    }
 }
 
 // ---- 4-lane wrappers used by the tree-specialised (hipRTC) kernels ------------------------------------------

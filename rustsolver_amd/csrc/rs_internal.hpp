@@ -46,6 +46,7 @@ struct NodeJob {
     uint32_t pitch;           // elements
     float scale;
     int32_t n_actions;
+    uint32_t node_index;      // ActionNode.index: part of the opponent-sampling hash
 };
 
 // chance node: expand (top-down) / reduce (bottom-up) between a parent round and a child round
@@ -67,10 +68,12 @@ struct KernelCfg {
 
 hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
                          KernelCfg cfg, hipStream_t stream);
+// d_seed != nullptr selects the sampled-opponent form (cfr.rs:467-476) with *d_seed as the sweep seed
 hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
-                            KernelCfg cfg, hipStream_t stream);
+                            KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
 hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
-                        KernelCfg cfg, hipStream_t stream);
+                        KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
+hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
 hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);
 hipError_t launch_strategy(const void *src /*[A][pitch]*/, float *dst, uint32_t pitch, int n_actions, int dtype,
@@ -93,11 +96,12 @@ struct JitSubtree {
     std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
     std::vector<int> const_terms;  // terminal ids in the order of cval[]
     int max_actions = 0;
-    size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_cval = 0, off_reach_const = 0, off_scale = 0,
-           off_n_vec = 0, off_pitch = 0, args_size = 0;
+    size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_seed = 0, off_cval = 0, off_nidx = 0,
+           off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, args_size = 0;
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
-                      const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, JitSubtree &out);
+                      const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
+                      JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
 
 // opponent / read-only visit: util = sum_a u[a]*sigma[a] (cfr.rs:574,:588).  8A+4 bytes per lane.
 template <int A, int DT>
-__global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict__ jobs) {
+__global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict__ jobs, const uint64_t *__restrict__ d_seed) {
+    const bool sampled = d_seed != nullptr;
+    const unsigned long long seed = sampled ? *d_seed : 0ull;
     RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     using R = Row<DT>;
@@ -123,8 +125,14 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
             for (int a = 0; a < A; a++) rl[a] = r[a][j];
             regret_match<A, V>(rl, sig);
             float acc = 0.0f;
+            if (sampled) {   // cfr.rs:471-476: the value of the ONE sampled action
+                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)v * kVec + j));
 #pragma unroll
-            for (int a = 0; a < A; a++) acc += u[a][j] * sig[a];
+                for (int a = 0; a < A; a++) acc = (a == a_s) ? u[a][j] : acc;
+            } else {
+#pragma unroll
+                for (int a = 0; a < A; a++) acc += u[a][j] * sig[a];
+            }
             util[j] = acc;
         }
         store_f32_row(job.out_util, v, util);
@@ -133,7 +141,9 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
 
 // opponent reach, top-down: out_reach[a] = sigma[a] * reach (cfr.rs:585) for the children that need it
 template <int A, int DT>
-__global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jobs) {
+__global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jobs, const uint64_t *__restrict__ d_seed) {
+    const bool sampled = d_seed != nullptr;
+    const unsigned long long seed = sampled ? *d_seed : 0ull;
     RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
     using R = Row<DT>;
@@ -155,8 +165,14 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
 #pragma unroll
             for (int a = 0; a < A; a++) rl[a] = r[a][j];
             regret_match<A, V>(rl, sig);
+            if (sampled) {   // only the sampled action's subtree stays active (NaN reach = inactive lane)
+                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)v * kVec + j));
 #pragma unroll
-            for (int a = 0; a < A; a++) out[a][j] = sig[a] * reach[j];
+                for (int a = 0; a < A; a++) out[a][j] = (a == a_s) ? reach[j] * sig[a] : __builtin_nanf("");
+            } else {
+#pragma unroll
+                for (int a = 0; a < A; a++) out[a][j] = sig[a] * reach[j];
+            }
         }
 #pragma unroll
         for (int a = 0; a < A; a++)
@@ -271,11 +287,13 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
 }
 
 // ---- synthetic fills (bench / tests); mirrored in rustsolver_amd/synth.py ------------------------------------------
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
+// state = {base seed, call index, seed of the current sweep}: first launch of every sampled-opponent plan, so that
+// a captured hipGraph advances the sweep seed on every replay without any host involvement
+__global__ void k_next_seed(uint64_t *state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state[2] = sweep_seed(state[0], state[1]);
+        state[1] += 1;
+    }
 }
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_fill_random(void *__restrict__ dst, size_t n, uint64_t seed, int64_t lo,
@@ -362,24 +380,24 @@ hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uin
 }
 
 hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
-                            KernelCfg cfg, hipStream_t stream) {
+                            KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream) {
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
 #define RS_NU(A_)                                                                                  \
-    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_node_util<A_, RS_I32>), grid, block, 0, stream, d_jobs); \
-    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_node_util<A_, RS_F32>), grid, block, 0, stream, d_jobs); \
-    else hipLaunchKernelGGL((k_node_util<A_, RS_F16>), grid, block, 0, stream, d_jobs)
+    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_node_util<A_, RS_I32>), grid, block, 0, stream, d_jobs, d_seed); \
+    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_node_util<A_, RS_F32>), grid, block, 0, stream, d_jobs, d_seed); \
+    else hipLaunchKernelGGL((k_node_util<A_, RS_F16>), grid, block, 0, stream, d_jobs, d_seed)
     RS_DISPATCH_A(n_actions, RS_NU)
 #undef RS_NU
     return hipGetLastError();
 }
 
 hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
-                        KernelCfg cfg, hipStream_t stream) {
+                        KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream) {
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
 #define RS_RE(A_)                                                                              \
-    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_reach<A_, RS_I32>), grid, block, 0, stream, d_jobs); \
-    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_reach<A_, RS_F32>), grid, block, 0, stream, d_jobs); \
-    else hipLaunchKernelGGL((k_reach<A_, RS_F16>), grid, block, 0, stream, d_jobs)
+    if (cfg.dtype == RS_I32) hipLaunchKernelGGL((k_reach<A_, RS_I32>), grid, block, 0, stream, d_jobs, d_seed); \
+    else if (cfg.dtype == RS_F32) hipLaunchKernelGGL((k_reach<A_, RS_F32>), grid, block, 0, stream, d_jobs, d_seed); \
+    else hipLaunchKernelGGL((k_reach<A_, RS_F16>), grid, block, 0, stream, d_jobs, d_seed)
     RS_DISPATCH_A(n_actions, RS_RE)
 #undef RS_RE
     return hipGetLastError();
@@ -395,6 +413,11 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs
     return hipGetLastError();
 }
 
+
+hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {
+    hipLaunchKernelGGL(k_next_seed, dim3(1), dim3(64), 0, stream, d_state);
+    return hipGetLastError();
+}
 
 hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, int n_actions, int dtype, hipStream_t stream) {
     dim3 grid(grid_for(pitch / kVec)), block(kBlock);

@@ -20,7 +20,7 @@ using namespace rs;
 
 namespace {
 
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED };
 
 struct Launch {
     int kind;
@@ -74,6 +74,8 @@ struct rs_solver {
     uint32_t n_clusters = 0;
     size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
     int n_rounds = 0;
+    uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
+    const uint64_t *d_seed() const { return d_seed_state ? d_seed_state + 2 : nullptr; }
 };
 
 namespace {
@@ -234,6 +236,7 @@ struct Builder {
         job.scale = s->params.scale;
         job.reach = reach[id].ptr;
         job.reach_const = reach[id].cst;
+        job.node_index = uint32_t(nd.index);
     }
 
     double lanes(int id) const { return double(s->n_boards[lane_round[id]]) * s->n_clusters; }
@@ -283,6 +286,11 @@ struct Builder {
         std::vector<std::vector<int>> by_depth(max_depth + 1);
         for (size_t id = 0; id < n; ++id) by_depth[depth[id]].push_back(int(id));
 
+        if (s->params.opp_mode == RS_OPP_SAMPLE) {   // advance the sweep seed (part of the plan, hence of the hipGraph)
+            Launch L;
+            L.kind = L_SEED;
+            plan.launches.push_back(L);
+        }
         reach[0] = ReachSrc{nullptr, 1.0f, true};  // self.cfr(0, player, hand, 1f32, ..), cfr.rs:217
         // ---- top-down ------------------------------------------------------------------------------
         for (int d = 0; d <= max_depth; ++d) {
@@ -387,7 +395,8 @@ struct Builder {
                         leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
                     }
                     JitSubtree js;
-                    jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK, js);
+                    jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
+                                     s->params.opp_mode == RS_OPP_SAMPLE, js);
                     hipFunction_t fn = nullptr;
                     if (int rc = jit_get_kernel(js.source, t->device, &fn)) return rc;
                     auto bi = by_fn.find(fn);
@@ -409,6 +418,7 @@ struct Builder {
                         const rs_tree_node &an = nodes[js.node_ids[k]];
                         put_ptr(js.off_reg + 8 * k, t->regrets_ptr(an.index));
                         put_ptr(js.off_ssm + 8 * k, t->ssum_ptr(an.index));
+                        put_u32(js.off_nidx + 4 * k, uint32_t(an.index));
                         bytes += lanes(js.node_ids[k]) * an.n_children * es * (an.player == p ? 4.0 : 1.0);
                     }
                     for (size_t k = 0; k < js.leaf_terms.size(); ++k) put_ptr(js.off_leaf + 8 * k, s->leaves[p][js.leaf_terms[k]].d_buf);
@@ -419,6 +429,7 @@ struct Builder {
                     }
                     put_ptr(js.off_reach, reach[id].ptr);
                     put_ptr(js.off_out, aptr(util_off[id]));
+                    put_ptr(js.off_seed, s->d_seed());
                     put_f32(js.off_reach_const, reach[id].cst);
                     put_f32(js.off_scale, s->params.scale);
                     const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / kVec);
@@ -474,17 +485,21 @@ struct Builder {
 
 int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     rs_table *t = s->table;
-    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE};
+    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE};
+    if (L.kind == L_SEED) {
+        RS_HIP(launch_next_seed(s->d_seed_state, t->stream), "k_next_seed");
+        return RS_OK;
+    }
     prof_begin(t, prof_kind[L.kind], L.bytes);
     hipError_t e = hipSuccess;
     const NodeJob *jobs = plan.d_jobs + L.first_job;
     const KernelCfg cfg{t->dtype, s->params.mode};
     switch (L.kind) {
-    case L_REACH: e = launch_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_REACH: e = launch_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
     case L_PRUNE_REACH: e = launch_prune_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
     case L_EXPAND: e = launch_chance_expand(L.chance, t->stream); break;
     case L_UPDATE: e = launch_update(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
-    case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
     case L_REDUCE: e = launch_chance_reduce(L.chance, t->stream); break;
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
@@ -543,6 +558,9 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
     if (params->fuse_subtrees < 0 || params->fuse_subtrees > 1) return fail(RS_ERR_INVALID, "rs_solver_create: fuse_subtrees must be 0 or 1");
     if (params->fuse_subtrees && !jit_available())
         return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: fuse_subtrees needs libhiprtc.so (tree-specialised kernels); pass 0 for the level plan");
+    if (params->opp_mode != RS_OPP_FULL && params->opp_mode != RS_OPP_SAMPLE) return fail(RS_ERR_INVALID, "rs_solver_create: bad opp_mode");
+    if (params->opp_mode == RS_OPP_SAMPLE && params->chance_mode != RS_CHANCE_PASS)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: RS_OPP_SAMPLE is mccfr(), whose chance nodes pass through (cfr.rs:306-313): use RS_CHANCE_PASS");
     if (tree->nodes.empty() || tree->nodes[0].kind != RS_NODE_PRIVATE_CHANCE)
         return fail(RS_ERR_INVALID, "rs_solver_create: node 0 must be the private chance root (tree_builder.rs:60-66)");
 
@@ -573,6 +591,15 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
     if (e != hipSuccess) {
         delete s;
         return hip_fail(e, "hipSetDevice");
+    }
+    if (params->opp_mode == RS_OPP_SAMPLE) {
+        const uint64_t init[3] = {params->sample_seed, 0, 0};
+        if ((e = hipMalloc((void **)&s->d_seed_state, sizeof(init))) != hipSuccess ||
+            (e = hipMemcpy(s->d_seed_state, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: seed state");
+            rs_solver_destroy(s);
+            return rc;
+        }
     }
     Builder b0(s, 0), b1(s, 1);
     if ((rc = b0.build()) != RS_OK || (rc = b1.build()) != RS_OK) {
@@ -635,6 +662,7 @@ void rs_solver_destroy(rs_solver *s) {
             if (JL.d_blob) (void)hipFree(JL.d_blob);
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
+    if (s->d_seed_state) (void)hipFree(s->d_seed_state);
     delete s;
 }
 
@@ -673,7 +701,7 @@ int rs_jit_available(void) { return jit_available() ? 1 : 0; }
 
 // Generates and compiles (no GPU needed) the tree-specialised kernel of every chance-free subtree of `tree`, for
 // both traversers, assuming one shared sign buffer per round.  *n_kernels = distinct kernels.
-int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int *n_kernels) {
+int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels) {
     if (!tree || tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_jit_check_tree: bad tree");
     const std::vector<rs_tree_node> &nodes = tree->nodes;
     const size_t n = nodes.size();
@@ -701,7 +729,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int *n_kernels) 
             if (nd.kind != RS_NODE_ACTION || !closed[i]) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;

@@ -444,6 +444,7 @@ static void base_job(const rs_table *t, int node, NodeJob &job) {
     job.n_vec = uint32_t(t->pitch[node] / kVec);
     job.n_actions = int32_t(t->nodes[node].n_actions);
     job.reach_const = 1.0f;
+    job.node_index = uint32_t(node);
 }
 
 int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
@@ -517,7 +518,7 @@ int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_no
     if (int rc = stage_job(t, job)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_NODE_UTIL, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + 4.0));
-    hipError_t e = launch_node_util(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, t->stream);
+    hipError_t e = launch_node_util(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
     prof_end(t);
     RS_HIP(e, "k_node_util");
     return RS_OK;
@@ -534,7 +535,7 @@ int rs_child_reach(rs_table *t, int node, const float *d_reach, float *d_child_r
     if (int rc = stage_job(t, job)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_REACH, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + (d_reach ? 4.0 : 0.0)));
-    hipError_t e = launch_reach(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, t->stream);
+    hipError_t e = launch_reach(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
     prof_end(t);
     RS_HIP(e, "k_reach");
     return RS_OK;

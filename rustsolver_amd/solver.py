@@ -435,7 +435,7 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=True):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=True, opp_mode=L.OPP_FULL, sample_seed=0):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal"""
         self.game_tree, self.infosets = tree, infosets
         self._keep = [leaves, leaves_p1]
@@ -446,7 +446,7 @@ class MCCFRTrainer:
                 arr[nid].kind = kind
                 arr[nid].d_buf = buf.ptr
             arrs.append(arr)
-        p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees))
+        p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees), opp_mode, sample_seed)
         h = C.c_void_p()
         L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
         self._h = h
@@ -502,10 +502,10 @@ class MCCFRTrainer:
             pass
 
 
-def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64):
+def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64, opp_mode=L.OPP_FULL):
     """compile (no GPU needed) every tree-specialised kernel of `tree`; returns the number of distinct kernels"""
     n = C.c_int()
-    L.check(L.load().rs_jit_check_tree(tree._h, dtype, mode, C.byref(n)))
+    L.check(L.load().rs_jit_check_tree(tree._h, dtype, mode, opp_mode, C.byref(n)))
     return n.value
 
 

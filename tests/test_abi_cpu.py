@@ -148,5 +148,6 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     _, tree = rs.build_game_tree(rs.default_flop())
     assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64) == 2          # one kernel per traverser
     assert rs.jit_check_tree(tree, rs.F16, rs.UPD_CLAMP_I64) == 2
+    assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 2     # mccfr(): sampled opponent
     _, tree3 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5,), (1.0,)), raise_sizes=((3.0,), (3.0,))))
     assert rs.jit_check_tree(tree3, rs.I32, rs.UPD_WRAP_I32) >= 2

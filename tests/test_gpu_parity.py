@@ -344,6 +344,39 @@ def test_iterate_extension_dtypes_vs_oracle(dtype, fuse):
     compare_tables(tree, table, otab)
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("variant", ["river", "river+prune", "river-f32", "three-street"])
+def test_iterate_sampled_opponent_vs_oracle(fuse, graph, variant):
+    """mccfr(): opponent nodes draw ONE action from sigma with rand's WeightedIndex (cfr.rs:467-476); the
+    traverser update is cfr.rs:413-464 (clamp, scale 100).  Random bits = shared counter hash."""
+    prune = "prune" in variant
+    if variant == "three-street":
+        tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [3, 3, 3], 11, 71)
+    elif variant == "river-f32":
+        tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [2], 150, 72, rs.F32, orc.T_F32)
+    else:
+        tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [3], 333, 73)
+    scale = 1.0 if variant == "river-f32" else 100.0
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=rs.UPD_CLAMP_I64 | (rs.UPD_PRUNE if prune else 0),
+                         chance_mode=rs.CHANCE_PASS, use_graph=graph, fuse_subtrees=fuse, opp_mode=rs.OPP_SAMPLE, sample_seed=20261003)
+    osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=orc.UPD_CLAMP_I64, prune=prune, chance_mode=orc.CHANCE_PASS,
+                            opp_mode=orc.OPP_SAMPLE, base_seed=20261003)
+    for it in range(3):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player, threads=4)
+            assert_bits(got, want, "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+
+
+def test_sampled_mode_needs_pass_through_chance():
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [1, 2, 2], 4, 5)
+    with pytest.raises(rs.RsError) as e:
+        rs.MCCFRTrainer(tree, table, lg, chance_mode=rs.CHANCE_ENUM, opp_mode=rs.OPP_SAMPLE)
+    assert e.value.code == L.ERR_UNSUPPORTED
+
+
 def test_train_with_discount_schedule_vs_oracle():
     # cfr.rs:188-265 with a short interval so that several discount ticks happen
     tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [1], 64, 3)
