@@ -39,26 +39,47 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="replay each traverser sweep as one hipGraph")
     ap.add_argument("--fuse", type=int, default=1,
                     help="1: one tree-specialised (hipRTC) kernel per traverser sweep; 0: level-by-level node kernels")
+    ap.add_argument("--tree", choices=["river", "three-street"], default="river",
+                    help="river: options::default_flop() (BASELINE configs[1]); three-street: configs[2] (706 action nodes)")
+    ap.add_argument("--boards3", default="1,49,2352", help="--tree three-street: boards per round (flop,turn,river)")
+    ap.add_argument("--dtype", choices=["i32", "f32", "f16"], default="i32", help="table element type (f16 = BASELINE configs[4])")
+    ap.add_argument("--opp", choices=["full", "sample"], default="full", help="opponent nodes: cfr() full width or mccfr() sampled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1):
-    import numpy as np
-    n_actions, tree = rs.build_game_tree(rs.default_flop())
-    table = rs.create_infosets(n_actions, tree, [n_clusters], [n_boards], rs.I32, device)
-    # synthetic inputs generated on the device (SURVEY.md 8(d) config 2 distributions)
-    table.fill_random(seed, (-10**6, 10**6), (0, 10**6))
-    root = tree.nodes[tree.nodes[0].children[0]]
-    sign = table.lane_buffer(root.index, 1)
+def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full"):
+    """n_boards: int (river tree) or [flop, turn, river] (three-street tree)"""
     from rustsolver_amd import _lib as L
-    L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), seed + 17, -1.0, 1.0))
-    leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes)
-              if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
-    scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
-    trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=rs.CHANCE_PASS, use_graph=bool(graph),
-                              fuse_subtrees=int(fuse))
+    three = tree_kind == "three-street"
+    options = rs.three_street_options() if three else rs.default_flop()
+    boards = list(n_boards) if three else [n_boards]
+    dt = {"i32": rs.I32, "f32": rs.F32, "f16": rs.F16}[dtype]
+    n_actions, tree = rs.build_game_tree(options)
+    table = rs.create_infosets(n_actions, tree, [n_clusters], boards, dt, device)
+    # synthetic inputs generated on the device (SURVEY.md 8(d) config 2 / 3 distributions)
+    if dtype == "f16":
+        table.fill_random(seed, (-2000, 2000), (0, 2000))       # binary16 holds integers exactly up to 2048
+    else:
+        table.fill_random(seed, (-10**6, 10**6), (0, 10**6))
+    signs, leaves = {}, {}
+    for i, nd in enumerate(tree.nodes):
+        if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+            parent = tree.nodes[nd.parent]
+            r = parent.round_idx
+            if r not in signs:
+                signs[r] = table.lane_buffer(parent.index, 1)
+                L.check(L.load().rs_fill_uniform_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 17 + r, -1.0, 1.0))
+            leaves[i] = (rs.LEAF_SIGN, signs[r])
+    if dtype == "i32":
+        scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
+    else:
+        scale, m = 1.0, rs.UPD_CLAMP_I64
+    sampled = opp == "sample"
+    chance = rs.CHANCE_PASS if (not three or sampled) else rs.CHANCE_ENUM
+    trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=chance, use_graph=bool(graph),
+                              fuse_subtrees=int(fuse), opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
     table.sync()
     return trainer
 
@@ -111,7 +132,7 @@ def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
     import glob
-    if (a.boards, a.clusters, a.mode) != (9216, 1000, "clamp"):
+    if (a.boards, a.clusters, a.mode, a.tree, a.dtype, a.opp) != (9216, 1000, "clamp", "river", "i32", "full"):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_traffic_%s.json" % kernel)))
     if not files:
@@ -124,11 +145,18 @@ def pmc_traffic(a, kernel):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line: libraries that print banners there (RCCL's version block, hipRTC) are
+    # sent to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK / MASTER_ADDR set) use the process group even for one rank, so that the
+    # N > 1 code path can be exercised on a single-GPU box
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -140,7 +168,7 @@ def main():
     import rustsolver_amd as rs  # raises if the HIP library is missing (no fallback)
     if rs.device_count() < 1:
         raise RuntimeError("bench.py needs a GPU: the engine has no CPU fallback")
-    device = local_rank if world > 1 else 0
+    device = local_rank % max(1, rs.device_count())
 
     def barrier():
         trainer.infosets.sync()
@@ -149,7 +177,14 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    trainer = make_trainer(rs, a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse)
+    three = a.tree == "three-street"
+    boards3 = [int(x) for x in a.boards3.split(",")]
+    if three and a.opp == "sample":
+        boards3 = [boards3[-1]] * 3          # mccfr(): every lane is one full run-out (pass-through chance nodes)
+    trainer = make_trainer(rs, boards3 if three else a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse,
+                           a.tree, a.dtype, a.opp)
+    if three:
+        a.boards = boards3[-1]               # `value` counts river boards
     table = trainer.infosets
 
     # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides -------------
@@ -181,6 +216,12 @@ def main():
             dist.destroy_process_group()
         return
 
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj))
+        sys.stdout.flush()
+
     dom_name = "tree" if prof["tree"]["launches"] else "update"
     upd = prof[dom_name]
     achieved = upd["algo_bytes"] / (upd["ms"] * 1e-3) / 1e9 if upd["ms"] > 0 else 0.0
@@ -200,8 +241,8 @@ def main():
         obuf = table.lane_buffer(0, 1)
         L.check(lib.rs_fill_uniform_f32(table._h, ubuf.ptr, 3 * table.pitch(0), 5, -1035.0, 1035.0))
         L.check(lib.rs_fill_uniform_f32(table._h, rbuf.ptr, table.pitch(0), 6, 0.0, 1.0))
-        mode_flag = rs.UPD_CLAMP_I64 if a.mode == "clamp" else rs.UPD_WRAP_I32
-        scale = 100.0 if a.mode == "clamp" else 10000.0
+        mode_flag = rs.UPD_CLAMP_I64 if (a.mode == "clamp" or a.dtype != "i32") else rs.UPD_WRAP_I32
+        scale = (100.0 if a.mode == "clamp" else 10000.0) if a.dtype == "i32" else 1.0
         for _ in range(3):
             L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
         table.profile_reset()
@@ -211,7 +252,8 @@ def main():
         pu = table.profile_read()["update"]
         table.profile_enable(False)
         gbs = pu["algo_bytes"] / (pu["ms"] * 1e-3) / 1e9
-        upd_node = {"kernel": "rs::k_update<3> via rs_update_node (20A+8 = 68 B per lane, all inputs buffers)",
+        upd_node = {"kernel": "rs::k_update<3> via rs_update_node (%s per lane, all inputs buffers)" %
+                              ("20A+8 = 68 B" if a.dtype != "f16" else "12A+8 = 44 B"),
                     "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "launches": pu["launches"], "avg_launch_ms": pu["ms"] / max(1, pu["launches"]),
                     "algo_bytes_per_launch": pu["algo_bytes"] / max(1, pu["launches"])}
@@ -230,11 +272,15 @@ def main():
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i32", "data": "synthetic",
+        "dtype": a.dtype, "data": "synthetic",
         "config": {
-            "workload": "config2 river-only: 14-action-node tree of options::default_flop(), %d clusters, A in {2,3}, "
-                        "%d boards per GPU, i32 tables, %s update; 1 step = 1 CFR iteration (both traversers, all lanes)"
-                        % (a.clusters, a.boards, "cfr.rs:413-464 clamp scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap scale 10000"),
+            "workload": ("config2 river-only: 14-action-node tree of options::default_flop(), %d clusters, A in {2,3}, "
+                         "%d boards per GPU" % (a.clusters, a.boards) if not three else
+                         "config3 flop+turn+river: 706-action-node tree, %d clusters per round, boards %s per GPU"
+                         % (a.clusters, "/".join(str(b) for b in boards3))) +
+                        ", %s tables, %s update, opponent %s; 1 step = 1 CFR iteration (both traversers, all lanes)"
+                        % (a.dtype, "cfr.rs:413-464 clamp scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap scale 10000",
+                           "full width (cfr.rs:576-589)" if a.opp == "full" else "sampled (mccfr, cfr.rs:467-476)"),
             "n_boards_per_gpu": a.boards, "n_clusters": a.clusters, "lanes_per_gpu": a.boards * a.clusters,
             "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
             "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
@@ -254,12 +300,12 @@ def main():
         },
         "roofline_update_node": upd_node,
         "kernels": kernels,
-        "lane_updates_per_sec": a.boards * n_gpus * a.clusters * 14 * a.steps / elapsed,
+        "lane_updates_per_sec": sum(table.lanes(n) for n in range(table.n_nodes)) * n_gpus * a.steps / elapsed,
     }
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:
-        small = make_trainer(rs, 1, a.clusters, a.mode, 1, device, 99, a.fuse)
+        small = make_trainer(rs, [1, 1, 1] if three else 1, a.clusters, a.mode, 1, device, 99, a.fuse, a.tree, a.dtype, a.opp)
         run_steps(small, 20)
         small.infosets.sync()
         t0 = time.perf_counter()
@@ -275,8 +321,9 @@ def main():
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
+        os.dup2(2, 1)
         dist.destroy_process_group()
 
 

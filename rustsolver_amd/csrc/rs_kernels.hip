@@ -238,23 +238,29 @@ __global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ sr
 // ---- public chance nodes (cfr.rs:502-522) ----------------------------------------------------------------
 // top-down: child_cfr_reach = cfr_reach * (1.0 / len) for each of the `fan` deals of a parent board
 __global__ __launch_bounds__(kBlock) void k_chance_expand(ChanceJob job) {
+    // lane counts are < 2^31 per node (checked at table creation): 32-bit index math
     const uint32_t C = job.n_clusters, fan = job.fan;
-    const size_t n_child = (size_t)job.n_parent_lanes * fan;
-    for (size_t l = (size_t)blockIdx.x * kBlock + threadIdx.x; l < n_child; l += (size_t)gridDim.x * kBlock) {
-        const uint32_t bc = (uint32_t)(l / C), c = (uint32_t)(l % C);
+    const uint32_t n_child = job.n_parent_lanes * fan;
+    const float *__restrict__ src = job.src;
+    float *__restrict__ dst = job.dst;
+    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n_child; l += gridDim.x * kBlock) {
+        const uint32_t bc = l / C, c = l - bc * C;
         const uint32_t bp = bc / fan;
-        const float rp = job.src ? job.src[(size_t)bp * C + c] : job.src_const;
-        job.dst[l] = rp * job.inv;
+        const float rp = src ? src[bp * C + c] : job.src_const;
+        dst[l] = rp * job.inv;
     }
 }
 // bottom-up: util = 0 + u_0 + u_1 + ... in deal order (util.store(util.load() + u), cfr.rs:519)
 __global__ __launch_bounds__(kBlock) void k_chance_reduce(ChanceJob job) {
     const uint32_t C = job.n_clusters, fan = job.fan;
-    for (size_t l = (size_t)blockIdx.x * kBlock + threadIdx.x; l < job.n_parent_lanes; l += (size_t)gridDim.x * kBlock) {
-        const uint32_t b = (uint32_t)(l / C), c = (uint32_t)(l % C);
+    const float *__restrict__ src = job.src;
+    float *__restrict__ dst = job.dst;
+    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < job.n_parent_lanes; l += gridDim.x * kBlock) {
+        const uint32_t b = l / C, c = l - b * C;
+        const float *p = src + (size_t)b * fan * C + c;
         float acc = 0.0f;
-        for (uint32_t d = 0; d < fan; d++) acc = acc + job.src[((size_t)b * fan + d) * C + c];
-        job.dst[l] = acc;
+        for (uint32_t d = 0; d < fan; d++) acc = acc + p[(size_t)d * C];
+        dst[l] = acc;
     }
 }
 
