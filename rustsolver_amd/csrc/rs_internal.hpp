@@ -78,8 +78,8 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n
                               int n_actions, KernelCfg cfg, hipStream_t stream);
 hipError_t launch_strategy(const void *src /*[A][pitch]*/, float *dst, uint32_t pitch, int n_actions, int dtype,
                            hipStream_t stream);
-hipError_t launch_chance_expand(const ChanceJob &job, hipStream_t stream);
-hipError_t launch_chance_reduce(const ChanceJob &job, hipStream_t stream);
+hipError_t launch_chance_expand(const ChanceJob *d_jobs, int n_jobs, size_t max_child_lanes, bool vec4, hipStream_t stream);
+hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_parent_lanes, bool vec4, hipStream_t stream);
 hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream);
 hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
                               hipStream_t stream);

@@ -237,30 +237,54 @@ __global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ sr
 
 // ---- public chance nodes (cfr.rs:502-522) ----------------------------------------------------------------
 // top-down: child_cfr_reach = cfr_reach * (1.0 / len) for each of the `fan` deals of a parent board
-__global__ __launch_bounds__(kBlock) void k_chance_expand(ChanceJob job) {
+// All chance nodes of one tree depth share a launch (blockIdx.y = chance node).  VEC = 4 when n_clusters % 4 == 0:
+// 4 consecutive lanes then belong to one board and move as one 16-byte access.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_chance_expand(const ChanceJob *__restrict__ jobs) {
+    const ChanceJob job = jobs[blockIdx.y];
     // lane counts are < 2^31 per node (checked at table creation): 32-bit index math
     const uint32_t C = job.n_clusters, fan = job.fan;
-    const uint32_t n_child = job.n_parent_lanes * fan;
-    const float *__restrict__ src = job.src;
-    float *__restrict__ dst = job.dst;
-    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n_child; l += gridDim.x * kBlock) {
+    const uint32_t n_child = job.n_parent_lanes * fan / VEC;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_child; i += gridDim.x * kBlock) {
+        const uint32_t l = i * VEC;
         const uint32_t bc = l / C, c = l - bc * C;
         const uint32_t bp = bc / fan;
-        const float rp = src ? src[bp * C + c] : job.src_const;
-        dst[l] = rp * job.inv;
+        if constexpr (VEC == 4) {
+            float rp[4];
+            if (job.src) load_f32_row(job.src + (size_t)bp * C + c, 0, rp);
+            else rp[0] = rp[1] = rp[2] = rp[3] = job.src_const;
+            const float out[4] = {rp[0] * job.inv, rp[1] * job.inv, rp[2] * job.inv, rp[3] * job.inv};
+            store_f32_row(job.dst + l, 0, out);
+        } else {
+            const float rp = job.src ? job.src[(size_t)bp * C + c] : job.src_const;
+            job.dst[l] = rp * job.inv;
+        }
     }
 }
 // bottom-up: util = 0 + u_0 + u_1 + ... in deal order (util.store(util.load() + u), cfr.rs:519)
-__global__ __launch_bounds__(kBlock) void k_chance_reduce(ChanceJob job) {
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_chance_reduce(const ChanceJob *__restrict__ jobs) {
+    const ChanceJob job = jobs[blockIdx.y];
     const uint32_t C = job.n_clusters, fan = job.fan;
-    const float *__restrict__ src = job.src;
-    float *__restrict__ dst = job.dst;
-    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < job.n_parent_lanes; l += gridDim.x * kBlock) {
+    const uint32_t n_par = job.n_parent_lanes / VEC;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_par; i += gridDim.x * kBlock) {
+        const uint32_t l = i * VEC;
         const uint32_t b = l / C, c = l - b * C;
-        const float *p = src + (size_t)b * fan * C + c;
-        float acc = 0.0f;
-        for (uint32_t d = 0; d < fan; d++) acc = acc + p[(size_t)d * C];
-        dst[l] = acc;
+        const float *p = job.src + (size_t)b * fan * C + c;
+        if constexpr (VEC == 4) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t d = 0; d < fan; d++) {
+                float u[4];
+                load_f32_row(p + (size_t)d * C, 0, u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = acc[j] + u[j];
+            }
+            store_f32_row(job.dst + l, 0, acc);
+        } else {
+            float acc = 0.0f;
+            for (uint32_t d = 0; d < fan; d++) acc = acc + p[(size_t)d * C];
+            job.dst[l] = acc;
+        }
     }
 }
 
@@ -436,14 +460,16 @@ hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, int n_ac
     return hipGetLastError();
 }
 
-hipError_t launch_chance_expand(const ChanceJob &job, hipStream_t stream) {
-    dim3 grid(grid_for((size_t)job.n_parent_lanes * job.fan)), block(kBlock);
-    hipLaunchKernelGGL(k_chance_expand, grid, block, 0, stream, job);
+hipError_t launch_chance_expand(const ChanceJob *d_jobs, int n_jobs, size_t max_child_lanes, bool vec4, hipStream_t stream) {
+    dim3 grid(grid_for(max_child_lanes / (vec4 ? 4 : 1)), (uint32_t)n_jobs), block(kBlock);
+    if (vec4) hipLaunchKernelGGL((k_chance_expand<4>), grid, block, 0, stream, d_jobs);
+    else hipLaunchKernelGGL((k_chance_expand<1>), grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
-hipError_t launch_chance_reduce(const ChanceJob &job, hipStream_t stream) {
-    dim3 grid(grid_for(job.n_parent_lanes)), block(kBlock);
-    hipLaunchKernelGGL(k_chance_reduce, grid, block, 0, stream, job);
+hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_parent_lanes, bool vec4, hipStream_t stream) {
+    dim3 grid(grid_for(max_parent_lanes / (vec4 ? 4 : 1)), (uint32_t)n_jobs), block(kBlock);
+    if (vec4) hipLaunchKernelGGL((k_chance_reduce<4>), grid, block, 0, stream, d_jobs);
+    else hipLaunchKernelGGL((k_chance_reduce<1>), grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
 

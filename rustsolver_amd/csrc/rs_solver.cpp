@@ -27,7 +27,7 @@ struct Launch {
     int n_actions = 0;
     int first_job = 0, n_jobs = 0;
     uint32_t max_n_vec = 0;
-    ChanceJob chance{};
+    size_t max_lanes = 0;   // chance launches: largest lane count among the jobs
     double bytes = 0.0;
 };
 
@@ -49,6 +49,8 @@ struct JitLaunch {
 };
 
 struct Plan {
+    std::vector<ChanceJob> chance_jobs;   // L_EXPAND / L_REDUCE launches index into this (first_job, n_jobs)
+    ChanceJob *d_chance_jobs = nullptr;
     std::vector<JitLaunch> jit;
     std::vector<NodeJob> jobs;
     NodeJob *d_jobs = nullptr;
@@ -295,6 +297,9 @@ struct Builder {
         // ---- top-down ------------------------------------------------------------------------------
         for (int d = 0; d <= max_depth; ++d) {
             std::map<int, std::vector<int>> reach_groups, prune_groups;  // by n_actions
+            Launch LE;   // every ENUM chance node of this depth that has to expand a reach buffer
+            LE.kind = L_EXPAND;
+            LE.first_job = int(plan.chance_jobs.size());
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
                 if (nd.kind == RS_NODE_TERMINAL || fused_root[id] || inside[id]) continue;
@@ -318,15 +323,15 @@ struct Builder {
                 else if (own && prune) prune_groups[nd.n_children].push_back(id);
                 else if (chance_enum(nd)) {
                     const int c = nd.children[0];
-                    Launch L;
-                    L.kind = L_EXPAND;
                     const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
-                    L.chance = ChanceJob{reach[id].ptr, aptr(reach_off[c]), reach[id].cst, 1.0f / float(fan), fan, s->n_clusters,
-                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)};
-                    L.bytes = lanes(c) * 4.0 + lanes(id) * 4.0;
-                    plan.launches.push_back(L);
+                    plan.chance_jobs.push_back(ChanceJob{reach[id].ptr, aptr(reach_off[c]), reach[id].cst, 1.0f / float(fan), fan,
+                                                         s->n_clusters, uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)});
+                    LE.max_lanes = std::max(LE.max_lanes, size_t(lanes(c)));
+                    LE.bytes += lanes(c) * 4.0 + lanes(id) * 4.0;
                 }
             }
+            LE.n_jobs = int(plan.chance_jobs.size()) - LE.first_job;
+            if (LE.n_jobs) plan.launches.push_back(LE);
             for (int which = 0; which < 2; ++which) {
                 for (auto &g : (which == 0 ? reach_groups : prune_groups)) {
                     Launch L;
@@ -358,6 +363,9 @@ struct Builder {
         for (int d = max_depth; d >= 0; --d) {
             std::map<int, std::vector<int>> upd_groups, util_groups;
             std::vector<int> sub_roots;
+            Launch LR;   // every ENUM chance node of this depth
+            LR.kind = L_REDUCE;
+            LR.first_job = int(plan.chance_jobs.size());
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
                 if (inside[id]) continue;
@@ -370,15 +378,15 @@ struct Builder {
                     const int c = nd.children[0];
                     const ChildSrc src = child_source(c);
                     if (src.kind != CH_BUF) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: chance node above a terminal");
-                    Launch L;
-                    L.kind = L_REDUCE;
                     const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
-                    L.chance = ChanceJob{src.buf, aptr(util_off[id]), 0.0f, 0.0f, fan, s->n_clusters,
-                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)};
-                    L.bytes = lanes(c) * 4.0 + lanes(id) * 4.0;
-                    plan.launches.push_back(L);
+                    plan.chance_jobs.push_back(ChanceJob{src.buf, aptr(util_off[id]), 0.0f, 0.0f, fan, s->n_clusters,
+                                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)});
+                    LR.max_lanes = std::max(LR.max_lanes, size_t(lanes(id)));
+                    LR.bytes += lanes(c) * 4.0 + lanes(id) * 4.0;
                 }
             }
+            LR.n_jobs = int(plan.chance_jobs.size()) - LR.first_job;
+            if (LR.n_jobs) plan.launches.push_back(LR);
             if (!sub_roots.empty()) {
                 // tree-specialised kernels: subtrees of one shape share a kernel and a launch (blockIdx.y = subtree)
                 std::map<hipFunction_t, int> by_fn;
@@ -497,10 +505,14 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     switch (L.kind) {
     case L_REACH: e = launch_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
     case L_PRUNE_REACH: e = launch_prune_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
-    case L_EXPAND: e = launch_chance_expand(L.chance, t->stream); break;
+    case L_EXPAND:
+        e = launch_chance_expand(plan.d_chance_jobs + L.first_job, L.n_jobs, L.max_lanes, s->n_clusters % 4 == 0, t->stream);
+        break;
     case L_UPDATE: e = launch_update(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
     case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
-    case L_REDUCE: e = launch_chance_reduce(L.chance, t->stream); break;
+    case L_REDUCE:
+        e = launch_chance_reduce(plan.d_chance_jobs + L.first_job, L.n_jobs, L.max_lanes, s->n_clusters % 4 == 0, t->stream);
+        break;
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
         size_t blocks = (size_t(JL.max_n_vec) + kBlock - 1) / kBlock;
@@ -626,6 +638,13 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
             rs_solver_destroy(s);
             return rc;
         }
+        if ((e = hipMalloc((void **)&pl.d_chance_jobs, std::max<size_t>(pl.chance_jobs.size(), 1) * sizeof(ChanceJob))) != hipSuccess ||
+            (e = hipMemcpyAsync(pl.d_chance_jobs, pl.chance_jobs.data(), pl.chance_jobs.size() * sizeof(ChanceJob),
+                                hipMemcpyHostToDevice, table->stream)) != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: chance job upload");
+            rs_solver_destroy(s);
+            return rc;
+        }
         for (JitLaunch &JL : pl.jit) {
             if ((e = hipMalloc((void **)&JL.d_blob, JL.blob.size())) != hipSuccess ||
                 (e = hipMemcpyAsync(JL.d_blob, JL.blob.data(), JL.blob.size(), hipMemcpyHostToDevice, table->stream)) != hipSuccess) {
@@ -658,6 +677,7 @@ void rs_solver_destroy(rs_solver *s) {
         if (s->plan[p].graph_exec) (void)hipGraphExecDestroy(s->plan[p].graph_exec);
         if (s->plan[p].graph) (void)hipGraphDestroy(s->plan[p].graph);
         if (s->plan[p].d_jobs) (void)hipFree(s->plan[p].d_jobs);
+        if (s->plan[p].d_chance_jobs) (void)hipFree(s->plan[p].d_chance_jobs);
         for (JitLaunch &JL : s->plan[p].jit)
             if (JL.d_blob) (void)hipFree(JL.d_blob);
     }

@@ -314,8 +314,9 @@ def test_iterate_river_tree_vs_oracle(C, B, mode, graph, fuse):
 
 @pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([1, 1, 1], "enum"), ([2, 2, 2], "pass"), ([1, 3, 3], "enum")])
 @pytest.mark.parametrize("fuse", [1, 0])
-def test_iterate_three_street_tree_vs_oracle(boards, chance, fuse):
-    C = 9
+@pytest.mark.parametrize("C", [9, 8])
+def test_iterate_three_street_tree_vs_oracle(boards, chance, fuse, C):
+    # C = 8 takes the 16-byte chance kernels (n_clusters % 4 == 0), C = 9 the scalar ones
     tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), boards, C, 42)
     cm_g, cm_o = (rs.CHANCE_ENUM, orc.CHANCE_ENUM) if chance == "enum" else (rs.CHANCE_PASS, orc.CHANCE_PASS)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=cm_g, fuse_subtrees=fuse)
