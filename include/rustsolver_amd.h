@@ -235,6 +235,21 @@ typedef struct rs_solver_params {
  * pass the same array twice unless RS_LEAF_UTIL buffers differ per traverser. */
 int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
                      const rs_solver_params *params, rs_solver **out);   /* MCCFRTrainer::init, cfr.rs:159-184 */
+/* Deal batches: lanes are DEALS.  Every deal carries, per (round_idx, player), the dense cluster id that
+ * ICardAbstraction::get_cluster() returned for it (card_abstraction.rs:204-209, :245-251, :287-293; cfr.rs:361-365) and
+ * the table keeps the reference's own shape  infosets[an.index][cluster_idx]  (n_boards = 1; cluster counts may differ
+ * per player and round).  Several deals of a batch may address the same info set, which the reference lets race
+ * (cfr.rs:414); here the sweep is BATCH-SYNCHRONOUS and deterministic: every deal reads the table as it was when the
+ * sweep started, its update becomes the i32 delta (new - old) against the value it read, deltas are accumulated with
+ * atomic adds (wrapping, order-independent) and applied when the sweep ends.  RS_I32 tables, RS_CHANCE_PASS (one run-out
+ * per deal, cfr.rs:306-313).  Leaf buffers and d_root_util hold one float per deal, pitch = round_up(n_deals, 64);
+ * cluster-id vectors have the same pitch (padding ignored). */
+typedef struct rs_deal_batch {
+    uint32_t n_deals;
+    const uint32_t *d_cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS];   /* device; [round_idx][player] */
+} rs_deal_batch;
+int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
+                           const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out);
 void rs_solver_destroy(rs_solver *solver);
 /* one traverser sweep over every lane: `self.cfr(0, player, hand, 1f32, ..)` (cfr.rs:217) for all lanes.
  * d_root_util[pitch of the root round] (NULL = discard) receives the value returned at node 0. */
@@ -247,6 +262,24 @@ int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fus
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
 int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
+
+/* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------
+ * The canonical hand index comes from rust_poker's hand_indexer_s (third party, out of scope) and is an INPUT here. */
+typedef struct rs_dense_map rs_dense_map;
+/* bucket files: flat little-endian u32 per canonical hand index (gen_abstraction/main.rs:372-380 writes,
+ * card_abstraction.rs:227-229 / :269-271 read).  *out is malloc'ed: release it with rs_free_u32. */
+int rs_cluster_file_read(const char *path, uint32_t **out, size_t *n_out);
+int rs_cluster_file_write(const char *path, const uint32_t *clusters, size_t n);   /* fails if the file exists (create_new) */
+void rs_free_u32(uint32_t *p);
+/* index_to_cluster (card_abstraction.rs:20-29); cluster_arr = NULL is the ISOMORPHIC abstraction (bucket = index) */
+int rs_index_to_cluster(const uint32_t *cluster_arr, size_t arr_len, const uint64_t *indices, size_t n, uint64_t *out);
+/* dense ids 0..size: generate_maps (card_abstraction.rs:75-184) in first-appearance order of `buckets` (the reference's
+ * channel-arrival order is nondeterministic) */
+int rs_dense_map_create(const uint64_t *buckets, size_t n, rs_dense_map **out);
+void rs_dense_map_destroy(rs_dense_map *map);
+size_t rs_dense_map_size(const rs_dense_map *map);                                  /* get_size, card_abstraction.rs:211-213 */
+int rs_dense_map_lookup(const rs_dense_map *map, const uint64_t *buckets, size_t n, uint32_t *dense_out); /* get_cluster's map step */
+int rs_dense_map_keys(const rs_dense_map *map, uint64_t *keys_out);                 /* dense id -> bucket, size() entries */
 
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
 enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,

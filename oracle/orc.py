@@ -63,6 +63,10 @@ class Leaf(C.Structure):
     _fields_ = [("kind", C.c_int), ("buf", C.POINTER(C.c_float))]
 
 
+class DealCtx(C.Structure):
+    pass
+
+
 class Ctx(C.Structure):
     _fields_ = [
         ("tree", C.POINTER(Tree)), ("table", C.POINTER(Table)),
@@ -71,6 +75,10 @@ class Ctx(C.Structure):
         ("scale", C.c_float), ("mode", C.c_int), ("prune", C.c_int), ("rmplus", C.c_int),
         ("chance_mode", C.c_int), ("opp_mode", C.c_int), ("sample_seed", C.c_uint64), ("ref_alloc", C.c_int),
     ]
+
+
+DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
+                    ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t)]
 
 
 def build(force=False):
@@ -141,6 +149,11 @@ def lib():
     L.orc_weighted_index.restype = C.c_int
     L.orc_sweep_seed.argtypes = [C.c_uint64, C.c_uint64]
     L.orc_sweep_seed.restype = C.c_uint64
+    L.orc_traverse_deal.argtypes = [C.POINTER(DealCtx), C.c_int, C.c_int, C.c_size_t, C.c_float]
+    L.orc_traverse_deal.restype = C.c_float
+    L.orc_iterate_deals.argtypes = [C.POINTER(DealCtx), C.c_int, f32p]
+    L.orc_table_create_sizes.argtypes = [C.POINTER(Tree), C.POINTER((C.c_uint32 * 2) * MAX_ROUNDS), C.c_int, C.POINTER(Table)]
+    L.orc_table_create_sizes.restype = C.c_int
     L.orc_iterate_mt.argtypes = [C.POINTER(Ctx), C.c_int, f32p, C.c_int]
     L.orc_run_iterations_mt.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_int]
     _lib = L
@@ -397,3 +410,56 @@ class OracleSolver:
 
     def train(self, iterations, discount_interval=100000, discount_cap=20000000):
         lib().orc_train(C.byref(self.ctx), iterations, discount_interval, discount_cap)
+
+
+class OracleDealTable(OracleTable):
+    """The reference's own table shape: [action_node][cluster], sizes per (round_idx, player) (infoset.rs:28-32)."""
+
+    def __init__(self, tree, sizes):
+        """sizes[round_idx] = (size_p0, size_p1)"""
+        self.tree = tree
+        self.sizes = [tuple(s) for s in sizes] + [(0, 0)] * (MAX_ROUNDS - len(sizes))
+        self.n_boards = [1] * MAX_ROUNDS
+        self.n_clusters = 0
+        self.dtype = T_I32
+        self.tb = Table()
+        arr = ((C.c_uint32 * 2) * MAX_ROUNDS)()
+        for r in range(MAX_ROUNDS):
+            arr[r][0], arr[r][1] = self.sizes[r]
+        if lib().orc_table_create_sizes(C.byref(tree.t), C.byref(arr), T_I32, C.byref(self.tb)) != 0:
+            raise MemoryError
+        self._node_by_index = {}
+        for i in range(tree.n_nodes):
+            n = tree.node(i)
+            if n.kind == ACTION:
+                self._node_by_index[n.index] = (n.n_children, n.round_idx, n.player)
+
+    def node_shape(self, index):
+        a, r, p = self._node_by_index[index]
+        return a, self.sizes[r][p]
+
+
+class OracleDealSolver(OracleSolver):
+    """Batch-synchronous deal sweeps (orc_iterate_deals)."""
+
+    def __init__(self, tree, table, leaves, cidx, n_deals, **kw):
+        """cidx: dict (round_idx, player) -> uint32 array [n_deals]"""
+        super().__init__(tree, table, leaves, chance_mode=CHANCE_PASS, **kw)
+        self.delta = OracleDealTable(tree, table.sizes)
+        self.n_deals = n_deals
+        dc = DealCtx()
+        dc.ctx = C.pointer(self.ctx)
+        dc.delta = C.pointer(self.delta.tb)
+        dc.n_deals = n_deals
+        for (r, p), arr in cidx.items():
+            a = np.ascontiguousarray(arr, dtype=np.uint32)
+            self._keep.append(a)
+            dc.cidx[r][p] = a.ctypes.data_as(C.POINTER(C.c_uint32))
+        self.dc = dc
+
+    def iterate(self, player, threads=1, seed=None):
+        self.ctx.sample_seed = lib().orc_sweep_seed(self.base_seed, self.calls) if seed is None else seed
+        self.calls += 1
+        out = np.zeros(self.n_deals, dtype=np.float32)
+        lib().orc_iterate_deals(C.byref(self.dc), player, _f32(out))
+        return out

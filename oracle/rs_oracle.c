@@ -754,6 +754,74 @@ float orc_traverse(const orc_ctx *ctx, int node_id, int player, uint32_t b, uint
     }
 }
 
+/* ======================================================================================
+ * deal batches: cfr.rs:299-479 / :481-627 with real get_cluster() addressing, batch-synchronous
+ * ==================================================================================== */
+float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach) {
+    const orc_ctx *ctx = dc->ctx;
+    const orc_tree *t = ctx->tree;
+    const orc_node *nd = &t->nodes[node_id];
+    if (nd->kind == ORC_PRIVATE_CHANCE || nd->kind == ORC_PUBLIC_CHANCE) /* cfr.rs:306-313: one run-out per deal */
+        return orc_traverse_deal(dc, nd->children[0], player, deal, cfr_reach);
+    if (nd->kind == ORC_TERMINAL) return terminal_value(ctx, node_id, nd, player, deal);
+    {
+        int n_actions = nd->n_children, i;
+        /* let cluster_idx = card_abs[round_idx].get_cluster(&hand.board, an.player), cfr.rs:361-365 */
+        size_t cluster_idx = dc->cidx[nd->round_idx][nd->player][deal];
+        const orc_infoset *infoset = &ctx->table->rows[nd->index][cluster_idx];
+        orc_infoset *dinfo = &dc->delta->rows[nd->index][cluster_idx];
+        float utils[ORC_MAX_ACTIONS], strategy[ORC_MAX_ACTIONS], util = 0.0f;
+        orc_get_strategy(infoset->regrets, n_actions, strategy);
+        if (nd->player == player) {
+            int32_t r[ORC_MAX_ACTIONS], s[ORC_MAX_ACTIONS];
+            for (i = 0; i < n_actions; i++) {
+                if (ctx->prune && !(infoset->regrets[i] > ORC_PRUNE_THRESHOLD)) {
+                    utils[i] = 0.0f;
+                    continue;
+                }
+                utils[i] = orc_traverse_deal(dc, nd->children[i], player, deal, cfr_reach);
+            }
+            memcpy(r, infoset->regrets, (size_t)n_actions * sizeof(int32_t));
+            memcpy(s, infoset->strategy_sum, (size_t)n_actions * sizeof(int32_t));
+            if (ctx->rmplus) util = orc_update_infoset_rmplus(r, s, n_actions, utils, cfr_reach, ctx->scale);
+            else util = orc_update_infoset(r, s, n_actions, utils, cfr_reach, ctx->scale, ctx->mode, ctx->prune);
+            for (i = 0; i < n_actions; i++) { /* delta against the snapshot value, accumulated with wrapping adds */
+                dinfo->regrets[i] = wrapping_add_i32(dinfo->regrets[i], (int32_t)((uint32_t)r[i] - (uint32_t)infoset->regrets[i]));
+                dinfo->strategy_sum[i] =
+                    wrapping_add_i32(dinfo->strategy_sum[i], (int32_t)((uint32_t)s[i] - (uint32_t)infoset->strategy_sum[i]));
+            }
+        } else if (ctx->opp_mode == ORC_OPP_SAMPLE) { /* cfr.rs:467-476; the hash lane is the deal */
+            int a_idx = orc_weighted_index(strategy, n_actions, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, deal));
+            util = orc_traverse_deal(dc, nd->children[a_idx], player, deal, cfr_reach * strategy[a_idx]);
+        } else {
+            for (i = 0; i < n_actions; i++) {
+                utils[i] = orc_traverse_deal(dc, nd->children[i], player, deal, strategy[i] * cfr_reach);
+                util += utils[i] * strategy[i];
+            }
+        }
+        return util;
+    }
+}
+
+void orc_iterate_deals(const orc_deal_ctx *dc, int player, float *root_util) {
+    size_t d, j;
+    int i, k;
+    for (d = 0; d < dc->n_deals; d++) {
+        float u = orc_traverse_deal(dc, 0, player, d, 1.0f);
+        if (root_util) root_util[d] = u;
+    }
+    for (i = 0; i < dc->ctx->table->n_rows; i++)
+        for (j = 0; j < dc->ctx->table->row_len[i]; j++) {
+            orc_infoset *is = &dc->ctx->table->rows[i][j], *di = &dc->delta->rows[i][j];
+            for (k = 0; k < is->n_actions; k++) {
+                is->regrets[k] = wrapping_add_i32(is->regrets[k], di->regrets[k]);
+                is->strategy_sum[k] = wrapping_add_i32(is->strategy_sum[k], di->strategy_sum[k]);
+                di->regrets[k] = 0;
+                di->strategy_sum[k] = 0;
+            }
+        }
+}
+
 void orc_iterate_range(const orc_ctx *ctx, int player, size_t lane_lo, size_t lane_hi, float *root_util) {
     size_t lane;
     for (lane = lane_lo; lane < lane_hi; lane++) {

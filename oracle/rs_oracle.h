@@ -198,6 +198,23 @@ uint64_t orc_sweep_seed(uint64_t base_seed, uint64_t call_index);   /* seed of t
 /* one lane, one traverser, from `node_id` with lane (board b, cluster c) at that node's round */
 float orc_traverse(const orc_ctx *ctx, int node_id, int player, uint32_t b, uint32_t c, float cfr_reach);
 
+/* ---- deal batches: get-infoset addressing through cluster ids -----------------------------------
+ * A lane is a DEAL: per (round_idx, player) it carries the dense cluster id that get_cluster() returned
+ * (cfr.rs:361-365); the table has the reference's own shape [action_node][cluster] (n_boards = 1, sizes may differ
+ * per player).  Several deals of one batch may address the same info set.  The reference lets its 8 threads race
+ * on such cells (cfr.rs:414); the deterministic restatement is BATCH-SYNCHRONOUS: every deal reads the table as it
+ * was when the sweep started, its update is turned into a delta (new - old, wrapping i32) against that snapshot
+ * value, deltas are summed with wrapping adds (order-independent) and applied when the sweep ends. */
+typedef struct {
+    const orc_ctx *ctx;                  /* table = the snapshot being read; n_boards ignored */
+    orc_table *delta;                    /* same shape as ctx->table, i32, zero at sweep start */
+    const uint32_t *cidx[ORC_MAX_ROUNDS][ORC_MAX_PLAYERS];   /* [n_deals] each */
+    size_t n_deals;
+} orc_deal_ctx;
+float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach);
+/* one traverser sweep over all deals, then table += delta (wrapping), delta = 0 */
+void orc_iterate_deals(const orc_deal_ctx *dc, int player, float *root_util);
+
 /* all root lanes for one traverser; root_util (may be NULL) gets n_boards[0]*n_clusters values */
 void orc_iterate(const orc_ctx *ctx, int player, float *root_util);
 /* same, lanes [lane_lo, lane_hi) of the root round only -- for threaded / sharded callers */

@@ -104,3 +104,33 @@ void orc_table_get_node_f32(const orc_table *tb, int index, float *regrets, floa
         }
     }
 }
+
+
+/* create_infosets (infoset.rs:8-49) with the reference's own sizes: card_abs[round_idx].get_size(player) */
+static int create_sizes_rec(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUNDS][2], orc_table *tb, int node_id) {
+    const orc_node *nd = &t->nodes[node_id];
+    int i;
+    if (nd->kind == ORC_ACTION) {
+        size_t n = sizes[nd->round_idx][nd->player], k;
+        tb->rows[nd->index] = (orc_infoset *)calloc(n ? n : 1, sizeof(orc_infoset));
+        tb->row_len[nd->index] = n;
+        for (k = 0; k < n; k++) {
+            orc_infoset *is = &tb->rows[nd->index][k];
+            is->n_actions = nd->n_children;
+            is->regrets = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
+            is->strategy_sum = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
+            if (!is->regrets || !is->strategy_sum) return -1;
+        }
+    }
+    for (i = 0; i < nd->n_children; i++)
+        if (create_sizes_rec(t, sizes, tb, nd->children[i]) != 0) return -1;
+    return 0;
+}
+int orc_table_create_sizes(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUNDS][2], int dtype, orc_table *out) {
+    out->n_rows = t->n_action_nodes;
+    out->dtype = dtype;
+    out->rows = (orc_infoset **)calloc((size_t)out->n_rows, sizeof(orc_infoset *));
+    out->row_len = (size_t *)calloc((size_t)out->n_rows, sizeof(size_t));
+    if (!out->rows || !out->row_len || dtype != ORC_T_I32) return -1;
+    return create_sizes_rec(t, sizes, out, 0);
+}

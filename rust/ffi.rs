@@ -28,6 +28,9 @@ pub struct rs_leaf_desc { pub kind: i32, pub d_buf: *const f32 }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32, pub opp_mode: i32, pub sample_seed: u64 }
 
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct rs_deal_batch { pub n_deals: u32, pub d_cluster: [[*const u32; 2]; RS_MAX_ROUNDS] }
+
 pub const RS_I32: c_int = 0;
 pub const RS_UPD_CLAMP_I64: c_int = 0;   // cfr.rs:413-464
 pub const RS_UPD_WRAP_I32: c_int = 1;    // cfr.rs:612-621
@@ -57,6 +60,9 @@ extern "C" {
     pub fn rs_solver_create(table: *mut rs_table, tree: *const rs_tree, leaves_p0: *const rs_leaf_desc,
                             leaves_p1: *const rs_leaf_desc, params: *const rs_solver_params,
                             out: *mut *mut rs_solver) -> c_int;
+    pub fn rs_solver_create_deals(table: *mut rs_table, tree: *const rs_tree, deals: *const rs_deal_batch,
+                                  leaves_p0: *const rs_leaf_desc, leaves_p1: *const rs_leaf_desc,
+                                  params: *const rs_solver_params, out: *mut *mut rs_solver) -> c_int;
     pub fn rs_solver_destroy(solver: *mut rs_solver);
     pub fn rs_iterate(solver: *mut rs_solver, traverser: c_int, d_root_util: *mut f32) -> c_int;
     pub fn rs_train(solver: *mut rs_solver, iterations: u64, discount_interval: u64, discount_cap: u64) -> c_int;

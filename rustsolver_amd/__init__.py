@@ -19,9 +19,11 @@ if not _BUILDING:
     _lib.load()  # ImportError if librustsolver_amd.so is missing
 
 from .solver import (DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
-                     build_game_tree, create_infosets, default_flop, device_count, discount_factor, jit_check_tree,
+                     build_game_tree, create_infosets, deal_buffer, deal_pitch, default_flop, device_count, discount_factor,
+                     jit_check_tree,
                      three_street_options, tree_from_nodes)
 from . import synth  # noqa: E402
+from . import abstraction  # noqa: E402
 
 __all__ = ["Options", "default_flop", "three_street_options", "build_game_tree", "tree_from_nodes", "create_infosets",
            "InfosetTable", "Infoset", "GameTree", "MCCFRTrainer", "DeviceBuffer", "device_count", "discount_factor",

@@ -48,6 +48,10 @@ class LeafDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d_buf", C.c_void_p)]
 
 
+class DealBatch(C.Structure):
+    _fields_ = [("n_deals", C.c_uint32), ("d_cluster", (C.c_void_p * MAX_PLAYERS) * MAX_ROUNDS)]
+
+
 class SolverParams(C.Structure):
     _fields_ = [("scale", C.c_float), ("mode", C.c_int32), ("chance_mode", C.c_int32), ("use_graph", C.c_int32),
                 ("fuse_subtrees", C.c_int32), ("opp_mode", C.c_int32), ("sample_seed", C.c_uint64)]
@@ -109,6 +113,8 @@ SYMBOLS = {
     "rs_discount": (C.c_int, [_P, C.c_float]),
     "rs_discount_factor": (C.c_float, [C.c_uint64, C.c_uint64]),
     "rs_solver_create": (C.c_int, [_P, _P, C.POINTER(LeafDesc), C.POINTER(LeafDesc), C.POINTER(SolverParams), _PP]),
+    "rs_solver_create_deals": (C.c_int, [_P, _P, C.POINTER(DealBatch), C.POINTER(LeafDesc), C.POINTER(LeafDesc),
+                                        C.POINTER(SolverParams), _PP]),
     "rs_solver_destroy": (None, [_P]),
     "rs_iterate": (C.c_int, [_P, C.c_int, _P]),
     "rs_train": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -116,6 +122,15 @@ SYMBOLS = {
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
     "rs_jit_available": (C.c_int, []),
     "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rs_cluster_file_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]),
+    "rs_cluster_file_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.c_size_t]),
+    "rs_free_u32": (None, [C.POINTER(C.c_uint32)]),
+    "rs_index_to_cluster": (C.c_int, [C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64)]),
+    "rs_dense_map_create": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t, _PP]),
+    "rs_dense_map_destroy": (None, [_P]),
+    "rs_dense_map_size": (C.c_size_t, [_P]),
+    "rs_dense_map_lookup": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint32)]),
+    "rs_dense_map_keys": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rs_profile_enable": (C.c_int, [_P, C.c_int]),
     "rs_profile_read": (C.c_int, [_P, C.POINTER(Profile)]),
     "rs_profile_reset": (C.c_int, [_P]),

@@ -116,6 +116,35 @@ __device__ __forceinline__ void sign_to_util(float (&x)[kVecD], bool p1, float p
     }
 }
 
+// ---- deal batches: get-infoset addressing through per-lane cluster ids (cfr.rs:361-375) -------------------------
+// A lane is a deal; idx[j] is the dense cluster id get_cluster() returned for the acting player on this round.
+// Reads gather from the table (i32 only), writes become atomic adds of (new - old) into a delta table that is
+// applied after the sweep: several deals may hit one info set, integer adds commute, so the result is deterministic.
+__device__ __forceinline__ void load_u32_row(const unsigned *base, unsigned v, unsigned (&out)[kVecD]) {
+    const i32x4 x = *(as_global<i32x4>(base) + v);
+    out[0] = (unsigned)x.x; out[1] = (unsigned)x.y; out[2] = (unsigned)x.z; out[3] = (unsigned)x.w;
+}
+__device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, const unsigned (&idx)[kVecD], int (&out)[kVecD]) {
+    const RS_GLOBAL int *p = as_global<int>((const int *)base + row_off);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) out[j] = p[idx[j]];
+}
+__device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, const unsigned (&idx)[kVecD], const int (&now)[kVecD],
+                                                const int (&before)[kVecD]) {
+    RS_GLOBAL int *p = as_global<int>((int *)base + row_off);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        const int delta = (int)((unsigned)now[j] - (unsigned)before[j]);
+        if (delta != 0) __hip_atomic_fetch_add(p + idx[j], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// lanes past the end of the batch (pitch padding) must not touch the table: mark them inactive
+__device__ __forceinline__ void mask_tail_lanes(float (&reach)[kVecD], unsigned v, unsigned n_lanes) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++)
+        if (v * kVecD + j >= n_lanes) reach[j] = __builtin_nanf("");
+}
+
 // ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
 template <int A, typename V>
 __device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {

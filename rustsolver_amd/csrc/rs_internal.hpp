@@ -47,6 +47,11 @@ struct NodeJob {
     float scale;
     int32_t n_actions;
     uint32_t node_index;      // ActionNode.index: part of the opponent-sampling hash
+    // deal batches (lanes = deals): table rows are gathered through cidx and updated through atomic deltas
+    const uint32_t *cidx;     // [lane pitch] dense cluster id of the acting player on this round, or nullptr
+    void *dreg;               // delta rows matching regrets / ssum
+    void *dssm;
+    uint32_t n_lanes;         // deals in the batch (lanes beyond are padding)
 };
 
 // chance node: expand (top-down) / reduce (bottom-up) between a parent round and a child round
@@ -73,6 +78,7 @@ hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *h_job, int n_j
                             KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
 hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
                         KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
+hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
 hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);
@@ -98,10 +104,11 @@ struct JitSubtree {
     int max_actions = 0;
     size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_seed = 0, off_cval = 0, off_nidx = 0,
            off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, args_size = 0;
+    size_t off_dreg = 0, off_dssm = 0, off_cidx = 0, off_tpitch = 0, off_n_lanes = 0;   // deal batches only
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      JitSubtree &out);
+                      bool deals, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);
@@ -152,6 +159,8 @@ struct rs_table {
     size_t rep_cells = 0;
     void *h_stage = nullptr;          // pinned staging for small synchronous copies
     size_t h_stage_bytes = 0;
+    void *d_dregrets = nullptr;       // deal batches: delta tables (same layout as the table), zero between sweeps
+    void *d_dssum = nullptr;
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 

@@ -51,6 +51,19 @@ __device__ __forceinline__ void finish_child(const ChildSrc &c, uint32_t v, floa
     }
 }
 
+// table row of a node for the thread's 4 lanes: vector access (lane model) or gather through cluster ids (deal batches)
+template <int DT>
+__device__ __forceinline__ void load_table_row(const NodeJob &job, const void *base, uint32_t row_off, uint32_t v,
+                                               const unsigned (&idx)[kVec], typename Row<DT>::val (&out)[kVec]) {
+    if constexpr (DT == RS_I32) {
+        if (job.cidx) {
+            gather_i32(base, row_off, idx, out);
+            return;
+        }
+    }
+    Row<DT>::load(base, row_off, v, out);
+}
+
 // =====================================================================================================
 // update kernel: one traverser visit of every lane of the node(s) in `jobs` (blockIdx.y = job)
 // algorithmic bytes per lane: A*(4 regret + 4 ssum + 4 util) + 4 reach read, A*(4+4) + 4 written = 20A+8
@@ -65,10 +78,12 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
         V r[A][kVec], s[A][kVec];
         float u[A][kVec], reach[kVec];
+        unsigned idx[kVec] = {0, 0, 0, 0};
+        if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(job.ssum, a * pitch, v, s[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.ssum, a * pitch, v, idx, s[a]);
 #pragma unroll
         for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
@@ -78,6 +93,12 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
         }
 #pragma unroll
         for (int a = 0; a < A; a++) finish_child(job.child[a], v, u[a]);
+        if (job.cidx) mask_tail_lanes(reach, v, job.n_lanes);
+        V r0[A][kVec], s0[A][kVec];   // values before the visit (deal batches turn the update into a delta)
+#pragma unroll
+        for (int a = 0; a < A; a++)
+#pragma unroll
+            for (int j = 0; j < kVec; j++) { r0[a][j] = r[a][j]; s0[a][j] = s[a][j]; }
         float util[kVec];
 #pragma unroll
         for (int j = 0; j < kVec; j++) {
@@ -90,10 +111,22 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
 #pragma unroll
             for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
         }
+        bool scattered = false;
+        if constexpr (DT == RS_I32) {
+            if (job.cidx) {
 #pragma unroll
-        for (int a = 0; a < A; a++) R::store(job.regrets, a * pitch, v, r[a]);
+                for (int a = 0; a < A; a++) scatter_add_i32(job.dreg, a * pitch, idx, r[a], r0[a]);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::store(job.ssum, a * pitch, v, s[a]);
+                for (int a = 0; a < A; a++) scatter_add_i32(job.dssm, a * pitch, idx, s[a], s0[a]);
+                scattered = true;
+            }
+        }
+        if (!scattered) {
+#pragma unroll
+            for (int a = 0; a < A; a++) R::store(job.regrets, a * pitch, v, r[a]);
+#pragma unroll
+            for (int a = 0; a < A; a++) R::store(job.ssum, a * pitch, v, s[a]);
+        }
         if (job.out_util) store_f32_row(job.out_util, v, util);
     }
 }
@@ -110,8 +143,10 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
         V r[A][kVec];
         float u[A][kVec];
+        unsigned idx[kVec] = {0, 0, 0, 0};
+        if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
 #pragma unroll
         for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
 #pragma unroll
@@ -151,8 +186,10 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
         V r[A][kVec];
         float reach[kVec], out[A][kVec];
+        unsigned idx[kVec] = {0, 0, 0, 0};
+        if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
         else {
 #pragma unroll
@@ -186,12 +223,13 @@ template <int A>
 __global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restrict__ jobs) {
     RS_JOB_DECL(NodeJob)
     const uint32_t n_vec = job.n_vec, pitch = job.pitch;
-    using R = Row<RS_I32>;
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
         int32_t r[A][kVec];
         float reach[kVec];
+        unsigned idx[kVec] = {0, 0, 0, 0};
+        if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(job.regrets, a * pitch, v, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<RS_I32>(job, job.regrets, a * pitch, v, idx, r[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
         else {
 #pragma unroll
@@ -313,6 +351,29 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
         }
         R::store(rb, 0, 0, r);
         R::store(sb, 0, 0, s);
+    }
+}
+
+// ---- deal batches: table += delta (wrapping), delta = 0; 32 bytes per cell, whole table, end of every sweep ------
+__global__ __launch_bounds__(kBlock) void k_apply_delta(int32_t *__restrict__ regrets, int32_t *__restrict__ dregrets,
+                                                        int32_t *__restrict__ ssum, int32_t *__restrict__ dssum, size_t n_vec) {
+    const i32x4 zero = {0, 0, 0, 0};
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * kBlock) {
+        const i32x4 dr = ((const i32x4 *)dregrets)[v], ds = ((const i32x4 *)dssum)[v];
+        if (dr.x | dr.y | dr.z | dr.w) {
+            const i32x4 r = ((i32x4 *)regrets)[v];
+            const i32x4 n = {(int)((unsigned)r.x + (unsigned)dr.x), (int)((unsigned)r.y + (unsigned)dr.y),
+                             (int)((unsigned)r.z + (unsigned)dr.z), (int)((unsigned)r.w + (unsigned)dr.w)};
+            ((i32x4 *)regrets)[v] = n;
+            ((i32x4 *)dregrets)[v] = zero;
+        }
+        if (ds.x | ds.y | ds.z | ds.w) {
+            const i32x4 q = ((i32x4 *)ssum)[v];
+            const i32x4 n = {(int)((unsigned)q.x + (unsigned)ds.x), (int)((unsigned)q.y + (unsigned)ds.y),
+                             (int)((unsigned)q.z + (unsigned)ds.z), (int)((unsigned)q.w + (unsigned)ds.w)};
+            ((i32x4 *)ssum)[v] = n;
+            ((i32x4 *)dssum)[v] = zero;
+        }
     }
 }
 
@@ -444,6 +505,13 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs
 }
 
 
+hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream) {
+    const size_t n_vec = n_cells / kVec;
+    dim3 grid(grid_for(n_vec)), block(kBlock);
+    hipLaunchKernelGGL(k_apply_delta, grid, block, 0, stream, (int32_t *)regrets, (int32_t *)dregrets, (int32_t *)ssum,
+                       (int32_t *)dssum, n_vec);
+    return hipGetLastError();
+}
 hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {
     hipLaunchKernelGGL(k_next_seed, dim3(1), dim3(64), 0, stream, d_state);
     return hipGetLastError();

@@ -20,7 +20,7 @@ using namespace rs;
 
 namespace {
 
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY };
 
 struct Launch {
     int kind;
@@ -76,6 +76,8 @@ struct rs_solver {
     uint32_t n_clusters = 0;
     size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
     int n_rounds = 0;
+    bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
+    rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
     const uint64_t *d_seed() const { return d_seed_state ? d_seed_state + 2 : nullptr; }
 };
@@ -95,6 +97,28 @@ int derive_geometry(rs_solver *s) {
     if (int(t->nodes.size()) != tr.n_action_nodes)
         return fail(RS_ERR_INVALID, "rs_solver_create: table has " + std::to_string(t->nodes.size()) +
                                         " rows but the tree has " + std::to_string(tr.n_action_nodes) + " action nodes");
+    if (s->deal_mode) {
+        // lanes = deals on every round; the table keeps the reference's [action_node][cluster] shape
+        const size_t deal_pitch = round_up(s->deals.n_deals, kLanePad);
+        for (const rs_tree_node &nd : tr.nodes) {
+            if (nd.kind != RS_NODE_ACTION) continue;
+            const rs_node_desc &d = t->nodes[nd.index];
+            if (d.n_actions != uint32_t(nd.n_children) || d.player != nd.player || d.round_idx != nd.round_idx)
+                return fail(RS_ERR_INVALID, "rs_solver_create_deals: table row " + std::to_string(nd.index) + " does not match the tree");
+            if (d.n_boards != 1)
+                return fail(RS_ERR_INVALID, "rs_solver_create_deals: the table must have n_boards = 1 (deals index clusters, not boards)");
+            if (!s->deals.d_cluster[nd.round_idx][nd.player])
+                return fail(RS_ERR_INVALID, "rs_solver_create_deals: no cluster ids for round " + std::to_string(nd.round_idx) +
+                                                " player " + std::to_string(nd.player));
+            s->n_rounds = std::max(s->n_rounds, nd.round_idx + 1);
+        }
+        for (int r = 0; r < RS_MAX_ROUNDS; ++r) {
+            s->n_boards[r] = 1;
+            s->pitch[r] = deal_pitch;
+        }
+        s->n_clusters = s->deals.n_deals;   // lanes per round = n_boards * n_clusters = n_deals
+        return RS_OK;
+    }
     bool seen[RS_MAX_ROUNDS] = {false, false, false};
     for (const rs_tree_node &nd : tr.nodes) {
         if (nd.kind != RS_NODE_ACTION) continue;
@@ -239,6 +263,13 @@ struct Builder {
         job.reach = reach[id].ptr;
         job.reach_const = reach[id].cst;
         job.node_index = uint32_t(nd.index);
+        if (s->deal_mode) {
+            job.n_vec = uint32_t(s->pitch[0] / kVec);
+            job.cidx = s->deals.d_cluster[nd.round_idx][nd.player];
+            job.dreg = (char *)t->d_dregrets + t->cell_off[nd.index] * 4;
+            job.dssm = (char *)t->d_dssum + t->cell_off[nd.index] * 4;
+            job.n_lanes = s->deals.n_deals;
+        }
     }
 
     double lanes(int id) const { return double(s->n_boards[lane_round[id]]) * s->n_clusters; }
@@ -404,7 +435,7 @@ struct Builder {
                     }
                     JitSubtree js;
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                                     s->params.opp_mode == RS_OPP_SAMPLE, js);
+                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, js);
                     hipFunction_t fn = nullptr;
                     if (int rc = jit_get_kernel(js.source, t->device, &fn)) return rc;
                     auto bi = by_fn.find(fn);
@@ -443,6 +474,22 @@ struct Builder {
                     const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / kVec);
                     put_u32(js.off_n_vec, n_vec);
                     put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
+                    if (s->deal_mode) {
+                        const int r = nodes[id].round_idx;
+                        const uint32_t *cx[2] = {s->deals.d_cluster[r][0], s->deals.d_cluster[r][1]};
+                        uint32_t tp[2] = {0, 0};
+                        for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                            const rs_tree_node &an = nodes[js.node_ids[k]];
+                            put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
+                            put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
+                            tp[an.player] = uint32_t(t->pitch[an.index]);
+                        }
+                        for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
+                            put_ptr(js.off_cidx + 8 * q, cx[q] ? cx[q] : cx[1 - q]);
+                        put_u32(js.off_tpitch, tp[0]);
+                        put_u32(js.off_tpitch + 4, tp[1]);
+                        put_u32(js.off_n_lanes, s->deals.n_deals);
+                    }
                     JL.n_jobs += 1;
                     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
                     JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
@@ -482,6 +529,12 @@ struct Builder {
                 }
             }
         }
+        if (s->deal_mode) {   // table += delta, delta = 0
+            Launch L;
+            L.kind = L_APPLY;
+            L.bytes = double(t->n_cells) * 32.0;
+            plan.launches.push_back(L);
+        }
         // value returned at node 0
         const ChildSrc root = child_source(0);
         if (root.kind != CH_BUF) return fail(RS_ERR_INVALID, "rs_solver_create: the root has no action node below it");
@@ -493,7 +546,14 @@ struct Builder {
 
 int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     rs_table *t = s->table;
-    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE};
+    static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
+    if (L.kind == L_APPLY) {
+        prof_begin(t, RS_K_DISCOUNT, L.bytes);
+        hipError_t ea = launch_apply_delta(t->d_regrets, t->d_dregrets, t->d_ssum, t->d_dssum, t->n_cells, t->stream);
+        prof_end(t);
+        RS_HIP(ea, "k_apply_delta");
+        return RS_OK;
+    }
     if (L.kind == L_SEED) {
         RS_HIP(launch_next_seed(s->d_seed_state, t->stream), "k_next_seed");
         return RS_OK;
@@ -555,8 +615,37 @@ int run_plan(rs_solver *s, int p) {
 
 extern "C" {
 
+static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out);
+
 int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
                      const rs_solver_params *params, rs_solver **out) {
+    return solver_create_impl(table, tree, nullptr, leaves_p0, leaves_p1, params, out);
+}
+
+int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
+                           const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
+    if (!deals || deals->n_deals == 0) return fail(RS_ERR_INVALID, "rs_solver_create_deals: empty deal batch");
+    if (table && table->dtype != RS_I32)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: deal batches accumulate i32 deltas; use an RS_I32 table");
+    if (params && params->chance_mode != RS_CHANCE_PASS)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: a deal has one run-out: use RS_CHANCE_PASS (cfr.rs:306-313)");
+    if (table && (!table->d_dregrets || !table->d_dssum)) {
+        hipError_t e = hipSetDevice(table->device);
+        const size_t bytes = table->n_cells * 4;
+        if (e == hipSuccess && !table->d_dregrets) e = hipMalloc(&table->d_dregrets, bytes);
+        if (e == hipSuccess && !table->d_dssum) e = hipMalloc(&table->d_dssum, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(table->d_dregrets, 0, bytes, table->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(table->d_dssum, 0, bytes, table->stream);
+        if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: delta tables");
+    }
+    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out);
+}
+
+}  // extern "C"
+
+static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
         return fail(RS_ERR_INVALID, "rs_solver_create: NULL argument");
     const int arith = params->mode & RS_UPD_ARITH_MASK;
@@ -581,6 +670,10 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
     s->table = table;
     s->tree = *tree;
     s->params = *params;
+    if (deals) {
+        s->deal_mode = true;
+        s->deals = *deals;
+    }
     const size_t n = tree->nodes.size();
     s->leaves[0].assign(leaves_p0, leaves_p0 + n);
     s->leaves[1].assign(leaves_p1, leaves_p1 + n);
@@ -669,6 +762,8 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
     return RS_OK;
 }
 
+extern "C" {
+
 void rs_solver_destroy(rs_solver *s) {
     if (!s) return;
     (void)hipSetDevice(s->table->device);
@@ -749,7 +844,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind != RS_NODE_ACTION || !closed[i]) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;

@@ -246,6 +246,8 @@ void rs_table_destroy(rs_table *t) {
     if (t->d_snap_regrets) (void)hipFree(t->d_snap_regrets);
     if (t->d_snap_ssum) (void)hipFree(t->d_snap_ssum);
     if (t->d_job) (void)hipFree(t->d_job);
+    if (t->d_dregrets) (void)hipFree(t->d_dregrets);
+    if (t->d_dssum) (void)hipFree(t->d_dssum);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;

@@ -435,10 +435,26 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=True, opp_mode=L.OPP_FULL, sample_seed=0):
-        """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal"""
+                 use_graph=False, leaves_p1=None, fuse_subtrees=True, opp_mode=L.OPP_FULL, sample_seed=0, deals=None):
+        """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal.
+        deals: None (lane model) or dict (round_idx, player) -> uint32 array of dense cluster ids, one per deal
+        (what get_cluster() returned, cfr.rs:361-365): batch-synchronous deal sweeps on the reference-shaped table."""
         self.game_tree, self.infosets = tree, infosets
         self._keep = [leaves, leaves_p1]
+        self.n_deals = None
+        batch = None
+        if deals is not None:
+            self.n_deals = len(next(iter(deals.values())))
+            batch = L.DealBatch()
+            batch.n_deals = self.n_deals
+            pitch = deal_pitch(self.n_deals)
+            for (r, pl), arr in deals.items():
+                host = np.zeros(pitch, dtype=np.uint32)
+                host[: self.n_deals] = np.asarray(arr, dtype=np.uint32)
+                buf = DeviceBuffer.from_numpy(infosets, host)
+                self._keep.append(buf)
+                batch.d_cluster[r][pl] = buf.ptr
+            chance_mode = L.CHANCE_PASS
         arrs = []
         for lv in (leaves, leaves if leaves_p1 is None else leaves_p1):
             arr = (L.LeafDesc * tree.n_nodes)()
@@ -448,7 +464,10 @@ class MCCFRTrainer:
             arrs.append(arr)
         p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees), opp_mode, sample_seed)
         h = C.c_void_p()
-        L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
+        if batch is None:
+            L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
+        else:
+            L.check(L.load().rs_solver_create_deals(infosets._h, tree._h, C.byref(batch), arrs[0], arrs[1], C.byref(p), C.byref(h)))
         self._h = h
         infosets._solvers.add(self)
         self.workspace_bytes = L.load().rs_solver_workspace_bytes(h)
@@ -480,6 +499,10 @@ class MCCFRTrainer:
         if not want_root_util:
             L.check(L.load().rs_iterate(self._h, player, None))
             return None
+        if self.n_deals is not None:
+            out = deal_buffer(self.infosets, self.n_deals)
+            L.check(L.load().rs_iterate(self._h, player, out.ptr))
+            return out.download(np.float32, deal_pitch(self.n_deals))[: self.n_deals]
         out = self.infosets.lane_buffer(root.index, 1)
         L.check(L.load().rs_iterate(self._h, player, out.ptr))
         return self.infosets.read_lane_buffer(out, root.index)[0]
@@ -500,6 +523,19 @@ class MCCFRTrainer:
             self.destroy()
         except Exception:
             pass
+
+
+def deal_pitch(n_deals):
+    """per-deal device vectors are padded to a multiple of 64 lanes"""
+    return (n_deals + 63) // 64 * 64
+
+
+def deal_buffer(table, n_deals, data=None):
+    """float32 device vector with one value per deal"""
+    host = np.zeros(deal_pitch(n_deals), dtype=np.float32)
+    if data is not None:
+        host[:n_deals] = np.asarray(data, dtype=np.float32)
+    return DeviceBuffer.from_numpy(table, host)
 
 
 def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64, opp_mode=L.OPP_FULL):

@@ -151,3 +151,42 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 2     # mccfr(): sampled opponent
     _, tree3 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5,), (1.0,)), raise_sizes=((3.0,), (3.0,))))
     assert rs.jit_check_tree(tree3, rs.I32, rs.UPD_WRAP_I32) >= 2
+
+
+# ---- card-abstraction plumbing (card_abstraction.rs) --------------------------------------------------
+
+def test_cluster_file_roundtrip_and_format(tmp_path):
+    from rustsolver_amd import abstraction as ab
+    rng = np.random.Generator(np.random.PCG64(3))
+    arr = rng.integers(0, 5000, size=12345, dtype=np.uint32)
+    path = str(tmp_path / "round_1_emd.dat")
+    ab.write_cluster_file(path, arr)
+    raw = open(path, "rb").read()
+    assert len(raw) == 4 * len(arr) and raw[:8] == arr[:2].astype("<u4").tobytes()      # flat little-endian u32
+    assert (ab.read_cluster_file(path) == arr).all()
+    with pytest.raises(rs.RsError):                                                      # create_new(true): never overwrite
+        ab.write_cluster_file(path, arr)
+    with pytest.raises(rs.RsError):                                                      # File::open(..).unwrap()
+        ab.read_cluster_file(str(tmp_path / "missing.dat"))
+    open(str(tmp_path / "odd.dat"), "wb").write(b"abcde")
+    with pytest.raises(rs.RsError):
+        ab.read_cluster_file(str(tmp_path / "odd.dat"))
+
+
+def test_index_to_cluster_and_dense_map():
+    from rustsolver_amd import abstraction as ab
+    cluster_arr = np.array([7, 7, 3, 9, 3, 0], dtype=np.uint32)
+    idx = np.array([5, 0, 1, 2, 4, 3], dtype=np.uint64)
+    assert ab.index_to_cluster(idx).tolist() == idx.tolist()                             # ISOMORPHIC: the index itself
+    b = ab.index_to_cluster(idx, cluster_arr)
+    assert b.tolist() == [0, 7, 7, 3, 3, 9]
+    with pytest.raises(IndexError):                                                      # arr[index] out of bounds panics
+        ab.index_to_cluster([6], cluster_arr)
+    m = ab.DenseMap(b)
+    assert len(m) == 4 and m.keys().tolist() == [0, 7, 3, 9]                              # first-appearance order, deterministic
+    assert m.lookup([9, 0, 3, 7, 7]).tolist() == [3, 0, 2, 1, 1]
+    with pytest.raises(KeyError):                                                        # .get(&cluster).unwrap() on None
+        m.lookup([5])
+    # two players, different ranges -> different sizes (size[0] != size[1] in general, infoset.rs:28-32)
+    m2 = ab.DenseMap(ab.index_to_cluster([0, 1], cluster_arr))
+    assert len(m2) == 1

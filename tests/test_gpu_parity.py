@@ -378,6 +378,71 @@ def test_sampled_mode_needs_pass_through_chance():
     assert e.value.code == L.ERR_UNSUPPORTED
 
 
+# ---- deal batches: get-infoset addressing through cluster ids, batch-synchronous atomics -----------------
+
+def setup_deals(options_rs, options_orc, sizes, n_deals, seed):
+    """sizes[round_idx] = (clusters of player 0, clusters of player 1), different on purpose"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_actions, tree = rs.build_game_tree(options_rs)
+    table = rs.create_infosets(n_actions, tree, sizes, [1, 1, 1])
+    otree = orc.OracleTree(options_orc)
+    otab = orc.OracleDealTable(otree, sizes)
+    for nd in tree.action_nodes():
+        a, n = nd.n_children, sizes[nd.round_idx][nd.player]
+        R = rng.integers(-10**6, 10**6, size=(a, n)).astype(np.int32)
+        S = rng.integers(0, 10**6, size=(a, n)).astype(np.int32)
+        R[0, ::5] = -10_000_001
+        R[a - 1, ::7] = 2_147_000_000
+        table.upload_node(nd.index, R, S)
+        otab.set_node(nd.index, R, S)
+    cidx = {(r, p): rng.integers(0, sizes[r][p], size=n_deals).astype(np.uint32) for r in range(len(sizes)) for p in (0, 1)}
+    sign = rng.integers(-1, 2, size=n_deals).astype(np.float32)
+    sbuf = rs.deal_buffer(table, n_deals, sign)
+    lg = {i: (rs.LEAF_SIGN, sbuf) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    lo = {i: (orc.LEAF_SIGN, sign) for i in lg}
+    return tree, table, otree, otab, lg, lo, cidx
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("variant", ["river-clamp", "river-wrap", "river-clamp+prune", "river-sampled", "three-street-sampled",
+                                     "three-street-full"])
+def test_deal_batches_vs_oracle(fuse, variant):
+    """Many deals per info set (1000 deals on 13 / 17 clusters): collisions are the rule, results must still be exact."""
+    three = variant.startswith("three")
+    sampled, prune, wrap = "sampled" in variant, "prune" in variant, "wrap" in variant
+    n_deals = 1000 if not three else 300
+    if three:
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(),
+                                                             [(7, 9), (11, 8), (13, 17)], n_deals, 31)
+    else:
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(13, 17)], n_deals, 32)
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if wrap else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), fuse_subtrees=fuse, deals=cidx,
+                         opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=777, use_graph=(variant == "river-clamp"))
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune,
+                                opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=777)
+    for it in range(3):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player)
+            assert_bits(got, want, "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
+def test_deal_batches_reject_bad_inputs():
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(5, 6)], 10, 3)
+    with pytest.raises(rs.RsError):
+        rs.MCCFRTrainer(tree, table, lg, deals={(0, 0): cidx[(0, 0)]})          # player 1 ids missing
+    n, t2 = rs.build_game_tree(rs.default_flop())
+    tf = rs.create_infosets(n, t2, [(5, 6)], [1], rs.F32)
+    with pytest.raises(rs.RsError) as e:
+        rs.MCCFRTrainer(t2, tf, lg, deals=cidx)
+    assert e.value.code == L.ERR_UNSUPPORTED
+
+
 def test_train_with_discount_schedule_vs_oracle():
     # cfr.rs:188-265 with a short interval so that several discount ticks happen
     tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [1], 64, 3)
