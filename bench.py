@@ -128,6 +128,88 @@ def cpu_baseline(n_clusters, mode, seconds):
     }
 
 
+def cpu_baseline_tuned(n_clusters, mode, seconds):
+    """Non-strawman CPU number: the same per-lane arithmetic on a contiguous pooled layout, no per-visit
+    allocations, ALL host cores."""
+    import numpy as np
+    from oracle import orc
+    threads = os.cpu_count() or 1
+    boards = max(64, 4 * threads)
+    tree = orc.OracleTree(orc.options_default_river())
+    tb = orc.OracleFlatTable(tree, [boards], n_clusters, seed=7)
+    rng = np.random.Generator(np.random.PCG64(77))
+    sign = np.sign(rng.uniform(-1, 1, size=boards * n_clusters)).astype(np.float32)
+    leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in tree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    scale, m = (100.0, orc.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, orc.UPD_WRAP_I32)
+    sol = orc.OracleSolver(tree, tb, leaves, scale=scale, mode=m, chance_mode=orc.CHANCE_PASS, ref_alloc=False)
+    t0 = time.perf_counter()
+    sol.run_iterations(2, threads)
+    t1 = (time.perf_counter() - t0) / 2
+    iters = max(2, int(seconds / max(t1, 1e-6)))
+    t0 = time.perf_counter()
+    sol.run_iterations(iters, threads)
+    dt = time.perf_counter() - t0
+    return {"value": boards * iters / dt, "unit": "board-iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d iterations x %d boards x %d clusters, pooled contiguous layout, no per-visit allocations, %d threads, %.1f s"
+                      % (iters, boards, n_clusters, threads, dt)}
+
+
+def deal_batch_leg(rs, device, n_deals, n_clusters, with_cpu, cpu_seconds):
+    """SURVEY N2 measured: the reference's own train() loop, batched.  One DEAL-ITERATION = one sampled deal traversed by
+    mccfr for both players (cfr.rs:209-226): sampled opponents (cfr.rs:467-476), clamp update scale 100 (cfr.rs:413-464),
+    real get_cluster addressing into the reference-shaped table [action_node][cluster] (1000 clusters, river tree)."""
+    import numpy as np
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [n_clusters], [1], rs.I32, device)
+    table.fill_random(4321, (-10**6, 10**6), (0, 10**6))
+    rng = np.random.Generator(np.random.PCG64(4321))
+    cidx = {(0, p): rng.integers(0, n_clusters, size=n_deals).astype(np.uint32) for p in (0, 1)}
+    sign = np.sign(rng.uniform(-1, 1, size=n_deals)).astype(np.float32)
+    sbuf = rs.deal_buffer(table, n_deals, sign)
+    leaves = {i: (rs.LEAF_SIGN, sbuf) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    tr = rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=1,
+                         use_graph=True)
+    run_steps(tr, 5)
+    table.sync()
+    k = 50
+    t0 = time.perf_counter()
+    run_steps(tr, k)
+    table.sync()
+    dt = time.perf_counter() - t0
+    out = {"what": "batched mccfr over sampled deals (reference iteration = 1 deal x both players), river tree, %d clusters, "
+                   "%d deals per batch, sampled opponents, i32 clamp update, cluster-id gathers + atomic deltas" % (n_clusters, n_deals),
+           "value": n_deals * k / dt, "unit": "deal-iterations/s", "ms_per_batch": dt / k * 1e3, "n_deals": n_deals,
+           "launches_per_batch": tr.n_launches(0) + tr.n_launches(1)}
+    tr.destroy()
+    table.destroy()
+    if with_cpu:
+        from oracle import orc
+        threads = min(8, os.cpu_count() or 1)
+        nd_cpu = 200_000
+        otree = orc.OracleTree(orc.options_default_river())
+        otab = orc.OracleDealTable(otree, [(n_clusters, n_clusters)])
+        for d in otree.as_dicts():
+            if d["kind"] == orc.ACTION:
+                a_, n_ = otab.node_shape(d["index"])
+                otab.set_node(d["index"], rng.integers(-10**6, 10**6, size=(a_, n_)).astype(np.int32),
+                              rng.integers(0, 10**6, size=(a_, n_)).astype(np.int32))
+        oc = {(0, p): cidx[(0, p)][:nd_cpu] for p in (0, 1)}
+        ol = {d["id"]: (orc.LEAF_SIGN, sign[:nd_cpu]) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+        osol = orc.OracleDealSolver(otree, otab, ol, oc, nd_cpu, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=1)
+        t0 = time.perf_counter()
+        osol.run_sweeps(1, threads)
+        t1 = time.perf_counter() - t0
+        sweeps = max(1, int(cpu_seconds / max(t1, 1e-6)))
+        t0 = time.perf_counter()
+        osol.run_sweeps(sweeps, threads)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nd_cpu * sweeps / dtc, "unit": "deal-iterations/s", "cores": threads, "kind": "port",
+                               "sample": "%d sweeps x %d deals, reference layout + per-visit allocations, %d threads, %.1f s"
+                                         % (sweeps, nd_cpu, threads, dtc)}
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
@@ -318,9 +400,19 @@ def main():
     except Exception as e:  # the headline number must still be reported
         out["single_board"] = {"error": str(e)}
 
+    try:
+        out["deal_batch"] = deal_batch_leg(rs, device, 1 << 22, a.clusters, not a.no_cpu, min(a.cpu_seconds, 6.0))
+    except Exception as e:
+        out["deal_batch"] = {"error": str(e)}
+
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        try:
+            out["cpu_baseline_tuned"] = cpu_baseline_tuned(a.clusters, a.mode, min(a.cpu_seconds, 8.0))
+            out["gpu_over_cpu_tuned"] = out["value"] / out["cpu_baseline_tuned"]["value"]
+        except Exception as e:
+            out["cpu_baseline_tuned"] = {"error": str(e)}
     emit(out)
     if dist is not None:
         os.dup2(2, 1)

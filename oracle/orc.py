@@ -154,6 +154,10 @@ def lib():
     L.orc_iterate_deals.argtypes = [C.POINTER(DealCtx), C.c_int, f32p]
     L.orc_table_create_sizes.argtypes = [C.POINTER(Tree), C.POINTER((C.c_uint32 * 2) * MAX_ROUNDS), C.c_int, C.POINTER(Table)]
     L.orc_table_create_sizes.restype = C.c_int
+    L.orc_table_create_flat.argtypes = [C.POINTER(Tree), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Table)]
+    L.orc_table_create_flat.restype = C.c_int
+    L.orc_table_fill_flat.argtypes = [C.POINTER(Table), C.POINTER(Tree), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64]
+    L.orc_run_deal_sweeps_mt.argtypes = [C.POINTER(DealCtx), C.POINTER(Ctx), C.c_size_t, C.c_int]
     L.orc_iterate_mt.argtypes = [C.POINTER(Ctx), C.c_int, f32p, C.c_int]
     L.orc_run_iterations_mt.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_int]
     _lib = L
@@ -463,3 +467,26 @@ class OracleDealSolver(OracleSolver):
         out = np.zeros(self.n_deals, dtype=np.float32)
         lib().orc_iterate_deals(C.byref(self.dc), player, _f32(out))
         return out
+
+    def run_sweeps(self, sweeps, threads):
+        """timed CPU baseline: `sweeps` x (both players over all deals), reference-style allocations, `threads` workers"""
+        lib().orc_run_deal_sweeps_mt(C.byref(self.dc), C.byref(self.ctx), sweeps, threads)
+
+
+class OracleFlatTable(OracleTable):
+    """Tuned CPU layout (one contiguous pool per node, nothing boxed) for the non-strawman CPU baseline."""
+
+    def __init__(self, tree, n_boards, n_clusters, seed=1):
+        self.tree = tree
+        self.n_boards = list(n_boards) + [0] * (MAX_ROUNDS - len(n_boards))
+        self.n_clusters = n_clusters
+        self.dtype = T_I32
+        self.tb = Table()
+        nb = (C.c_uint32 * MAX_ROUNDS)(*self.n_boards)
+        if lib().orc_table_create_flat(C.byref(tree.t), nb, n_clusters, C.byref(self.tb)) != 0:
+            raise MemoryError
+        lib().orc_table_fill_flat(C.byref(self.tb), C.byref(tree.t), nb, n_clusters, seed)
+        self._node_by_index = {}
+
+    def __del__(self):
+        pass   # pools are intentionally not freed (bounded baseline run)

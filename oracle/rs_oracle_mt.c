@@ -134,3 +134,153 @@ int orc_table_create_sizes(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUND
     if (!out->rows || !out->row_len || dtype != ORC_T_I32) return -1;
     return create_sizes_rec(t, sizes, out, 0);
 }
+
+
+/* ---- threaded deal sweeps for the timed CPU baseline of the deal-batch leg -----------------------------------------
+ * Deals are split across threads; each thread accumulates into the shared delta table with relaxed atomic adds
+ * (integer adds commute, so the result equals the single-threaded sweep), then one thread applies the deltas. */
+typedef struct {
+    const orc_deal_ctx *dc;
+    int player;
+    size_t lo, hi;
+} deal_job;
+
+static float traverse_deal_mt(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach);
+
+static void *deal_worker(void *arg) {
+    deal_job *j = (deal_job *)arg;
+    size_t d;
+    for (d = j->lo; d < j->hi; d++) (void)traverse_deal_mt(j->dc, 0, j->player, d, 1.0f);
+    return NULL;
+}
+
+/* same recursion as orc_traverse_deal (rs_oracle.c), reference-style per-visit allocations, atomic delta adds */
+static float traverse_deal_mt(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach) {
+    const orc_ctx *ctx = dc->ctx;
+    const orc_node *nd = &ctx->tree->nodes[node_id];
+    if (nd->kind == ORC_PRIVATE_CHANCE || nd->kind == ORC_PUBLIC_CHANCE)
+        return traverse_deal_mt(dc, nd->children[0], player, deal, cfr_reach);
+    if (nd->kind == ORC_TERMINAL) {
+        const orc_leaf *lf = &ctx->leaves[node_id];
+        float s, v = (float)nd->value;
+        if (nd->ttype == ORC_UNCONTESTED) return (player == nd->last_to_act) ? -1.0f * v : 1.0f * v;
+        s = lf->buf[deal];
+        if (lf->kind == ORC_LEAF_UTIL) return s;
+        if (s == 0.0f) return 0.0f;
+        return ((player == 0) ? (s > 0.0f) : (s < 0.0f)) ? 1.0f * v : -1.0f * v;
+    }
+    {
+        int n = nd->n_children, i;
+        size_t cluster_idx = dc->cidx[nd->round_idx][nd->player][deal];
+        const orc_infoset *infoset = &ctx->table->rows[nd->index][cluster_idx];
+        orc_infoset *dinfo = &dc->delta->rows[nd->index][cluster_idx];
+        float *utils = (float *)calloc((size_t)n, sizeof(float));      /* vec![0f32; n_actions], cfr.rs:372 */
+        float *strategy = (float *)calloc((size_t)n, sizeof(float));   /* infoset.rs:85 */
+        float util = 0.0f;
+        orc_get_strategy(infoset->regrets, n, strategy);
+        if (nd->player == player) {
+            int32_t r[ORC_MAX_ACTIONS], s[ORC_MAX_ACTIONS];
+            for (i = 0; i < n; i++) utils[i] = traverse_deal_mt(dc, nd->children[i], player, deal, cfr_reach);
+            for (i = 0; i < n; i++) { r[i] = infoset->regrets[i]; s[i] = infoset->strategy_sum[i]; }
+            util = orc_update_infoset(r, s, n, utils, cfr_reach, ctx->scale, ctx->mode, 0);
+            for (i = 0; i < n; i++) {
+                __atomic_fetch_add(&dinfo->regrets[i], (int32_t)((uint32_t)r[i] - (uint32_t)infoset->regrets[i]), __ATOMIC_RELAXED);
+                __atomic_fetch_add(&dinfo->strategy_sum[i], (int32_t)((uint32_t)s[i] - (uint32_t)infoset->strategy_sum[i]), __ATOMIC_RELAXED);
+            }
+        } else if (ctx->opp_mode == ORC_OPP_SAMPLE) {
+            int a = orc_weighted_index(strategy, n, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, deal));
+            util = traverse_deal_mt(dc, nd->children[a], player, deal, cfr_reach * strategy[a]);
+        } else {
+            for (i = 0; i < n; i++) {
+                utils[i] = traverse_deal_mt(dc, nd->children[i], player, deal, strategy[i] * cfr_reach);
+                util += utils[i] * strategy[i];
+            }
+        }
+        free(utils);
+        free(strategy);
+        return util;
+    }
+}
+
+/* `sweeps` iterations (both players each) over all deals with n_threads workers; returns nothing, times are the caller's */
+void orc_run_deal_sweeps_mt(orc_deal_ctx *dc, orc_ctx *ctx, size_t sweeps, int n_threads) {
+    size_t t;
+    int player, i;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    deal_job *jobs = (deal_job *)malloc((size_t)n_threads * sizeof(deal_job));
+    for (t = 0; t < sweeps; t++)
+        for (player = 0; player < 2; player++) {
+            size_t row, j;
+            int k;
+            ctx->sample_seed = orc_sweep_seed(12345, 2 * t + (size_t)player);
+            for (i = 0; i < n_threads; i++) {
+                jobs[i].dc = dc;
+                jobs[i].player = player;
+                jobs[i].lo = dc->n_deals * (size_t)i / (size_t)n_threads;
+                jobs[i].hi = dc->n_deals * (size_t)(i + 1) / (size_t)n_threads;
+                pthread_create(&th[i], NULL, deal_worker, &jobs[i]);
+            }
+            for (i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+            for (row = 0; row < (size_t)ctx->table->n_rows; row++)
+                for (j = 0; j < ctx->table->row_len[row]; j++) {
+                    orc_infoset *is = &ctx->table->rows[row][j], *di = &dc->delta->rows[row][j];
+                    for (k = 0; k < is->n_actions; k++) {
+                        is->regrets[k] = (int32_t)((uint32_t)is->regrets[k] + (uint32_t)di->regrets[k]);
+                        is->strategy_sum[k] = (int32_t)((uint32_t)is->strategy_sum[k] + (uint32_t)di->strategy_sum[k]);
+                        di->regrets[k] = di->strategy_sum[k] = 0;
+                    }
+                }
+        }
+    free(th);
+    free(jobs);
+}
+
+
+/* ---- tuned CPU layout for the non-strawman baseline (SURVEY.md 8(d) "cpu_soa"): every info set of a node lives in ONE
+ * contiguous pool (regrets then strategy_sum, [lane][A]), so neighbouring lanes share cache lines and nothing is boxed.
+ * The orc_infoset pointers simply point into the pools, so the same orc_traverse runs on it (with ref_alloc = 0). */
+int orc_table_create_flat(const orc_tree *t, const uint32_t *n_boards, uint32_t n_clusters, orc_table *out) {
+    int i;
+    out->n_rows = t->n_action_nodes;
+    out->dtype = ORC_T_I32;
+    out->rows = (orc_infoset **)calloc((size_t)out->n_rows, sizeof(orc_infoset *));
+    out->row_len = (size_t *)calloc((size_t)out->n_rows, sizeof(size_t));
+    if (!out->rows || !out->row_len) return -1;
+    for (i = 0; i < t->n_nodes; i++) {
+        const orc_node *nd = &t->nodes[i];
+        size_t n, k;
+        int32_t *pool;
+        if (nd->kind != ORC_ACTION) continue;
+        n = (size_t)n_boards[nd->round_idx] * n_clusters;
+        out->rows[nd->index] = (orc_infoset *)malloc(n * sizeof(orc_infoset));
+        pool = (int32_t *)calloc(n * (size_t)nd->n_children * 2, sizeof(int32_t));   /* leaked with the table: baseline only */
+        if (!out->rows[nd->index] || !pool) return -1;
+        out->row_len[nd->index] = 0;   /* orc_table_free must not free the pooled slices */
+        for (k = 0; k < n; k++) {
+            orc_infoset *is = &out->rows[nd->index][k];
+            is->n_actions = nd->n_children;
+            is->regrets = pool + k * (size_t)nd->n_children * 2;
+            is->strategy_sum = is->regrets + nd->n_children;
+            is->fregrets = is->fstrategy_sum = NULL;
+        }
+    }
+    return 0;
+}
+void orc_table_fill_flat(orc_table *tb, const orc_tree *t, const uint32_t *n_boards, uint32_t n_clusters, uint64_t seed) {
+    int i;
+    uint64_t x = seed;
+    for (i = 0; i < t->n_nodes; i++) {
+        const orc_node *nd = &t->nodes[i];
+        size_t n, k;
+        int a;
+        if (nd->kind != ORC_ACTION) continue;
+        n = (size_t)n_boards[nd->round_idx] * n_clusters;
+        for (k = 0; k < n; k++)
+            for (a = 0; a < nd->n_children; a++) {
+                x = x * 6364136223846793005ull + 1442695040888963407ull;
+                tb->rows[nd->index][k].regrets[a] = (int32_t)((x >> 33) % 2000001u) - 1000000;
+                x = x * 6364136223846793005ull + 1442695040888963407ull;
+                tb->rows[nd->index][k].strategy_sum[a] = (int32_t)((x >> 33) % 1000001u);
+            }
+    }
+}
