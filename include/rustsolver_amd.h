@@ -281,6 +281,18 @@ size_t rs_dense_map_size(const rs_dense_map *map);                              
 int rs_dense_map_lookup(const rs_dense_map *map, const uint64_t *buckets, size_t n, uint32_t *dense_out); /* get_cluster's map step */
 int rs_dense_map_keys(const rs_dense_map *map, uint64_t *keys_out);                 /* dense id -> bucket, size() entries */
 
+/* ---- showdown evaluation on the device ---------------------------------------------------------------
+ * d_cards[9][pitch] (u8, pitch = round_up(n_deals, 64)): rows 0-4 the board, 5-6 player 0's hole cards, 7-8 player 1's;
+ * card = 4*rank + suit, rank 0..12 = 2..A (cfr.rs:592).  d_sign[lane] = sign(evaluate(hand0) - evaluate(hand1)) exactly as
+ * cfr.rs:324-333 compares the two scores: ready to be used as an RS_LEAF_SIGN buffer. */
+int rs_showdown_sign(rs_table *table, const uint8_t *d_cards, uint32_t n_deals, float *d_sign);
+
+/* ---- table checkpoints (the reference never persists the trained table) ----------------------------
+ * "RSTB" v1: header, node descriptors, then per node regrets[A][lanes] and strategy_sum[A][lanes] (no pitch padding),
+ * then a 64-bit FNV-1a checksum.  rs_table_load creates the table on `device`. */
+int rs_table_save(rs_table *table, const char *path);
+int rs_table_load(const char *path, int device, rs_table **out);
+
 /* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
 enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,
        RS_K_TREE = 6, RS_K_COUNT = 7 };

@@ -154,6 +154,9 @@ def lib():
     L.orc_iterate_deals.argtypes = [C.POINTER(DealCtx), C.c_int, f32p]
     L.orc_table_create_sizes.argtypes = [C.POINTER(Tree), C.POINTER((C.c_uint32 * 2) * MAX_ROUNDS), C.c_int, C.POINTER(Table)]
     L.orc_table_create_sizes.restype = C.c_int
+    L.orc_evaluate7.argtypes = [C.POINTER(C.c_uint8)]
+    L.orc_evaluate7.restype = C.c_uint32
+    L.orc_showdown_sign.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, f32p]
     L.orc_table_create_flat.argtypes = [C.POINTER(Tree), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Table)]
     L.orc_table_create_flat.restype = C.c_int
     L.orc_table_fill_flat.argtypes = [C.POINTER(Table), C.POINTER(Tree), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64]
@@ -490,3 +493,16 @@ class OracleFlatTable(OracleTable):
 
     def __del__(self):
         pass   # pools are intentionally not freed (bounded baseline run)
+
+
+def evaluate7(cards7):
+    a = np.ascontiguousarray(cards7, dtype=np.uint8)
+    return int(lib().orc_evaluate7(a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+
+def showdown_sign(cards):
+    """cards: uint8 [9][n] -> float32 [n], brute-force best-of-21 evaluator"""
+    a = np.ascontiguousarray(cards, dtype=np.uint8)
+    out = np.zeros(a.shape[1], dtype=np.float32)
+    lib().orc_showdown_sign(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], _f32(out))
+    return out

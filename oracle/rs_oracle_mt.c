@@ -284,3 +284,68 @@ void orc_table_fill_flat(orc_table *tb, const orc_tree *t, const uint32_t *n_boa
             }
     }
 }
+
+
+/* ---- showdown oracle (checker for rs_showdown_sign): the value of 7 cards is the best of its C(7,5) = 21 five-card
+ * hands, each ranked by the textbook rules.  Deliberately brute force and unrelated to the product's bit tricks.
+ * card = 4*rank + suit (cfr.rs:592). */
+static uint32_t rank5(const uint8_t *c) {
+    int r[5], i, j, flush = 1, straight = 0, high;
+    int cnt[13] = {0};
+    for (i = 0; i < 5; i++) {
+        r[i] = c[i] >> 2;
+        cnt[r[i]]++;
+        if ((c[i] & 3) != (c[0] & 3)) flush = 0;
+    }
+    for (i = 0; i < 5; i++)   /* sort ranks descending */
+        for (j = i + 1; j < 5; j++)
+            if (r[j] > r[i]) { int t = r[i]; r[i] = r[j]; r[j] = t; }
+    high = r[0];
+    if (r[0] - r[4] == 4 && r[0] != r[1] && r[1] != r[2] && r[2] != r[3] && r[3] != r[4]) straight = 1;
+    if (r[0] == 12 && r[1] == 3 && r[2] == 2 && r[3] == 1 && r[4] == 0) { straight = 1; high = 3; } /* wheel */
+    {
+        /* order ranks by (count desc, rank desc) */
+        int ord[5], n = 0, q, k;
+        for (k = 4; k >= 1; k--)
+            for (q = 12; q >= 0; q--)
+                if (cnt[q] == k) ord[n++] = q;
+        if (straight && flush) return (8u << 20) | (uint32_t)high;
+        if (cnt[ord[0]] == 4) return (7u << 20) | ((uint32_t)ord[0] << 4) | (uint32_t)ord[1];
+        if (cnt[ord[0]] == 3 && cnt[ord[1]] == 2) return (6u << 20) | ((uint32_t)ord[0] << 4) | (uint32_t)ord[1];
+        if (flush) return (5u << 20) | ((uint32_t)r[0] << 16) | ((uint32_t)r[1] << 12) | ((uint32_t)r[2] << 8) | ((uint32_t)r[3] << 4) | (uint32_t)r[4];
+        if (straight) return (4u << 20) | (uint32_t)high;
+        if (cnt[ord[0]] == 3) return (3u << 20) | ((uint32_t)ord[0] << 8) | ((uint32_t)ord[1] << 4) | (uint32_t)ord[2];
+        if (cnt[ord[0]] == 2 && cnt[ord[1]] == 2) return (2u << 20) | ((uint32_t)ord[0] << 8) | ((uint32_t)ord[1] << 4) | (uint32_t)ord[2];
+        if (cnt[ord[0]] == 2) return (1u << 20) | ((uint32_t)ord[0] << 12) | ((uint32_t)ord[1] << 8) | ((uint32_t)ord[2] << 4) | (uint32_t)ord[3];
+        return ((uint32_t)r[0] << 16) | ((uint32_t)r[1] << 12) | ((uint32_t)r[2] << 8) | ((uint32_t)r[3] << 4) | (uint32_t)r[4];
+    }
+}
+uint32_t orc_evaluate7(const uint8_t *c7) {
+    uint32_t best = 0;
+    int a, b, i, n;
+    for (a = 0; a < 7; a++)
+        for (b = a + 1; b < 7; b++) {
+            uint8_t h[5];
+            uint32_t v;
+            for (i = 0, n = 0; i < 7; i++)
+                if (i != a && i != b) h[n++] = c7[i];
+            v = rank5(h);
+            if (v > best) best = v;
+        }
+    return best;
+}
+/* cards[9][n]: board x5, player-0 hole x2, player-1 hole x2 -> sign(score0 - score1), cfr.rs:324-333 */
+void orc_showdown_sign(const uint8_t *cards, size_t n, float *sign) {
+    size_t l;
+    for (l = 0; l < n; l++) {
+        uint8_t h0[7], h1[7];
+        uint32_t s0, s1;
+        int i;
+        for (i = 0; i < 5; i++) h0[i + 2] = h1[i + 2] = cards[(size_t)i * n + l];
+        h0[0] = cards[5 * n + l]; h0[1] = cards[6 * n + l];
+        h1[0] = cards[7 * n + l]; h1[1] = cards[8 * n + l];
+        s0 = orc_evaluate7(h0);
+        s1 = orc_evaluate7(h1);
+        sign[l] = s0 == s1 ? 0.0f : (s0 > s1 ? 1.0f : -1.0f);
+    }
+}

@@ -131,6 +131,9 @@ SYMBOLS = {
     "rs_dense_map_size": (C.c_size_t, [_P]),
     "rs_dense_map_lookup": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint32)]),
     "rs_dense_map_keys": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "rs_showdown_sign": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "rs_table_save": (C.c_int, [_P, C.c_char_p]),
+    "rs_table_load": (C.c_int, [C.c_char_p, C.c_int, _PP]),
     "rs_profile_enable": (C.c_int, [_P, C.c_int]),
     "rs_profile_read": (C.c_int, [_P, C.POINTER(Profile)]),
     "rs_profile_reset": (C.c_int, [_P]),

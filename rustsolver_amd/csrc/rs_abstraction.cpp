@@ -114,3 +114,128 @@ int rs_dense_map_keys(const rs_dense_map *m, uint64_t *keys_out) {
 }
 
 }  // extern "C"
+
+// ---- table checkpoints: the reference never writes the trained table anywhere ---------------------------
+// File = header {magic "RSTB", u32 version, u32 dtype, u32 n_nodes}, n_nodes x rs_node_desc{u32 A, u32 clusters, u32 boards,
+// u8 player, u8 round, u16 0}, then per node regrets[A][lanes] and strategy_sum[A][lanes] (table element type, little
+// endian, WITHOUT pitch padding, lanes = boards*clusters), then a u64 FNV-1a of everything before it.
+namespace {
+constexpr uint32_t kCkptMagic = 0x42545352u;   // "RSTB"
+constexpr uint32_t kCkptVersion = 1;
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void add(const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; ++i) {
+            h ^= b[i];
+            h *= 1099511628211ull;
+        }
+    }
+};
+bool put(FILE *f, Fnv &fnv, const void *p, size_t n) {
+    fnv.add(p, n);
+    return std::fwrite(p, 1, n, f) == n;
+}
+bool get(FILE *f, Fnv &fnv, void *p, size_t n) {
+    if (std::fread(p, 1, n, f) != n) return false;
+    fnv.add(p, n);
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int rs_table_save(rs_table *t, const char *path) {
+    if (!t || !path) return fail(RS_ERR_INVALID, "rs_table_save: NULL argument");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(RS_ERR_INVALID, std::string("rs_table_save: cannot create ") + path);
+    Fnv fnv;
+    const uint32_t head[4] = {kCkptMagic, kCkptVersion, uint32_t(t->dtype), uint32_t(t->nodes.size())};
+    bool ok = put(f, fnv, head, sizeof(head));
+    for (const rs_node_desc &d : t->nodes) {
+        const uint32_t rec[4] = {d.n_actions, d.n_clusters, d.n_boards, uint32_t(d.player) | uint32_t(d.round_idx) << 8};
+        ok = ok && put(f, fnv, rec, sizeof(rec));
+    }
+    const size_t es = elem_size(t->dtype);
+    std::vector<char> buf;
+    int rc = RS_OK;
+    for (int n = 0; ok && rc == RS_OK && n < int(t->nodes.size()); ++n) {
+        const rs_node_desc &d = t->nodes[n];
+        const size_t lanes = size_t(d.n_boards) * d.n_clusters;
+        buf.resize(lanes * d.n_actions * es);
+        for (int which = 0; which < 2 && ok && rc == RS_OK; ++which) {
+            const void *src = which == 0 ? t->regrets_ptr(n) : t->ssum_ptr(n);
+            hipError_t e = hipSetDevice(t->device);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(buf.data(), lanes * es, src, t->pitch[n] * es, lanes * es, d.n_actions, hipMemcpyDeviceToHost, t->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "rs_table_save: device read");
+            else ok = put(f, fnv, buf.data(), buf.size());
+        }
+    }
+    const uint64_t sum = fnv.h;
+    ok = ok && std::fwrite(&sum, 1, 8, f) == 8;
+    std::fclose(f);
+    if (rc != RS_OK) return rc;
+    return ok ? RS_OK : fail(RS_ERR_INVALID, "rs_table_save: short write");
+}
+
+int rs_table_load(const char *path, int device, rs_table **out) {
+    if (!path || !out) return fail(RS_ERR_INVALID, "rs_table_load: NULL argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(RS_ERR_INVALID, std::string("rs_table_load: cannot open ") + path);
+    Fnv fnv;
+    uint32_t head[4];
+    if (!get(f, fnv, head, sizeof(head)) || head[0] != kCkptMagic || head[1] != kCkptVersion || head[3] == 0 || head[3] > (1u << 24)) {
+        std::fclose(f);
+        return fail(RS_ERR_INVALID, "rs_table_load: not a version-1 RSTB checkpoint");
+    }
+    std::vector<rs_node_desc> descs(head[3]);
+    for (rs_node_desc &d : descs) {
+        uint32_t rec[4];
+        if (!get(f, fnv, rec, sizeof(rec))) {
+            std::fclose(f);
+            return fail(RS_ERR_INVALID, "rs_table_load: truncated header");
+        }
+        d.n_actions = rec[0];
+        d.n_clusters = rec[1];
+        d.n_boards = rec[2];
+        d.player = uint8_t(rec[3] & 0xff);
+        d.round_idx = uint8_t(rec[3] >> 8);
+    }
+    rs_table *t = nullptr;
+    int rc = rs_table_create(descs.data(), int(descs.size()), int(head[2]), device, &t);
+    if (rc != RS_OK) {
+        std::fclose(f);
+        return rc;
+    }
+    const size_t es = elem_size(t->dtype);
+    std::vector<char> buf;
+    bool ok = true;
+    for (int n = 0; ok && rc == RS_OK && n < int(descs.size()); ++n) {
+        const rs_node_desc &d = descs[n];
+        const size_t lanes = size_t(d.n_boards) * d.n_clusters;
+        buf.resize(lanes * d.n_actions * es);
+        for (int which = 0; which < 2 && ok && rc == RS_OK; ++which) {
+            ok = get(f, fnv, buf.data(), buf.size());
+            if (!ok) break;
+            void *dst = which == 0 ? t->regrets_ptr(n) : t->ssum_ptr(n);
+            hipError_t e = hipMemcpy2DAsync(dst, t->pitch[n] * es, buf.data(), lanes * es, lanes * es, d.n_actions, hipMemcpyHostToDevice, t->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "rs_table_load: device write");
+        }
+    }
+    uint64_t want = 0;
+    const uint64_t have = fnv.h;
+    ok = ok && std::fread(&want, 1, 8, f) == 8 && want == have;
+    std::fclose(f);
+    if (rc == RS_OK && !ok) rc = fail(RS_ERR_INVALID, "rs_table_load: truncated file or checksum mismatch");
+    if (rc != RS_OK) {
+        rs_table_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return RS_OK;
+}
+
+}  // extern "C"

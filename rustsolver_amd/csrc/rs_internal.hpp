@@ -79,6 +79,7 @@ hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *h_job, int n_j
 hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
                         KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
+hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
 hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);

@@ -377,6 +377,101 @@ __global__ __launch_bounds__(kBlock) void k_apply_delta(int32_t *__restrict__ re
     }
 }
 
+// ---- showdown evaluation on the device (cfr.rs:38-46, :324-333) ------------------------------------------
+// card = 4 * rank + suit, rank 0..12 = 2..A (cfr.rs:592, bin/gen_ehs.rs:67-68).  The reference only ever COMPARES the two
+// evaluate() scores, so any correct hold'em ranking yields the same sign.  Score = category << 20 | five 4-bit kickers.
+__device__ __forceinline__ int straight_high(uint32_t ranks) {   // highest card of the best straight in a 13-bit rank set, -1 if none
+    const uint32_t wheel = ranks | ((ranks >> 12) & 1u) << 13;   // not used directly; handled below
+    (void)wheel;
+    const uint32_t r = (ranks << 1) | ((ranks >> 12) & 1u);      // bit 0 = ace playing low, bit i+1 = rank i
+    const uint32_t run = r & (r >> 1) & (r >> 2) & (r >> 3) & (r >> 4);   // bit i set: i..i+4 all present
+    if (!run) return -1;
+    return (31 - __builtin_clz(run)) + 4 - 1;                     // top bit index -> rank of the high card (wheel gives 3 = five)
+}
+__device__ __forceinline__ uint32_t top_bits(uint32_t mask, int n) {   // the n highest set ranks, packed 4 bits each, highest first
+    uint32_t out = 0;
+    for (int i = 0; i < n; i++) {
+        const int hi = mask ? 31 - __builtin_clz(mask) : 0;
+        out = (out << 4) | (mask ? (uint32_t)hi : 0u);
+        mask &= ~(1u << hi);
+    }
+    return out;
+}
+__device__ __forceinline__ uint32_t evaluate7(const uint8_t (&c)[7]) {
+    uint32_t suit_mask[4] = {0, 0, 0, 0};
+    uint32_t cnt[13];
+#pragma unroll
+    for (int r = 0; r < 13; r++) cnt[r] = 0;
+    uint32_t ranks = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint32_t r = c[i] >> 2, su = c[i] & 3;
+        ranks |= 1u << r;
+        uint32_t m0 = su == 0, m1 = su == 1, m2 = su == 2, m3 = su == 3;
+        suit_mask[0] |= m0 << r; suit_mask[1] |= m1 << r; suit_mask[2] |= m2 << r; suit_mask[3] |= m3 << r;
+#pragma unroll
+        for (int q = 0; q < 13; q++) cnt[q] += (r == (uint32_t)q);
+    }
+    uint32_t flush = 0;
+#pragma unroll
+    for (int su = 0; su < 4; su++)
+        if (__builtin_popcount(suit_mask[su]) >= 5) flush = suit_mask[su];
+    if (flush) {
+        const int sf = straight_high(flush);
+        if (sf >= 0) return (8u << 20) | (uint32_t)sf;                       // straight flush
+    }
+    uint32_t quads = 0, trips = 0, pairs = 0;
+#pragma unroll
+    for (int q = 0; q < 13; q++) {
+        quads |= (uint32_t)(cnt[q] == 4) << q;
+        trips |= (uint32_t)(cnt[q] == 3) << q;
+        pairs |= (uint32_t)(cnt[q] == 2) << q;
+    }
+    if (quads) {
+        const int qr = 31 - __builtin_clz(quads);
+        return (7u << 20) | ((uint32_t)qr << 4) | top_bits(ranks & ~(1u << qr), 1);
+    }
+    if (trips && (pairs || (trips & (trips - 1)))) {                           // full house: best trips + best remaining pair/trips
+        const int tr = 31 - __builtin_clz(trips);
+        const uint32_t rest = (trips & ~(1u << tr)) | pairs;
+        return (6u << 20) | ((uint32_t)tr << 4) | (uint32_t)(31 - __builtin_clz(rest));
+    }
+    if (flush) return (5u << 20) | top_bits(flush, 5);
+    const int st = straight_high(ranks);
+    if (st >= 0) return (4u << 20) | (uint32_t)st;
+    if (trips) {
+        const int tr = 31 - __builtin_clz(trips);
+        return (3u << 20) | ((uint32_t)tr << 8) | top_bits(ranks & ~(1u << tr), 2);
+    }
+    if (pairs & (pairs - 1)) {                                                 // two pair (three pairs possible with 7 cards)
+        const int p1 = 31 - __builtin_clz(pairs);
+        const uint32_t rest = pairs & ~(1u << p1);
+        const int p2 = 31 - __builtin_clz(rest);
+        return (2u << 20) | ((uint32_t)p1 << 8) | ((uint32_t)p2 << 4) | top_bits(ranks & ~(1u << p1) & ~(1u << p2), 1);
+    }
+    if (pairs) {
+        const int p1 = 31 - __builtin_clz(pairs);
+        return (1u << 20) | ((uint32_t)p1 << 12) | top_bits(ranks & ~(1u << p1), 3);
+    }
+    return top_bits(ranks, 5);
+}
+
+// cards[9][pitch] u8: rows 0-4 board, 5-6 player 0 hole cards, 7-8 player 1 hole cards; sign[lane] = sign(score0 - score1)
+__global__ __launch_bounds__(kBlock) void k_showdown_sign(const uint8_t *__restrict__ cards, float *__restrict__ sign, uint32_t n,
+                                                          uint32_t pitch) {
+    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
+        uint8_t h0[7], h1[7];
+#pragma unroll
+        for (int i = 0; i < 5; i++) h0[i + 2] = h1[i + 2] = cards[(size_t)i * pitch + l];   // TrainHand.board[2..7], cfr.rs:42-44
+        h0[0] = cards[(size_t)5 * pitch + l];
+        h0[1] = cards[(size_t)6 * pitch + l];
+        h1[0] = cards[(size_t)7 * pitch + l];
+        h1[1] = cards[(size_t)8 * pitch + l];
+        const uint32_t s0 = evaluate7(h0), s1 = evaluate7(h1);
+        sign[l] = s0 == s1 ? 0.0f : (s0 > s1 ? 1.0f : -1.0f);                   // cfr.rs:326-333
+    }
+}
+
 // ---- synthetic fills (bench / tests); mirrored in rustsolver_amd/synth.py ------------------------------------------
 // state = {base seed, call index, seed of the current sweep}: first launch of every sampled-opponent plan, so that
 // a captured hipGraph advances the sweep seed on every replay without any host involvement
@@ -510,6 +605,11 @@ hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *d
     dim3 grid(grid_for(n_vec)), block(kBlock);
     hipLaunchKernelGGL(k_apply_delta, grid, block, 0, stream, (int32_t *)regrets, (int32_t *)dregrets, (int32_t *)ssum,
                        (int32_t *)dssum, n_vec);
+    return hipGetLastError();
+}
+hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    hipLaunchKernelGGL(k_showdown_sign, grid, block, 0, stream, cards, sign, n, pitch);
     return hipGetLastError();
 }
 hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {

@@ -575,12 +575,14 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         break;
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
-        size_t blocks = (size_t(JL.max_n_vec) + kBlock - 1) / kBlock;
-        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 16);
+        static const int threads = [] { const char *e2 = getenv("RS_JIT_THREADS"); const int v = e2 ? atoi(e2) : kBlock; return (v == 64 || v == 128 || v == 256) ? v : kBlock; }();
+        static const size_t cap = [] { const char *e2 = getenv("RS_JIT_GRIDCAP"); const long v = e2 ? atol(e2) : 256 * 16; return size_t(v > 0 ? v : 256 * 16); }();
+        size_t blocks = (size_t(JL.max_n_vec) + threads - 1) / threads;
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), cap);
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
-        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, kBlock, 1, 1, 0, t->stream, params, nullptr);
+        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, threads, 1, 1, 0, t->stream, params, nullptr);
         break;
     }
     }

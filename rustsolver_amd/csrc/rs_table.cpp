@@ -559,6 +559,15 @@ int rs_discount(rs_table *t, float d) {
     return RS_OK;
 }
 
+// ---- showdown signs from cards ------------------------------------------------------------------------------
+int rs_showdown_sign(rs_table *t, const uint8_t *d_cards, uint32_t n_deals, float *d_sign) {
+    if (!t || !d_cards || !d_sign) return fail(RS_ERR_INVALID, "rs_showdown_sign: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const uint32_t pitch = uint32_t(round_up(n_deals, kLanePad));
+    RS_HIP(launch_showdown_sign(d_cards, d_sign, n_deals, pitch, t->stream), "k_showdown_sign");
+    return RS_OK;
+}
+
 // ---- profiling ----------------------------------------------------------------------------------------------------------------
 int rs_profile_enable(rs_table *t, int on) {
     if (!t) return fail(RS_ERR_INVALID, "rs_profile_enable: table is NULL");

@@ -376,6 +376,16 @@ class InfosetTable:
         L.check(L.load().rs_child_reach(self._h, node, None if r is None else r.ptr, out.ptr))
         return self.read_lane_buffer(out, node, a)
 
+    def save(self, path):
+        """checkpoint ("RSTB" v1)"""
+        L.check(L.load().rs_table_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path, device=0):
+        h = C.c_void_p()
+        L.check(L.load().rs_table_load(path.encode(), device, C.byref(h)))
+        return cls(h)
+
     def discount(self, d):
         """cfr.rs:250-261"""
         L.check(L.load().rs_discount(self._h, float(d)))
@@ -536,6 +546,19 @@ def deal_buffer(table, n_deals, data=None):
     if data is not None:
         host[:n_deals] = np.asarray(data, dtype=np.float32)
     return DeviceBuffer.from_numpy(table, host)
+
+
+def showdown_sign(table, cards):
+    """cards: uint8 [9][n_deals] (board x5, P0 hole x2, P1 hole x2) -> (DeviceBuffer of signs, numpy copy)"""
+    cards = np.asarray(cards, dtype=np.uint8)
+    n = cards.shape[1]
+    pitch = deal_pitch(n)
+    host = np.zeros((9, pitch), dtype=np.uint8)
+    host[:, :n] = cards
+    dc = DeviceBuffer.from_numpy(table, host)
+    out = deal_buffer(table, n)
+    L.check(L.load().rs_showdown_sign(table._h, dc.ptr, n, out.ptr))
+    return out, out.download(np.float32, pitch)[:n]
 
 
 def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64, opp_mode=L.OPP_FULL):

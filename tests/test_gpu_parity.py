@@ -539,6 +539,74 @@ def test_full_size_config2_sampled_boards_match_oracle(fuse):
         assert (r == ro[:, C:2 * C]).all() and (s == so[:, C:2 * C]).all()
 
 
+def _random_deals(rng, n):
+    cards = np.zeros((9, n), dtype=np.uint8)
+    for k in range(n):
+        cards[:, k] = rng.permutation(52)[:9]
+    return cards
+
+
+def test_showdown_sign_vs_bruteforce_oracle():
+    """rs_showdown_sign (bit-trick 7-card evaluator) vs the oracle's best-of-21 brute force, cfr.rs:324-333"""
+    rng = np.random.Generator(np.random.PCG64(123))
+    n = 20000
+    cards = _random_deals(rng, n)
+    # craft ties and near-ties: board plays (both players' holes irrelevant), shared straights / flushes
+    R, S = "23456789TJQKA", "cdhs"
+    c = lambda t: [4 * R.index(x[0]) + S.index(x[1]) for x in t.split()]
+    crafted = [c("As Ks Qs Js Ts 2c 3d 4h 5c"), c("2c 7d 9h Js Kc Ac Ad Ah As"), c("5c 6d 7h 8s 9c Ad Kh Ac Kd"),
+               c("2h 5h 9h Jh Kh Ah 3c Qh 4d"), c("9c 9d Kh Ks 2c Qc 3h Qd 4h"), c("Ac 2d 3h 4s 9c 5d Kh 5c Qh")]
+    for i, h in enumerate(crafted):
+        cards[:, i] = h
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [4], [1])
+    buf, got = rs.showdown_sign(table, cards)
+    want = orc.showdown_sign(cards)
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
+    assert set(np.unique(got).tolist()) == {-1.0, 0.0, 1.0} and got[0] == 0.0 and got[2] == 0.0
+
+
+def test_cards_to_iteration_pipeline():
+    """cards -> device showdown signs -> deal-batch sweep, against the oracle fed with its own brute-force signs"""
+    rng = np.random.Generator(np.random.PCG64(9))
+    n_deals = 500
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(20, 20)], n_deals, 44)
+    cards = _random_deals(rng, n_deals)
+    sbuf, _ = rs.showdown_sign(table, cards)
+    osign = orc.showdown_sign(cards)
+    lg = {i: (rs.LEAF_SIGN, sbuf) for i in lg}
+    lo = {i: (orc.LEAF_SIGN, osign) for i in lo}
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=5)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=5)
+    for player in (0, 1):
+        assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util")
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all()
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    for dtype, odt in ((rs.I32, orc.T_I32), (rs.F16, orc.T_F16)):
+        tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [1, 2, 4], 7, 5, dtype, odt)
+        path = str(tmp_path / ("t%d.rstb" % dtype))
+        table.save(path)
+        t2 = rs.InfosetTable.load(path)
+        assert t2.n_nodes == table.n_nodes and t2.dtype == table.dtype
+        for nd in tree.action_nodes():
+            a, b = table.download_node(nd.index), t2.download_node(nd.index)
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+            assert bytes(t2.node_desc(nd.index)) == bytes(table.node_desc(nd.index))
+        raw = bytearray(open(path, "rb").read())
+        raw[len(raw) // 2] ^= 0x40                                   # corrupt one byte -> checksum mismatch
+        open(path, "wb").write(bytes(raw))
+        with pytest.raises(rs.RsError):
+            rs.InfosetTable.load(path)
+        open(path, "wb").write(bytes(raw[:100]))                    # truncated
+        with pytest.raises(rs.RsError):
+            rs.InfosetTable.load(path)
+
+
 # ---- multi-GPU primitive on one rank ------------------------------------------------------------------------------------
 
 def test_allreduce_replicated_single_rank_is_identity():
