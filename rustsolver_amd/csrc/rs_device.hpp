@@ -29,11 +29,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define RS_GLOBAL __attribute__((address_space(1)))
 // streaming accesses: every table row is read once and written once per sweep, so keep it out of the caches' way
 #ifdef RS_PLAIN_ACCESS
-#define RS_LD(p) (*(p))
-#define RS_ST(v, p) (*(p) = (v))
+#define RS_LOADG(p) (*(p))
+#define RS_STOREG(v, p) (*(p) = (v))
 #else
-#define RS_LD(p) __builtin_nontemporal_load(p)
-#define RS_ST(v, p) __builtin_nontemporal_store(v, p)
+#define RS_LOADG(p) __builtin_nontemporal_load(p)
+#define RS_STOREG(v, p) __builtin_nontemporal_store(v, p)
 #endif
 #ifdef RS_AB_FLAT
 template <typename T> __device__ __forceinline__ const T *as_global(const void *p) { return (const T *)p; }
@@ -74,44 +74,44 @@ template <int DT> struct Row;
 template <> struct Row<kDT_I32> {
     using val = int;
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
-        i32x4 x = RS_LD(as_global<i32x4>((const int *)base + row_off) + v);
+        i32x4 x = RS_LOADG(as_global<i32x4>((const int *)base + row_off) + v);
         out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
         i32x4 x = {in[0], in[1], in[2], in[3]};
-        RS_ST(x, as_global<i32x4>((int *)base + row_off) + v);
+        RS_STOREG(x, as_global<i32x4>((int *)base + row_off) + v);
     }
 };
 template <> struct Row<kDT_F32> {
     using val = float;
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
-        f32x4 x = RS_LD(as_global<f32x4>((const float *)base + row_off) + v);
+        f32x4 x = RS_LOADG(as_global<f32x4>((const float *)base + row_off) + v);
         out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
         f32x4 x = {in[0], in[1], in[2], in[3]};
-        RS_ST(x, as_global<f32x4>((float *)base + row_off) + v);
+        RS_STOREG(x, as_global<f32x4>((float *)base + row_off) + v);
     }
 };
 template <> struct Row<kDT_F16> {
     using val = float;  // binary16 in HBM, f32 in registers
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
-        f16x4 x = RS_LD(as_global<f16x4>((const _Float16 *)base + row_off) + v);
+        f16x4 x = RS_LOADG(as_global<f16x4>((const _Float16 *)base + row_off) + v);
         out[0] = (float)x.x; out[1] = (float)x.y; out[2] = (float)x.z; out[3] = (float)x.w;
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
         f16x4 x = {(_Float16)in[0], (_Float16)in[1], (_Float16)in[2], (_Float16)in[3]};  // RNE
-        RS_ST(x, as_global<f16x4>((_Float16 *)base + row_off) + v);
+        RS_STOREG(x, as_global<f16x4>((_Float16 *)base + row_off) + v);
     }
 };
 
 __device__ __forceinline__ void load_f32_row(const float *base, unsigned v, float (&out)[kVecD]) {
-    f32x4 x = RS_LD(as_global<f32x4>(base) + v);
+    f32x4 x = RS_LOADG(as_global<f32x4>(base) + v);
     out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
 }
 __device__ __forceinline__ void store_f32_row(float *base, unsigned v, const float (&in)[kVecD]) {
     f32x4 x = {in[0], in[1], in[2], in[3]};
-    RS_ST(x, as_global<f32x4>(base) + v);
+    RS_STOREG(x, as_global<f32x4>(base) + v);
 }
 
 // showdown / all-in leaf from a sign row: compare as evaluate() scores (cfr.rs:323-334); p1 flips the view
