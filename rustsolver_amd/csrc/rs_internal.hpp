@@ -162,6 +162,7 @@ struct rs_table {
     size_t h_stage_bytes = 0;
     void *d_dregrets = nullptr;       // deal batches: delta tables (same layout as the table), zero between sweeps
     void *d_dssum = nullptr;
+    std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 
@@ -170,6 +171,7 @@ struct rs_table {
 };
 
 namespace rs {
+void solver_release_device(struct rs_solver *s);   // frees a solver's device state and detaches it from its table
 // profiling hooks used around launches
 void prof_begin(rs_table *t, int kind, double bytes);
 void prof_end(rs_table *t);

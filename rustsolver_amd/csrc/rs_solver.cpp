@@ -575,14 +575,12 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         break;
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
-        static const int threads = [] { const char *e2 = getenv("RS_JIT_THREADS"); const int v = e2 ? atoi(e2) : kBlock; return (v == 64 || v == 128 || v == 256) ? v : kBlock; }();
-        static const size_t cap = [] { const char *e2 = getenv("RS_JIT_GRIDCAP"); const long v = e2 ? atol(e2) : 256 * 16; return size_t(v > 0 ? v : 256 * 16); }();
-        size_t blocks = (size_t(JL.max_n_vec) + threads - 1) / threads;
-        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), cap);
+        size_t blocks = (size_t(JL.max_n_vec) + kBlock - 1) / kBlock;   // interleaved A/B: block size and grid cap are irrelevant here
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 16);
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
-        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, threads, 1, 1, 0, t->stream, params, nullptr);
+        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, kBlock, 1, 1, 0, t->stream, params, nullptr);
         break;
     }
     }
@@ -646,6 +644,29 @@ int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_b
 
 }  // extern "C"
 
+void rs::solver_release_device(rs_solver *s) {
+    if (!s || !s->table) return;   // already detached (its table was destroyed first)
+    rs_table *t = s->table;
+    (void)hipSetDevice(t->device);
+    (void)hipStreamSynchronize(t->stream);
+    for (int p = 0; p < 2; ++p) {
+        Plan &pl = s->plan[p];
+        if (pl.graph_exec) (void)hipGraphExecDestroy(pl.graph_exec);
+        if (pl.graph) (void)hipGraphDestroy(pl.graph);
+        if (pl.d_jobs) (void)hipFree(pl.d_jobs);
+        if (pl.d_chance_jobs) (void)hipFree(pl.d_chance_jobs);
+        for (JitLaunch &JL : pl.jit)
+            if (JL.d_blob) (void)hipFree(JL.d_blob);
+        pl = Plan{};
+    }
+    if (s->d_arena) (void)hipFree(s->d_arena);
+    if (s->d_seed_state) (void)hipFree(s->d_seed_state);
+    s->d_arena = nullptr;
+    s->d_seed_state = nullptr;
+    t->solvers.erase(std::remove(t->solvers.begin(), t->solvers.end(), s), t->solvers.end());
+    s->table = nullptr;
+}
+
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                               const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
@@ -670,6 +691,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     rs_solver *s = new (std::nothrow) rs_solver();
     if (!s) return fail(RS_ERR_OOM, "rs_solver_create: out of host memory");
     s->table = table;
+    table->solvers.push_back(s);
     s->tree = *tree;
     s->params = *params;
     if (deals) {
@@ -691,12 +713,12 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         }
     }
     if (rc != RS_OK) {
-        delete s;
+        rs_solver_destroy(s);
         return rc;
     }
     hipError_t e = hipSetDevice(table->device);
     if (e != hipSuccess) {
-        delete s;
+        rs_solver_destroy(s);
         return hip_fail(e, "hipSetDevice");
     }
     if (params->opp_mode == RS_OPP_SAMPLE) {
@@ -710,13 +732,13 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     }
     Builder b0(s, 0), b1(s, 1);
     if ((rc = b0.build()) != RS_OK || (rc = b1.build()) != RS_OK) {
-        delete s;
+        rs_solver_destroy(s);
         return rc;
     }
     s->arena_bytes = std::max(s->plan[0].arena_bytes, s->plan[1].arena_bytes);
     if ((e = hipMalloc((void **)&s->d_arena, std::max<size_t>(s->arena_bytes, 256))) != hipSuccess) {
         rc = hip_fail(e, "rs_solver_create: workspace hipMalloc");
-        delete s;
+        rs_solver_destroy(s);
         return rc;
     }
     // padding lanes are read by the vector kernels: keep them finite
@@ -768,23 +790,13 @@ extern "C" {
 
 void rs_solver_destroy(rs_solver *s) {
     if (!s) return;
-    (void)hipSetDevice(s->table->device);
-    (void)hipStreamSynchronize(s->table->stream);
-    for (int p = 0; p < 2; ++p) {
-        if (s->plan[p].graph_exec) (void)hipGraphExecDestroy(s->plan[p].graph_exec);
-        if (s->plan[p].graph) (void)hipGraphDestroy(s->plan[p].graph);
-        if (s->plan[p].d_jobs) (void)hipFree(s->plan[p].d_jobs);
-        if (s->plan[p].d_chance_jobs) (void)hipFree(s->plan[p].d_chance_jobs);
-        for (JitLaunch &JL : s->plan[p].jit)
-            if (JL.d_blob) (void)hipFree(JL.d_blob);
-    }
-    if (s->d_arena) (void)hipFree(s->d_arena);
-    if (s->d_seed_state) (void)hipFree(s->d_seed_state);
+    solver_release_device(s);
     delete s;
 }
 
 int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
     if (!s) return fail(RS_ERR_INVALID, "rs_iterate: solver is NULL");
+    if (!s->table) return fail(RS_ERR_INVALID, "rs_iterate: the solver's table has been destroyed");
     if (traverser != 0 && traverser != 1) return fail(RS_ERR_INVALID, "rs_iterate: traverser must be 0 or 1");
     RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
     if (int rc = run_plan(s, traverser)) return rc;
@@ -797,6 +809,7 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
 
 int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap) {
     if (!s) return fail(RS_ERR_INVALID, "rs_train: solver is NULL");
+    if (!s->table) return fail(RS_ERR_INVALID, "rs_train: the solver's table has been destroyed");
     if (discount_interval == 0) return fail(RS_ERR_INVALID, "rs_train: discount_interval must be > 0");
     uint64_t t = 0, threshold = discount_interval;
     while (t < iterations) {                       // cfr.rs:207

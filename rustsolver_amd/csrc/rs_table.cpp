@@ -236,6 +236,7 @@ void rs_table_destroy(rs_table *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    while (!t->solvers.empty()) solver_release_device(t->solvers.back());   // they stay valid handles, but inert
     for (Profile::Pending &p : t->prof.pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
