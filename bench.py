@@ -344,6 +344,21 @@ def main():
     except Exception as e:
         upd_node = {"error": str(e)}
 
+    # ---- discount sweep (cfr.rs:250-261, row a8): 16 bytes per cell, whole table --------------------------------------
+    disc = None
+    try:
+        table.profile_reset()
+        table.profile_enable(True)
+        for _ in range(10):
+            table.discount(0.999)
+        pd = table.profile_read()["discount"]
+        table.profile_enable(False)
+        gbs = pd["algo_bytes"] / (pd["ms"] * 1e-3) / 1e9
+        disc = {"kernel": "rs::k_discount (16 B per cell)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": pd["ms"] / max(1, pd["launches"])}
+    except Exception as e:
+        disc = {"error": str(e)}
+
     dom_kernel = ("rs_tree_kernel (tree-specialised, hipRTC: regret matching, reach, utilities and the regret / strategy_sum "
                   "update of all 14 river nodes in one launch per traverser)") if dom_name == "tree" else \
                  "rs::k_update (river regret/strategy_sum update, all action counts)"
@@ -381,9 +396,16 @@ def main():
                     "event-bracketed pass over the same K steps (ms_per_step there: %.3f)" % (elapsed_prof / a.steps * 1e3),
         },
         "roofline_update_node": upd_node,
+        "roofline_discount": disc,
         "kernels": kernels,
         "lane_updates_per_sec": sum(table.lanes(n) for n in range(table.n_nodes)) * n_gpus * a.steps / elapsed,
     }
+
+    if n_gpus > 1:   # the extra legs (single board, deal batches, CPU baselines) are N = 1 material
+        emit(out)
+        os.dup2(2, 1)
+        dist.destroy_process_group()
+        return
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:

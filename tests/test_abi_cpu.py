@@ -190,3 +190,14 @@ def test_index_to_cluster_and_dense_map():
     # two players, different ranges -> different sizes (size[0] != size[1] in general, infoset.rs:28-32)
     m2 = ab.DenseMap(ab.index_to_cluster([0, 1], cluster_arr))
     assert len(m2) == 1
+
+
+def test_oversize_and_malformed_tables_are_rejected_before_touching_the_gpu():
+    from rustsolver_amd import _lib as L2
+    with pytest.raises(rs.RsError) as e:                    # a node of 2^31+ cells must be sharded over the board axis
+        rs.InfosetTable.create([(8, 5000, 60000, 0, 0)])
+    assert e.value.code == L2.ERR_UNSUPPORTED
+    for bad in ([(0, 10, 1, 0, 0)], [(3, 0, 1, 0, 0)], [(3, 10, 0, 0, 0)], [(3, 10, 1, 2, 0)], [(3, 10, 1, 0, 3)], [(9, 10, 1, 0, 0)]):
+        with pytest.raises(rs.RsError) as e:
+            rs.InfosetTable.create(bad)
+        assert e.value.code == L2.ERR_INVALID

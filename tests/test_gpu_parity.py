@@ -443,6 +443,21 @@ def test_deal_batches_reject_bad_inputs():
     assert e.value.code == L.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_wide_nodes_through_both_plans(fuse):
+    """four bet sizes and two raise sizes: nodes with up to 6 actions (RS_MAX_ACTIONS = 8), tree kernels with A > 3"""
+    opts_g = rs.Options((800, 800), 40, 5, [[0.25, 0.5, 1.0, 2.0]], [[2.0, 3.0]])
+    opts_o = orc.make_options((800, 800), 40, 5, [[0.25, 0.5, 1.0, 2.0]], [[2.0, 3.0]])
+    tree, table, otree, otab, lg, lo = setup_pair(opts_g, opts_o, [2], 37, 88)
+    assert max(nd.n_children for nd in tree.action_nodes()) >= 5
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse)
+    osol = orc.OracleSolver(otree, otab, lo, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player, threads=4), "root util")
+    compare_tables(tree, table, otab)
+
+
 def test_train_with_discount_schedule_vs_oracle():
     # cfr.rs:188-265 with a short interval so that several discount ticks happen
     tree, table, otree, otab, lg, lo = setup_pair(rs.default_flop(), orc.options_default_river(), [1], 64, 3)
