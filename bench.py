@@ -359,7 +359,7 @@ def main():
     except Exception as e:
         disc = {"error": str(e)}
 
-    dom_kernel = ("rs_tree_kernel (tree-specialised, hipRTC: regret matching, reach, utilities and the regret / strategy_sum "
+    dom_kernel = ("rs_tree_p{0,1}_lanes (tree-specialised, hipRTC: regret matching, reach, utilities and the regret / strategy_sum "
                   "update of all 14 river nodes in one launch per traverser)") if dom_name == "tree" else \
                  "rs::k_update (river regret/strategy_sum update, all action counts)"
     out = {

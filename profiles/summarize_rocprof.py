@@ -49,7 +49,7 @@ per_kernel = collections.defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace)):
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_kernel")):
+        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_")):
             per_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     lines += ["## full-size dispatches (>= 1M work-items), kernel trace", "",
               "| kernel | dispatches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
@@ -58,6 +58,10 @@ if trace:
     upd = [d for k, v in per_kernel.items() if "k_update" in k for d in v]
     if upd:
         lines += ["", "all `k_update` full-size dispatches: %d, average %.1f us" % (len(upd), sum(upd) / len(upd) / 1e3), ""]
+    tre = [d for k, v in per_kernel.items() if "rs_tree_p" in k and "_lanes" in k and "_sampled" not in k for d in v]
+    if tre:
+        lines += ["all `rs_tree_p*_lanes` (river tree, lane model) full-size dispatches: %d, average %.1f us"
+                  % (len(tre), sum(tre) / len(tre) / 1e3), ""]
 
 traffic = {}
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -66,7 +70,7 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and ("rs::" in r["Kernel_Name"] or "rs_tree_kernel" in r["Kernel_Name"]):
+        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and ("rs::" in r["Kernel_Name"] or "rs_tree_" in r["Kernel_Name"]):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     traffic[counter] = agg
 if traffic:
@@ -81,7 +85,7 @@ if traffic:
         total = fa * 2 * 1024 + wa * 1024
         lines.append("| `%s` | %d | %.0f | %.4g | %.0f | %.4g | %.4g |" % (k, max(len(fv), len(wv)), fa, fa * 2048, wa, wa * 1024, total))
         for name in fam:
-            if ("k_" + name in k) or (name == "tree" and "rs_tree_kernel" in k):
+            if ("k_" + name in k) or (name == "tree" and "rs_tree_p" in k and "_lanes" in k and "_sampled" not in k):
                 fam[name][0] += total * max(len(fv), len(wv))
                 fam[name][1] += max(len(fv), len(wv))
     for name, (tot, n) in fam.items():

@@ -71,17 +71,17 @@ struct KernelCfg {
     int mode;        // RS_UPD_* bits (update only)
 };
 
-hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_update(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                          KernelCfg cfg, hipStream_t stream);
 // d_seed != nullptr selects the sampled-opponent form (cfr.rs:467-476) with *d_seed as the sweep seed
-hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_node_util(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                             KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
-hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                         KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
-hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *h_job, int n_jobs, uint32_t max_n_vec,
+hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);
 hipError_t launch_strategy(const void *src /*[A][pitch]*/, float *dst, uint32_t pitch, int n_actions, int dtype,
                            hipStream_t stream);
@@ -91,14 +91,13 @@ hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, i
 hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
                               hipStream_t stream);
 hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream);
-hipError_t launch_convert_f32_to_f16(const float *src, void *dst, size_t n, hipStream_t stream);
-hipError_t launch_convert_f16_to_f32(const void *src, float *dst, size_t n, hipStream_t stream);
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
 
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
 struct JitSubtree {
     std::string source;
+    std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals}[_sampled]
     std::vector<int> node_ids;     // tree node id of every action node, in the order the kernel indexes reg[] / ssm[]
     std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
     std::vector<int> const_terms;  // terminal ids in the order of cval[]
@@ -111,12 +110,11 @@ void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, c
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, JitSubtree &out);
 bool jit_available();
-int jit_get_kernel(const std::string &source, int device, hipFunction_t *fn);
+int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);
 const char *jit_device_source();
 
 // ---- host-side objects ----------------------------------------------------------------------------
-void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
@@ -158,8 +156,6 @@ struct rs_table {
     std::vector<int> rep_nodes;       // replicated node indices
     std::vector<size_t> rep_off;      // element offset of each of them inside the compact snapshot
     size_t rep_cells = 0;
-    void *h_stage = nullptr;          // pinned staging for small synchronous copies
-    size_t h_stage_bytes = 0;
     void *d_dregrets = nullptr;       // deal batches: delta tables (same layout as the table), zero between sweeps
     void *d_dssum = nullptr;
     std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away

@@ -332,25 +332,37 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
                                                      float d) {
     using R = Row<DT>;
     using V = typename R::val;
-    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * kBlock) {
-        constexpr size_t esize = (DT == RS_F16) ? 2 : 4;
-        char *rb = (char *)regrets + v * kVec * esize;   // 64-bit offsets: a table can exceed 2^32 cells
-        char *sb = (char *)ssum + v * kVec * esize;
-        V r[kVec], s[kVec];
-        R::load(rb, 0, 0, r);
-        R::load(sb, 0, 0, s);
+    constexpr size_t esize = (DT == RS_F16) ? 2 : 4;
+    constexpr int U = 4;   // vectors per array per thread and trip: 8 x 16-byte loads in flight before the first use
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t v0 = (size_t)blockIdx.x * kBlock + threadIdx.x; v0 < n_vec; v0 += stride * U) {
+        V r[U][kVec], s[U][kVec];
 #pragma unroll
-        for (int j = 0; j < kVec; j++) {
-            if constexpr (DT == RS_I32) {
-                r[j] = f32_as_i32((float)r[j] * d);   // cfr.rs:256
-                s[j] = f32_as_i32((float)s[j] * d);   // cfr.rs:257
-            } else {
-                r[j] = r[j] * d;
-                s[j] = s[j] * d;
+        for (int u = 0; u < U; u++) {
+            const size_t v = v0 + (size_t)u * stride;
+            if (v < n_vec) {   // 64-bit offsets: a table can exceed 2^32 cells
+                R::load((char *)regrets + v * kVec * esize, 0, 0, r[u]);
+                R::load((char *)ssum + v * kVec * esize, 0, 0, s[u]);
             }
         }
-        R::store(rb, 0, 0, r);
-        R::store(sb, 0, 0, s);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t v = v0 + (size_t)u * stride;
+            if (v < n_vec) {
+#pragma unroll
+                for (int j = 0; j < kVec; j++) {
+                    if constexpr (DT == RS_I32) {
+                        r[u][j] = f32_as_i32((float)r[u][j] * d);   // cfr.rs:256
+                        s[u][j] = f32_as_i32((float)s[u][j] * d);   // cfr.rs:257
+                    } else {
+                        r[u][j] = r[u][j] * d;
+                        s[u][j] = s[u][j] * d;
+                    }
+                }
+                R::store((char *)regrets + v * kVec * esize, 0, 0, r[u]);
+                R::store((char *)ssum + v * kVec * esize, 0, 0, s[u]);
+            }
+        }
     }
 }
 
@@ -501,13 +513,6 @@ __global__ __launch_bounds__(kBlock) void k_fill_uniform(float *__restrict__ dst
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_f32_to_f16(const float *__restrict__ src, _Float16 *__restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = (_Float16)src[i];
-}
-__global__ __launch_bounds__(kBlock) void k_f16_to_f32(const _Float16 *__restrict__ src, float *__restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) dst[i] = (float)src[i];
-}
-
 // replicated-round deltas for the multi-GPU all-reduce: x -= snap / x += snap (wrapping for i32)
 template <int DT, int SIGN>
 __global__ __launch_bounds__(kBlock) void k_delta(void *__restrict__ x, const void *__restrict__ snap, size_t n) {
@@ -547,7 +552,7 @@ static inline uint32_t grid_for(size_t n_threads_needed) {
     default: return hipErrorInvalidValue;                          \
     }
 
-hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_update(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                          KernelCfg cfg, hipStream_t stream) {
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
     const int arith = cfg.mode & RS_UPD_ARITH_MASK, flags = cfg.mode & ~RS_UPD_ARITH_MASK;
@@ -565,7 +570,7 @@ hipError_t launch_update(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uin
     return hipGetLastError();
 }
 
-hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_node_util(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                             KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream) {
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
 #define RS_NU(A_)                                                                                  \
@@ -577,7 +582,7 @@ hipError_t launch_node_util(const NodeJob *d_jobs, const NodeJob *, int n_jobs, 
     return hipGetLastError();
 }
 
-hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                         KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream) {
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
 #define RS_RE(A_)                                                                              \
@@ -589,7 +594,7 @@ hipError_t launch_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint
     return hipGetLastError();
 }
 
-hipError_t launch_prune_reach(const NodeJob *d_jobs, const NodeJob *, int n_jobs, uint32_t max_n_vec, int n_actions,
+hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                               KernelCfg cfg, hipStream_t stream) {
     if (cfg.dtype != RS_I32) return hipErrorInvalidValue;
     dim3 grid(grid_for(max_n_vec), (uint32_t)n_jobs), block(kBlock);
@@ -643,7 +648,7 @@ hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_
 
 hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream) {
     const size_t n_vec = n_cells / kVec;
-    dim3 grid(grid_for(n_vec)), block(kBlock);
+    dim3 grid(grid_for((n_vec + 3) / 4)), block(kBlock);
     if (dtype == RS_I32) hipLaunchKernelGGL((k_discount<RS_I32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
     else if (dtype == RS_F32) hipLaunchKernelGGL((k_discount<RS_F32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
     else hipLaunchKernelGGL((k_discount<RS_F16>), grid, block, 0, stream, regrets, ssum, n_vec, d);
@@ -662,16 +667,6 @@ hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t 
 hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream) {
     dim3 grid(grid_for(n)), block(kBlock);
     hipLaunchKernelGGL(k_fill_uniform, grid, block, 0, stream, dst, n, seed, lo, hi - lo);
-    return hipGetLastError();
-}
-hipError_t launch_convert_f32_to_f16(const float *src, void *dst, size_t n, hipStream_t stream) {
-    dim3 grid(grid_for(n)), block(kBlock);
-    hipLaunchKernelGGL(k_f32_to_f16, grid, block, 0, stream, src, (_Float16 *)dst, n);
-    return hipGetLastError();
-}
-hipError_t launch_convert_f16_to_f32(const void *src, float *dst, size_t n, hipStream_t stream) {
-    dim3 grid(grid_for(n)), block(kBlock);
-    hipLaunchKernelGGL(k_f16_to_f32, grid, block, 0, stream, (const _Float16 *)src, dst, n);
     return hipGetLastError();
 }
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream) {

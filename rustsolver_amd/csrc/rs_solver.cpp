@@ -437,7 +437,7 @@ struct Builder {
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, js);
                     hipFunction_t fn = nullptr;
-                    if (int rc = jit_get_kernel(js.source, t->device, &fn)) return rc;
+                    if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
                     auto bi = by_fn.find(fn);
                     if (bi == by_fn.end()) {
                         bi = by_fn.emplace(fn, int(plan.jit.size())).first;
@@ -563,13 +563,13 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     const NodeJob *jobs = plan.d_jobs + L.first_job;
     const KernelCfg cfg{t->dtype, s->params.mode};
     switch (L.kind) {
-    case L_REACH: e = launch_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
-    case L_PRUNE_REACH: e = launch_prune_reach(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_REACH: e = launch_reach(jobs, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
+    case L_PRUNE_REACH: e = launch_prune_reach(jobs, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
     case L_EXPAND:
         e = launch_chance_expand(plan.d_chance_jobs + L.first_job, L.n_jobs, L.max_lanes, s->n_clusters % 4 == 0, t->stream);
         break;
-    case L_UPDATE: e = launch_update(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
-    case L_NODE_UTIL: e = launch_node_util(jobs, nullptr, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
+    case L_UPDATE: e = launch_update(jobs, L.n_jobs, L.max_n_vec, L.n_actions, cfg, t->stream); break;
+    case L_NODE_UTIL: e = launch_node_util(jobs, L.n_jobs, L.max_n_vec, L.n_actions, cfg, s->d_seed(), t->stream); break;
     case L_REDUCE:
         e = launch_chance_reduce(plan.d_chance_jobs + L.first_job, L.n_jobs, L.max_lanes, s->n_clusters % 4 == 0, t->stream);
         break;

@@ -12,7 +12,6 @@ namespace rs {
 
 static thread_local std::string g_last_error;
 
-void set_error(const std::string &msg) { g_last_error = msg; }
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
@@ -77,16 +76,6 @@ static int check_node(const rs_table *t, int node, const char *fn) {
     if (node < 0 || node >= int(t->nodes.size()))
         return fail(RS_ERR_OOB, std::string(fn) + ": node index " + std::to_string(node) + " out of bounds (len " +
                                     std::to_string(t->nodes.size()) + ")");
-    return RS_OK;
-}
-
-static int ensure_stage(rs_table *t, size_t bytes) {
-    if (t->h_stage_bytes >= bytes) return RS_OK;
-    if (t->h_stage) (void)hipHostFree(t->h_stage);
-    t->h_stage = nullptr;
-    t->h_stage_bytes = 0;
-    RS_HIP(hipHostMalloc(&t->h_stage, bytes, hipHostMallocDefault), "hipHostMalloc(stage)");
-    t->h_stage_bytes = bytes;
     return RS_OK;
 }
 
@@ -249,7 +238,6 @@ void rs_table_destroy(rs_table *t) {
     if (t->d_job) (void)hipFree(t->d_job);
     if (t->d_dregrets) (void)hipFree(t->d_dregrets);
     if (t->d_dssum) (void)hipFree(t->d_dssum);
-    if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
@@ -504,7 +492,7 @@ int rs_update_node(rs_table *t, int node, const float *d_action_utils, const flo
     job.scale = scale;
     if (int rc = stage_job(t, job)) return rc;
     prof_begin(t, RS_K_UPDATE, algo_bytes_update(t, node, job.n_actions, d_reach != nullptr, d_node_util != nullptr));
-    hipError_t e = launch_update(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, mode}, t->stream);
+    hipError_t e = launch_update(t->d_job, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, mode}, t->stream);
     prof_end(t);
     RS_HIP(e, "k_update");
     return RS_OK;
@@ -521,7 +509,7 @@ int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_no
     if (int rc = stage_job(t, job)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_NODE_UTIL, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + 4.0));
-    hipError_t e = launch_node_util(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
+    hipError_t e = launch_node_util(t->d_job, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
     prof_end(t);
     RS_HIP(e, "k_node_util");
     return RS_OK;
@@ -538,7 +526,7 @@ int rs_child_reach(rs_table *t, int node, const float *d_reach, float *d_child_r
     if (int rc = stage_job(t, job)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_REACH, double(nd.n_boards) * nd.n_clusters * (nd.n_actions * (elem_size(t->dtype) + 4.0) + (d_reach ? 4.0 : 0.0)));
-    hipError_t e = launch_reach(t->d_job, nullptr, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
+    hipError_t e = launch_reach(t->d_job, 1, job.n_vec, job.n_actions, KernelCfg{t->dtype, 0}, nullptr, t->stream);
     prof_end(t);
     RS_HIP(e, "k_reach");
     return RS_OK;
