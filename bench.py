@@ -37,8 +37,9 @@ def parse():
     ap.add_argument("--mode", choices=["clamp", "wrap"], default="clamp",
                     help="clamp: cfr.rs:413-464 scale 100 (the live mccfr update); wrap: cfr.rs:612-621 scale 10000")
     ap.add_argument("--graph", type=int, default=0, help="replay each traverser sweep as one hipGraph")
-    ap.add_argument("--fuse", type=int, default=1,
-                    help="1: one tree-specialised (hipRTC) kernel per traverser sweep; 0: level-by-level node kernels")
+    ap.add_argument("--fuse", type=int, default=-1,
+                    help="1: one tree-specialised (hipRTC) kernel per traverser sweep; 0: level-by-level node kernels; "
+                         "-1: 1 if libhiprtc can be loaded")
     ap.add_argument("--tree", choices=["river", "three-street"], default="river",
                     help="river: options::default_flop() (BASELINE configs[1]); three-street: configs[2] (706 action nodes)")
     ap.add_argument("--boards3", default="1,49,2352", help="--tree three-street: boards per round (flop,turn,river)")
@@ -79,7 +80,7 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
     sampled = opp == "sample"
     chance = rs.CHANCE_PASS if (not three or sampled) else rs.CHANCE_ENUM
     trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=chance, use_graph=bool(graph),
-                              fuse_subtrees=int(fuse), opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
+                              fuse_subtrees=(None if int(fuse) < 0 else int(fuse)), opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
     table.sync()
     return trainer
 
@@ -381,7 +382,7 @@ def main():
             "n_boards_per_gpu": a.boards, "n_clusters": a.clusters, "lanes_per_gpu": a.boards * a.clusters,
             "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
             "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
-            "fused_subtrees": int(a.fuse),
+            "fused_subtrees": bool(trainer.fused),
             "parallelism": "boards sharded x%d, no collective (nothing replicated in a river-only tree)" % n_gpus,
         },
         "roofline": {

@@ -635,6 +635,7 @@ uint64_t orc_sweep_seed(uint64_t base_seed, uint64_t call_index) {
 
 int orc_weighted_index(const float *weights, int n, uint32_t bits) {
     float cumulative[ORC_MAX_ACTIONS];
+    if (n <= 0) abort();   /* WeightedIndex::new(&[]) is Err(NoItem); the reference unwrap()s it (cfr.rs:471) */
     float total_weight = weights[0];          /* WeightedIndex::new: first weight seeds the total */
     float u01, chosen;
     int i, idx = 0;

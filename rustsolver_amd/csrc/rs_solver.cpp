@@ -179,7 +179,7 @@ struct Builder {
         const rs_tree_node &nd = nodes[id];
         if (nd.kind == RS_NODE_ACTION) round = nd.round_idx;
         lane_round[id] = round;
-        bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+        bool own = nd.kind == RS_NODE_ACTION && nd.player == p && nd.n_children > 0;
         bool cl = nd.kind != RS_NODE_PUBLIC_CHANCE && nd.kind != RS_NODE_PRIVATE_CHANCE;
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
@@ -202,13 +202,16 @@ struct Builder {
     void mark_fused(int id) {
         const rs_tree_node &nd = nodes[id];
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;   // prune keeps the level plan (NaN-reach bookkeeping)
-        if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && closed[id]) {
+        if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
             fused_root[id] = 1;
             mark_inside(id);
             return;
         }
         for (int k = 0; k < nd.n_children; ++k) mark_fused(nd.children[k]);
     }
+
+    // an action node without valid actions (state.rs:125-157 can return none): worth 0, owns nothing, launches nothing
+    bool dead_end(int id) const { return nodes[id].kind == RS_NODE_ACTION && nodes[id].n_children == 0; }
 
     bool chance_enum(const rs_tree_node &nd) const {
         return nd.kind == RS_NODE_PUBLIC_CHANCE && s->params.chance_mode == RS_CHANCE_ENUM;
@@ -218,7 +221,7 @@ struct Builder {
     void layout(int id) {
         const rs_tree_node &nd = nodes[id];
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
-        if (nd.kind == RS_NODE_ACTION || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);
+        if ((nd.kind == RS_NODE_ACTION && nd.n_children > 0) || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);
         if (fused_root[id]) return;   // everything below lives in registers / LDS of k_subtree
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
@@ -235,7 +238,9 @@ struct Builder {
     ChildSrc child_source(int c) const {
         const rs_tree_node &cn = nodes[c];
         switch (cn.kind) {
-        case RS_NODE_ACTION: return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
+        case RS_NODE_ACTION:
+            if (cn.n_children == 0) return ChildSrc{nullptr, 0.0f, CH_CONST};   // util = 0f32 and empty loops, cfr.rs:571-589
+            return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
         case RS_NODE_PRIVATE_CHANCE: return child_source(cn.children[0]);
         case RS_NODE_PUBLIC_CHANCE:
             if (chance_enum(cn)) return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
@@ -333,7 +338,7 @@ struct Builder {
             LE.first_job = int(plan.chance_jobs.size());
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
-                if (nd.kind == RS_NODE_TERMINAL || fused_root[id] || inside[id]) continue;
+                if (nd.kind == RS_NODE_TERMINAL || fused_root[id] || inside[id] || dead_end(id)) continue;
                 const bool opp = nd.kind == RS_NODE_ACTION && nd.player != p;
                 const bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
                 bool any_child_buf = false;
@@ -399,7 +404,7 @@ struct Builder {
             LR.first_job = int(plan.chance_jobs.size());
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
-                if (inside[id]) continue;
+                if (inside[id] || dead_end(id)) continue;
                 if (fused_root[id]) {
                     sub_roots.push_back(id);
                     continue;
@@ -687,6 +692,11 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: RS_OPP_SAMPLE is mccfr(), whose chance nodes pass through (cfr.rs:306-313): use RS_CHANCE_PASS");
     if (tree->nodes.empty() || tree->nodes[0].kind != RS_NODE_PRIVATE_CHANCE)
         return fail(RS_ERR_INVALID, "rs_solver_create: node 0 must be the private chance root (tree_builder.rs:60-66)");
+    if (params->opp_mode == RS_OPP_SAMPLE)
+        for (const rs_tree_node &nd : tree->nodes)
+            if (nd.kind == RS_NODE_ACTION && nd.n_children == 0)
+                return fail(RS_ERR_INVALID, "rs_solver_create: action node " + std::to_string(nd.index) +
+                                                " has no valid action; mccfr would panic in WeightedIndex::new(&[]).unwrap() (cfr.rs:471)");
 
     rs_solver *s = new (std::nothrow) rs_solver();
     if (!s) return fail(RS_ERR_OOM, "rs_solver_create: out of host memory");
@@ -856,7 +866,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
         }
         for (size_t i = 0; i < n; ++i) {
             const rs_tree_node &nd = nodes[i];
-            if (nd.kind != RS_NODE_ACTION || !closed[i]) continue;
+            if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
             jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, js);

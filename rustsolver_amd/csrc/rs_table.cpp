@@ -159,8 +159,9 @@ int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int devic
     if (dtype != RS_I32 && dtype != RS_F32 && dtype != RS_F16) return fail(RS_ERR_INVALID, "rs_table_create: bad dtype");
     for (int i = 0; i < n_nodes; ++i) {
         const rs_node_desc &nd = nodes[i];
-        if (nd.n_actions < 1 || nd.n_actions > RS_MAX_ACTIONS || nd.n_clusters < 1 || nd.n_boards < 1 || nd.player > 1 ||
-            nd.round_idx >= RS_MAX_ROUNDS)
+        // n_actions == 0 is legal: state.rs:125-157 can return no valid action (a short all-in raise that stays below the
+        // bet); such a node owns no cells, is worth 0 (cfr.rs:571-589 with empty loops) and is never launched
+        if (nd.n_actions > RS_MAX_ACTIONS || nd.n_clusters < 1 || nd.n_boards < 1 || nd.player > 1 || nd.round_idx >= RS_MAX_ROUNDS)
             return fail(RS_ERR_INVALID, "rs_table_create: bad descriptor for node " + std::to_string(i));
         if (size_t(nd.n_boards) * nd.n_clusters * nd.n_actions > (size_t(1) << 31))
             return fail(RS_ERR_UNSUPPORTED, "rs_table_create: a node exceeds 2^31 cells; shard the board axis");
@@ -268,6 +269,7 @@ void *rs_stream(rs_table *t) { return t ? (void *)t->stream : nullptr; }
 static int board_copy(rs_table *t, int node, int board, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
     const rs_node_desc &nd = t->nodes[node];
+    if (nd.n_actions == 0) return RS_OK;
     if (board < 0 || uint32_t(board) >= nd.n_boards) return fail(RS_ERR_OOB, std::string(fn) + ": board out of bounds");
     const size_t col0 = size_t(board) * nd.n_clusters;
     if (regrets)
@@ -285,6 +287,7 @@ int rs_table_download(rs_table *t, int node, int board, void *regrets, void *ssu
 static int node_copy(rs_table *t, int node, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
     const rs_node_desc &nd = t->nodes[node];
+    if (nd.n_actions == 0) return RS_OK;   // nothing to copy
     const size_t lanes = size_t(nd.n_boards) * nd.n_clusters;
     if (regrets)
         if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], 0, regrets, nd.n_actions, lanes, dir)) return rc;
@@ -303,6 +306,7 @@ int rs_table_download_node(rs_table *t, int node, void *regrets, void *ssum) {
 static int infoset_copy(rs_table *t, int node, int board, int cluster, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
     const rs_node_desc &nd = t->nodes[node];
+    if (nd.n_actions == 0) return RS_OK;
     if (board < 0 || uint32_t(board) >= nd.n_boards || cluster < 0 || uint32_t(cluster) >= nd.n_clusters)
         return fail(RS_ERR_OOB, std::string(fn) + ": index out of bounds: the len is " + std::to_string(nd.n_clusters) +
                                     " but the index is " + std::to_string(cluster));
@@ -326,6 +330,7 @@ static int single_strategy(rs_table *t, int node, int board, int cluster, float 
     if (int rc = check_node(t, node, fn)) return rc;
     if (!out) return fail(RS_ERR_INVALID, std::string(fn) + ": out is NULL");
     const rs_node_desc &nd = t->nodes[node];
+    if (nd.n_actions == 0) return RS_OK;   // vec![0.0; 0]
     if (board < 0 || uint32_t(board) >= nd.n_boards || cluster < 0 || uint32_t(cluster) >= nd.n_clusters)
         return fail(RS_ERR_OOB, std::string(fn) + ": index out of bounds");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -440,6 +445,7 @@ static void base_job(const rs_table *t, int node, NodeJob &job) {
 
 int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
     if (int rc = check_node(t, node, "rs_regret_match_node")) return rc;
+    if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_strategy) return fail(RS_ERR_INVALID, "rs_regret_match_node: d_strategy is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     const rs_node_desc &nd = t->nodes[node];
@@ -451,6 +457,7 @@ int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
 }
 int rs_final_strategy_node(rs_table *t, int node, float *d_strategy) {
     if (int rc = check_node(t, node, "rs_final_strategy_node")) return rc;
+    if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_strategy) return fail(RS_ERR_INVALID, "rs_final_strategy_node: d_strategy is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     const rs_node_desc &nd = t->nodes[node];
@@ -481,6 +488,7 @@ static int check_mode(const rs_table *t, int mode, const char *fn) {
 int rs_update_node(rs_table *t, int node, const float *d_action_utils, const float *d_reach, float scale, int mode,
                    float *d_node_util) {
     if (int rc = check_node(t, node, "rs_update_node")) return rc;
+    if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_action_utils) return fail(RS_ERR_INVALID, "rs_update_node: d_action_utils is NULL");
     if (int rc = check_mode(t, mode, "rs_update_node")) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -500,6 +508,7 @@ int rs_update_node(rs_table *t, int node, const float *d_action_utils, const flo
 
 int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_node_util) {
     if (int rc = check_node(t, node, "rs_node_util")) return rc;
+    if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_action_utils || !d_node_util) return fail(RS_ERR_INVALID, "rs_node_util: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     NodeJob job;
@@ -517,6 +526,7 @@ int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_no
 
 int rs_child_reach(rs_table *t, int node, const float *d_reach, float *d_child_reach) {
     if (int rc = check_node(t, node, "rs_child_reach")) return rc;
+    if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_child_reach) return fail(RS_ERR_INVALID, "rs_child_reach: d_child_reach is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     NodeJob job;

@@ -264,7 +264,7 @@ int rs_tree_from_nodes(const rs_tree_node *nodes, int n_nodes, rs_tree **out) {
                   nd.n_children <= RS_MAX_ACTIONS && nd.parent < i;
         for (int k = 0; ok && k < nd.n_children; ++k) ok = nd.children[k] > i && nd.children[k] < n_nodes;
         if (nd.kind == RS_NODE_ACTION) {
-            ok = ok && nd.n_children >= 1 && nd.player < 2 && nd.round_idx < RS_MAX_ROUNDS && nd.index >= 0;
+            ok = ok && nd.player < 2 && nd.round_idx < RS_MAX_ROUNDS && nd.index >= 0;   // zero actions is possible (state.rs:125-157)
             ++n_act;
         }
         if (nd.kind == RS_NODE_TERMINAL) ok = ok && nd.n_children == 0 && nd.last_to_act < 2;

@@ -445,12 +445,15 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=True, opp_mode=L.OPP_FULL, sample_seed=0, deals=None):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal.
         deals: None (lane model) or dict (round_idx, player) -> uint32 array of dense cluster ids, one per deal
         (what get_cluster() returned, cfr.rs:361-365): batch-synchronous deal sweeps on the reference-shaped table."""
         self.game_tree, self.infosets = tree, infosets
         self._keep = [leaves, leaves_p1]
+        if fuse_subtrees is None:   # tree-specialised kernels need hipRTC at run time; the level plan does not
+            fuse_subtrees = bool(L.load().rs_jit_available())
+        self.fused = bool(fuse_subtrees)
         self.n_deals = None
         batch = None
         if deals is not None:

@@ -197,7 +197,7 @@ def test_oversize_and_malformed_tables_are_rejected_before_touching_the_gpu():
     with pytest.raises(rs.RsError) as e:                    # a node of 2^31+ cells must be sharded over the board axis
         rs.InfosetTable.create([(8, 5000, 60000, 0, 0)])
     assert e.value.code == L2.ERR_UNSUPPORTED
-    for bad in ([(0, 10, 1, 0, 0)], [(3, 0, 1, 0, 0)], [(3, 10, 0, 0, 0)], [(3, 10, 1, 2, 0)], [(3, 10, 1, 0, 3)], [(9, 10, 1, 0, 0)]):
+    for bad in ([(3, 0, 1, 0, 0)], [(3, 10, 0, 0, 0)], [(3, 10, 1, 2, 0)], [(3, 10, 1, 0, 3)], [(9, 10, 1, 0, 0)]):
         with pytest.raises(rs.RsError) as e:
             rs.InfosetTable.create(bad)
         assert e.value.code == L2.ERR_INVALID

@@ -254,7 +254,7 @@ def setup_pair(options_rs, options_orc, n_boards, C, seed, dtype=rs.I32, odtype=
         if dtype == rs.I32:
             R = rng.integers(-regret_scale, regret_scale, size=(a, lanes)).astype(np.int32)
             S = rng.integers(0, regret_scale, size=(a, lanes)).astype(np.int32)
-            if regret_scale >= 10**6:                                        # prune + saturation lanes
+            if regret_scale >= 10**6 and a > 0:                                        # prune + saturation lanes
                 R[0, ::11] = -10_000_001
                 R[a - 1, ::13] = 2_147_000_000
         else:
@@ -391,8 +391,9 @@ def setup_deals(options_rs, options_orc, sizes, n_deals, seed):
         a, n = nd.n_children, sizes[nd.round_idx][nd.player]
         R = rng.integers(-10**6, 10**6, size=(a, n)).astype(np.int32)
         S = rng.integers(0, 10**6, size=(a, n)).astype(np.int32)
-        R[0, ::5] = -10_000_001
-        R[a - 1, ::7] = 2_147_000_000
+        if a > 0:
+            R[0, ::5] = -10_000_001
+            R[a - 1, ::7] = 2_147_000_000
         table.upload_node(nd.index, R, S)
         otab.set_node(nd.index, R, S)
     cidx = {(r, p): rng.integers(0, sizes[r][p], size=n_deals).astype(np.uint32) for r in range(len(sizes)) for p in (0, 1)}
@@ -456,6 +457,79 @@ def test_wide_nodes_through_both_plans(fuse):
         for player in (0, 1):
             assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player, threads=4), "root util")
     compare_tables(tree, table, otab)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_randomised_differential(seed):
+    """random game options x engine modes, GPU vs oracle, bit for bit"""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    nb = int(rng.choice([5, 5, 4, 3]))
+    rounds = 6 - nb
+    bets = [sorted(rng.choice([0.25, 0.33, 0.5, 0.75, 1.0, 1.5, 2.0], size=int(rng.integers(1, 4)), replace=False).tolist()) for _ in range(rounds)]
+    raises = [sorted(rng.choice([2.0, 2.5, 3.0, 4.0], size=int(rng.integers(1, 3)), replace=False).tolist()) for _ in range(rounds)]
+    stacks = (int(rng.integers(50, 1500)), int(rng.integers(50, 1500)))
+    pot = int(rng.integers(4, 200))
+    og, oo = rs.Options(stacks, pot, nb, bets, raises), orc.make_options(stacks, pot, nb, bets, raises)
+    deals = bool(rng.integers(0, 3) == 0)
+    sampled = bool(rng.integers(0, 2)) if (deals or rounds == 1 or rng.integers(0, 2)) else False
+    fuse, graph = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    prune = bool(rng.integers(0, 4) == 0)
+    wrap = bool(rng.integers(0, 2)) and not prune
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if wrap else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    mgf = mg | (rs.UPD_PRUNE if prune else 0)
+    tag = dict(nb=nb, bets=bets, raises=raises, stacks=stacks, pot=pot, deals=deals, sampled=sampled, fuse=fuse, graph=graph, prune=prune, wrap=wrap)
+    _, probe = rs.build_game_tree(og)
+    if any(nd.n_children == 0 for nd in probe.action_nodes()):
+        sampled = False    # a node without valid actions makes mccfr panic (WeightedIndex::new(&[]).unwrap()); cfr() is fine
+    if deals:
+        sizes = [(int(rng.integers(3, 40)), int(rng.integers(3, 40))) for _ in range(rounds)]
+        n_deals = int(rng.integers(70, 600))
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(og, oo, sizes, n_deals, 5000 + seed)
+        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, fuse_subtrees=fuse, deals=cidx, use_graph=graph,
+                             opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
+        osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune,
+                                    opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=seed)
+    else:
+        C = int(rng.integers(3, 70))
+        if sampled or rng.integers(0, 2):
+            b = int(rng.integers(1, 4))
+            boards, cm_g, cm_o = [b] * rounds, rs.CHANCE_PASS, orc.CHANCE_PASS
+        else:
+            boards = [1]
+            for _ in range(rounds - 1):
+                boards.append(boards[-1] * int(rng.integers(1, 4)))
+            cm_g, cm_o = rs.CHANCE_ENUM, orc.CHANCE_ENUM
+        tree, table, otree, otab, lg, lo = setup_pair(og, oo, boards, C, 6000 + seed)
+        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, chance_mode=cm_g, fuse_subtrees=fuse, use_graph=graph,
+                             opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
+        osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, prune=prune, chance_mode=cm_o,
+                                opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=seed)
+    for it in range(2):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player)
+            assert_bits(got, want, "root util %r" % (tag,))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d: %r" % (nd.index, tag)
+
+
+def test_action_node_without_valid_actions():
+    """state.rs:125-157 can return no action: a short all-in raise that stays below the bet.  cfr(): value 0, no update;
+    mccfr(): WeightedIndex::new(&[]).unwrap() panics -> rs_solver_create refuses the sampled mode."""
+    og, oo = rs.Options((60, 1000), 100, 5, [[2.0]], [[3.0]]), orc.make_options((60, 1000), 100, 5, [[2.0]], [[3.0]])
+    _, probe = rs.build_game_tree(og)
+    assert any(nd.n_children == 0 for nd in probe.action_nodes())
+    for fuse in (1, 0):
+        tree, table, otree, otab, lg, lo = setup_pair(og, oo, [2], 9, 4)
+        tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse)
+        osol = orc.OracleSolver(otree, otab, lo, scale=100.0, mode=orc.UPD_CLAMP_I64, chance_mode=orc.CHANCE_PASS)
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util")
+        compare_tables(tree, table, otab)
+        with pytest.raises(rs.RsError):
+            rs.MCCFRTrainer(tree, table, lg, chance_mode=rs.CHANCE_PASS, opp_mode=rs.OPP_SAMPLE)
 
 
 def test_train_with_discount_schedule_vs_oracle():
