@@ -146,6 +146,33 @@ __device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, co
         if (delta != 0) __hip_atomic_fetch_add(p + idx[j], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// LDS-privatised form for deal batches: a workgroup first sums its deltas for one traverser node in LDS
+// (ds_add, conflict = same cell only), then flushes the non-zero cells with COALESCED global atomics
+// (consecutive threads -> consecutive cells), instead of 64 lanes adding into 64 different rows.
+// Layout of `lds`: [2][A][tpitch] ints (regret deltas, then strategy_sum deltas), same indexing as the delta tables.
+__device__ __forceinline__ void lds_zero(int *lds, unsigned n) {
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void lds_add_i32(int *lds, unsigned row_off, const unsigned (&idx)[kVecD], const int (&now)[kVecD],
+                                            const int (&before)[kVecD]) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        const int delta = (int)((unsigned)now[j] - (unsigned)before[j]);
+        if (delta != 0) __hip_atomic_fetch_add(lds + row_off + idx[j], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+__device__ __forceinline__ void lds_flush(int *lds, unsigned n_cells, void *dreg, void *dssm) {
+    __syncthreads();
+    RS_GLOBAL int *pr = as_global<int>(dreg), *ps = as_global<int>(dssm);
+    for (unsigned i = threadIdx.x; i < n_cells; i += blockDim.x) {
+        const int a = lds[i], b = lds[n_cells + i];
+        if (a != 0) __hip_atomic_fetch_add(pr + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != 0) __hip_atomic_fetch_add(ps + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
 // lanes past the end of the batch (pitch padding) must not touch the table: mark them inactive
 __device__ __forceinline__ void mask_tail_lanes(float (&reach)[kVecD], unsigned v, unsigned n_lanes) {
 #pragma unroll

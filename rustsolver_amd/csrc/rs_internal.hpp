@@ -97,7 +97,8 @@ hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipS
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
 struct JitSubtree {
     std::string source;
-    std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals}[_sampled]
+    std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals|deals_lds}[_sampled]
+    int threads = 256;             // workgroup size the kernel was generated for
     std::vector<int> node_ids;     // tree node id of every action node, in the order the kernel indexes reg[] / ssm[]
     std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
     std::vector<int> const_terms;  // terminal ids in the order of cval[]
@@ -108,7 +109,7 @@ struct JitSubtree {
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, JitSubtree &out);
+                      bool deals, bool lds, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

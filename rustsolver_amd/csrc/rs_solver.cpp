@@ -10,6 +10,7 @@
 // children cost no launch and no buffer: their utility is a constant or a sign lookup folded into
 // the consuming kernel.  rs_iterate replays the plan (optionally as one hipGraph).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -46,6 +47,8 @@ struct JitLaunch {
     uint32_t max_n_vec = 0;
     unsigned char *d_blob = nullptr;
     double bytes = 0.0;
+    int threads = 256;
+    size_t lds_bytes = 0;
 };
 
 struct Plan {
@@ -438,9 +441,24 @@ struct Builder {
                         leaf_buf[t2] = it->second;
                         leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
                     }
+                    // deal batches: privatise the deltas of a traverser node in LDS when [2][A][table pitch] ints fit in 64 KiB
+                    size_t lds_need = 0;
+                    if (s->deal_mode) {
+                        std::vector<int> stack{id};
+                        while (!stack.empty()) {
+                            const int q = stack.back();
+                            stack.pop_back();
+                            const rs_tree_node &qn = nodes[q];
+                            if (qn.kind == RS_NODE_ACTION && qn.player == p && qn.n_children > 0)
+                                lds_need = std::max(lds_need, size_t(2) * qn.n_children * t->pitch[qn.index] * 4);
+                            for (int k = 0; k < qn.n_children; ++k) stack.push_back(qn.children[k]);
+                        }
+                    }
+                    static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
+                    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= 64 * 1024 && !lds_off;
                     JitSubtree js;
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, js);
+                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, js);
                     hipFunction_t fn = nullptr;
                     if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
                     auto bi = by_fn.find(fn);
@@ -449,6 +467,7 @@ struct Builder {
                         plan.jit.emplace_back();
                         plan.jit.back().fn = fn;
                         plan.jit.back().stride = js.args_size;
+                        plan.jit.back().threads = js.threads;
                     }
                     JitLaunch &JL = plan.jit[bi->second];
                     const size_t base = JL.blob.size();
@@ -497,6 +516,7 @@ struct Builder {
                     }
                     JL.n_jobs += 1;
                     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
+                    if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_need);
                     JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
                 }
                 for (auto &kv : by_fn) {
@@ -580,12 +600,12 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         break;
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
-        size_t blocks = (size_t(JL.max_n_vec) + kBlock - 1) / kBlock;   // interleaved A/B: block size and grid cap are irrelevant here
-        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 16);
+        size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
-        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, kBlock, 1, 1, 0, t->stream, params, nullptr);
+        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, t->stream, params, nullptr);
         break;
     }
     }
@@ -869,7 +889,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;
