@@ -655,6 +655,15 @@ def test_showdown_sign_vs_bruteforce_oracle():
     assert set(np.unique(got).tolist()) == {-1.0, 0.0, 1.0} and got[0] == 0.0 and got[2] == 0.0
 
 
+def test_showdown_golden_fixture(golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "known_answers_n2_n3.json")))
+    cards = np.array([d["board"] + d["p0"] + d["p1"] for d in fx["showdown"]], dtype=np.uint8).T
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [4], [1])
+    _, got = rs.showdown_sign(table, cards)
+    assert got.tolist() == [float(d["sign"]) for d in fx["showdown"]]
+
+
 def test_cards_to_iteration_pipeline():
     """cards -> device showdown signs -> deal-batch sweep, against the oracle fed with its own brute-force signs"""
     rng = np.random.Generator(np.random.PCG64(9))
