@@ -229,6 +229,17 @@ typedef struct rs_solver_params {
                                kernels.  Results are bit-identical either way. */
     int32_t opp_mode;       /* RS_OPP_* */
     uint64_t sample_seed;   /* RS_OPP_SAMPLE: base seed of the sweep-seed sequence */
+    /* Multi-GPU sharding of a multi-round RS_CHANCE_ENUM sweep (BASELINE configs[3]); shard_world <= 1 = off.
+     * The boards of round `shard_round` (and of every later round) are split contiguously over the ranks, sizes differing
+     * by at most one; earlier rounds are REPLICATED.  This table holds only the rank's boards:
+     * n_boards[shard_round] = hi - lo with lo = rank*base + min(rank, rem), base = shard_global_boards / shard_world.
+     * At every chance node entering shard_round the ranks exchange the utility rows of their boards (one all-gather),
+     * after which each rank sums all deals in the reference order and applies IDENTICAL updates to the replicated
+     * rounds: results equal the single-GPU sweep bit for bit, for any rank count. */
+    int32_t shard_world;
+    int32_t shard_rank;
+    int32_t shard_round;
+    uint32_t shard_global_boards;   /* boards of shard_round over all ranks */
 } rs_solver_params;
 
 /* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
@@ -257,6 +268,14 @@ int rs_iterate(rs_solver *solver, int traverser, float *d_root_util);
 /* MCCFRTrainer::train (cfr.rs:188-265), deterministic: per iteration both traversers sweep, t += 1, then
  * the discount check `t > threshold` (d = p/(p+1), p = t/interval) until t > discount_cap. */
 int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap);
+/* Sharded sweeps: rs_iterate = phase 0 (everything inside the sharded rounds) + exchange + phase 1 (the replicated rounds).
+ * With a communicator attached the exchange is one in-place ncclAllGather over xGMI; without one the host runs the phases
+ * itself and moves the ranks' slots (tests emulate several ranks on one GPU this way). */
+int rs_solver_attach_comm(rs_solver *solver, rs_comm *comm);
+int rs_iterate_phase(rs_solver *solver, int traverser, int phase, float *d_root_util /* phase 1 only, may be NULL */);
+/* the exchange buffer of a traverser: [shard_world][bytes_per_rank]; rank r's slot is the r-th */
+int rs_solver_exchange_info(rs_solver *solver, int traverser, void **d_buf, size_t *bytes_per_rank);
+int rs_comm_allgather(rs_comm *comm, rs_table *table, void *d_buf, size_t bytes_per_rank);
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */

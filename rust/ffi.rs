@@ -26,7 +26,8 @@ pub struct rs_node_desc { pub n_actions: u32, pub n_clusters: u32, pub n_boards:
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_leaf_desc { pub kind: i32, pub d_buf: *const f32 }
 #[repr(C)] #[derive(Clone, Copy)]
-pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32, pub opp_mode: i32, pub sample_seed: u64 }
+pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32, pub opp_mode: i32, pub sample_seed: u64,
+                               pub shard_world: i32, pub shard_rank: i32, pub shard_round: i32, pub shard_global_boards: u32 }
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_deal_batch { pub n_deals: u32, pub d_cluster: [[*const u32; 2]; RS_MAX_ROUNDS] }

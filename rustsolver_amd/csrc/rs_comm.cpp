@@ -31,6 +31,7 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -48,8 +49,9 @@ Rccl *rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.GetErrorString) {
         dlclose(r.handle);
         r.handle = nullptr;
         return nullptr;
@@ -115,6 +117,21 @@ void rs_comm_destroy(rs_comm *c) {
         (void)r->CommDestroy(c->comm);
     }
     delete c;
+}
+
+// in-place all-gather of the exchange buffer [n_ranks][bytes_per_rank]: rank r contributes its r-th slot (xGMI: every rank
+// sends its slot to 7 peers over dedicated links; the slots are ~MBs, so the call is latency-bound)
+int rs_comm_allgather(rs_comm *c, rs_table *t, void *d_buf, size_t bytes_per_rank) {
+    if (!c || !t || !d_buf) return fail(RS_ERR_INVALID, "rs_comm_allgather: NULL argument");
+    if (bytes_per_rank % 4 != 0) return fail(RS_ERR_INVALID, "rs_comm_allgather: slot size must be a multiple of 4 bytes");
+    Rccl *r = rccl();
+    if (!r) return fail(RS_ERR_COMM, "rs_comm_allgather: librccl.so could not be loaded");
+    hipError_t e = hipSetDevice(t->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (bytes_per_rank == 0) return RS_OK;
+    const int rc = r->AllGather((const char *)d_buf + size_t(c->rank) * bytes_per_rank, d_buf, bytes_per_rank / 4, ncclFloat32_, c->comm, t->stream);
+    if (rc != ncclSuccess_) return comm_fail(rc, "ncclAllGather");
+    return RS_OK;
 }
 
 int rs_replicated_begin(rs_table *t, uint32_t round_mask) {

@@ -63,6 +63,12 @@ struct ChanceJob {
     uint32_t fan;       // deals per parent board
     uint32_t n_clusters;
     uint32_t n_parent_lanes;  // n_boards_parent * n_clusters
+    // board axis of the child round sharded over ranks (shard_world == 0: not sharded)
+    uint32_t board_off;       // expand: global index of this rank's first child board
+    uint32_t n_child_lanes;   // expand: child lanes to write (local boards * n_clusters)
+    uint32_t shard_world;     // reduce: src is the exchange buffer [rank][..] instead of one contiguous [boards][C]
+    uint32_t rank_stride;     // reduce: floats between two ranks' slots
+    uint32_t shard_lo[9];     // reduce: first global board of every rank, then the total
 };
 
 // ---- kernel launchers (rs_kernels.hip) ----------------------------------------------------------

@@ -282,11 +282,11 @@ __global__ __launch_bounds__(kBlock) void k_chance_expand(const ChanceJob *__res
     const ChanceJob job = jobs[blockIdx.y];
     // lane counts are < 2^31 per node (checked at table creation): 32-bit index math
     const uint32_t C = job.n_clusters, fan = job.fan;
-    const uint32_t n_child = job.n_parent_lanes * fan / VEC;
+    const uint32_t n_child = job.n_child_lanes / VEC;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_child; i += gridDim.x * kBlock) {
         const uint32_t l = i * VEC;
         const uint32_t bc = l / C, c = l - bc * C;
-        const uint32_t bp = bc / fan;
+        const uint32_t bp = (bc + job.board_off) / fan;   // board_off: this rank's first board when the child round is sharded
         if constexpr (VEC == 4) {
             float rp[4];
             if (job.src) load_f32_row(job.src + (size_t)bp * C + c, 0, rp);
@@ -308,19 +308,26 @@ __global__ __launch_bounds__(kBlock) void k_chance_reduce(const ChanceJob *__res
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_par; i += gridDim.x * kBlock) {
         const uint32_t l = i * VEC;
         const uint32_t b = l / C, c = l - b * C;
-        const float *p = job.src + (size_t)b * fan * C + c;
+        // row of deal d: contiguous [boards][C], or, when the child round is sharded, inside the owning rank's slot
+        auto row = [&](uint32_t d) -> const float * {
+            const uint32_t gb = b * fan + d;
+            if (job.shard_world == 0) return job.src + (size_t)gb * C + c;
+            uint32_t g = 0;
+            while (g + 1 < job.shard_world && gb >= job.shard_lo[g + 1]) ++g;
+            return job.src + (size_t)g * job.rank_stride + (size_t)(gb - job.shard_lo[g]) * C + c;
+        };
         if constexpr (VEC == 4) {
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (uint32_t d = 0; d < fan; d++) {
                 float u[4];
-                load_f32_row(p + (size_t)d * C, 0, u);
+                load_f32_row(row(d), 0, u);
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[j] = acc[j] + u[j];
             }
             store_f32_row(job.dst + l, 0, acc);
         } else {
             float acc = 0.0f;
-            for (uint32_t d = 0; d < fan; d++) acc = acc + p[(size_t)d * C];
+            for (uint32_t d = 0; d < fan; d++) acc = acc + *row(d);
             job.dst[l] = acc;
         }
     }

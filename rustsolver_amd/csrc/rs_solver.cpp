@@ -58,6 +58,8 @@ struct Plan {
     std::vector<NodeJob> jobs;
     NodeJob *d_jobs = nullptr;
     std::vector<Launch> launches;
+    size_t split = 0;                   // sharded sweeps: launches [0, split) = phase 0, [split, end) = phase 1
+    int n_boundary = 0;                 // chance nodes entering the sharded round
     size_t arena_bytes = 0;
     const float *root_util = nullptr;   // inside the arena
     size_t root_lanes = 0;
@@ -79,6 +81,13 @@ struct rs_solver {
     uint32_t n_clusters = 0;
     size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
     int n_rounds = 0;
+    // multi-GPU sharding (rs_solver_params.shard_*)
+    bool sharded = false;
+    uint32_t shard_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // first global board of every rank at shard_round, then the total
+    size_t slot_lanes = 0;              // floats per (rank, boundary node) in the exchange buffer
+    float *d_exchange = nullptr;        // [world][n_boundary][slot_lanes]
+    size_t exchange_floats_per_rank = 0;
+    rs_comm *comm = nullptr;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -144,7 +153,23 @@ int derive_geometry(rs_solver *s) {
     }
     for (int r = 0; r < s->n_rounds; ++r)
         if (!seen[r]) return fail(RS_ERR_INVALID, "rs_solver_create: no action node in round " + std::to_string(r));
+    if (s->params.shard_world > 1) {
+        const int W = s->params.shard_world, g = s->params.shard_rank, sr = s->params.shard_round;
+        if (W > 8 || g < 0 || g >= W || sr < 1 || sr >= s->n_rounds)
+            return fail(RS_ERR_INVALID, "rs_solver_create: bad shard_world / shard_rank / shard_round (world <= 8, 1 <= round < n_rounds)");
+        if (s->params.chance_mode != RS_CHANCE_ENUM)
+            return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: board sharding of a multi-round sweep needs RS_CHANCE_ENUM");
+        const uint32_t G = s->params.shard_global_boards, base = G / W, rem = G % W;
+        if (G % s->n_boards[sr - 1] != 0) return fail(RS_ERR_INVALID, "rs_solver_create: shard_global_boards must be a multiple of the parent round's boards");
+        for (int q = 0; q <= W; ++q) s->shard_lo[q] = uint32_t(q) * base + std::min<uint32_t>(uint32_t(q), rem);
+        if (s->n_boards[sr] != s->shard_lo[g + 1] - s->shard_lo[g] || s->n_boards[sr] == 0)
+            return fail(RS_ERR_INVALID, "rs_solver_create: this rank must hold boards [" + std::to_string(s->shard_lo[g]) + ", " +
+                                            std::to_string(s->shard_lo[g + 1]) + ") of the sharded round");
+        s->sharded = true;
+        s->slot_lanes = round_up(size_t(base + (rem ? 1 : 0)) * s->n_clusters, kLanePad);
+    }
     for (int r = 1; r < s->n_rounds; ++r) {
+        if (s->sharded && r == s->params.shard_round) continue;   // local boards of the sharded round are a slice
         if (s->n_boards[r] % s->n_boards[r - 1] != 0)
             return fail(RS_ERR_INVALID, "rs_solver_create: n_boards of a round must be a multiple of the previous round's");
         if (s->params.chance_mode == RS_CHANCE_PASS && s->n_boards[r] != s->n_boards[r - 1])
@@ -175,6 +200,18 @@ struct Builder {
         return off + 1;
     }
     float *aptr(size_t off1) const { return reinterpret_cast<float *>(s->d_arena + (off1 - 1)); }
+    std::vector<float *> util_override;   // sharded: the utility rows of boundary children live in the exchange buffer
+    std::vector<int> boundary_k;          // chance node id -> index among the boundary nodes, -1 otherwise
+    float *uptr(int id) const { return util_override[id] ? util_override[id] : aptr(util_off[id]); }
+    // deals below a chance node: global count when its child round is the sharded one
+    uint32_t fan_of(int chance_id) const {
+        const int c = nodes[chance_id].children[0];
+        if (s->sharded && lane_round[c] == s->params.shard_round) return s->params.shard_global_boards / s->n_boards[lane_round[chance_id]];
+        return s->n_boards[lane_round[c]] / s->n_boards[lane_round[chance_id]];
+    }
+    bool boundary(int chance_id) const {
+        return s->sharded && nodes[chance_id].kind == RS_NODE_PUBLIC_CHANCE && lane_round[nodes[chance_id].children[0]] == s->params.shard_round;
+    }
 
     void annotate(int id, int d, int round) {
         depth[id] = d;
@@ -243,10 +280,10 @@ struct Builder {
         switch (cn.kind) {
         case RS_NODE_ACTION:
             if (cn.n_children == 0) return ChildSrc{nullptr, 0.0f, CH_CONST};   // util = 0f32 and empty loops, cfr.rs:571-589
-            return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
+            return ChildSrc{uptr(c), 0.0f, CH_BUF};
         case RS_NODE_PRIVATE_CHANCE: return child_source(cn.children[0]);
         case RS_NODE_PUBLIC_CHANCE:
-            if (chance_enum(cn)) return ChildSrc{aptr(util_off[c]), 0.0f, CH_BUF};
+            if (chance_enum(cn)) return ChildSrc{uptr(c), 0.0f, CH_BUF};
             return child_source(cn.children[0]);  // cfr.rs:306-309
         default: break;
         }
@@ -291,9 +328,14 @@ struct Builder {
         fused_root.assign(n, 0);
         inside.assign(n, 0);
         reach.assign(n, ReachSrc{});
+        util_override.assign(n, nullptr);
+        boundary_k.assign(n, -1);
         util_off.assign(n, 0);
         reach_off.assign(n, 0);
         annotate(0, 0, 0);
+        plan.n_boundary = 0;
+        for (size_t id = 0; id < n; ++id)
+            if (boundary(int(id))) boundary_k[id] = plan.n_boundary++;
         mark_fused(0);
         layout(0);
         // ENUM chance children: need their own reach buffer when the chance node's reach is a buffer.
@@ -326,6 +368,11 @@ struct Builder {
         const double es = double(elem_size(t->dtype));
         std::vector<std::vector<int>> by_depth(max_depth + 1);
         for (size_t id = 0; id < n; ++id) by_depth[depth[id]].push_back(int(id));
+        if (s->sharded)
+            for (size_t id = 0; id < n; ++id)
+                if (boundary_k[id] >= 0)   // this rank's slot for the k-th boundary node
+                    util_override[nodes[id].children[0]] =
+                        s->d_exchange + (size_t(s->params.shard_rank) * plan.n_boundary + boundary_k[id]) * s->slot_lanes;
 
         if (s->params.opp_mode == RS_OPP_SAMPLE) {   // advance the sweep seed (part of the plan, hence of the hipGraph)
             Launch L;
@@ -353,7 +400,7 @@ struct Builder {
                         any_child_buf = true;
                     } else if (chance_enum(nd)) {
                         // constant incoming reach: fold cfr_reach * (1.0 / len) on the host (same f32 ops)
-                        const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
+                        const uint32_t fan = fan_of(id);
                         reach[c] = ReachSrc{nullptr, reach[id].cst * (1.0f / float(fan)), true};
                     } else reach[c] = reach[id];  // own node (cfr.rs:580) or pass-through chance
                 }
@@ -362,9 +409,18 @@ struct Builder {
                 else if (own && prune) prune_groups[nd.n_children].push_back(id);
                 else if (chance_enum(nd)) {
                     const int c = nd.children[0];
-                    const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
-                    plan.chance_jobs.push_back(ChanceJob{reach[id].ptr, aptr(reach_off[c]), reach[id].cst, 1.0f / float(fan), fan,
-                                                         s->n_clusters, uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)});
+                    const uint32_t fan = fan_of(id);
+                    ChanceJob cj{};
+                    cj.src = reach[id].ptr;
+                    cj.dst = aptr(reach_off[c]);
+                    cj.src_const = reach[id].cst;
+                    cj.inv = 1.0f / float(fan);
+                    cj.fan = fan;
+                    cj.n_clusters = s->n_clusters;
+                    cj.n_parent_lanes = uint32_t(s->n_boards[lane_round[id]] * s->n_clusters);
+                    cj.n_child_lanes = uint32_t(s->n_boards[lane_round[c]] * s->n_clusters);   // local boards when sharded
+                    cj.board_off = boundary(id) ? s->shard_lo[s->params.shard_rank] : 0;
+                    plan.chance_jobs.push_back(cj);
                     LE.max_lanes = std::max(LE.max_lanes, size_t(lanes(c)));
                     LE.bytes += lanes(c) * 4.0 + lanes(id) * 4.0;
                 }
@@ -399,6 +455,11 @@ struct Builder {
             }
         }
         // ---- bottom-up -----------------------------------------------------------------------------
+        // sharded sweeps: pass 0 = everything inside the sharded rounds (phase 0, before the exchange), pass 1 = the
+        // replicated rounds including the boundary reduces (phase 1); unsharded: one pass
+        for (int pass = 0; pass < (s->sharded ? 2 : 1); ++pass) {
+        if (pass == 1) plan.split = plan.launches.size();
+        auto in_pass = [&](int id) { return !s->sharded || (lane_round[id] >= s->params.shard_round) == (pass == 0); };
         for (int d = max_depth; d >= 0; --d) {
             std::map<int, std::vector<int>> upd_groups, util_groups;
             std::vector<int> sub_roots;
@@ -407,7 +468,7 @@ struct Builder {
             LR.first_job = int(plan.chance_jobs.size());
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
-                if (inside[id] || dead_end(id)) continue;
+                if (inside[id] || dead_end(id) || !in_pass(id)) continue;
                 if (fused_root[id]) {
                     sub_roots.push_back(id);
                     continue;
@@ -417,9 +478,19 @@ struct Builder {
                     const int c = nd.children[0];
                     const ChildSrc src = child_source(c);
                     if (src.kind != CH_BUF) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: chance node above a terminal");
-                    const uint32_t fan = s->n_boards[lane_round[c]] / s->n_boards[lane_round[id]];
-                    plan.chance_jobs.push_back(ChanceJob{src.buf, aptr(util_off[id]), 0.0f, 0.0f, fan, s->n_clusters,
-                                                         uint32_t(s->n_boards[lane_round[id]] * s->n_clusters)});
+                    ChanceJob cj{};
+                    cj.src = src.buf;
+                    cj.dst = aptr(util_off[id]);
+                    cj.fan = fan_of(id);
+                    cj.n_clusters = s->n_clusters;
+                    cj.n_parent_lanes = uint32_t(s->n_boards[lane_round[id]] * s->n_clusters);
+                    if (boundary(id)) {   // the deals live in the exchange buffer, one slot per rank
+                        cj.src = s->d_exchange + size_t(boundary_k[id]) * s->slot_lanes;
+                        cj.shard_world = uint32_t(s->params.shard_world);
+                        cj.rank_stride = uint32_t(size_t(plan.n_boundary) * s->slot_lanes);
+                        std::memcpy(cj.shard_lo, s->shard_lo, sizeof(cj.shard_lo));
+                    }
+                    plan.chance_jobs.push_back(cj);
                     LR.max_lanes = std::max(LR.max_lanes, size_t(lanes(id)));
                     LR.bytes += lanes(c) * 4.0 + lanes(id) * 4.0;
                 }
@@ -491,7 +562,7 @@ struct Builder {
                         put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
                     }
                     put_ptr(js.off_reach, reach[id].ptr);
-                    put_ptr(js.off_out, aptr(util_off[id]));
+                    put_ptr(js.off_out, uptr(id));
                     put_ptr(js.off_seed, s->d_seed());
                     put_f32(js.off_reach_const, reach[id].cst);
                     put_f32(js.off_scale, s->params.scale);
@@ -542,7 +613,7 @@ struct Builder {
                             job.child[k] = child_source(nd.children[k]);
                             if ((job.child[k].kind & 0xff) != CH_CONST) ++n_buf;
                         }
-                        job.out_util = aptr(util_off[id]);
+                        job.out_util = uptr(id);
                         if (which == 0 && !reach[id].valid) return fail(RS_ERR_INVALID, "rs_solver_create: internal: no reach for a traverser node");
                         L.max_n_vec = std::max(L.max_n_vec, job.n_vec);
                         if (which == 0) L.bytes += lanes(id) * (nd.n_children * 4.0 * es + 4.0 * n_buf + (job.reach ? 4.0 : 0.0) + 4.0);
@@ -554,6 +625,8 @@ struct Builder {
                 }
             }
         }
+        }   // pass
+        if (!s->sharded) plan.split = plan.launches.size();
         if (s->deal_mode) {   // table += delta, delta = 0
             Launch L;
             L.kind = L_APPLY;
@@ -614,10 +687,11 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     return RS_OK;
 }
 
-int run_plan(rs_solver *s, int p) {
+// phase -1: the whole plan; 0: launches before the exchange; 1: after it (sharded sweeps only)
+int run_plan(rs_solver *s, int p, int phase = -1) {
     Plan &plan = s->plan[p];
     rs_table *t = s->table;
-    if (s->params.use_graph && !t->prof.on) {
+    if (phase < 0 && s->params.use_graph && !t->prof.on && !s->sharded) {
         if (!plan.graph_exec) {
             RS_HIP(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
             int rc = RS_OK;
@@ -631,8 +705,9 @@ int run_plan(rs_solver *s, int p) {
         RS_HIP(hipGraphLaunch(plan.graph_exec, t->stream), "hipGraphLaunch");
         return RS_OK;
     }
-    for (const Launch &L : plan.launches)
-        if (int rc = run_launch(s, plan, L)) return rc;
+    const size_t lo = phase == 1 ? plan.split : 0, hi = phase == 0 ? plan.split : plan.launches.size();
+    for (size_t i = lo; i < hi; ++i)
+        if (int rc = run_launch(s, plan, plan.launches[i])) return rc;
     return RS_OK;
 }
 
@@ -686,6 +761,8 @@ void rs::solver_release_device(rs_solver *s) {
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
     if (s->d_seed_state) (void)hipFree(s->d_seed_state);
+    if (s->d_exchange) (void)hipFree(s->d_exchange);
+    s->d_exchange = nullptr;
     s->d_arena = nullptr;
     s->d_seed_state = nullptr;
     t->solvers.erase(std::remove(t->solvers.begin(), t->solvers.end(), s), t->solvers.end());
@@ -773,6 +850,16 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     }
     // padding lanes are read by the vector kernels: keep them finite
     (void)hipMemsetAsync(s->d_arena, 0, std::max<size_t>(s->arena_bytes, 256), table->stream);
+    if (s->sharded) {
+        const size_t nb = size_t(std::max(s->plan[0].n_boundary, s->plan[1].n_boundary));
+        s->exchange_floats_per_rank = nb * s->slot_lanes;
+        const size_t bytes = std::max<size_t>(size_t(s->params.shard_world) * s->exchange_floats_per_rank * sizeof(float), 256);
+        if ((e = hipMalloc((void **)&s->d_exchange, bytes)) != hipSuccess || (e = hipMemsetAsync(s->d_exchange, 0, bytes, table->stream)) != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: exchange buffer");
+            rs_solver_destroy(s);
+            return rc;
+        }
+    }
     if ((rc = b0.emit()) != RS_OK || (rc = b1.emit()) != RS_OK) {
         rs_solver_destroy(s);
         return rc;
@@ -824,16 +911,52 @@ void rs_solver_destroy(rs_solver *s) {
     delete s;
 }
 
+static int copy_root(rs_solver *s, int traverser, float *d_root_util) {
+    if (d_root_util)
+        RS_HIP(hipMemcpyAsync(d_root_util, s->plan[traverser].root_util, s->plan[traverser].root_lanes * sizeof(float),
+                              hipMemcpyDeviceToDevice, s->table->stream),
+               "rs_iterate: root util copy");
+    return RS_OK;
+}
+
 int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
     if (!s) return fail(RS_ERR_INVALID, "rs_iterate: solver is NULL");
     if (!s->table) return fail(RS_ERR_INVALID, "rs_iterate: the solver's table has been destroyed");
     if (traverser != 0 && traverser != 1) return fail(RS_ERR_INVALID, "rs_iterate: traverser must be 0 or 1");
     RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+    if (s->sharded) {
+        if (!s->comm) return fail(RS_ERR_INVALID, "rs_iterate: sharded solver without a communicator: rs_solver_attach_comm, or drive the "
+                                                  "phases with rs_iterate_phase and exchange the slots yourself");
+        if (int rc = run_plan(s, traverser, 0)) return rc;
+        if (int rc = rs_comm_allgather(s->comm, s->table, s->d_exchange, size_t(s->plan[traverser].n_boundary) * s->slot_lanes * sizeof(float)))
+            return rc;
+        if (int rc = run_plan(s, traverser, 1)) return rc;
+        return copy_root(s, traverser, d_root_util);
+    }
     if (int rc = run_plan(s, traverser)) return rc;
-    if (d_root_util)
-        RS_HIP(hipMemcpyAsync(d_root_util, s->plan[traverser].root_util, s->plan[traverser].root_lanes * sizeof(float),
-                              hipMemcpyDeviceToDevice, s->table->stream),
-               "rs_iterate: root util copy");
+    return copy_root(s, traverser, d_root_util);
+}
+
+int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util) {
+    if (!s || !s->table) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad solver");
+    if ((traverser != 0 && traverser != 1) || (phase != 0 && phase != 1)) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad traverser / phase");
+    if (!s->sharded) return fail(RS_ERR_INVALID, "rs_iterate_phase: the solver is not sharded");
+    RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+    if (int rc = run_plan(s, traverser, phase)) return rc;
+    return phase == 1 ? copy_root(s, traverser, d_root_util) : RS_OK;
+}
+
+int rs_solver_attach_comm(rs_solver *s, rs_comm *comm) {
+    if (!s) return fail(RS_ERR_INVALID, "rs_solver_attach_comm: solver is NULL");
+    s->comm = comm;
+    return RS_OK;
+}
+
+int rs_solver_exchange_info(rs_solver *s, int traverser, void **d_buf, size_t *bytes_per_rank) {
+    if (!s || !d_buf || !bytes_per_rank || traverser < 0 || traverser > 1) return fail(RS_ERR_INVALID, "rs_solver_exchange_info: bad argument");
+    if (!s->sharded) return fail(RS_ERR_INVALID, "rs_solver_exchange_info: the solver is not sharded");
+    *d_buf = s->d_exchange;
+    *bytes_per_rank = size_t(s->plan[traverser].n_boundary) * s->slot_lanes * sizeof(float);
     return RS_OK;
 }
 

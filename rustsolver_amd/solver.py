@@ -445,7 +445,7 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None, shard=None):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal.
         deals: None (lane model) or dict (round_idx, player) -> uint32 array of dense cluster ids, one per deal
         (what get_cluster() returned, cfr.rs:361-365): batch-synchronous deal sweeps on the reference-shaped table."""
@@ -475,7 +475,8 @@ class MCCFRTrainer:
                 arr[nid].kind = kind
                 arr[nid].d_buf = buf.ptr
             arrs.append(arr)
-        p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees), opp_mode, sample_seed)
+        sw, sr, srd, sg = shard if shard else (0, 0, 0, 0)   # (world, rank, round, global boards of that round)
+        p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees), opp_mode, sample_seed, sw, sr, srd, sg)
         h = C.c_void_p()
         if batch is None:
             L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))
@@ -519,6 +520,22 @@ class MCCFRTrainer:
         out = self.infosets.lane_buffer(root.index, 1)
         L.check(L.load().rs_iterate(self._h, player, out.ptr))
         return self.infosets.read_lane_buffer(out, root.index)[0]
+
+    def iterate_phase(self, player, phase, want_root_util=False):
+        """sharded sweeps driven by the host: phase 0, <exchange the slots>, phase 1"""
+        root = self.game_tree.nodes[self.game_tree.nodes[0].children[0]]
+        out = self.infosets.lane_buffer(root.index, 1) if (want_root_util and phase == 1) else None
+        L.check(L.load().rs_iterate_phase(self._h, player, phase, None if out is None else out.ptr))
+        return None if out is None else self.infosets.read_lane_buffer(out, root.index)[0]
+
+    def exchange_info(self, player):
+        """(device pointer, bytes per rank) of the exchange buffer [world][bytes per rank]"""
+        buf, n = C.c_void_p(), C.c_size_t()
+        L.check(L.load().rs_solver_exchange_info(self._h, player, C.byref(buf), C.byref(n)))
+        return buf.value, n.value
+
+    def attach_comm(self, comm_handle):
+        L.check(L.load().rs_solver_attach_comm(self._h, comm_handle))
 
     def train(self, iterations, discount_interval=None, discount_cap=None):
         """cfr.rs:188"""

@@ -705,6 +705,96 @@ def test_checkpoint_roundtrip(tmp_path):
             rs.InfosetTable.load(path)
 
 
+# ---- sharded multi-round sweep (BASELINE configs[3]): W ranks emulated on one GPU ------------------------------------------
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_sharded_enum_sweep_equals_single_gpu(world, fuse):
+    """Turn and river boards sharded over `world` ranks, flop replicated; the ranks exchange the turn-root utility rows at the
+    sharded chance nodes (here: copied by the test between the ranks' exchange buffers; in production one ncclAllGather).
+    Every rank must end up with the SAME flop table as the unsharded sweep and with its slice of the turn / river tables."""
+    from rustsolver_amd.dist import shard_boards
+    Cn, G = 8, [1, 5, 10]                       # global boards per round; turn = sharded round (5 boards over 2 or 3 ranks)
+    fan_river = G[2] // G[1]
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), G, Cn, 99)
+    full = {nd.index: table.download_node(nd.index) for nd in tree.action_nodes()}
+    # global leaf signs per round, re-read from the full run's buffers
+    signs = {}
+    for i, nd in enumerate(tree.nodes):
+        if i in lg:
+            r = tree.nodes[nd.parent].round_idx
+            if r not in signs:
+                signs[r] = table.read_lane_buffer(lg[i][1], tree.nodes[nd.parent].index)[0].copy()
+    ref = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse)
+    osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=orc.CHANCE_ENUM)
+
+    ranks = []
+    for g in range(world):
+        tlo, thi = shard_boards(G[1], g, world)
+        boards = [1, thi - tlo, (thi - tlo) * fan_river]
+        n_actions, tr_tree = rs.build_game_tree(rs.three_street_options())
+        tb = rs.create_infosets(n_actions, tr_tree, [Cn], boards)
+        cols = {0: slice(0, Cn), 1: slice(tlo * Cn, thi * Cn), 2: slice(tlo * fan_river * Cn, thi * fan_river * Cn)}
+        for nd in tr_tree.action_nodes():
+            R, S = full[nd.index]
+            tb.upload_node(nd.index, R[:, cols[nd.round_idx]], S[:, cols[nd.round_idx]])
+        leaves, bufs = {}, {}
+        for i, nd in enumerate(tr_tree.nodes):
+            if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+                parent = tr_tree.nodes[nd.parent]
+                r = parent.round_idx
+                if r not in bufs:
+                    bufs[r] = tb.lane_buffer(parent.index, 1, signs[r][cols[r]])
+                leaves[i] = (rs.LEAF_SIGN, bufs[r])
+        sv = rs.MCCFRTrainer(tr_tree, tb, leaves, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse,
+                             shard=(world, g, 1, G[1]))
+        ranks.append((tr_tree, tb, sv, cols))
+
+    lib = L.load()
+    for it in range(2):
+        for player in (0, 1):
+            want_g = ref.iterate(player, want_root_util=True)
+            want_o = osol.iterate(player, threads=4)
+            assert_bits(want_g, want_o, "unsharded GPU vs oracle")
+            for (_, tb, sv, _) in ranks:
+                sv.iterate_phase(player, 0)
+            # the all-gather, done by hand: rank g's slot g goes to everybody
+            slots = []
+            for g, (_, tb, sv, _) in enumerate(ranks):
+                ptr, nbytes = sv.exchange_info(player)
+                host = np.empty(nbytes // 4, dtype=np.float32)
+                L.check(lib.rs_d2h(tb._h, host.ctypes.data, ptr + g * nbytes, nbytes))
+                slots.append(host)
+            for (_, tb, sv, _) in ranks:
+                ptr, nbytes = sv.exchange_info(player)
+                for g, host in enumerate(slots):
+                    L.check(lib.rs_h2d(tb._h, ptr + g * nbytes, host.ctypes.data, nbytes))
+            for (_, tb, sv, _) in ranks:
+                got = sv.iterate_phase(player, 1, want_root_util=True)
+                assert_bits(got, want_g, "root util of a sharded rank")
+    for (tr_tree, tb, sv, cols) in ranks:
+        for nd in tr_tree.action_nodes():
+            r, s2 = tb.download_node(nd.index)
+            R, S = table.download_node(nd.index)
+            assert (r == R[:, cols[nd.round_idx]]).all() and (s2 == S[:, cols[nd.round_idx]]).all(), "node %d" % nd.index
+    compare_tables(tree, table, otab)
+
+
+def test_sharded_solver_validates_its_slice():
+    n, tree = rs.build_game_tree(rs.three_street_options())
+    tb = rs.create_infosets(n, tree, [4], [1, 2, 4])
+    sign = {r: tb.lane_buffer([nd.index for nd in tree.action_nodes() if nd.round_idx == r][0], 1) for r in range(3)}
+    leaves = {i: (rs.LEAF_SIGN, sign[tree.nodes[nd.parent].round_idx]) for i, nd in enumerate(tree.nodes)
+              if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    with pytest.raises(rs.RsError):      # rank 0 of 2 over 5 global boards must hold 3 boards, not 2
+        rs.MCCFRTrainer(tree, tb, leaves, chance_mode=rs.CHANCE_ENUM, shard=(2, 0, 1, 5))
+    with pytest.raises(rs.RsError):      # sharding needs the enumerating chance nodes
+        rs.MCCFRTrainer(tree, tb, leaves, chance_mode=rs.CHANCE_PASS, shard=(2, 1, 1, 5))
+    sv = rs.MCCFRTrainer(tree, tb, leaves, chance_mode=rs.CHANCE_ENUM, shard=(2, 1, 1, 5))
+    with pytest.raises(rs.RsError):      # no communicator attached: rs_iterate refuses, phases must be driven by hand
+        sv.iterate(0)
+
+
 # ---- multi-GPU primitive on one rank ------------------------------------------------------------------------------------
 
 def test_allreduce_replicated_single_rank_is_identity():
@@ -717,6 +807,11 @@ def test_allreduce_replicated_single_rank_is_identity():
     L.check(lib.rs_comm_create(table._h, ident, 0, 1, C.byref(comm)))
     tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM)
     osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=orc.CHANCE_ENUM)
+    # in-place all-gather with one rank: the buffer must come back unchanged
+    probe = rs.DeviceBuffer.from_numpy(table, np.arange(256, dtype=np.float32))
+    L.check(lib.rs_comm_allgather(comm, table._h, probe.ptr, 1024))
+    table.sync()
+    assert (probe.download(np.float32, 256) == np.arange(256, dtype=np.float32)).all()
     L.check(lib.rs_replicated_begin(table._h, 0b001))
     tr.iterate(0), tr.iterate(1)
     L.check(lib.rs_allreduce_replicated(table._h, comm, 0b001))
