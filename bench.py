@@ -50,7 +50,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full"):
+def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full", shard=None):
     """n_boards: int (river tree) or [flop, turn, river] (three-street tree)"""
     from rustsolver_amd import _lib as L
     three = tree_kind == "three-street"
@@ -80,7 +80,8 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
     sampled = opp == "sample"
     chance = rs.CHANCE_PASS if (not three or sampled) else rs.CHANCE_ENUM
     trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=chance, use_graph=bool(graph),
-                              fuse_subtrees=(None if int(fuse) < 0 else int(fuse)), opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
+                              fuse_subtrees=(None if int(fuse) < 0 else int(fuse)), opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed,
+                              shard=shard)
     table.sync()
     return trainer
 
@@ -264,10 +265,33 @@ def main():
     boards3 = [int(x) for x in a.boards3.split(",")]
     if three and a.opp == "sample":
         boards3 = [boards3[-1]] * 3          # mccfr(): every lane is one full run-out (pass-through chance nodes)
+    shard = None
+    if three and n_gpus > 1 and a.opp == "full":
+        # BASELINE configs[3]: turn and river boards sharded over the ranks, flop replicated, one RCCL all-gather per sweep
+        # (STRONG scaling: the global problem is fixed).  Not yet run on more than one physical GPU.
+        from rustsolver_amd.dist import shard_boards
+        tlo, thi = shard_boards(boards3[1], rank, n_gpus)
+        fan = boards3[2] // boards3[1]
+        shard = (n_gpus, rank, 1, boards3[1])
+        global_river = boards3[2]
+        boards3 = [boards3[0], thi - tlo, (thi - tlo) * fan]
     trainer = make_trainer(rs, boards3 if three else a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse,
-                           a.tree, a.dtype, a.opp)
+                           a.tree, a.dtype, a.opp, shard)
+    if shard is not None:
+        import ctypes as C2
+        import torch
+        from rustsolver_amd import _lib as L
+        ident = (C2.c_char * L.COMM_ID_BYTES)()
+        if rank == 0:
+            L.check(L.load().rs_comm_unique_id(ident))
+        t_id = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t_id, src=0)
+        ident = (C2.c_char * L.COMM_ID_BYTES).from_buffer_copy(bytes(t_id.cpu().tolist()))
+        comm = C2.c_void_p()
+        L.check(L.load().rs_comm_create(trainer.infosets._h, ident, rank, n_gpus, C2.byref(comm)))
+        trainer.attach_comm(comm)
     if three:
-        a.boards = boards3[-1]               # `value` counts river boards
+        a.boards = boards3[-1] if shard is None else global_river / n_gpus   # `value` counts river boards (global when sharded)
     table = trainer.infosets
 
     # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides -------------
@@ -369,7 +393,7 @@ def main():
         "unit": "board-iterations/s",
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {
             "workload": ("config2 river-only: 14-action-node tree of options::default_flop(), %d clusters, A in {2,3}, "

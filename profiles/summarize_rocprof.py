@@ -6,7 +6,7 @@
 Writes <prefix>_kernel_stats.csv (rocprofv3 --stats as-is), <prefix>_summary.md and
 <prefix>_roofline_traffic.json (read back by bench.py for `roofline.traffic`).
 
-Only dispatches with >= 1M work-items are summarised as "full-size": bench.py also times a
+Only dispatches with >= 512K work-items are summarised as "full-size": bench.py also times a
 single-board trainer whose ~5 us launches would otherwise dominate the --stats averages.
 PMC handling follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate passes,
 are in KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is
@@ -21,7 +21,7 @@ import shutil
 import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
-FULL = 1 << 20
+FULL = 1 << 19   # the LDS deal-batch kernels run 1024 workgroups of 512 threads
 
 
 def one(pattern):
@@ -51,7 +51,7 @@ if trace:
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
         if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_")):
             per_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    lines += ["## full-size dispatches (>= 1M work-items), kernel trace", "",
+    lines += ["## full-size dispatches (>= 512K work-items), kernel trace", "",
               "| kernel | dispatches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for k, v in sorted(per_kernel.items(), key=lambda kv: -sum(kv[1])):
         lines.append("| `%s` | %d | %.1f | %.1f | %.1f | %.2f |" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, sum(v) / 1e6))

@@ -166,6 +166,7 @@ struct rs_table {
     void *d_dregrets = nullptr;       // deal batches: delta tables (same layout as the table), zero between sweeps
     void *d_dssum = nullptr;
     std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away
+    void *d_query = nullptr;          // scratch of the single-info-set strategy queries (rs_get_strategy)
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 

@@ -237,6 +237,7 @@ void rs_table_destroy(rs_table *t) {
     if (t->d_snap_regrets) (void)hipFree(t->d_snap_regrets);
     if (t->d_snap_ssum) (void)hipFree(t->d_snap_ssum);
     if (t->d_job) (void)hipFree(t->d_job);
+    if (t->d_query) (void)hipFree(t->d_query);
     if (t->d_dregrets) (void)hipFree(t->d_dregrets);
     if (t->d_dssum) (void)hipFree(t->d_dssum);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -337,14 +338,10 @@ static int single_strategy(rs_table *t, int node, int board, int cluster, float 
     const size_t lane = size_t(board) * nd.n_clusters + size_t(cluster);
     const size_t g0 = lane / kLanePad * kLanePad;  // 64-lane aligned group
     const size_t es = elem_size(t->dtype);
-    // gather the group's A rows into a compact [A][64] block, run the kernel with pitch 64
-    void *d_in = nullptr;
-    float *d_out = nullptr;
-    RS_HIP(hipMalloc(&d_in, nd.n_actions * kLanePad * es), "hipMalloc");
-    if (hipMalloc((void **)&d_out, nd.n_actions * kLanePad * sizeof(float)) != hipSuccess) {
-        (void)hipFree(d_in);
-        return fail(RS_ERR_OOM, std::string(fn) + ": hipMalloc failed");
-    }
+    // gather the group's A rows into a compact [A][64] block (cached per-table scratch), run the kernel with pitch 64
+    if (!t->d_query) RS_HIP(hipMalloc(&t->d_query, RS_MAX_ACTIONS * kLanePad * (4 + sizeof(float))), "hipMalloc(query scratch)");
+    void *d_in = t->d_query;
+    float *d_out = reinterpret_cast<float *>((char *)t->d_query + RS_MAX_ACTIONS * kLanePad * 4);
     const char *src = (const char *)(final_ ? t->ssum_ptr(node) : t->regrets_ptr(node)) + g0 * es;
     hipError_t e = hipMemcpy2DAsync(d_in, kLanePad * es, src, t->pitch[node] * es, kLanePad * es, nd.n_actions,
                                     hipMemcpyDeviceToDevice, t->stream);
@@ -353,8 +350,6 @@ static int single_strategy(rs_table *t, int node, int board, int cluster, float 
     if (e == hipSuccess)
         e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return hip_fail(e, fn);
     for (uint32_t a = 0; a < nd.n_actions; ++a) out[a] = host[a * kLanePad + (lane - g0)];
     return RS_OK;
