@@ -283,7 +283,8 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
 
 /* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------
- * The canonical hand index comes from rust_poker's hand_indexer_s (third party, out of scope) and is an INPUT here. */
+ * These entry points take canonical hand indices as INPUT (e.g. from the Rust side's own hand_indexer_s); the index itself is
+ * computed by rs_hand_indexer / rs_card_abs further down. */
 typedef struct rs_dense_map rs_dense_map;
 /* bucket files: flat little-endian u32 per canonical hand index (gen_abstraction/main.rs:372-380 writes,
  * card_abstraction.rs:227-229 / :269-271 read).  *out is malloc'ed: release it with rs_free_u32. */
@@ -299,6 +300,88 @@ void rs_dense_map_destroy(rs_dense_map *map);
 size_t rs_dense_map_size(const rs_dense_map *map);                                  /* get_size, card_abstraction.rs:211-213 */
 int rs_dense_map_lookup(const rs_dense_map *map, const uint64_t *buckets, size_t n, uint32_t *dense_out); /* get_cluster's map step */
 int rs_dense_map_keys(const rs_dense_map *map, uint64_t *keys_out);                 /* dense id -> bucket, size() entries */
+
+/* ---- canonical hand index: rust_poker::hand_indexer_s (Cargo.toml:18, crate not vendored) -------------------------------------
+ * The suit-isomorphic index of K. Waugh, "A Fast and Optimal Hand Isomorphism Algorithm" (AAAI 2013 workshop), which the crate
+ * wraps.  card = 4*rank + suit, rank 0..12 = 2..A.  A hand is its rounds' cards in order (hole cards first); cards inside a round
+ * may come in any order.  The partition into classes is pinned by the reference's own numbers (1 286 792 flop hands, out.txt:1;
+ * 12 888 turn clusters, card_abstraction.rs:315); the ORDER of indices follows the published algorithm and is not pinned by any
+ * reference fixture. */
+typedef struct rs_hand_indexer rs_hand_indexer;
+/* hand_indexer_s::init(rounds, cards_per_round) (card_abstraction.rs:88-90, gen_abstraction/ehs.rs:30-33) */
+int rs_hand_indexer_create(int rounds, const uint8_t *cards_per_round, rs_hand_indexer **out);
+void rs_hand_indexer_destroy(rs_hand_indexer *indexer);
+uint64_t rs_hand_indexer_size(const rs_hand_indexer *indexer, int round);      /* .size(round) (gen_abstraction/main.rs:91,359) */
+int rs_hand_indexer_rounds(const rs_hand_indexer *indexer);
+int rs_hand_indexer_n_cards(const rs_hand_indexer *indexer, int round);        /* cards of rounds 0..round */
+/* .get_index(cards) for n hands (card_abstraction.rs:205); cards[n][n_cards(round)]; `round` = rounds-1 is what get_index returns */
+int rs_hand_index(const rs_hand_indexer *indexer, int round, const uint8_t *cards, size_t n, uint64_t *out);
+/* .get_hand(round, index, cards) (gen_abstraction/main.rs:117,195): one representative hand per index; cards_out[n][n_cards(round)] */
+int rs_hand_unindex(const rs_hand_indexer *indexer, int round, const uint64_t *indices, size_t n, uint8_t *cards_out);
+/* get_index on the GPU: d_cards[n_cards(round)][pitch] (u8, row i = card i, pitch = round_up(n, 64)), d_out[n]; asynchronous */
+int rs_hand_index_device(rs_table *table, rs_hand_indexer *indexer, int round, const uint8_t *d_cards, uint32_t n, uint64_t *d_out);
+
+/* ---- one round's card abstraction: ISOMORPHIC / EMD / OCHS (card_abstraction.rs:31-298) ----------------------------------------
+ * ::init = generate_maps (card_abstraction.rs:75-184): every hand of every range x every way to complete the board to the round is
+ * indexed with hand_indexer_s::init(2, [2, 3 + betting_round]), mapped through the bucket file if there is one (index_to_cluster,
+ * :20-29) and given the next dense id on first sight.  hands_p*: (u8,u8) combos = HandRange.hands after remove_invalid_combos
+ * (cfr.rs:161-163).  cluster_arr = NULL: ISOMORPHIC (bucket = index); otherwise the round_{r}_emd.dat / _ochs.dat contents
+ * (rs_cluster_file_read), copied.  Dense ids follow first appearance in the reference's loop order (its own order is a race). */
+typedef struct rs_card_abs rs_card_abs;
+int rs_card_abs_create(int betting_round /* 0 flop, 1 turn, 2 river */, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
+                       size_t n_hands_p1, uint64_t initial_board_mask, const uint32_t *cluster_arr, size_t arr_len, rs_card_abs **out);
+void rs_card_abs_destroy(rs_card_abs *abs);
+int rs_card_abs_round(const rs_card_abs *abs);
+size_t rs_card_abs_size(const rs_card_abs *abs, int player);                     /* get_size (card_abstraction.rs:211-213) */
+uint64_t rs_card_abs_index_size(const rs_card_abs *abs);                         /* hand_indexer.size(1): length a bucket file must have */
+int rs_card_abs_keys(const rs_card_abs *abs, int player, uint64_t *keys_out);    /* dense id -> bucket, size(player) entries */
+/* get_cluster(&cards, player) (card_abstraction.rs:204-209, :245-251, :287-293) for n hands on the host;
+ * cards[n][5 + betting_round] = the player's hole cards, then the board (cfr.rs:357-365) */
+int rs_card_abs_get_cluster(const rs_card_abs *abs, const uint8_t *cards, size_t n, int player, uint32_t *out);
+/* get_cluster for every deal of a batch on the GPU.  d_cards[9][pitch] u8 as for rs_showdown_sign: rows 0-4 the board, 5-6 player 0's
+ * hole cards, 7-8 player 1's.  d_cluster_p0 / d_cluster_p1 [pitch] receive the dense ids (either may be NULL): ready to be an
+ * rs_deal_batch.d_cluster[round_idx][player].  Asynchronous on the table's stream.  A deal whose bucket has no dense id (Rust:
+ * unwrap on None) gets id 0 and raises an error word that rs_card_abs_status reports. */
+int rs_card_abs_clusters_device(rs_card_abs *abs, rs_table *table, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0,
+                                uint32_t *d_cluster_p1);
+int rs_card_abs_status(rs_card_abs *abs, rs_table *table);   /* synchronises; RS_ERR_OOB if a deal since the last call had no cluster */
+
+/* ---- generate_hand for a batch of deals (cfr.rs:100-143) ---------------------------------------------------------------------------
+ * Board cards missing from board_mask are drawn uniformly without replacement by rejection (cfr.rs:115-122), then one combo per range
+ * by rejection against everything dealt (cfr.rs:126-137); Uniform::from(0..52) and slice::choose are rand 0.7's widening-multiply
+ * samplers.  The random bits are a counter hash of (seed, first_deal + i) -- the reference's SmallRng is seeded from thread_rng and is
+ * not reproducible.  d_hands_p*: DEVICE arrays of (u8,u8) combos.  d_cards[9][pitch] as above.  d_err (device u32, may be NULL): bit 2 is
+ * raised when a deal found no valid combo within 4096 draws (the reference would loop forever). */
+int rs_deals_sample(rs_table *table, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0,
+                    uint32_t n_hands_p0, const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err);
+
+/* ---- MCCFRTrainer on the GPU: init + train over sampled deals (cfr.rs:159-297) -----------------------------------------------------
+ * Per batch, all on the table's stream: rs_deals_sample -> rs_card_abs_clusters_device for every round -> rs_showdown_sign -> one
+ * sampled-opponent sweep per traverser (rs_solver_create_deals).  One deal = one reference iteration (cfr.rs:209-226). */
+typedef struct rs_deal_trainer rs_deal_trainer;
+typedef struct rs_deal_trainer_params {
+    uint64_t board_mask;           /* Options.board_mask (options.rs:17): 3, 4 or 5 cards */
+    uint32_t deals_per_batch;
+    uint64_t seed;
+    uint64_t discount_interval;    /* cfr.rs:190 DISCOUNT_INTERVAL (0 = never discount) */
+    uint64_t discount_cap;         /* cfr.rs:240: no discount once t exceeds it */
+    rs_solver_params solver;       /* scale 100, RS_UPD_CLAMP_I64, RS_OPP_SAMPLE = the reference's mccfr(); chance_mode is forced to PASS */
+} rs_deal_trainer_params;
+/* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
+ * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */
+int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, int n_rounds, const uint8_t *hands_p0, size_t n_hands_p0,
+                           const uint8_t *hands_p1, size_t n_hands_p1, const rs_deal_trainer_params *params, int device,
+                           rs_deal_trainer **out);
+void rs_deal_trainer_destroy(rs_deal_trainer *trainer);
+rs_table *rs_deal_trainer_table(rs_deal_trainer *trainer);      /* trainer.infosets; owned by the trainer */
+rs_solver *rs_deal_trainer_solver(rs_deal_trainer *trainer);
+int rs_deal_trainer_train(rs_deal_trainer *trainer, uint64_t n_batches);   /* train(): deals_per_batch iterations per batch */
+int rs_deal_trainer_deal(rs_deal_trainer *trainer);             /* only the dealing half of a batch (cards, cluster ids, signs) */
+int rs_deal_trainer_status(rs_deal_trainer *trainer);           /* synchronises; error if a deal could not be sampled / addressed */
+uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *trainer);   /* t of cfr.rs:200 */
+const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *trainer);  /* device: the current batch's d_cards[9][pitch] */
+const float *rs_deal_trainer_signs(const rs_deal_trainer *trainer);    /* device: its showdown signs [pitch] */
+const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *trainer, int round_idx, int player);   /* device: its cluster ids [pitch] */
 
 /* ---- showdown evaluation on the device ---------------------------------------------------------------
  * d_cards[9][pitch] (u8, pitch = round_up(n_deals, 64)): rows 0-4 the board, 5-6 player 0's hole cards, 7-8 player 1's;

@@ -77,13 +77,21 @@ class Ctx(C.Structure):
     ]
 
 
+class HandIndexerC(C.Structure):   # orc_hand_indexer (hand_index.h)
+    _fields_ = [("rounds", C.c_int), ("cards_per_round", C.c_uint8 * 8), ("round_start", C.c_uint8 * 8),
+                ("configurations", C.c_uint32 * 8), ("permutations", C.c_uint32 * 8), ("round_size", C.c_uint64 * 8),
+                ("permutation_to_configuration", C.c_void_p * 8), ("permutation_to_pi", C.c_void_p * 8),
+                ("configuration_to_equal", C.c_void_p * 8), ("configuration", C.c_void_p * 8),
+                ("configuration_to_suit_size", C.c_void_p * 8), ("configuration_to_offset", C.c_void_p * 8)]
+
+
 DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
                     ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t)]
 
 
 def build(force=False):
     """Compile oracle/librs_oracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -163,6 +171,23 @@ def lib():
     L.orc_run_deal_sweeps_mt.argtypes = [C.POINTER(DealCtx), C.POINTER(Ctx), C.c_size_t, C.c_int]
     L.orc_iterate_mt.argtypes = [C.POINTER(Ctx), C.c_int, f32p, C.c_int]
     L.orc_run_iterations_mt.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_int]
+    hp = C.POINTER(HandIndexerC)
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_hand_indexer_init.argtypes = [C.c_int, u8p, hp]
+    L.orc_hand_indexer_free.argtypes = [hp]
+    L.orc_hand_indexer_size.argtypes = [hp, C.c_int]
+    L.orc_hand_indexer_size.restype = C.c_uint64
+    L.orc_hand_index_round.argtypes = [hp, C.c_int, C.c_void_p]
+    L.orc_hand_index_round.restype = C.c_uint64
+    L.orc_hand_index_last.argtypes = [hp, C.c_void_p]
+    L.orc_hand_index_last.restype = C.c_uint64
+    L.orc_hand_unindex.argtypes = [hp, C.c_int, C.c_uint64, C.c_void_p]
+    L.orc_hand_canon.argtypes = [C.c_int, u8p, C.c_void_p, C.c_void_p]
+    L.orc_generate_map.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_generate_map.restype = C.c_size_t
+    L.orc_deal_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    L.orc_deal_bits.restype = C.c_uint64
+    L.orc_generate_hand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -506,3 +531,71 @@ def showdown_sign(cards):
     out = np.zeros(a.shape[1], dtype=np.float32)
     lib().orc_showdown_sign(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], _f32(out))
     return out
+
+
+# ---- canonical hand index / card abstraction / deal sampler (hand_index.c) ---------------------------------------------------
+class HandIndexer:
+    """orc_hand_indexer: hand_indexer_s::init / size / get_index / get_hand restated on the CPU"""
+
+    def __init__(self, cards_per_round):
+        self.cards_per_round = tuple(cards_per_round)
+        self.rounds = len(cards_per_round)
+        self.ix = HandIndexerC()
+        if lib().orc_hand_indexer_init(self.rounds, (C.c_uint8 * self.rounds)(*cards_per_round), C.byref(self.ix)) != 0:
+            raise ValueError("orc_hand_indexer_init failed")
+
+    def size(self, round_):
+        return int(lib().orc_hand_indexer_size(C.byref(self.ix), round_))
+
+    def n_cards(self, round_):
+        return sum(self.cards_per_round[: round_ + 1])
+
+    def get_index(self, cards, round_=None):
+        r = self.rounds - 1 if round_ is None else round_
+        c = np.ascontiguousarray(cards, dtype=np.uint8)
+        if c.ndim == 1:
+            return int(lib().orc_hand_index_round(C.byref(self.ix), r, c.ctypes.data))
+        return np.array([lib().orc_hand_index_round(C.byref(self.ix), r, c[i].ctypes.data) for i in range(len(c))], dtype=np.uint64)
+
+    def get_hand(self, round_, index):
+        out = np.zeros(self.n_cards(round_), dtype=np.uint8)
+        if lib().orc_hand_unindex(C.byref(self.ix), round_, int(index), out.ctypes.data) != 0:
+            raise IndexError(index)
+        return out
+
+    def canon(self, cards, round_=None):
+        """brute-force canonical form (minimum over the 24 suit relabellings), independent of the index arithmetic"""
+        r = self.rounds - 1 if round_ is None else round_
+        c = np.ascontiguousarray(cards, dtype=np.uint8)[: self.n_cards(r)].copy()
+        out = np.zeros(len(c), dtype=np.uint8)
+        lib().orc_hand_canon(r + 1, (C.c_uint8 * (r + 1))(*self.cards_per_round[: r + 1]), c.ctypes.data, out.ctypes.data)
+        return bytes(out)
+
+    def generate_map(self, hands, initial_board_mask, n_round_board_cards, cluster_arr=None):
+        """generate_maps for one player (card_abstraction.rs:75-184): distinct buckets in first-appearance order"""
+        h = np.ascontiguousarray(hands, dtype=np.uint8).reshape(-1, 2)
+        arr = None if cluster_arr is None else np.ascontiguousarray(cluster_arr, dtype=np.uint32)
+        ap = None if arr is None else arr.ctypes.data
+        n = lib().orc_generate_map(C.byref(self.ix), h.ctypes.data, len(h), initial_board_mask, n_round_board_cards, ap, None, 0)
+        if n == C.c_size_t(-1).value:
+            raise ValueError("orc_generate_map failed")
+        keys = np.zeros(n, dtype=np.uint64)
+        lib().orc_generate_map(C.byref(self.ix), h.ctypes.data, len(h), initial_board_mask, n_round_board_cards, ap, keys.ctypes.data, n)
+        return keys
+
+    def __del__(self):
+        try:
+            lib().orc_hand_indexer_free(C.byref(self.ix))
+        except Exception:
+            pass
+
+
+def generate_hands(seed, first_deal, board_mask, hands0, hands1, n_deals):
+    """orc_generate_hand for deals first_deal .. first_deal + n_deals - 1 -> uint8 [9][n_deals]"""
+    h0 = np.ascontiguousarray(hands0, dtype=np.uint8).reshape(-1, 2)
+    h1 = np.ascontiguousarray(hands1, dtype=np.uint8).reshape(-1, 2)
+    out = np.zeros((n_deals, 9), dtype=np.uint8)
+    for i in range(n_deals):
+        if lib().orc_generate_hand(seed, first_deal + i, board_mask, h0.ctypes.data, len(h0), h1.ctypes.data, len(h1), out[i].ctypes.data) != 0:
+            raise RuntimeError("orc_generate_hand: no valid deal")
+    return np.ascontiguousarray(out.T)

@@ -18,7 +18,7 @@ from ._lib import (ACT_BET, ACT_CALL, ACT_CHECK, ACT_FOLD, ACT_RAISE, CHANCE_ENU
 if not _BUILDING:
     _lib.load()  # ImportError if librustsolver_amd.so is missing
 
-from .solver import (DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
+from .solver import (DealTrainer, DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
                      build_game_tree, create_infosets, deal_buffer, deal_pitch, default_flop, device_count, discount_factor,
                      jit_check_tree, showdown_sign,
                      three_street_options, tree_from_nodes)
@@ -26,5 +26,5 @@ from . import synth  # noqa: E402
 from . import abstraction  # noqa: E402
 
 __all__ = ["Options", "default_flop", "three_street_options", "build_game_tree", "tree_from_nodes", "create_infosets",
-           "InfosetTable", "Infoset", "GameTree", "MCCFRTrainer", "DeviceBuffer", "device_count", "discount_factor",
+           "InfosetTable", "Infoset", "GameTree", "MCCFRTrainer", "DealTrainer", "DeviceBuffer", "device_count", "discount_factor",
            "synth", "RsError"]

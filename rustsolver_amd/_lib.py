@@ -58,6 +58,11 @@ class SolverParams(C.Structure):
                 ("shard_world", C.c_int32), ("shard_rank", C.c_int32), ("shard_round", C.c_int32), ("shard_global_boards", C.c_uint32)]
 
 
+class DealTrainerParams(C.Structure):
+    _fields_ = [("board_mask", C.c_uint64), ("deals_per_batch", C.c_uint32), ("seed", C.c_uint64), ("discount_interval", C.c_uint64),
+                ("discount_cap", C.c_uint64), ("solver", SolverParams)]
+
+
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64 * K_COUNT), ("ms", C.c_double * K_COUNT), ("algo_bytes", C.c_double * K_COUNT)]
 
@@ -136,6 +141,35 @@ SYMBOLS = {
     "rs_dense_map_size": (C.c_size_t, [_P]),
     "rs_dense_map_lookup": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint32)]),
     "rs_dense_map_keys": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "rs_hand_indexer_create": (C.c_int, [C.c_int, C.POINTER(C.c_uint8), _PP]),
+    "rs_hand_indexer_destroy": (None, [_P]),
+    "rs_hand_indexer_size": (C.c_uint64, [_P, C.c_int]),
+    "rs_hand_indexer_rounds": (C.c_int, [_P]),
+    "rs_hand_indexer_n_cards": (C.c_int, [_P, C.c_int]),
+    "rs_hand_index": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P]),
+    "rs_hand_unindex": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P]),
+    "rs_hand_index_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_uint32, _P]),
+    "rs_card_abs_create": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t, _PP]),
+    "rs_card_abs_destroy": (None, [_P]),
+    "rs_card_abs_round": (C.c_int, [_P]),
+    "rs_card_abs_size": (C.c_size_t, [_P, C.c_int]),
+    "rs_card_abs_index_size": (C.c_uint64, [_P]),
+    "rs_card_abs_keys": (C.c_int, [_P, C.c_int, _P]),
+    "rs_card_abs_get_cluster": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
+    "rs_card_abs_clusters_device": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    "rs_card_abs_status": (C.c_int, [_P, _P]),
+    "rs_deals_sample": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "rs_deal_trainer_create": (C.c_int, [_P, _PP, C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(DealTrainerParams), C.c_int, _PP]),
+    "rs_deal_trainer_destroy": (None, [_P]),
+    "rs_deal_trainer_table": (C.c_void_p, [_P]),
+    "rs_deal_trainer_solver": (C.c_void_p, [_P]),
+    "rs_deal_trainer_train": (C.c_int, [_P, C.c_uint64]),
+    "rs_deal_trainer_deal": (C.c_int, [_P]),
+    "rs_deal_trainer_status": (C.c_int, [_P]),
+    "rs_deal_trainer_iterations": (C.c_uint64, [_P]),
+    "rs_deal_trainer_cards": (C.c_void_p, [_P]),
+    "rs_deal_trainer_signs": (C.c_void_p, [_P]),
+    "rs_deal_trainer_clusters": (C.c_void_p, [_P, C.c_int, C.c_int]),
     "rs_showdown_sign": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rs_table_save": (C.c_int, [_P, C.c_char_p]),
     "rs_table_load": (C.c_int, [C.c_char_p, C.c_int, _PP]),

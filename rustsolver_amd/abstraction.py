@@ -1,5 +1,5 @@
 """Host mirror of the card-abstraction plumbing (card_abstraction.rs) on top of the C ABI: bucket files, index_to_cluster,
-deterministic dense-id maps.  The canonical hand index (rust_poker hand_indexer_s) is an input."""
+deterministic dense-id maps, the canonical hand index (rust_poker hand_indexer_s) and the per-round card abstractions."""
 import ctypes as C
 
 import numpy as np
@@ -70,3 +70,180 @@ class DenseMap:
             L.load().rs_dense_map_destroy(self._h)
         except Exception:
             pass
+
+
+# ---- cards -------------------------------------------------------------------------------------------------------------------
+RANKS = "23456789TJQKA"
+SUITS = "shdc"   # only the NUMBER of distinct suits matters to anything in this package (suit isomorphism)
+
+
+def card(text):
+    """'As' -> 4*rank + suit (cfr.rs:592, gen_abstraction/ehs.rs:109: 48, 49 is AA)"""
+    return 4 * RANKS.index(text[0].upper()) + SUITS.index(text[1].lower())
+
+
+def card_mask(text):
+    """rust_poker::hand_range::get_card_mask("4d5dAs3cKs") (options.rs:57)"""
+    m = 0
+    for i in range(0, len(text), 2):
+        m |= 1 << card(text[i:i + 2])
+    return m
+
+
+def random_range(board_mask=0):
+    """HandRange::from_string("random") after remove_invalid_combos(board_mask) (options.rs:63-64, cfr.rs:161-163):
+    every two-card combo that avoids the board, as a uint8 [n][2] array"""
+    return np.array([(a, b) for a in range(52) for b in range(a) if not ((board_mask >> a) & 1 or (board_mask >> b) & 1)], dtype=np.uint8)
+
+
+class HandIndexer:
+    """rust_poker::hand_indexer_s: init(rounds, cards_per_round) / size / get_index / get_hand"""
+
+    def __init__(self, cards_per_round):
+        cpr = (C.c_uint8 * len(cards_per_round))(*cards_per_round)
+        h = C.c_void_p()
+        L.check(L.load().rs_hand_indexer_create(len(cards_per_round), cpr, C.byref(h)))
+        self._h = h
+        self.cards_per_round = tuple(cards_per_round)
+        self.rounds = len(cards_per_round)
+
+    def size(self, round_):
+        return int(L.load().rs_hand_indexer_size(self._h, round_))
+
+    def n_cards(self, round_):
+        return sum(self.cards_per_round[: round_ + 1])
+
+    def get_index(self, cards, round_=None):
+        """cards: uint8 [n][n_cards(round)] (or one hand) -> uint64 [n]; round_ defaults to the last, like get_index"""
+        r = self.rounds - 1 if round_ is None else round_
+        c = np.ascontiguousarray(cards, dtype=np.uint8)
+        one = c.ndim == 1
+        c = c.reshape(-1, c.shape[-1])
+        if c.shape[1] < self.n_cards(r):
+            raise ValueError("a hand of round %d has %d cards" % (r, self.n_cards(r)))
+        c = np.ascontiguousarray(c[:, : self.n_cards(r)])   # like the reference, extra cards are ignored (card_abstraction.rs:319)
+        out = np.empty(len(c), dtype=np.uint64)
+        L.check(L.load().rs_hand_index(self._h, r, c.ctypes.data, len(c), out.ctypes.data))
+        return int(out[0]) if one else out
+
+    def get_hand(self, round_, indices):
+        idx = np.ascontiguousarray(np.atleast_1d(indices), dtype=np.uint64)
+        out = np.empty((len(idx), self.n_cards(round_)), dtype=np.uint8)
+        rc = L.load().rs_hand_unindex(self._h, round_, idx.ctypes.data, len(idx), out.ctypes.data)
+        if rc == L.ERR_OOB:
+            raise IndexError(L.load().rs_last_error().decode())
+        L.check(rc)
+        return out
+
+    def get_index_device(self, table, cards, round_=None):
+        """same on the GPU: cards uint8 [n][n_cards] -> uint64 [n] (uploads SoA rows, downloads the indices)"""
+        from .solver import DeviceBuffer, deal_pitch
+        r = self.rounds - 1 if round_ is None else round_
+        c = np.ascontiguousarray(cards, dtype=np.uint8)
+        n, nc = c.shape[0], self.n_cards(r)
+        pitch = deal_pitch(n)
+        host = np.zeros((nc, pitch), dtype=np.uint8)
+        host[:, :n] = c[:, :nc].T
+        dc = DeviceBuffer.from_numpy(table, host)
+        do = DeviceBuffer(table, max(pitch, 1) * 8)
+        L.check(L.load().rs_hand_index_device(table._h, self._h, r, dc.ptr, n, do.ptr))
+        return do.download(np.uint64, pitch)[:n]
+
+    def __del__(self):
+        try:
+            L.load().rs_hand_indexer_destroy(self._h)
+        except Exception:
+            pass
+
+
+FLOP, TURN, RIVER = 0, 1, 2   # BettingRound (state.rs)
+
+
+class CardAbstraction:
+    """One round's ICardAbstraction (card_abstraction.rs:31-298): `ISOMORPHIC.init` / `EMD.init` / `OCHS.init` are
+    `CardAbstraction.init(..., cluster_arr=None | the bucket file)`; get_cluster / get_size as in the reference."""
+
+    def __init__(self, hand_ranges, initial_board_mask, round_, cluster_arr=None):
+        h0 = np.ascontiguousarray(hand_ranges[0], dtype=np.uint8).reshape(-1, 2)
+        h1 = np.ascontiguousarray(hand_ranges[1], dtype=np.uint8).reshape(-1, 2)
+        arr = None if cluster_arr is None else np.ascontiguousarray(cluster_arr, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = L.load().rs_card_abs_create(round_, h0.ctypes.data, len(h0), h1.ctypes.data, len(h1), initial_board_mask,
+                                         None if arr is None else arr.ctypes.data, 0 if arr is None else len(arr), C.byref(h))
+        if rc == L.ERR_OOB:
+            raise IndexError(L.load().rs_last_error().decode())
+        L.check(rc)
+        self._h = h
+        self.round = round_
+        self.n_cards = 5 + round_
+
+    init = classmethod(lambda cls, hand_ranges, board_mask, round_, cluster_arr=None: cls(hand_ranges, board_mask, round_, cluster_arr))
+
+    def get_size(self, player):
+        return int(L.load().rs_card_abs_size(self._h, player))
+
+    def index_size(self):
+        return int(L.load().rs_card_abs_index_size(self._h))
+
+    def keys(self, player):
+        out = np.empty(self.get_size(player), dtype=np.uint64)
+        L.check(L.load().rs_card_abs_keys(self._h, player, out.ctypes.data))
+        return out
+
+    def get_cluster(self, cards, player):
+        """cards: the player's two hole cards then the board (cfr.rs:357-365), one hand or [n][>= 5 + round]"""
+        c = np.ascontiguousarray(cards, dtype=np.uint8)
+        one = c.ndim == 1
+        c = np.ascontiguousarray(c.reshape(-1, c.shape[-1])[:, : self.n_cards])
+        out = np.empty(len(c), dtype=np.uint32)
+        rc = L.load().rs_card_abs_get_cluster(self._h, c.ctypes.data, len(c), player, out.ctypes.data)
+        if rc == L.ERR_OOB:
+            raise KeyError(L.load().rs_last_error().decode())
+        L.check(rc)
+        return int(out[0]) if one else out
+
+    def get_clusters_device(self, table, cards9):
+        """cards9: uint8 [9][n] deal matrix (board x5, P0 x2, P1 x2) -> (ids of player 0, ids of player 1), computed on the GPU"""
+        from .solver import DeviceBuffer, deal_pitch
+        c = np.ascontiguousarray(cards9, dtype=np.uint8)
+        n = c.shape[1]
+        pitch = deal_pitch(n)
+        host = np.zeros((9, pitch), dtype=np.uint8)
+        host[:, :n] = c
+        dc = DeviceBuffer.from_numpy(table, host)
+        d0, d1 = DeviceBuffer(table, max(pitch, 1) * 4), DeviceBuffer(table, max(pitch, 1) * 4)
+        L.check(L.load().rs_card_abs_clusters_device(self._h, table._h, dc.ptr, n, d0.ptr, d1.ptr))
+        rc = L.load().rs_card_abs_status(self._h, table._h)
+        if rc == L.ERR_OOB:
+            raise KeyError(L.load().rs_last_error().decode())
+        L.check(rc)
+        return d0.download(np.uint32, pitch)[:n], d1.download(np.uint32, pitch)[:n]
+
+    def destroy(self):
+        if self._h:
+            L.load().rs_card_abs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def sample_deals(table, seed, first_deal, board_mask, hand_ranges, n_deals):
+    """generate_hand (cfr.rs:100-143) for n_deals deals on the GPU -> uint8 [9][n_deals]"""
+    from .solver import DeviceBuffer, deal_pitch
+    h0 = np.ascontiguousarray(hand_ranges[0], dtype=np.uint8).reshape(-1, 2)
+    h1 = np.ascontiguousarray(hand_ranges[1], dtype=np.uint8).reshape(-1, 2)
+    d0, d1 = DeviceBuffer.from_numpy(table, h0), DeviceBuffer.from_numpy(table, h1)
+    pitch = deal_pitch(n_deals)
+    dc = DeviceBuffer(table, 9 * max(pitch, 1))
+    dc.zero()
+    de = DeviceBuffer(table, 4)
+    de.zero()
+    L.check(L.load().rs_deals_sample(table._h, seed, first_deal, board_mask, d0.ptr, len(h0), d1.ptr, len(h1), n_deals, dc.ptr, de.ptr))
+    err = int(de.download(np.uint32, 1)[0])
+    if err:
+        raise RuntimeError("generate_hand: no valid combo for some deal (error word %d)" % err)
+    return dc.download(np.uint8, 9 * pitch).reshape(9, pitch)[:, :n_deals]

@@ -167,6 +167,7 @@ struct rs_table {
     void *d_dssum = nullptr;
     std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away
     void *d_query = nullptr;          // scratch of the single-info-set strategy queries (rs_get_strategy)
+    uint32_t *d_err_sink = nullptr;   // error word for card kernels whose caller passed none (rs_deals_sample)
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 

@@ -1,0 +1,194 @@
+// rs_trainer.cpp -- MCCFRTrainer::init + train (cfr.rs:159-297) with everything between "pick a deal" and "write the
+// regrets" on the GPU: generate_hand (cfr.rs:100-143), get_cluster for every round and player (cfr.rs:357-365), the showdown
+// comparison (cfr.rs:323-347) and the sampled mccfr sweep (cfr.rs:299-479) run as one stream-ordered chain per batch of deals.
+// The reference's unit of work -- one deal traversed once per player (cfr.rs:209-226) -- is one lane of a batch; where its eight
+// threads race on shared info sets (cfr.rs:414) a batch is synchronous.
+// Host code only: it drives the C ABI of this library.
+#include <cstring>
+#include <new>
+
+#include "rs_internal.hpp"
+
+using namespace rs;
+
+struct rs_deal_trainer {
+    rs_table *table = nullptr;     // trainer.infosets
+    rs_solver *solver = nullptr;
+    rs_tree *tree = nullptr;       // private copy of the caller's tree (trainer.game_tree)
+    rs_card_abs *abs[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};   // borrowed (trainer.card_abs)
+    int n_rounds = 0;
+    rs_deal_trainer_params params{};
+    uint32_t n_hands[2] = {0, 0};
+    uint8_t *d_hands[2] = {nullptr, nullptr};   // trainer.hand_ranges
+    uint8_t *d_cards = nullptr;                 // [9][pitch]
+    uint32_t *d_cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS] = {};
+    float *d_sign = nullptr;
+    uint32_t *d_err = nullptr;
+    uint64_t t = 0;                // iterations done (deals), the shared counter of cfr.rs:200
+    uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
+    uint64_t batches = 0;
+};
+
+extern "C" {
+
+void rs_deal_trainer_destroy(rs_deal_trainer *tr) {
+    if (!tr) return;
+    if (tr->solver) rs_solver_destroy(tr->solver);
+    if (tr->table) {
+        for (int p = 0; p < 2; ++p)
+            if (tr->d_hands[p]) rs_dfree(tr->table, tr->d_hands[p]);
+        if (tr->d_cards) rs_dfree(tr->table, tr->d_cards);
+        if (tr->d_sign) rs_dfree(tr->table, tr->d_sign);
+        if (tr->d_err) rs_dfree(tr->table, tr->d_err);
+        for (int r = 0; r < RS_MAX_ROUNDS; ++r)
+            for (int p = 0; p < RS_MAX_PLAYERS; ++p)
+                if (tr->d_cluster[r][p]) rs_dfree(tr->table, tr->d_cluster[r][p]);
+        rs_table_destroy(tr->table);
+    }
+    if (tr->tree) rs_tree_destroy(tr->tree);
+    delete tr;
+}
+
+int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, int n_rounds, const uint8_t *hands_p0, size_t n_hands_p0,
+                           const uint8_t *hands_p1, size_t n_hands_p1, const rs_deal_trainer_params *params, int device, rs_deal_trainer **out) {
+    if (!tree || !card_abs || !hands_p0 || !hands_p1 || !params || !out) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: NULL argument");
+    if (n_rounds < 1 || n_rounds > RS_MAX_ROUNDS) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: 1..3 rounds");
+    if (params->deals_per_batch == 0) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: deals_per_batch must be > 0");
+    if (n_hands_p0 == 0 || n_hands_p1 == 0 || n_hands_p0 > 0xffffffffull || n_hands_p1 > 0xffffffffull)
+        return fail(RS_ERR_INVALID, "rs_deal_trainer_create: empty hand range (Rust: choose().unwrap() on None, cfr.rs:129)");
+    const int n_board = __builtin_popcountll(params->board_mask);
+    if (n_board < 3 || n_board > 5 || params->board_mask >> 52) return fail(RS_ERR_INVALID, "invalid board mask");   // options.rs:41
+    const int first_round = n_board - 3;   // BettingRound of tree round_idx 0 (options.rs:36-42)
+    if (first_round + n_rounds > 3) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: more tree rounds than streets left after the board");
+    uint32_t n_clusters[RS_MAX_ROUNDS][RS_MAX_PLAYERS] = {};
+    uint32_t n_boards[RS_MAX_ROUNDS] = {1, 1, 1};
+    for (int r = 0; r < n_rounds; ++r) {
+        if (!card_abs[r]) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: card_abs[" + std::to_string(r) + "] is NULL");
+        if (rs_card_abs_round(card_abs[r]) != first_round + r)
+            return fail(RS_ERR_INVALID, "rs_deal_trainer_create: card_abs[" + std::to_string(r) + "] is not the abstraction of betting round " +
+                                            std::to_string(first_round + r));
+        for (int p = 0; p < 2; ++p) {
+            n_clusters[r][p] = uint32_t(rs_card_abs_size(card_abs[r], p));   // get_size (infoset.rs:28-32)
+            if (n_clusters[r][p] == 0) return fail(RS_ERR_INVALID, "rs_deal_trainer_create: an abstraction without clusters");
+        }
+    }
+    rs_deal_trainer *tr = new (std::nothrow) rs_deal_trainer();
+    if (!tr) return fail(RS_ERR_OOM, "rs_deal_trainer_create: out of memory");
+    tr->params = *params;
+    tr->n_rounds = n_rounds;
+    tr->threshold = params->discount_interval;
+    for (int r = 0; r < n_rounds; ++r) tr->abs[r] = card_abs[r];
+    int rc = RS_OK;
+    {   // private copy of the tree: the caller may drop theirs
+        const int n = rs_tree_n_nodes(tree);
+        std::vector<rs_tree_node> nodes(size_t(n > 0 ? n : 0));
+        for (int i = 0; rc == RS_OK && i < n; ++i) rc = rs_tree_get_node(tree, i, &nodes[size_t(i)]);
+        if (rc == RS_OK) rc = rs_tree_from_nodes(nodes.data(), n, &tr->tree);
+        for (int i = 0; rc == RS_OK && i < n; ++i)
+            if (nodes[size_t(i)].kind == RS_NODE_ACTION && nodes[size_t(i)].round_idx >= n_rounds)
+                rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: the tree has more rounds than abstractions were passed");
+    }
+    if (rc == RS_OK) rc = rs_create_infosets(tr->tree, n_clusters, n_boards, RS_I32, device, &tr->table);   // cfr.rs:176
+    const size_t pitch = round_up(params->deals_per_batch, kLanePad);
+    const size_t n_hands[2] = {n_hands_p0, n_hands_p1};
+    const uint8_t *hands[2] = {hands_p0, hands_p1};
+    for (int p = 0; rc == RS_OK && p < 2; ++p) {
+        tr->n_hands[p] = uint32_t(n_hands[p]);
+        for (size_t h = 0; rc == RS_OK && h < n_hands[p]; ++h) {
+            const uint8_t a = hands[p][2 * h], b = hands[p][2 * h + 1];
+            if (a >= 52 || b >= 52 || a == b) rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: bad hole cards in a range");
+            else if ((1ull << a | 1ull << b) & params->board_mask)
+                rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: a range combo uses a board card (remove_invalid_combos first, cfr.rs:163)");
+        }
+        if (rc == RS_OK) rc = rs_dmalloc(tr->table, n_hands[p] * 2, reinterpret_cast<void **>(&tr->d_hands[p]));
+        if (rc == RS_OK) rc = rs_h2d(tr->table, tr->d_hands[p], hands[p], n_hands[p] * 2);
+    }
+    if (rc == RS_OK) rc = rs_dmalloc(tr->table, 9 * pitch, reinterpret_cast<void **>(&tr->d_cards));
+    if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_cards, 0, 9 * pitch);
+    if (rc == RS_OK) rc = rs_dmalloc(tr->table, pitch * sizeof(float), reinterpret_cast<void **>(&tr->d_sign));
+    if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_sign, 0, pitch * sizeof(float));
+    if (rc == RS_OK) rc = rs_dmalloc(tr->table, 256, reinterpret_cast<void **>(&tr->d_err));
+    if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_err, 0, 256);
+    rs_deal_batch batch{};
+    batch.n_deals = params->deals_per_batch;
+    for (int r = 0; rc == RS_OK && r < n_rounds; ++r)
+        for (int p = 0; rc == RS_OK && p < 2; ++p) {
+            rc = rs_dmalloc(tr->table, pitch * sizeof(uint32_t), reinterpret_cast<void **>(&tr->d_cluster[r][p]));
+            if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_cluster[r][p], 0, pitch * sizeof(uint32_t));
+            batch.d_cluster[r][p] = tr->d_cluster[r][p];
+        }
+    if (rc == RS_OK) {
+        const int n = rs_tree_n_nodes(tr->tree);
+        std::vector<rs_leaf_desc> leaves(size_t(n), rs_leaf_desc{RS_LEAF_UNCONTESTED, nullptr});
+        for (int i = 0; i < n; ++i) {
+            rs_tree_node nd;
+            rs_tree_get_node(tr->tree, i, &nd);
+            if (nd.kind == RS_NODE_TERMINAL && nd.ttype != RS_TERM_UNCONTESTED) leaves[size_t(i)] = rs_leaf_desc{RS_LEAF_SIGN, tr->d_sign};
+        }
+        rs_solver_params sp = params->solver;
+        sp.chance_mode = RS_CHANCE_PASS;   // one run-out per deal: the board is dealt up front (cfr.rs:115-122, :306-313)
+        rc = rs_solver_create_deals(tr->table, tr->tree, &batch, leaves.data(), leaves.data(), &sp, &tr->solver);
+    }
+    if (rc != RS_OK) {
+        rs_deal_trainer_destroy(tr);
+        return rc;
+    }
+    *out = tr;
+    return RS_OK;
+}
+
+rs_table *rs_deal_trainer_table(rs_deal_trainer *tr) { return tr ? tr->table : nullptr; }
+rs_solver *rs_deal_trainer_solver(rs_deal_trainer *tr) { return tr ? tr->solver : nullptr; }
+uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *tr) { return tr ? tr->t : 0; }
+const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *tr) { return tr ? tr->d_cards : nullptr; }
+const float *rs_deal_trainer_signs(const rs_deal_trainer *tr) { return tr ? tr->d_sign : nullptr; }
+const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *tr, int round_idx, int player) {
+    return tr && round_idx >= 0 && round_idx < tr->n_rounds && (player == 0 || player == 1) ? tr->d_cluster[round_idx][player] : nullptr;
+}
+
+// deal the next batch and derive everything the sweep reads from the cards (no table access)
+int rs_deal_trainer_deal(rs_deal_trainer *tr) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_deal: trainer is NULL");
+    const uint32_t n = tr->params.deals_per_batch;
+    if (int rc = rs_deals_sample(tr->table, tr->params.seed, tr->batches * uint64_t(n), tr->params.board_mask, tr->d_hands[0], tr->n_hands[0],
+                                 tr->d_hands[1], tr->n_hands[1], n, tr->d_cards, tr->d_err))
+        return rc;
+    for (int r = 0; r < tr->n_rounds; ++r)
+        if (int rc = rs_card_abs_clusters_device(tr->abs[r], tr->table, tr->d_cards, n, tr->d_cluster[r][0], tr->d_cluster[r][1])) return rc;
+    if (int rc = rs_showdown_sign(tr->table, tr->d_cards, n, tr->d_sign)) return rc;
+    tr->batches += 1;
+    return RS_OK;
+}
+
+// train(): every batch is deals_per_batch iterations of cfr.rs:207-226; the discount check of cfr.rs:240-262 runs between batches
+int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_train: trainer is NULL");
+    for (uint64_t b = 0; b < n_batches; ++b) {
+        if (int rc = rs_deal_trainer_deal(tr)) return rc;
+        for (int player = 0; player < 2; ++player)   // cfr.rs:216-224
+            if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
+        tr->t += tr->params.deals_per_batch;          // cfr.rs:226, once per deal
+        if (tr->params.discount_interval == 0 || tr->t > tr->params.discount_cap) continue;   // cfr.rs:240-242
+        if (tr->t > tr->threshold) {                  // cfr.rs:243
+            if (int rc = rs_discount(tr->table, rs_discount_factor(tr->t, tr->params.discount_interval))) return rc;   // cfr.rs:248-261
+            tr->threshold = tr->t + tr->params.discount_interval;   // cfr.rs:262
+        }
+    }
+    return RS_OK;
+}
+
+// synchronises; fails if any deal since the last call could not be sampled or addressed (the reference would spin or panic)
+int rs_deal_trainer_status(rs_deal_trainer *tr) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_status: trainer is NULL");
+    uint32_t err = 0;
+    if (int rc = rs_d2h(tr->table, &err, tr->d_err, sizeof(err))) return rc;
+    if (err) {
+        rs_dmemset(tr->table, tr->d_err, 0, sizeof(err));
+        return fail(RS_ERR_INVALID, "generate_hand: no combo of a range fits the board and the other hand (the reference loops forever, cfr.rs:127-137)");
+    }
+    for (int r = 0; r < tr->n_rounds; ++r)
+        if (int rc = rs_card_abs_status(tr->abs[r], tr->table)) return rc;
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -230,8 +230,9 @@ class _Row:
 class InfosetTable:
     """`InfosetTable = Vec<Vec<Infoset>>` (infoset.rs:6), resident in HBM."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owned=True):
         self._h = handle
+        self._owned = owned   # False: a view of a table that a native object (rs_deal_trainer) owns
         lib = L.load()
         self.n_nodes = lib.rs_table_n_nodes(handle)
         self.dtype = lib.rs_table_dtype(handle)
@@ -411,7 +412,8 @@ class InfosetTable:
         if self._h:
             for sv in list(self._solvers):
                 sv.destroy()
-            L.load().rs_table_destroy(self._h)
+            if self._owned:
+                L.load().rs_table_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -546,6 +548,74 @@ class MCCFRTrainer:
     def destroy(self):
         if self._h:
             L.load().rs_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class DealTrainer:
+    """MCCFRTrainer::init + train (cfr.rs:159-297) with the whole deal pipeline on the GPU (rs_deal_trainer): generate_hand,
+    get_cluster for every round and player, the showdown comparison and the sampled mccfr sweep, batch after batch."""
+
+    def __init__(self, tree, card_abs, hand_ranges, board_mask, deals_per_batch, seed=0, scale=100.0, mode=L.UPD_CLAMP_I64,
+                 opp_mode=L.OPP_SAMPLE, discount_interval=MCCFRTrainer.DISCOUNT_INTERVAL, discount_cap=MCCFRTrainer.DISCOUNT_CAP,
+                 use_graph=False, fuse_subtrees=None, device=0):
+        if fuse_subtrees is None:
+            fuse_subtrees = bool(L.load().rs_jit_available())
+        self.game_tree, self.card_abs = tree, list(card_abs)
+        p = L.DealTrainerParams()
+        p.board_mask, p.deals_per_batch, p.seed = board_mask, deals_per_batch, seed
+        p.discount_interval, p.discount_cap = discount_interval, discount_cap
+        p.solver.scale, p.solver.mode, p.solver.chance_mode = scale, mode, L.CHANCE_PASS
+        p.solver.use_graph, p.solver.fuse_subtrees = int(use_graph), int(bool(fuse_subtrees))
+        p.solver.opp_mode, p.solver.sample_seed = opp_mode, seed
+        h0 = np.ascontiguousarray(hand_ranges[0], dtype=np.uint8).reshape(-1, 2)
+        h1 = np.ascontiguousarray(hand_ranges[1], dtype=np.uint8).reshape(-1, 2)
+        abs_arr = (C.c_void_p * len(self.card_abs))(*[a._h for a in self.card_abs])
+        h = C.c_void_p()
+        L.check(L.load().rs_deal_trainer_create(tree._h, abs_arr, len(self.card_abs), _vp(h0), len(h0), _vp(h1), len(h1), C.byref(p), device,
+                                                C.byref(h)))
+        self._h = h
+        self.n_deals = deals_per_batch
+        self.infosets = InfosetTable(C.c_void_p(L.load().rs_deal_trainer_table(h)), owned=False)
+
+    def train(self, n_batches):
+        L.check(L.load().rs_deal_trainer_train(self._h, n_batches))
+
+    def deal(self):
+        L.check(L.load().rs_deal_trainer_deal(self._h))
+
+    def status(self):
+        L.check(L.load().rs_deal_trainer_status(self._h))
+
+    @property
+    def iterations(self):
+        return int(L.load().rs_deal_trainer_iterations(self._h))
+
+    def _download(self, ptr, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        L.check(L.load().rs_d2h(self.infosets._h, _vp(out), ptr, out.nbytes))
+        return out
+
+    def cards(self):
+        """the current batch: uint8 [9][n_deals]"""
+        pitch = deal_pitch(self.n_deals)
+        return self._download(L.load().rs_deal_trainer_cards(self._h), np.uint8, 9 * pitch).reshape(9, pitch)[:, : self.n_deals]
+
+    def signs(self):
+        return self._download(L.load().rs_deal_trainer_signs(self._h), np.float32, deal_pitch(self.n_deals))[: self.n_deals]
+
+    def clusters(self, round_idx, player):
+        return self._download(L.load().rs_deal_trainer_clusters(self._h, round_idx, player), np.uint32, deal_pitch(self.n_deals))[: self.n_deals]
+
+    def destroy(self):
+        if self._h:
+            self.infosets._h = None
+            L.load().rs_deal_trainer_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,0 +1,266 @@
+"""GPU (-m gpu): the card kernels in front of the update path, through the C ABI, bit-exact against the CPU oracle:
+canonical hand index, get_cluster for deal batches, the deal sampler, and the whole MCCFRTrainer loop on the device
+(sample -> index -> bucket -> dense id -> showdown -> sampled mccfr sweep -> discount)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustsolver_amd as rs
+from oracle import orc
+from rustsolver_amd import abstraction as ab
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if rs.device_count() < 1:
+        pytest.fail("no HIP device visible: GPU parity tests need a real MI355X (there is no CPU fallback)")
+
+
+@pytest.fixture(scope="module")
+def table():
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    return rs.create_infosets(n_actions, tree, [4], [1])
+
+
+def random_hands(rng, n, n_cards):
+    return np.stack([rng.permutation(52)[:n_cards] for _ in range(n)]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("cpr", [[2], [2, 3], [2, 4], [2, 5], [2, 3, 1, 1], [1, 1, 1, 1, 1, 1, 1], [5, 2], [7]])
+def test_device_hand_index_equals_host_and_oracle(table, cpr):
+    rng = np.random.Generator(np.random.PCG64(sum(cpr) + 100 * len(cpr)))
+    pix, oix = ab.HandIndexer(cpr), orc.HandIndexer(cpr)
+    n = 20000 if len(cpr) < 4 else 5000
+    hands = random_hands(rng, n, sum(cpr))
+    for r in range(len(cpr)):
+        got = pix.get_index_device(table, hands, r)
+        assert (got == pix.get_index(hands, r)).all()
+        assert (got[:1500] == oix.get_index(hands[:1500, : pix.n_cards(r)].copy(), r)).all()
+        assert got.max() < pix.size(r)
+
+
+def test_device_hand_index_fixture_and_ragged_sizes(table, golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "hand_index.json")))
+    for key, cases in fx["restated"].items():
+        if key == "generate_hand":
+            continue
+        cpr = [int(x) for x in key.split(",")]
+        ix = ab.HandIndexer(cpr)
+        cards = np.array([c["cards"] for c in cases], dtype=np.uint8)
+        for r in range(len(cpr)):
+            assert ix.get_index_device(table, cards, r).tolist() == [c["index"][r] for c in cases]
+    ix = ab.HandIndexer([2, 5])
+    rng = np.random.Generator(np.random.PCG64(8))
+    for n in (0, 1, 63, 64, 65, 257):   # empty, below / at / above the 64-lane pitch
+        hands = random_hands(rng, n, 7) if n else np.zeros((0, 7), dtype=np.uint8)
+        assert (ix.get_index_device(table, hands) == (ix.get_index(hands) if n else np.zeros(0, np.uint64))).all()
+
+
+def whole_flop_on_device(table):
+    ix = ab.HandIndexer([2, 3])
+    n = ix.size(1)
+    idx = np.arange(n, dtype=np.uint64)
+    return ix, idx, ix.get_hand(1, idx)
+
+
+def test_device_hand_index_whole_flop_is_the_identity(table):
+    """size-independent property at full size: unindex (host) then index (GPU) over all 1 286 792 flop classes is the identity"""
+    ix, idx, hands = whole_flop_on_device(table)
+    assert (ix.get_index_device(table, hands, 1) == idx).all()
+
+
+def deals_from(rng, n, mask, h0, h1):
+    """valid deals (uint8 [9][n]) drawn with numpy: board completes `mask`, one combo per range, nothing dealt twice"""
+    board = [c for c in range(52) if mask >> c & 1]
+    out = np.zeros((9, n), dtype=np.uint8)
+    k = 0
+    while k < n:
+        a, b = h0[rng.integers(len(h0))], h1[rng.integers(len(h1))]
+        used = set(board) | set(a.tolist()) | set(b.tolist())
+        if len(used) != len(board) + 4:
+            continue
+        free = [c for c in range(52) if c not in used]
+        extra = rng.permutation(free)[: 5 - len(board)].tolist()
+        out[:, k] = board + extra + a.tolist() + b.tolist()
+        k += 1
+    return out
+
+
+@pytest.mark.parametrize("round_,n_board,bucketed", [(ab.RIVER, 5, False), (ab.TURN, 3, False), (ab.RIVER, 3, False), (ab.FLOP, 3, True),
+                                                    (ab.TURN, 3, True)])
+def test_device_get_cluster_equals_host(table, round_, n_board, bucketed):
+    rng = np.random.Generator(np.random.PCG64(round_ * 10 + n_board + 50 * bucketed))
+    mask = sum(1 << int(c) for c in rng.permutation(52)[:n_board])
+    allh = ab.random_range(mask)
+    h0 = allh if n_board == 5 else allh[rng.permutation(len(allh))[:60]]
+    h1 = allh[::-1] if n_board == 5 else allh[rng.permutation(len(allh))[:45]]
+    arr = None
+    if bucketed:
+        arr = rng.integers(0, 200, size=ab.HandIndexer([2, 3 + round_]).size(1), dtype=np.uint32)
+    card_abs = ab.CardAbstraction.init([h0, h1], mask, round_, arr)
+    n = 3000
+    deals = deals_from(rng, n, mask, h0, h1)
+    c0, c1 = card_abs.get_clusters_device(table, deals)
+    nb = 3 + round_
+    hand0 = np.concatenate([deals[5:7], deals[:nb]]).T   # the acting player's hole cards, then the board (cfr.rs:357-365)
+    hand1 = np.concatenate([deals[7:9], deals[:nb]]).T
+    assert (c0 == card_abs.get_cluster(hand0, 0)).all() and (c1 == card_abs.get_cluster(hand1, 1)).all()
+    assert c0.max() < card_abs.get_size(0) and c1.max() < card_abs.get_size(1)
+    # and against the oracle's own chain: index -> bucket -> position among the first-appearance keys
+    oix = orc.HandIndexer([2, 3 + round_])
+    keys0 = oix.generate_map(h0, mask, nb, arr).tolist()
+    pos = {k: i for i, k in enumerate(keys0)}
+    for i in range(0, n, 37):
+        b = oix.get_index(hand0[i])
+        b = int(arr[b]) if arr is not None else b
+        assert pos[b] == c0[i]
+
+
+def test_device_get_cluster_reports_hands_outside_the_map(table):
+    """Rust: `*self.cluster_map[player].get(&hand_index).unwrap()` panics (card_abstraction.rs:208); here an error code"""
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    card_abs = ab.CardAbstraction.init([hands[:10], hands[:10]], mask, ab.RIVER)
+    rng = np.random.Generator(np.random.PCG64(3))
+    deals = deals_from(rng, 200, mask, hands[500:600], hands[:10])   # player 0 holds hands the abstraction never saw
+    with pytest.raises(KeyError):
+        card_abs.get_clusters_device(table, deals)
+    ok = deals_from(rng, 200, mask, hands[:5], hands[5:10])
+    c0, c1 = card_abs.get_clusters_device(table, ok)                 # the error word was cleared: the next batch is fine
+    assert c0.max() < 10 and c1.max() < 10
+
+
+@pytest.mark.parametrize("n_board", [3, 4, 5])
+def test_device_deal_sampler_equals_oracle(table, n_board):
+    rng = np.random.Generator(np.random.PCG64(70 + n_board))
+    mask = sum(1 << int(c) for c in rng.permutation(52)[:n_board])
+    allh = ab.random_range(mask)
+    h0, h1 = allh[rng.permutation(len(allh))[:300]], allh[rng.permutation(len(allh))[:7]]
+    n = 5000
+    got = ab.sample_deals(table, 1234, 1000, mask, [h0, h1], n)
+    want = orc.generate_hands(1234, 1000, mask, h0, h1, n)
+    assert (got == want).all()
+    assert (ab.sample_deals(table, 1234, 1500, mask, [h0, h1], 100) == want[:, 500:600]).all()   # deal numbers, not batch positions
+    assert all(len(set(col.tolist())) == 9 for col in got.T[:500])
+
+
+def test_device_deal_sampler_gives_up_where_the_reference_would_spin(table):
+    with pytest.raises(RuntimeError):
+        ab.sample_deals(table, 3, 0, 0b111, [[(10, 11)], [(11, 12)]], 64)
+    with pytest.raises(rs.RsError):
+        ab.sample_deals(table, 3, 0, 0b11, [[(10, 11)], [(12, 13)]], 64)      # invalid board mask (options.rs:41)
+
+
+def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None):
+    mask = ab.card_mask(board) if isinstance(board, str) else board
+    n_actions, tree = rs.build_game_tree(options_rs)
+    first = bin(mask).count("1") - 3
+    card_abs = [ab.CardAbstraction.init(ranges, mask, first + r, None if bucket_files is None else bucket_files[r]) for r in range(rounds)]
+    tr = rs.DealTrainer(tree, card_abs, ranges, mask, n_deals, seed=seed, discount_interval=interval, discount_cap=cap, fuse_subtrees=fuse)
+    sizes = [(a.get_size(0), a.get_size(1)) for a in card_abs]
+    otree = orc.OracleTree(options_orc)
+    otab = orc.OracleDealTable(otree, sizes)
+    cidx = {(r, p): np.zeros(n_deals, dtype=np.uint32) for r in range(rounds) for p in (0, 1)}
+    sign = np.zeros(n_deals, dtype=np.float32)
+    leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    osol = orc.OracleDealSolver(otree, otab, leaves, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed)
+    return dict(tr=tr, tree=tree, card_abs=card_abs, mask=mask, first=first, otab=otab, osol=osol, cidx=cidx, sign=sign, ranges=ranges,
+                rounds=rounds, n_deals=n_deals, seed=seed, interval=interval, cap=cap, bucket_files=bucket_files, t=0, threshold=interval,
+                batches=0)
+
+
+def oracle_batch(ctx):
+    """one batch of MCCFRTrainer::train on the CPU: orc_generate_hand, oracle index -> bucket -> first-appearance id, brute-force
+    showdown, orc_iterate_deals for both players, then the discount check of cfr.rs:240-262"""
+    n = ctx["n_deals"]
+    cards = orc.generate_hands(ctx["seed"], ctx["batches"] * n, ctx["mask"], ctx["ranges"][0], ctx["ranges"][1], n)
+    for r in range(ctx["rounds"]):
+        nb = 3 + ctx["first"] + r
+        oix = orc.HandIndexer([2, nb])
+        arr = None if ctx["bucket_files"] is None else ctx["bucket_files"][r]
+        for p in (0, 1):
+            pos = {k: i for i, k in enumerate(oix.generate_map(ctx["ranges"][p], ctx["mask"], nb, arr).tolist())}
+            hands = np.concatenate([cards[5 + 2 * p: 7 + 2 * p], cards[:nb]]).T.copy()
+            idx = oix.get_index(hands)
+            buckets = idx if arr is None else arr[idx.astype(np.int64)]
+            ctx["cidx"][(r, p)][:] = [pos[int(b)] for b in buckets]
+    ctx["sign"][:] = orc.showdown_sign(cards)
+    for player in (0, 1):
+        ctx["osol"].iterate(player)
+    ctx["batches"] += 1
+    ctx["t"] += n
+    if ctx["interval"] and ctx["t"] <= ctx["cap"] and ctx["t"] > ctx["threshold"]:
+        orc.lib().orc_discount_table(C.byref(ctx["otab"].tb), orc.discount_factor(ctx["t"], ctx["interval"]))
+        ctx["threshold"] = ctx["t"] + ctx["interval"]
+    return cards
+
+
+def compare_trainer_tables(ctx):
+    for nd in ctx["tree"].action_nodes():
+        r, s = ctx["tr"].infosets.download_node(nd.index)
+        ro, so = ctx["otab"].get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs from the oracle at node %d" % nd.index
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_deal_trainer_reference_as_coded(fuse):
+    """options::default_flop(): board 4d5dAs3cKs, random ranges, ISOMORPHIC river abstraction (cfr.rs:159-184), discount ticks on"""
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    ctx = load_trainer_pair(rs.default_flop(), orc.options_default_river(), mask, [hands, hands], 1, 3000, seed=11, interval=4000, cap=13000,
+                            fuse=fuse)
+    assert [ctx["card_abs"][0].get_size(p) for p in (0, 1)] == [1081, 1081]
+    for b in range(5):
+        ctx["tr"].train(1)
+        cards = oracle_batch(ctx)
+        assert (ctx["tr"].cards() == cards).all()
+        for p in (0, 1):
+            assert (ctx["tr"].clusters(0, p) == ctx["cidx"][(0, p)]).all()
+        assert (ctx["tr"].signs() == ctx["sign"]).all()
+    ctx["tr"].status()
+    assert ctx["tr"].iterations == 15000 == ctx["t"]
+    compare_trainer_tables(ctx)
+
+
+def test_deal_trainer_three_streets_from_a_flop_with_bucket_files():
+    """flop start (3 board cards), three rounds: EMD-style bucket files on flop and turn, ISOMORPHIC river; narrow ranges so that many
+    deals share an info set; all five batches in one train() call"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    mask = ab.card_mask("7h8hQc")
+    allh = ab.random_range(mask)
+    ranges = [allh[rng.permutation(len(allh))[:40]], allh[rng.permutation(len(allh))[:55]]]
+    files = [rng.integers(0, 37, size=1286792, dtype=np.uint32), rng.integers(0, 61, size=13960050, dtype=np.uint32), None]
+    opts_rs, opts_orc = rs.three_street_options(), orc.options_three_street()
+    ctx = load_trainer_pair(opts_rs, opts_orc, mask, ranges, 3, 1500, seed=5, interval=2500, cap=10**9, bucket_files=files)
+    assert ctx["card_abs"][0].get_size(0) <= 37 and ctx["card_abs"][1].get_size(1) <= 61
+    ctx["tr"].train(5)
+    for b in range(5):
+        cards = oracle_batch(ctx)
+    assert (ctx["tr"].cards() == cards).all()
+    ctx["tr"].status()
+    compare_trainer_tables(ctx)
+
+
+def test_deal_trainer_rejects_bad_inputs():
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    river = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    turn = ab.CardAbstraction.init([hands[:5], hands[:5]], ab.card_mask("4d5dAs3c"), ab.TURN)
+    with pytest.raises(rs.RsError):
+        rs.DealTrainer(tree, [turn], [hands, hands], mask, 64)            # abstraction of the wrong street
+    with pytest.raises(rs.RsError):
+        rs.DealTrainer(tree, [river], [hands, hands], mask, 0)            # empty batch
+    with pytest.raises(rs.RsError):
+        rs.DealTrainer(tree, [river], [hands, hands], 0b11, 64)           # invalid board mask
+    with pytest.raises(rs.RsError):
+        rs.DealTrainer(tree, [river], [hands, ab.random_range(0)], mask, 64)   # a combo on the board
+    tr = rs.DealTrainer(tree, [river], [hands[:1], hands[:1]], mask, 64)   # both players can only hold the same combo
+    tr.train(1)
+    with pytest.raises(rs.RsError):
+        tr.status()
