@@ -93,7 +93,8 @@ RS_HD uint64_t hand_index(const HandIndexView &v, int upto, const uint8_t *cards
         const uint32_t n_cards = v.cards_per_round[r];
         for (uint32_t i = 0; i < n_cards; ++i) {
             const uint32_t c = cards[v.round_start[r] + i];
-            const uint32_t bit = 1u << (c >> 2);
+            const uint32_t rank = (c >> 2) < (uint32_t)kHiRanks ? (c >> 2) : (uint32_t)kHiRanks - 1;   // a byte that is no card stays in the tables
+            const uint32_t bit = 1u << rank;
 #pragma unroll
             for (int q = 0; q < kHiSuits; ++q) {   // selects instead of indexed writes: keeps the arrays in registers
                 const bool hit = (c & 3u) == (uint32_t)q;
