@@ -212,6 +212,70 @@ def deal_batch_leg(rs, device, n_deals, n_clusters, with_cpu, cpu_seconds):
     return out
 
 
+def deal_trainer_leg(rs, device, n_deals, with_cpu, cpu_seconds):
+    """The reference's train() as coded, end to end on the device: options::default_flop() (board 4d5dAs3cKs, random ranges, ISOMORPHIC river
+    abstraction = 1081 clusters per player, cfr.rs:159-184).  Per batch: generate_hand (cfr.rs:100-143) -> get_cluster for both players
+    (canonical hand index + dense id, cfr.rs:357-365) -> showdown comparison (cfr.rs:323-347) -> sampled mccfr sweep for both players
+    (cfr.rs:299-479).  One DEAL-ITERATION = one sampled deal traversed for both players (cfr.rs:209-226)."""
+    import numpy as np
+    from rustsolver_amd import abstraction as ab
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n_deals, seed=7, discount_interval=0, use_graph=True, device=device)
+    tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
+    tr.train(3)
+    tr.status()
+    k = 30
+    t0 = time.perf_counter()
+    tr.train(k)
+    tr.infosets.sync()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(k):
+        tr.deal()
+    tr.infosets.sync()
+    dt_deal = time.perf_counter() - t0
+    tr.status()
+    out = {"what": "MCCFRTrainer::train as coded (default_flop board, random ranges, ISOMORPHIC river abstraction, %d clusters): deal sampling, "
+                   "hand indexing + dense ids, showdown evaluation and the sampled mccfr sweep of both players, all on the device, %d deals per batch"
+                   % (card_abs.get_size(0), n_deals),
+           "value": n_deals * k / dt, "unit": "deal-iterations/s", "ms_per_batch": dt / k * 1e3, "ms_dealing_only": dt_deal / k * 1e3,
+           "n_deals": n_deals}
+    tr.destroy()
+    if with_cpu:
+        from oracle import orc
+        threads = min(8, os.cpu_count() or 1)
+        nd_cpu = 100_000
+        rng = np.random.Generator(np.random.PCG64(4321))
+        otree = orc.OracleTree(orc.options_default_river())
+        sizes = [(card_abs.get_size(0), card_abs.get_size(1))]
+        otab = orc.OracleDealTable(otree, sizes)
+        for d in otree.as_dicts():
+            if d["kind"] == orc.ACTION:
+                a_, n_ = otab.node_shape(d["index"])
+                otab.set_node(d["index"], rng.integers(-10**6, 10**6, size=(a_, n_)).astype(np.int32),
+                              rng.integers(0, 10**6, size=(a_, n_)).astype(np.int32))
+        cidx = {(0, p): np.zeros(nd_cpu, dtype=np.uint32) for p in (0, 1)}
+        sign = np.zeros(nd_cpu, dtype=np.float32)
+        ol = {d["id"]: (orc.LEAF_SIGN, sign) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+        osol = orc.OracleDealSolver(otree, otab, ol, cidx, nd_cpu, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=1)
+        t0 = time.perf_counter()
+        orc.run_train_from_cards(osol, cidx, sign, mask, [hands, hands], 7, 1, threads)
+        t1 = time.perf_counter() - t0
+        sweeps = max(1, int(cpu_seconds / max(t1, 1e-6)))
+        t0 = time.perf_counter()
+        orc.run_train_from_cards(osol, cidx, sign, mask, [hands, hands], 7, sweeps, threads)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nd_cpu * sweeps / dtc, "unit": "deal-iterations/s", "cores": threads, "kind": "port",
+                               "sample": "%d sweeps x %d deals from cards (generate_hand, hand index + dense id ONCE per deal and player, "
+                                         "brute-force showdown once per deal, sampled mccfr with reference-style allocations), %d threads, %.1f s"
+                                         % (sweeps, nd_cpu, threads, dtc)}
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
@@ -451,6 +515,11 @@ def main():
         out["deal_batch"] = deal_batch_leg(rs, device, 1 << 22, a.clusters, not a.no_cpu, min(a.cpu_seconds, 6.0))
     except Exception as e:
         out["deal_batch"] = {"error": str(e)}
+
+    try:
+        out["deal_trainer"] = deal_trainer_leg(rs, device, 1 << 22, not a.no_cpu, min(a.cpu_seconds, 6.0))
+    except Exception as e:
+        out["deal_trainer"] = {"error": str(e)}
 
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)

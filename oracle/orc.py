@@ -77,6 +77,13 @@ class Ctx(C.Structure):
     ]
 
 
+class CardsCtx(C.Structure):   # orc_cards_ctx (rs_oracle_mt.c)
+    _fields_ = [("ix", C.c_void_p * MAX_ROUNDS), ("cluster_arr", C.c_void_p * MAX_ROUNDS),
+                ("keys", (C.c_void_p * 2) * MAX_ROUNDS), ("ids", (C.c_void_p * 2) * MAX_ROUNDS), ("n_keys", (C.c_size_t * 2) * MAX_ROUNDS),
+                ("n_rounds", C.c_int), ("first_street", C.c_int), ("board_mask", C.c_uint64), ("seed", C.c_uint64),
+                ("hands", C.c_void_p * 2), ("n_hands", C.c_uint32 * 2), ("cidx", (C.c_void_p * 2) * MAX_ROUNDS), ("sign", C.c_void_p)]
+
+
 class HandIndexerC(C.Structure):   # orc_hand_indexer (hand_index.h)
     _fields_ = [("rounds", C.c_int), ("cards_per_round", C.c_uint8 * 8), ("round_start", C.c_uint8 * 8),
                 ("configurations", C.c_uint32 * 8), ("permutations", C.c_uint32 * 8), ("round_size", C.c_uint64 * 8),
@@ -188,6 +195,8 @@ def lib():
     L.orc_deal_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
     L.orc_deal_bits.restype = C.c_uint64
     L.orc_generate_hand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_run_train_cards_mt.argtypes = [C.POINTER(DealCtx), C.POINTER(Ctx), C.POINTER(CardsCtx), C.c_size_t, C.c_int]
+    L.orc_run_train_cards_mt.restype = C.c_int
     _lib = L
     return L
 
@@ -499,6 +508,40 @@ class OracleDealSolver(OracleSolver):
     def run_sweeps(self, sweeps, threads):
         """timed CPU baseline: `sweeps` x (both players over all deals), reference-style allocations, `threads` workers"""
         lib().orc_run_deal_sweeps_mt(C.byref(self.dc), C.byref(self.ctx), sweeps, threads)
+
+
+def run_train_from_cards(solver, cidx, sign, board_mask, ranges, seed, sweeps, threads, bucket_files=None):
+    """timed CPU baseline of the device-trainer leg: `sweeps` x (deal a batch from cards, then both players over all deals).
+    solver: an OracleDealSolver built on the SAME cidx / sign arrays (they are rewritten in place every sweep)."""
+    n_rounds = len({r for (r, _p) in cidx})
+    first = bin(board_mask).count("1") - 3
+    cc = CardsCtx()
+    keep = []
+    for r in range(n_rounds):
+        nb = 3 + first + r
+        ix = HandIndexer([2, nb])
+        keep.append(ix)
+        cc.ix[r] = C.addressof(ix.ix)
+        arr = None if bucket_files is None else bucket_files[r]
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=np.uint32)
+            keep.append(arr)
+            cc.cluster_arr[r] = arr.ctypes.data
+        for p in (0, 1):
+            keys = ix.generate_map(ranges[p], board_mask, nb, arr)
+            order = np.argsort(keys)
+            sk, ids = np.ascontiguousarray(keys[order]), np.ascontiguousarray(order.astype(np.uint32))
+            keep += [sk, ids]
+            cc.keys[r][p], cc.ids[r][p], cc.n_keys[r][p] = sk.ctypes.data, ids.ctypes.data, len(sk)
+            cc.cidx[r][p] = cidx[(r, p)].ctypes.data
+    cc.n_rounds, cc.first_street, cc.board_mask, cc.seed = n_rounds, first, board_mask, seed
+    for p in (0, 1):
+        h = np.ascontiguousarray(ranges[p], dtype=np.uint8).reshape(-1, 2)
+        keep.append(h)
+        cc.hands[p], cc.n_hands[p] = h.ctypes.data, len(h)
+    cc.sign = sign.ctypes.data
+    if lib().orc_run_train_cards_mt(C.byref(solver.dc), C.byref(solver.ctx), C.byref(cc), sweeps, threads) != 0:
+        raise RuntimeError("orc_run_train_cards_mt: a deal could not be sampled or addressed")
 
 
 class OracleFlatTable(OracleTable):

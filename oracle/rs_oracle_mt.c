@@ -349,3 +349,94 @@ void orc_showdown_sign(const uint8_t *cards, size_t n, float *sign) {
         sign[l] = s0 == s1 ? 0.0f : (s0 > s1 ? 1.0f : -1.0f);
     }
 }
+
+
+/* ---- threaded train() from CARDS for the timed CPU baseline of the device-trainer leg --------------------------------------------
+ * Per sweep every worker first deals its share of the batch -- generate_hand (cfr.rs:100-143), get_cluster for every (round, player)
+ * (canonical index, optional bucket file, dense id; the reference repeats this at every action node visit, cfr.rs:357-365, here it is
+ * done ONCE per deal, which favours the CPU), the showdown sign once per deal (the reference evaluates both hands at every showdown
+ * it reaches, cfr.rs:323-347) -- then traverses it for both players exactly like orc_run_deal_sweeps_mt. */
+#include "hand_index.h"
+
+typedef struct {
+    const orc_hand_indexer *ix[ORC_MAX_ROUNDS];       /* per tree round: init(2, [2, 3 + street]) */
+    const uint32_t *cluster_arr[ORC_MAX_ROUNDS];      /* bucket file or NULL */
+    const uint64_t *keys[ORC_MAX_ROUNDS][2];          /* sorted buckets of cluster_map[player] ... */
+    const uint32_t *ids[ORC_MAX_ROUNDS][2];           /* ... and their dense ids */
+    size_t n_keys[ORC_MAX_ROUNDS][2];
+    int n_rounds, first_street;
+    uint64_t board_mask, seed;
+    const uint8_t *hands[2];
+    uint32_t n_hands[2];
+    uint32_t *cidx[ORC_MAX_ROUNDS][2];                /* written per sweep; the orc_deal_ctx points at the same arrays */
+    float *sign;                                      /* likewise, shared by every showdown leaf */
+} orc_cards_ctx;
+
+typedef struct {
+    const orc_cards_ctx *cc;
+    size_t lo, hi, first_deal;
+    int failed;
+} cards_job;
+
+void orc_showdown_sign(const uint8_t *cards, size_t n, float *out);
+
+static void *cards_worker(void *arg) {
+    cards_job *j = (cards_job *)arg;
+    const orc_cards_ctx *cc = j->cc;
+    size_t d;
+    for (d = j->lo; d < j->hi; d++) {
+        uint8_t c9[9], hand[7];
+        int r, p, i;
+        if (orc_generate_hand(cc->seed, j->first_deal + d, cc->board_mask, cc->hands[0], cc->n_hands[0], cc->hands[1], cc->n_hands[1], c9) != 0) {
+            j->failed = 1;
+            continue;
+        }
+        for (r = 0; r < cc->n_rounds; r++)
+            for (p = 0; p < 2; p++) {
+                const int nb = 3 + cc->first_street + r;
+                uint64_t bucket;
+                size_t lo = 0, hi = cc->n_keys[r][p];
+                hand[0] = c9[5 + 2 * p];
+                hand[1] = c9[6 + 2 * p];
+                for (i = 0; i < nb; i++) hand[2 + i] = c9[i];
+                bucket = orc_hand_index_last(cc->ix[r], hand);
+                if (cc->cluster_arr[r]) bucket = cc->cluster_arr[r][bucket];
+                while (lo < hi) {   /* cluster_map[player].get(&bucket) */
+                    const size_t mid = (lo + hi) / 2;
+                    if (cc->keys[r][p][mid] < bucket) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo >= cc->n_keys[r][p] || cc->keys[r][p][lo] != bucket) j->failed = 1;   /* Rust: unwrap on None */
+                else cc->cidx[r][p][d] = cc->ids[r][p][lo];
+            }
+        {   /* orc_showdown_sign reads [9][n] column-major; one deal = n 1 */
+            orc_showdown_sign(c9, 1, &cc->sign[d]);
+        }
+    }
+    return NULL;
+}
+
+int orc_run_train_cards_mt(orc_deal_ctx *dc, orc_ctx *ctx, const orc_cards_ctx *cc, size_t sweeps, int n_threads) {
+    size_t t;
+    int i, failed = 0;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    cards_job *jobs = (cards_job *)malloc((size_t)n_threads * sizeof(cards_job));
+    for (t = 0; t < sweeps; t++) {
+        for (i = 0; i < n_threads; i++) {
+            jobs[i].cc = cc;
+            jobs[i].lo = dc->n_deals * (size_t)i / (size_t)n_threads;
+            jobs[i].hi = dc->n_deals * (size_t)(i + 1) / (size_t)n_threads;
+            jobs[i].first_deal = t * dc->n_deals;
+            jobs[i].failed = 0;
+            pthread_create(&th[i], NULL, cards_worker, &jobs[i]);
+        }
+        for (i = 0; i < n_threads; i++) {
+            pthread_join(th[i], NULL);
+            failed |= jobs[i].failed;
+        }
+        orc_run_deal_sweeps_mt(dc, ctx, 1, n_threads);
+    }
+    free(th);
+    free(jobs);
+    return failed ? -1 : 0;
+}

@@ -25,8 +25,8 @@ FULL = 1 << 19   # the LDS deal-batch kernels run 1024 workgroups of 512 threads
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # gpurun MERGES runs into gpurun_out/: newest wins
+    return g[-1] if g else None
 
 
 stats = one("trace/*/*_kernel_stats.csv")

@@ -67,6 +67,45 @@ extern "C" {
     pub fn rs_solver_destroy(solver: *mut rs_solver);
     pub fn rs_iterate(solver: *mut rs_solver, traverser: c_int, d_root_util: *mut f32) -> c_int;
     pub fn rs_train(solver: *mut rs_solver, iterations: u64, discount_interval: u64, discount_cap: u64) -> c_int;
+
+    // rust_poker::hand_indexer_s (card_abstraction.rs:88-90,205; gen_abstraction/main.rs:91,117)
+    pub fn rs_hand_indexer_create(rounds: c_int, cards_per_round: *const u8, out: *mut *mut rs_hand_indexer) -> c_int;
+    pub fn rs_hand_indexer_destroy(indexer: *mut rs_hand_indexer);
+    pub fn rs_hand_indexer_size(indexer: *const rs_hand_indexer, round: c_int) -> u64;
+    pub fn rs_hand_index(indexer: *const rs_hand_indexer, round: c_int, cards: *const u8, n: usize, out: *mut u64) -> c_int;
+    pub fn rs_hand_unindex(indexer: *const rs_hand_indexer, round: c_int, indices: *const u64, n: usize, cards_out: *mut u8) -> c_int;
+    // ISOMORPHIC / EMD / OCHS (card_abstraction.rs:186-298); hands = HandRange.hands as (u8,u8) pairs
+    pub fn rs_card_abs_create(betting_round: c_int, hands_p0: *const u8, n_hands_p0: usize, hands_p1: *const u8, n_hands_p1: usize,
+                              initial_board_mask: u64, cluster_arr: *const u32, arr_len: usize, out: *mut *mut rs_card_abs) -> c_int;
+    pub fn rs_card_abs_destroy(abs_: *mut rs_card_abs);
+    pub fn rs_card_abs_size(abs_: *const rs_card_abs, player: c_int) -> usize;
+    pub fn rs_card_abs_get_cluster(abs_: *const rs_card_abs, cards: *const u8, n: usize, player: c_int, out: *mut u32) -> c_int;
+    pub fn rs_card_abs_clusters_device(abs_: *mut rs_card_abs, table: *mut rs_table, d_cards: *const u8, n_deals: u32,
+                                       d_cluster_p0: *mut u32, d_cluster_p1: *mut u32) -> c_int;
+    pub fn rs_card_abs_status(abs_: *mut rs_card_abs, table: *mut rs_table) -> c_int;
+    // generate_hand (cfr.rs:100-143) and the whole MCCFRTrainer loop (cfr.rs:159-297) on the device
+    pub fn rs_deals_sample(table: *mut rs_table, seed: u64, first_deal: u64, board_mask: u64, d_hands_p0: *const u8, n_hands_p0: u32,
+                           d_hands_p1: *const u8, n_hands_p1: u32, n_deals: u32, d_cards: *mut u8, d_err: *mut u32) -> c_int;
+    pub fn rs_deal_trainer_create(tree: *const rs_tree, card_abs: *const *mut rs_card_abs, n_rounds: c_int, hands_p0: *const u8,
+                                  n_hands_p0: usize, hands_p1: *const u8, n_hands_p1: usize, params: *const rs_deal_trainer_params,
+                                  device: c_int, out: *mut *mut rs_deal_trainer) -> c_int;
+    pub fn rs_deal_trainer_destroy(trainer: *mut rs_deal_trainer);
+    pub fn rs_deal_trainer_table(trainer: *mut rs_deal_trainer) -> *mut rs_table;
+    pub fn rs_deal_trainer_train(trainer: *mut rs_deal_trainer, n_batches: u64) -> c_int;
+    pub fn rs_deal_trainer_status(trainer: *mut rs_deal_trainer) -> c_int;
+}
+
+#[repr(C)] pub struct rs_hand_indexer { _private: [u8; 0] }
+#[repr(C)] pub struct rs_card_abs { _private: [u8; 0] }
+#[repr(C)] pub struct rs_deal_trainer { _private: [u8; 0] }
+#[repr(C)]
+pub struct rs_deal_trainer_params {
+    pub board_mask: u64,          // Options.board_mask (options.rs:17)
+    pub deals_per_batch: u32,
+    pub seed: u64,
+    pub discount_interval: u64,   // cfr.rs:190
+    pub discount_cap: u64,        // cfr.rs:240
+    pub solver: rs_solver_params,
 }
 
 /// Flatten `Tree<GameTreeNode>` (tree.rs:14-17, nodes.rs:46-52) into the ABI's node array.

@@ -220,26 +220,33 @@ __global__ __launch_bounds__(kBlock) void k_hand_index(HandIndexView v, int upto
 // bucket file (Rust: index out of bounds), bit 2 = the deal sampler gave up
 __global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJob *__restrict__ jobs, const uint8_t *__restrict__ cards, uint32_t n,
                                                           uint32_t pitch, uint32_t *__restrict__ err) {
-    const ClusterJob job = jobs[blockIdx.y];
+    // read the job through its (wave-uniform) address: scalar loads.  A by-value copy would be indexed dynamically (rows.row[i],
+    // cards_per_round[r]) and therefore live in scratch: 168 B per lane, 700 MB of scratch writes per 4 M deals (profiles/r01e).
+    const ClusterJob *__restrict__ job = jobs + blockIdx.y;
+    const int n_cards = job->rows.n_cards;
+    const uint32_t *__restrict__ arr = job->cluster_arr;
+    const uint64_t arr_len = job->arr_len;
+    const DenseSlot *__restrict__ slots = job->slots;
+    const uint64_t mask = job->mask;
+    uint32_t *__restrict__ dst = job->out;
     for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
         uint8_t c[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) c[i] = i < job.rows.n_cards ? cards[(size_t)job.rows.row[i] * pitch + l] : (uint8_t)0;
-        uint64_t bucket = hand_index(job.view, job.upto, c);
-        uint32_t dense = 0;
-        if (job.cluster_arr) {
-            if (bucket < job.arr_len) bucket = job.cluster_arr[bucket];
+        for (int i = 0; i < 7; ++i) c[i] = i < n_cards ? cards[(size_t)job->rows.row[i] * pitch + l] : (uint8_t)0;
+        uint64_t bucket = hand_index(job->view, job->upto, c);
+        if (arr) {
+            if (bucket < arr_len) bucket = arr[bucket];
             else {
                 atomicOr(err, 2u);
                 bucket = ~0ull - 1;
             }
         }
-        dense = dense_lookup(job.slots, job.mask, bucket);
+        uint32_t dense = dense_lookup(slots, mask, bucket);
         if (dense == kDenseMissing) {
             atomicOr(err, 1u);
             dense = 0;   // stays inside the table; the error word makes the host refuse the batch
         }
-        job.out[l] = dense;
+        dst[l] = dense;
     }
 }
 

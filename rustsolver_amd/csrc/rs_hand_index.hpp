@@ -44,21 +44,37 @@ RS_HD uint32_t hi_popc(uint32_t x) {
 #endif
 }
 
-// C(n, k), k <= 4; exact while the result fits 64 bits (multiset group sizes of real poker hands are tiny)
+// C(n, k), k <= 4; exact while n*(n-1)*(n-2)*(n-3) fits 64 bits (n < 65536; multiset group sizes of real poker hands are far
+// smaller).  Closed forms with constant divisors: a dynamic-k division loop costs hundreds of GPU instructions per call.
 RS_HD uint64_t hi_choose(uint64_t n, int k) {
     if ((uint64_t)k > n) return 0;
-    uint64_t r = 1;
-    for (int i = 0; i < k; ++i) r = r * (n - (uint64_t)i) / (uint64_t)(i + 1);
-    return r;
+    switch (k) {
+        case 0: return 1;
+        case 1: return n;
+        case 2: return (n * (n - 1)) >> 1;
+        case 3: return (n * (n - 1) >> 1) * (n - 2) / 3;
+        default: return ((n * (n - 1) >> 1) * (n - 2) / 3) * (n - 3) / 4;
+    }
 }
 
-// C(n, k) for 0 <= k <= n <= 13 without a table
+// C(n, k) for 0 <= n <= 13 (row n of Pascal's triangle, k <= 13)
 RS_HD uint32_t hi_choose13(uint32_t n, uint32_t k) {
-    if (k > n) return 0;
-    if (k > n - k) k = n - k;
-    uint32_t r = 1;
-    for (uint32_t i = 0; i < k; ++i) r = r * (n - i) / (i + 1);
-    return r;
+    constexpr uint16_t kPascal[14][14] = {
+        {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 3, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 4, 6, 4, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 5, 10, 10, 5, 1, 0, 0, 0, 0, 0, 0, 0, 0},
+        {1, 6, 15, 20, 15, 6, 1, 0, 0, 0, 0, 0, 0, 0},
+        {1, 7, 21, 35, 35, 21, 7, 1, 0, 0, 0, 0, 0, 0},
+        {1, 8, 28, 56, 70, 56, 28, 8, 1, 0, 0, 0, 0, 0},
+        {1, 9, 36, 84, 126, 126, 84, 36, 9, 1, 0, 0, 0, 0},
+        {1, 10, 45, 120, 210, 252, 210, 120, 45, 10, 1, 0, 0, 0},
+        {1, 11, 55, 165, 330, 462, 462, 330, 165, 55, 11, 1, 0, 0},
+        {1, 12, 66, 220, 495, 792, 924, 792, 495, 220, 66, 12, 1, 0},
+        {1, 13, 78, 286, 715, 1287, 1716, 1716, 1287, 715, 286, 78, 13, 1}};
+    return n <= 13u && k <= 13u ? kPascal[n][k] : 0u;
 }
 
 struct HiSuit {
