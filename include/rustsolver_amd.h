@@ -383,6 +383,23 @@ const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *trainer);  /* device
 const float *rs_deal_trainer_signs(const rs_deal_trainer *trainer);    /* device: its showdown signs [pitch] */
 const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *trainer, int round_idx, int player);   /* device: its cluster ids [pitch] */
 
+/* ---- abstraction generator's distance sweep: gen_abstraction/kmeans.rs, emd.rs -----------------------------
+ * The sweep that WRITES the bucket files read above: Kmeans::predict over every canonical hand's histogram (main.rs:361-380).
+ * Histograms are f32[n_bins] (type Histogram = Vec<f32>), 1..64 bins.  Arithmetic is the reference's, bit for bit: f32, no FMA, the
+ * operation order of emd_1d (emd.rs:53-113) / l2_dist (kmeans.rs:622-630). */
+enum { RS_DIST_EMD = 0,   /* emd::emd_1d */
+       RS_DIST_L2 = 1 };  /* kmeans::l2_dist */
+/* one dist_func(p, q) on the host */
+int rs_histogram_distance(int dist, const float *p, const float *q, int n_bins, float *out);
+/* Kmeans::predict (kmeans.rs:173-211): d_dataset = DEVICE [n][n_bins] row-major, centers = HOST [n_centers][n_bins];
+ * d_clusters[n] (u32: first center with the strictly smallest distance) and d_min_dist[n] (that distance) are DEVICE buffers, either may
+ * be NULL.  The reference's returned `inertia` is a racy load+store (kmeans.rs:205); sum d_min_dist instead.  Asynchronous on the table's
+ * stream; `table` only lends its device and stream. */
+int rs_kmeans_predict(rs_table *table, int dist, const float *d_dataset, size_t n, const float *centers, int n_centers, int n_bins,
+                      uint32_t *d_clusters, float *d_min_dist);
+/* update_min_dists (kmeans.rs:603-619), the kmeans++ step: d_min_dists[i] = min(d_min_dists[i], dist(dataset[i], new_center)^2) */
+int rs_update_min_dists(rs_table *table, int dist, float *d_min_dists, const float *d_dataset, size_t n, const float *new_center, int n_bins);
+
 /* ---- showdown evaluation on the device ---------------------------------------------------------------
  * d_cards[9][pitch] (u8, pitch = round_up(n_deals, 64)): rows 0-4 the board, 5-6 player 0's hole cards, 7-8 player 1's;
  * card = 4*rank + suit, rank 0..12 = 2..A (cfr.rs:592).  d_sign[lane] = sign(evaluate(hand0) - evaluate(hand1)) exactly as

@@ -98,7 +98,7 @@ DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
 
 def build(force=False):
     """Compile oracle/librs_oracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "kmeans_emd.c", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -195,6 +195,13 @@ def lib():
     L.orc_deal_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
     L.orc_deal_bits.restype = C.c_uint64
     L.orc_generate_hand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_emd_1d.argtypes = [f32p, f32p, C.c_int]
+    L.orc_emd_1d.restype = C.c_float
+    L.orc_l2_dist.argtypes = [f32p, f32p, C.c_int]
+    L.orc_l2_dist.restype = C.c_float
+    L.orc_kmeans_predict.argtypes = [C.c_int, f32p, C.c_size_t, C.c_size_t, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint32), f32p]
+    L.orc_kmeans_predict_mt.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint32), f32p, C.c_int]
+    L.orc_update_min_dists.argtypes = [C.c_int, f32p, f32p, C.c_size_t, f32p, C.c_int]
     L.orc_run_train_cards_mt.argtypes = [C.POINTER(DealCtx), C.POINTER(Ctx), C.POINTER(CardsCtx), C.c_size_t, C.c_int]
     L.orc_run_train_cards_mt.restype = C.c_int
     _lib = L
@@ -642,3 +649,37 @@ def generate_hands(seed, first_deal, board_mask, hands0, hands1, n_deals):
         if lib().orc_generate_hand(seed, first_deal + i, board_mask, h0.ctypes.data, len(h0), h1.ctypes.data, len(h1), out[i].ctypes.data) != 0:
             raise RuntimeError("orc_generate_hand: no valid deal")
     return np.ascontiguousarray(out.T)
+
+
+# ---- abstraction generator's distance sweep (kmeans_emd.c) ------------------------------------------------------------------------
+DIST_EMD, DIST_L2 = 0, 1
+
+
+def emd_1d(p, q):
+    """gen_abstraction/emd.rs:53-113"""
+    a, b = np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+    assert a.shape == b.shape and a.ndim == 1
+    return np.float32(lib().orc_emd_1d(_f32(a), _f32(b), len(a)))
+
+
+def l2_dist(p, q):
+    """gen_abstraction/kmeans.rs:622-630"""
+    a, b = np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+    return np.float32(lib().orc_l2_dist(_f32(a), _f32(b), len(a)))
+
+
+def kmeans_predict(dataset, centers, kind=DIST_EMD, threads=1):
+    """Kmeans::predict (kmeans.rs:173-211) -> (clusters uint32 [n], min distances float32 [n])"""
+    d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.ascontiguousarray(centers, dtype=np.float32)
+    assert d.ndim == 2 and c.ndim == 2 and d.shape[1] == c.shape[1]
+    clusters, md = np.zeros(len(d), dtype=np.uint32), np.zeros(len(d), dtype=np.float32)
+    lib().orc_kmeans_predict_mt(kind, _f32(d), len(d), _f32(c), len(c), d.shape[1], clusters.ctypes.data_as(C.POINTER(C.c_uint32)), _f32(md), threads)
+    return clusters, md
+
+
+def update_min_dists(min_dists, dataset, new_center, kind=DIST_EMD):
+    """kmeans.rs:603-619, in place"""
+    d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.ascontiguousarray(new_center, dtype=np.float32)
+    assert min_dists.dtype == np.float32 and min_dists.flags.c_contiguous
+    lib().orc_update_min_dists(kind, _f32(min_dists), _f32(d), len(d), _f32(c), d.shape[1])
+    return min_dists

@@ -17,6 +17,7 @@ UPD_CLAMP_I64, UPD_WRAP_I32, UPD_RMPLUS, UPD_PRUNE = 0, 1, 0x100, 0x200
 LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
 CHANCE_PASS, CHANCE_ENUM = 0, 1
 OPP_FULL, OPP_SAMPLE = 0, 1
+DIST_EMD, DIST_L2 = 0, 1
 K_UPDATE, K_NODE_UTIL, K_REACH, K_CHANCE, K_DISCOUNT, K_STRATEGY, K_TREE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -170,6 +171,9 @@ SYMBOLS = {
     "rs_deal_trainer_cards": (C.c_void_p, [_P]),
     "rs_deal_trainer_signs": (C.c_void_p, [_P]),
     "rs_deal_trainer_clusters": (C.c_void_p, [_P, C.c_int, C.c_int]),
+    "rs_histogram_distance": (C.c_int, [C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float)]),
+    "rs_kmeans_predict": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
+    "rs_update_min_dists": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     "rs_showdown_sign": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rs_table_save": (C.c_int, [_P, C.c_char_p]),
     "rs_table_load": (C.c_int, [C.c_char_p, C.c_int, _PP]),

@@ -247,3 +247,50 @@ def sample_deals(table, seed, first_deal, board_mask, hand_ranges, n_deals):
     if err:
         raise RuntimeError("generate_hand: no valid combo for some deal (error word %d)" % err)
     return dc.download(np.uint8, 9 * pitch).reshape(9, pitch)[:, :n_deals]
+
+
+# ---- abstraction generator's distance sweep (gen_abstraction/kmeans.rs, emd.rs) -----------------------------------------------------
+DIST_EMD, DIST_L2 = L.DIST_EMD, L.DIST_L2
+
+
+def histogram_distance(p, q, dist=DIST_EMD):
+    """emd::emd_1d (emd.rs:53-113) or kmeans::l2_dist (kmeans.rs:622-630) of two histograms, on the host"""
+    a, b = np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+    if a.shape != b.shape or a.ndim != 1:
+        raise ValueError("two histograms of the same length")
+    out = C.c_float()
+    L.check(L.load().rs_histogram_distance(dist, a.ctypes.data, b.ctypes.data, len(a), C.byref(out)))
+    return np.float32(out.value)
+
+
+class Kmeans:
+    """The distance sweeps of gen_abstraction/kmeans.rs on the GPU: `predict` (kmeans.rs:173-211) and the kmeans++ `update_min_dists`
+    (kmeans.rs:603-619).  The dataset stays resident on the device between calls."""
+
+    def __init__(self, table, dataset):
+        from .solver import DeviceBuffer
+        d = np.ascontiguousarray(dataset, dtype=np.float32)
+        if d.ndim != 2:
+            raise ValueError("dataset is [n][n_bins]")
+        self.table, self.n, self.n_bins = table, d.shape[0], d.shape[1]
+        self._data = DeviceBuffer.from_numpy(table, d) if d.size else None
+        self._DeviceBuffer = DeviceBuffer
+
+    def predict(self, centers, dist=DIST_EMD):
+        """-> (clusters uint32 [n], distance to the chosen center float32 [n])"""
+        c = np.ascontiguousarray(centers, dtype=np.float32)
+        if c.ndim != 2 or c.shape[1] != self.n_bins:
+            raise ValueError("centers are [k][n_bins]")
+        dc = self._DeviceBuffer(self.table, max(self.n, 1) * 4)
+        dm = self._DeviceBuffer(self.table, max(self.n, 1) * 4)
+        L.check(L.load().rs_kmeans_predict(self.table._h, dist, self._data.ptr if self._data else None, self.n, c.ctypes.data, len(c), self.n_bins,
+                                           dc.ptr, dm.ptr))
+        return dc.download(np.uint32, self.n), dm.download(np.float32, self.n)
+
+    def update_min_dists(self, min_dists, new_center, dist=DIST_EMD):
+        m = np.ascontiguousarray(min_dists, dtype=np.float32)
+        c = np.ascontiguousarray(new_center, dtype=np.float32)
+        dm = self._DeviceBuffer.from_numpy(self.table, m) if self.n else None
+        L.check(L.load().rs_update_min_dists(self.table._h, dist, dm.ptr if dm else None, self._data.ptr if self._data else None, self.n, c.ctypes.data,
+                                             self.n_bins))
+        return dm.download(np.float32, self.n) if self.n else m

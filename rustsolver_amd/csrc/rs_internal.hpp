@@ -168,6 +168,8 @@ struct rs_table {
     std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away
     void *d_query = nullptr;          // scratch of the single-info-set strategy queries (rs_get_strategy)
     uint32_t *d_err_sink = nullptr;   // error word for card kernels whose caller passed none (rs_deals_sample)
+    void *d_km_scratch = nullptr;     // staged k-means centers (rs_kmeans_predict), grow-only
+    size_t km_scratch_bytes = 0;
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 

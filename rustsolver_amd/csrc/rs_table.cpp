@@ -239,6 +239,7 @@ void rs_table_destroy(rs_table *t) {
     if (t->d_job) (void)hipFree(t->d_job);
     if (t->d_query) (void)hipFree(t->d_query);
     if (t->d_err_sink) (void)hipFree(t->d_err_sink);
+    if (t->d_km_scratch) (void)hipFree(t->d_km_scratch);
     if (t->d_dregrets) (void)hipFree(t->d_dregrets);
     if (t->d_dssum) (void)hipFree(t->d_dssum);
     if (t->stream) (void)hipStreamDestroy(t->stream);

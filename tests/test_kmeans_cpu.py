@@ -1,0 +1,97 @@
+"""CPU (-m "not gpu"): the abstraction generator's distance functions.
+
+  * the oracle (oracle/kmeans_emd.c, a literal restatement of emd.rs:53-113 / kmeans.rs:622-630) against the reference's OWN known answers
+    (gen_abstraction/emd.rs:122-180, tolerance ERROR = 0.01 from emd.rs:120);
+  * the product's host-side distance (rs_histogram_distance: the bitmask formulation the GPU kernel uses) against the oracle, bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustsolver_amd as rs
+from oracle import orc
+from rustsolver_amd import abstraction as ab
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "kmeans_emd.json")))
+
+
+def f32bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def test_oracle_meets_the_reference_known_answers(fx):
+    tol = fx["reference"]["tolerance"]
+    for c in fx["reference"]["cases"]:
+        got = float(orc.emd_1d(c["p"], c["q"]))
+        assert abs(got - c["emd"]) < tol, (c["name"], got, c["emd"])   # assert!(emd < actual + ERROR && emd > actual - ERROR)
+
+
+def test_emd_of_a_histogram_with_itself_is_three_ulps_not_zero(fx):
+    """emd.rs:136 asserts emd(h, h) == 0.0 inside a #[bench].  Evaluated in f32 as written, w = sum of the normalised bins = 1 - 2^-24 for that
+    histogram, u = 3, so the function returns (1 - w) * u = 3 * 2^-24: far inside ERROR = 0.01, not equal to 0.0 (numpy float32 agrees)."""
+    c = fx["reference"]["cases"][0]
+    p = np.array(c["p"], dtype=np.float32)
+    s = np.float32(0)
+    for x in p:
+        s = np.float32(s + x)
+    w = np.float32(0)
+    for x in p:
+        w = np.float32(w + np.float32(x / s))
+    assert w == np.float32(1) - np.float32(2.0 ** -24)
+    assert orc.emd_1d(p, p) == np.float32(3 * 2.0 ** -24)
+
+
+def test_oracle_and_host_restated_fixture(fx):
+    for c in fx["restated"]:
+        p = np.array(c["p_bits"], dtype=np.uint32).view(np.float32)
+        q = np.array(c["q_bits"], dtype=np.uint32).view(np.float32)
+        assert f32bits(orc.emd_1d(p, q)) == c["emd_bits"] and f32bits(orc.l2_dist(p, q)) == c["l2_bits"]
+        assert f32bits(ab.histogram_distance(p, q)) == c["emd_bits"]
+        assert f32bits(ab.histogram_distance(p, q, ab.DIST_L2)) == c["l2_bits"]
+    for c in fx["reference"]["cases"]:
+        assert f32bits(ab.histogram_distance(c["p"], c["q"])) == f32bits(orc.emd_1d(c["p"], c["q"]))
+
+
+def test_host_distance_equals_oracle_on_fuzzed_histograms():
+    """the bitmask formulation (at most n_bins transfers) against the literal 2(u-1) x n_bins probe loop"""
+    rng = np.random.Generator(np.random.PCG64(17))
+    for _ in range(6000):
+        n = int(rng.integers(1, 65))
+        p = (rng.random(n) ** rng.integers(1, 7)).astype(np.float32)
+        q = (rng.random(n) ** rng.integers(1, 7)).astype(np.float32)
+        if rng.random() < 0.3:
+            p[rng.random(n) < 0.5] = 0
+        if rng.random() < 0.3:
+            q[rng.random(n) < 0.5] = 0
+        if rng.random() < 0.1:
+            q = np.roll(p, int(rng.integers(0, n)))       # same mass, shifted: pure cross-bin work
+        assert f32bits(ab.histogram_distance(p, q)) == f32bits(orc.emd_1d(p, q)), (n, p, q)
+        assert f32bits(ab.histogram_distance(p, q, ab.DIST_L2)) == f32bits(orc.l2_dist(p, q))
+
+
+def test_emd_edge_cases():
+    z = np.zeros(8, dtype=np.float32)
+    h = np.arange(8, dtype=np.float32)
+    for f in (orc.emd_1d, ab.histogram_distance):
+        assert f(z, h) == 0.0 and f(h, z) == 0.0 and f(z, z) == 0.0          # emd.rs:59-61
+        assert f(np.float32([1]), np.float32([5])) == 0.0                      # one bin: all mass matches
+    a = np.float32([1, 0, 0, 0]); b = np.float32([0, 0, 0, 1])
+    assert orc.emd_1d(a, b) == ab.histogram_distance(a, b) == np.float32(3.0)  # u = 4: offset 3 is reachable, cost 1 * 3
+    with pytest.raises(rs.RsError):
+        ab.histogram_distance(np.zeros(65, np.float32), np.zeros(65, np.float32))
+    with pytest.raises(ValueError):
+        ab.histogram_distance(np.zeros(4, np.float32), np.zeros(5, np.float32))
+
+
+def test_oracle_predict_takes_the_first_strict_minimum():
+    """kmeans.rs:194-202: `if variance[k] < min_variance` -- ties keep the earlier center"""
+    data = np.float32([[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 0]])
+    centers = np.float32([[0, 1, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0]])
+    cl, md = orc.kmeans_predict(data, centers, orc.DIST_EMD)
+    assert cl.tolist() == [1, 3, 0] and md.tolist() == [0.0, 1.0, 0.0]
+    cl2, _ = orc.kmeans_predict(data, centers, orc.DIST_L2, threads=3)
+    assert cl2.tolist() == [1, 0, 0]      # [0,0,0,1] and the empty histogram are equidistant from every center: the first one wins
