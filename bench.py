@@ -276,6 +276,49 @@ def deal_trainer_leg(rs, device, n_deals, with_cpu, cpu_seconds):
     return out
 
 
+def kmeans_leg(rs, device, with_cpu, cpu_seconds):
+    """SURVEY N4 measured at the reference's own size: gen_emd(1, 500, 250, 20) (gen_abstraction/main.rs:384) = Kmeans::predict of the
+    1 286 792 canonical flop histograms (20 bins, counts out of 250 samples) against 500 centers with emd_1d: the sweep whose output is
+    the round_1_emd.dat bucket file."""
+    import numpy as np
+    from rustsolver_amd import abstraction as ab
+    n, k, bins = 1286792, 500, 20
+    rng = np.random.Generator(np.random.PCG64(2024))
+    centre = rng.random(n)[:, None] * bins
+    width = (0.5 + 6 * rng.random(n))[:, None]
+    x = np.exp(-0.5 * ((np.arange(bins)[None, :] - centre) / width) ** 2)
+    data = (np.floor(x / x.sum(axis=1, keepdims=True) * 250) / 250.0).astype(np.float32)
+    centers = data[rng.choice(n, size=k, replace=False)]
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [4], [1], rs.I32, device)
+    km = ab.Kmeans(table, data)
+    km.predict(centers[:8])
+    t0 = time.perf_counter()
+    cl, md = km.predict(centers)
+    dt = time.perf_counter() - t0
+    out = {"what": "Kmeans::predict, emd_1d, %d histograms x %d centers x %d bins (gen_emd(1, 500, 250, 20)); time includes the result download" % (n, k, bins),
+           "value": n * k / dt, "unit": "distance evaluations/s", "seconds_per_sweep": dt}
+    if with_cpu:
+        from oracle import orc
+        threads = min(16, os.cpu_count() or 1)   # kmeans.rs:19 N_THREADS = 16 (rayon's pool in the reference)
+        ns = 4000
+        t0 = time.perf_counter()
+        ocl, omd = orc.kmeans_predict(data[:ns], centers, orc.DIST_EMD, threads=threads)
+        t1 = time.perf_counter() - t0
+        reps = max(1, int(cpu_seconds / max(t1, 1e-6)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ocl, omd = orc.kmeans_predict(data[:ns], centers, orc.DIST_EMD, threads=threads)
+        dtc = time.perf_counter() - t0
+        same = bool((ocl == cl[:ns]).all() and (omd.view(np.uint32) == md[:ns].view(np.uint32)).all())
+        out["cpu_baseline"] = {"value": ns * k * reps / dtc, "unit": "distance evaluations/s", "cores": threads, "kind": "port",
+                               "sample": "%d x (%d histograms x %d centers), literal emd.rs:53-113, %d threads, %.1f s; identical to the GPU result: %s"
+                                         % (reps, ns, k, threads, dtc, same)}
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    table.destroy()
+    return out
+
+
 def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
@@ -520,6 +563,11 @@ def main():
         out["deal_trainer"] = deal_trainer_leg(rs, device, 1 << 22, not a.no_cpu, min(a.cpu_seconds, 6.0))
     except Exception as e:
         out["deal_trainer"] = {"error": str(e)}
+
+    try:
+        out["kmeans_predict"] = kmeans_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))
+    except Exception as e:
+        out["kmeans_predict"] = {"error": str(e)}
 
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)

@@ -83,6 +83,12 @@ extern "C" {
     pub fn rs_card_abs_clusters_device(abs_: *mut rs_card_abs, table: *mut rs_table, d_cards: *const u8, n_deals: u32,
                                        d_cluster_p0: *mut u32, d_cluster_p1: *mut u32) -> c_int;
     pub fn rs_card_abs_status(abs_: *mut rs_card_abs, table: *mut rs_table) -> c_int;
+    // gen_abstraction: Kmeans::predict (kmeans.rs:173), update_min_dists (kmeans.rs:603), emd_1d (emd.rs:53) / l2_dist (kmeans.rs:622)
+    pub fn rs_histogram_distance(dist: c_int, p: *const f32, q: *const f32, n_bins: c_int, out: *mut f32) -> c_int;
+    pub fn rs_kmeans_predict(table: *mut rs_table, dist: c_int, d_dataset: *const f32, n: usize, centers: *const f32, n_centers: c_int,
+                             n_bins: c_int, d_clusters: *mut u32, d_min_dist: *mut f32) -> c_int;
+    pub fn rs_update_min_dists(table: *mut rs_table, dist: c_int, d_min_dists: *mut f32, d_dataset: *const f32, n: usize,
+                               new_center: *const f32, n_bins: c_int) -> c_int;
     // generate_hand (cfr.rs:100-143) and the whole MCCFRTrainer loop (cfr.rs:159-297) on the device
     pub fn rs_deals_sample(table: *mut rs_table, seed: u64, first_deal: u64, board_mask: u64, d_hands_p0: *const u8, n_hands_p0: u32,
                            d_hands_p1: *const u8, n_hands_p1: u32, n_deals: u32, d_cards: *mut u8, d_err: *mut u32) -> c_int;
