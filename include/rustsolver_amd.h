@@ -240,6 +240,11 @@ typedef struct rs_solver_params {
     int32_t shard_rank;
     int32_t shard_round;
     uint32_t shard_global_boards;   /* boards of shard_round over all ranks */
+    /* Data-parallel deal batches (rs_solver_create_deals on a REPLICATED table, one rank per GPU): the global index of this rank's
+     * first deal inside the union batch.  Only the opponent-sampling hash sees it, so that a deal draws the same bits whichever
+     * rank owns it.  With a communicator attached rs_iterate sweeps, all-reduces the i32 deltas (ncclInt32 sum) and applies the
+     * union: N ranks x n deals equal ONE GPU with N*n deals per batch, bit for bit. */
+    uint32_t deal_offset;
 } rs_solver_params;
 
 /* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
@@ -268,7 +273,9 @@ int rs_iterate(rs_solver *solver, int traverser, float *d_root_util);
 /* MCCFRTrainer::train (cfr.rs:188-265), deterministic: per iteration both traversers sweep, t += 1, then
  * the discount check `t > threshold` (d = p/(p+1), p = t/interval) until t > discount_cap. */
 int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap);
-/* Sharded sweeps: rs_iterate = phase 0 (everything inside the sharded rounds) + exchange + phase 1 (the replicated rounds).
+/* Deal-batch solvers: rs_iterate_phase(.., 0) = the sweep (deltas accumulated, table untouched), (.., 1) = table += delta, delta = 0;
+ * between the two the ranks' delta tables are summed (rs_comm_allreduce_deltas; tests emulate ranks and add them on the host).
+ * Sharded sweeps: rs_iterate = phase 0 (everything inside the sharded rounds) + exchange + phase 1 (the replicated rounds).
  * With a communicator attached the exchange is one in-place ncclAllGather over xGMI; without one the host runs the phases
  * itself and moves the ranks' slots (tests emulate several ranks on one GPU this way). */
 int rs_solver_attach_comm(rs_solver *solver, rs_comm *comm);
@@ -276,6 +283,9 @@ int rs_iterate_phase(rs_solver *solver, int traverser, int phase, float *d_root_
 /* the exchange buffer of a traverser: [shard_world][bytes_per_rank]; rank r's slot is the r-th */
 int rs_solver_exchange_info(rs_solver *solver, int traverser, void **d_buf, size_t *bytes_per_rank);
 int rs_comm_allgather(rs_comm *comm, rs_table *table, void *d_buf, size_t bytes_per_rank);
+int rs_comm_allreduce_deltas(rs_comm *comm, rs_table *table);   /* in-place ncclInt32 sum of the table's two delta arrays */
+/* the delta tables of a deal-batch table: two DEVICE i32 arrays of rs_table_cells() elements laid out like the table itself */
+int rs_table_deltas(rs_table *table, int32_t **d_dregrets, int32_t **d_dstrategy_sum);
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
@@ -365,7 +375,10 @@ typedef struct rs_deal_trainer_params {
     uint64_t seed;
     uint64_t discount_interval;    /* cfr.rs:190 DISCOUNT_INTERVAL (0 = never discount) */
     uint64_t discount_cap;         /* cfr.rs:240: no discount once t exceeds it */
-    rs_solver_params solver;       /* scale 100, RS_UPD_CLAMP_I64, RS_OPP_SAMPLE = the reference's mccfr(); chance_mode is forced to PASS */
+    rs_solver_params solver;       /* scale 100, RS_UPD_CLAMP_I64, RS_OPP_SAMPLE = the reference's mccfr(); chance_mode is forced to PASS,
+                                      deal_offset is set from rank */
+    uint32_t world, rank;          /* data-parallel training on replicated tables: this rank deals numbers (b*world + rank)*n .. + n of
+                                      global batch b; 0 / 0 or 1 / 0 = single GPU.  t advances by world * deals_per_batch per batch */
 } rs_deal_trainer_params;
 /* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
  * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */
@@ -376,6 +389,12 @@ void rs_deal_trainer_destroy(rs_deal_trainer *trainer);
 rs_table *rs_deal_trainer_table(rs_deal_trainer *trainer);      /* trainer.infosets; owned by the trainer */
 rs_solver *rs_deal_trainer_solver(rs_deal_trainer *trainer);
 int rs_deal_trainer_train(rs_deal_trainer *trainer, uint64_t n_batches);   /* train(): deals_per_batch iterations per batch */
+/* world > 1: the communicator whose all-reduce makes every rank apply the deltas of the union batch (rs_comm_create on this
+ * trainer's table) */
+int rs_deal_trainer_attach_comm(rs_deal_trainer *trainer, rs_comm *comm);
+/* the bookkeeping that ends a batch (t += world * deals_per_batch, discount check of cfr.rs:240-262); rs_deal_trainer_train calls it,
+ * callers that drive rs_deal_trainer_deal + rs_iterate_phase themselves call it once per batch */
+int rs_deal_trainer_finish_batch(rs_deal_trainer *trainer);
 int rs_deal_trainer_deal(rs_deal_trainer *trainer);             /* only the dealing half of a batch (cards, cluster ids, signs) */
 int rs_deal_trainer_status(rs_deal_trainer *trainer);           /* synchronises; error if a deal could not be sampled / addressed */
 uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *trainer);   /* t of cfr.rs:200 */

@@ -27,7 +27,8 @@ pub struct rs_node_desc { pub n_actions: u32, pub n_clusters: u32, pub n_boards:
 pub struct rs_leaf_desc { pub kind: i32, pub d_buf: *const f32 }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i32, pub use_graph: i32, pub fuse_subtrees: i32, pub opp_mode: i32, pub sample_seed: u64,
-                               pub shard_world: i32, pub shard_rank: i32, pub shard_round: i32, pub shard_global_boards: u32 }
+                               pub shard_world: i32, pub shard_rank: i32, pub shard_round: i32, pub shard_global_boards: u32,
+                               pub deal_offset: u32 }
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rs_deal_batch { pub n_deals: u32, pub d_cluster: [[*const u32; 2]; RS_MAX_ROUNDS] }
@@ -112,6 +113,8 @@ pub struct rs_deal_trainer_params {
     pub discount_interval: u64,   // cfr.rs:190
     pub discount_cap: u64,        // cfr.rs:240
     pub solver: rs_solver_params,
+    pub world: u32,               // data-parallel training on replicated tables
+    pub rank: u32,
 }
 
 /// Flatten `Tree<GameTreeNode>` (tree.rs:14-17, nodes.rs:46-52) into the ABI's node array.

@@ -56,12 +56,13 @@ class DealBatch(C.Structure):
 class SolverParams(C.Structure):
     _fields_ = [("scale", C.c_float), ("mode", C.c_int32), ("chance_mode", C.c_int32), ("use_graph", C.c_int32),
                 ("fuse_subtrees", C.c_int32), ("opp_mode", C.c_int32), ("sample_seed", C.c_uint64),
-                ("shard_world", C.c_int32), ("shard_rank", C.c_int32), ("shard_round", C.c_int32), ("shard_global_boards", C.c_uint32)]
+                ("shard_world", C.c_int32), ("shard_rank", C.c_int32), ("shard_round", C.c_int32), ("shard_global_boards", C.c_uint32),
+                ("deal_offset", C.c_uint32)]
 
 
 class DealTrainerParams(C.Structure):
     _fields_ = [("board_mask", C.c_uint64), ("deals_per_batch", C.c_uint32), ("seed", C.c_uint64), ("discount_interval", C.c_uint64),
-                ("discount_cap", C.c_uint64), ("solver", SolverParams)]
+                ("discount_cap", C.c_uint64), ("solver", SolverParams), ("world", C.c_uint32), ("rank", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -129,6 +130,10 @@ SYMBOLS = {
     "rs_iterate_phase": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rs_solver_exchange_info": (C.c_int, [_P, C.c_int, _PP, C.POINTER(C.c_size_t)]),
     "rs_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rs_comm_allreduce_deltas": (C.c_int, [_P, _P]),
+    "rs_table_deltas": (C.c_int, [_P, _PP, _PP]),
+    "rs_deal_trainer_attach_comm": (C.c_int, [_P, _P]),
+    "rs_deal_trainer_finish_batch": (C.c_int, [_P]),
     "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
     "rs_jit_available": (C.c_int, []),

@@ -134,6 +134,21 @@ int rs_comm_allgather(rs_comm *c, rs_table *t, void *d_buf, size_t bytes_per_ran
     return RS_OK;
 }
 
+// data-parallel deal batches: every rank swept its own deals into its delta tables; one in-place wrapping sum (ncclInt32) per
+// array makes them the deltas of the UNION batch on every rank (integer adds commute: any rank count, any order, same bits)
+int rs_comm_allreduce_deltas(rs_comm *c, rs_table *t) {
+    if (!c || !t) return fail(RS_ERR_INVALID, "rs_comm_allreduce_deltas: NULL argument");
+    if (!t->d_dregrets || !t->d_dssum) return fail(RS_ERR_INVALID, "rs_comm_allreduce_deltas: the table has no delta tables (rs_solver_create_deals makes them)");
+    Rccl *r = rccl();
+    if (!r) return fail(RS_ERR_COMM, "rs_comm_allreduce_deltas: librccl.so could not be loaded");
+    hipError_t e = hipSetDevice(t->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = r->AllReduce(t->d_dregrets, t->d_dregrets, t->n_cells, ncclInt32_, ncclSum_, c->comm, t->stream);
+    if (rc == ncclSuccess_) rc = r->AllReduce(t->d_dssum, t->d_dssum, t->n_cells, ncclInt32_, ncclSum_, c->comm, t->stream);
+    if (rc != ncclSuccess_) return comm_fail(rc, "ncclAllReduce(deal deltas)");
+    return RS_OK;
+}
+
 int rs_replicated_begin(rs_table *t, uint32_t round_mask) {
     if (!t) return fail(RS_ERR_INVALID, "rs_replicated_begin: table is NULL");
     if (t->dtype == RS_F16) return fail(RS_ERR_UNSUPPORTED, "rs_replicated_begin: RS_F16 tables are not reduced (use RS_F32 accumulators)");

@@ -289,13 +289,15 @@ __device__ __forceinline__ int weighted_index(const float (&w)[A], unsigned bits
 // sampled action of 4 lanes of one opponent node
 template <int A>
 __device__ __forceinline__ void lanes_sample(const float (&sig)[A][kVecD], unsigned long long seed, unsigned node_index,
-                                             unsigned v, int (&a_s)[kVecD]) {
+                                             unsigned v, int (&a_s)[kVecD], unsigned lane_base = 0) {
+    // lane_base: data-parallel deal batches -- the global index of this rank's first deal, so that a deal draws the same bits
+    // whichever rank owns it
 #pragma unroll
     for (int j = 0; j < kVecD; j++) {
         float w[A];
 #pragma unroll
         for (int a = 0; a < A; a++) w[a] = sig[a][j];
-        a_s[j] = weighted_index<A>(w, sample_bits(seed, node_index, (unsigned long long)v * kVecD + j));
+        a_s[j] = weighted_index<A>(w, sample_bits(seed, node_index, (unsigned long long)lane_base + (unsigned long long)v * kVecD + j));
     }
 }
 

@@ -52,6 +52,7 @@ struct NodeJob {
     void *dreg;               // delta rows matching regrets / ssum
     void *dssm;
     uint32_t n_lanes;         // deals in the batch (lanes beyond are padding)
+    uint32_t lane_base;       // data-parallel deal batches: global index of this rank's first deal (opponent-sampling hash only)
 };
 
 // chance node: expand (top-down) / reduce (bottom-up) between a parent round and a child round

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
             regret_match<A, V>(rl, sig);
             float acc = 0.0f;
             if (sampled) {   // cfr.rs:471-476: the value of the ONE sampled action
-                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)v * kVec + j));
+                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)job.lane_base + (unsigned long long)v * kVec + j));
 #pragma unroll
                 for (int a = 0; a < A; a++) acc = (a == a_s) ? u[a][j] : acc;
             } else {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
             for (int a = 0; a < A; a++) rl[a] = r[a][j];
             regret_match<A, V>(rl, sig);
             if (sampled) {   // only the sampled action's subtree stays active (NaN reach = inactive lane)
-                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)v * kVec + j));
+                const int a_s = weighted_index<A>(sig, sample_bits(seed, job.node_index, (unsigned long long)job.lane_base + (unsigned long long)v * kVec + j));
 #pragma unroll
                 for (int a = 0; a < A; a++) out[a][j] = (a == a_s) ? reach[j] * sig[a] : __builtin_nanf("");
             } else {

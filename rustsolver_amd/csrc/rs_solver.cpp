@@ -314,6 +314,7 @@ struct Builder {
             job.dreg = (char *)t->d_dregrets + t->cell_off[nd.index] * 4;
             job.dssm = (char *)t->d_dssum + t->cell_off[nd.index] * 4;
             job.n_lanes = s->deals.n_deals;
+            job.lane_base = s->params.deal_offset;
         }
     }
 
@@ -584,6 +585,7 @@ struct Builder {
                         put_u32(js.off_tpitch, tp[0]);
                         put_u32(js.off_tpitch + 4, tp[1]);
                         put_u32(js.off_n_lanes, s->deals.n_deals);
+                        put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
                     }
                     JL.n_jobs += 1;
                     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
@@ -626,7 +628,7 @@ struct Builder {
             }
         }
         }   // pass
-        if (!s->sharded) plan.split = plan.launches.size();
+        if (!s->sharded) plan.split = plan.launches.size();   // deal batches: phase 0 = the sweep, phase 1 = the apply below
         if (s->deal_mode) {   // table += delta, delta = 0
             Launch L;
             L.kind = L_APPLY;
@@ -691,7 +693,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
 int run_plan(rs_solver *s, int p, int phase = -1) {
     Plan &plan = s->plan[p];
     rs_table *t = s->table;
-    if (phase < 0 && s->params.use_graph && !t->prof.on && !s->sharded) {
+    if (phase < 0 && s->params.use_graph && !t->prof.on && !s->sharded && !s->comm) {
         if (!plan.graph_exec) {
             RS_HIP(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
             int rc = RS_OK;
@@ -933,6 +935,12 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
         if (int rc = run_plan(s, traverser, 1)) return rc;
         return copy_root(s, traverser, d_root_util);
     }
+    if (s->deal_mode && s->comm) {   // data-parallel deal batches: sweep, sum the deltas over the ranks, apply the union
+        if (int rc = run_plan(s, traverser, 0)) return rc;
+        if (int rc = rs_comm_allreduce_deltas(s->comm, s->table)) return rc;
+        if (int rc = run_plan(s, traverser, 1)) return rc;
+        return copy_root(s, traverser, d_root_util);
+    }
     if (int rc = run_plan(s, traverser)) return rc;
     return copy_root(s, traverser, d_root_util);
 }
@@ -940,7 +948,7 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
 int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util) {
     if (!s || !s->table) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad solver");
     if ((traverser != 0 && traverser != 1) || (phase != 0 && phase != 1)) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad traverser / phase");
-    if (!s->sharded) return fail(RS_ERR_INVALID, "rs_iterate_phase: the solver is not sharded");
+    if (!s->sharded && !s->deal_mode) return fail(RS_ERR_INVALID, "rs_iterate_phase: the solver is neither sharded nor a deal-batch solver");
     RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
     if (int rc = run_plan(s, traverser, phase)) return rc;
     return phase == 1 ? copy_root(s, traverser, d_root_util) : RS_OK;

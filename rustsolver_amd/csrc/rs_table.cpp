@@ -394,6 +394,13 @@ int rs_dfree(rs_table *t, void *d_ptr) {
     RS_HIP(hipFree(d_ptr), "hipFree");
     return RS_OK;
 }
+int rs_table_deltas(rs_table *t, int32_t **d_dregrets, int32_t **d_dssum) {
+    if (!t || !d_dregrets || !d_dssum) return fail(RS_ERR_INVALID, "rs_table_deltas: NULL argument");
+    if (!t->d_dregrets || !t->d_dssum) return fail(RS_ERR_INVALID, "rs_table_deltas: the table has no delta tables (rs_solver_create_deals makes them)");
+    *d_dregrets = static_cast<int32_t *>(t->d_dregrets);
+    *d_dssum = static_cast<int32_t *>(t->d_dssum);
+    return RS_OK;
+}
 int rs_h2d(rs_table *t, void *d_dst, const void *src, size_t bytes) {
     if (!t || !d_dst || !src) return fail(RS_ERR_INVALID, "rs_h2d: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");

@@ -27,6 +27,7 @@ struct rs_deal_trainer {
     uint64_t t = 0;                // iterations done (deals), the shared counter of cfr.rs:200
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
+    uint32_t world = 1, rank = 0;  // data-parallel training: this rank's share of every global batch
 };
 
 extern "C" {
@@ -75,6 +76,16 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     rs_deal_trainer *tr = new (std::nothrow) rs_deal_trainer();
     if (!tr) return fail(RS_ERR_OOM, "rs_deal_trainer_create: out of memory");
     tr->params = *params;
+    tr->world = params->world ? params->world : 1;
+    tr->rank = params->rank;
+    if (tr->rank >= tr->world) {
+        delete tr;
+        return fail(RS_ERR_INVALID, "rs_deal_trainer_create: rank must be below world");
+    }
+    if (uint64_t(tr->world) * params->deals_per_batch > 0xffffffffull) {
+        delete tr;
+        return fail(RS_ERR_INVALID, "rs_deal_trainer_create: world * deals_per_batch must fit 32 bits");
+    }
     tr->n_rounds = n_rounds;
     tr->threshold = params->discount_interval;
     for (int r = 0; r < n_rounds; ++r) tr->abs[r] = card_abs[r];
@@ -127,6 +138,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         }
         rs_solver_params sp = params->solver;
         sp.chance_mode = RS_CHANCE_PASS;   // one run-out per deal: the board is dealt up front (cfr.rs:115-122, :306-313)
+        sp.deal_offset = tr->rank * params->deals_per_batch;
         rc = rs_solver_create_deals(tr->table, tr->tree, &batch, leaves.data(), leaves.data(), &sp, &tr->solver);
     }
     if (rc != RS_OK) {
@@ -150,7 +162,8 @@ const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *tr, int round_id
 int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_deal: trainer is NULL");
     const uint32_t n = tr->params.deals_per_batch;
-    if (int rc = rs_deals_sample(tr->table, tr->params.seed, tr->batches * uint64_t(n), tr->params.board_mask, tr->d_hands[0], tr->n_hands[0],
+    const uint64_t first_deal = (tr->batches * tr->world + tr->rank) * uint64_t(n);   // global batch b = deals [b*world*n, (b+1)*world*n)
+    if (int rc = rs_deals_sample(tr->table, tr->params.seed, first_deal, tr->params.board_mask, tr->d_hands[0], tr->n_hands[0],
                                  tr->d_hands[1], tr->n_hands[1], n, tr->d_cards, tr->d_err))
         return rc;
     for (int r = 0; r < tr->n_rounds; ++r)
@@ -160,19 +173,31 @@ int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     return RS_OK;
 }
 
-// train(): every batch is deals_per_batch iterations of cfr.rs:207-226; the discount check of cfr.rs:240-262 runs between batches
+// the end of a batch: the shared iteration counter and the discount check of cfr.rs:240-262 (t counts deals over ALL ranks)
+int rs_deal_trainer_finish_batch(rs_deal_trainer *tr) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_finish_batch: trainer is NULL");
+    tr->t += uint64_t(tr->world) * tr->params.deals_per_batch;   // cfr.rs:226, once per deal
+    if (tr->params.discount_interval == 0 || tr->t > tr->params.discount_cap) return RS_OK;   // cfr.rs:240-242
+    if (tr->t > tr->threshold) {                                  // cfr.rs:243
+        if (int rc = rs_discount(tr->table, rs_discount_factor(tr->t, tr->params.discount_interval))) return rc;   // cfr.rs:248-261
+        tr->threshold = tr->t + tr->params.discount_interval;     // cfr.rs:262
+    }
+    return RS_OK;
+}
+
+int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_attach_comm: trainer is NULL");
+    return rs_solver_attach_comm(tr->solver, comm);
+}
+
+// train(): every batch is deals_per_batch iterations of cfr.rs:207-226 on this rank (world times as many over all ranks)
 int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_train: trainer is NULL");
     for (uint64_t b = 0; b < n_batches; ++b) {
         if (int rc = rs_deal_trainer_deal(tr)) return rc;
-        for (int player = 0; player < 2; ++player)   // cfr.rs:216-224
+        for (int player = 0; player < 2; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
             if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
-        tr->t += tr->params.deals_per_batch;          // cfr.rs:226, once per deal
-        if (tr->params.discount_interval == 0 || tr->t > tr->params.discount_cap) continue;   // cfr.rs:240-242
-        if (tr->t > tr->threshold) {                  // cfr.rs:243
-            if (int rc = rs_discount(tr->table, rs_discount_factor(tr->t, tr->params.discount_interval))) return rc;   // cfr.rs:248-261
-            tr->threshold = tr->t + tr->params.discount_interval;   // cfr.rs:262
-        }
+        if (int rc = rs_deal_trainer_finish_batch(tr)) return rc;
     }
     return RS_OK;
 }

@@ -563,12 +563,15 @@ class DealTrainer:
 
     def __init__(self, tree, card_abs, hand_ranges, board_mask, deals_per_batch, seed=0, scale=100.0, mode=L.UPD_CLAMP_I64,
                  opp_mode=L.OPP_SAMPLE, discount_interval=MCCFRTrainer.DISCOUNT_INTERVAL, discount_cap=MCCFRTrainer.DISCOUNT_CAP,
-                 use_graph=False, fuse_subtrees=None, device=0):
+                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0):
+        """world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
+        batch; attach_comm() makes every rank apply the deltas of the union batch."""
         if fuse_subtrees is None:
             fuse_subtrees = bool(L.load().rs_jit_available())
         self.game_tree, self.card_abs = tree, list(card_abs)
         p = L.DealTrainerParams()
         p.board_mask, p.deals_per_batch, p.seed = board_mask, deals_per_batch, seed
+        p.world, p.rank = world, rank
         p.discount_interval, p.discount_cap = discount_interval, discount_cap
         p.solver.scale, p.solver.mode, p.solver.chance_mode = scale, mode, L.CHANCE_PASS
         p.solver.use_graph, p.solver.fuse_subtrees = int(use_graph), int(bool(fuse_subtrees))
@@ -588,6 +591,30 @@ class DealTrainer:
 
     def deal(self):
         L.check(L.load().rs_deal_trainer_deal(self._h))
+
+    def attach_comm(self, comm_handle):
+        L.check(L.load().rs_deal_trainer_attach_comm(self._h, comm_handle))
+
+    def iterate_phase(self, player, phase):
+        """phase 0: the sweep (deltas accumulated), phase 1: table += delta; between them the ranks' deltas are summed"""
+        L.check(L.load().rs_iterate_phase(L.load().rs_deal_trainer_solver(self._h), player, phase, None))
+
+    def finish_batch(self):
+        L.check(L.load().rs_deal_trainer_finish_batch(self._h))
+
+    def deltas(self):
+        """(regret deltas, strategy_sum deltas) as int32 arrays of rs_table_cells() elements"""
+        a, b = C.c_void_p(), C.c_void_p()
+        L.check(L.load().rs_table_deltas(self.infosets._h, C.byref(a), C.byref(b)))
+        n = self.infosets.cells
+        return self._download(a.value, np.int32, n), self._download(b.value, np.int32, n)
+
+    def set_deltas(self, dreg, dssm):
+        a, b = C.c_void_p(), C.c_void_p()
+        L.check(L.load().rs_table_deltas(self.infosets._h, C.byref(a), C.byref(b)))
+        for ptr, arr in ((a.value, dreg), (b.value, dssm)):
+            arr = np.ascontiguousarray(arr, dtype=np.int32)
+            L.check(L.load().rs_h2d(self.infosets._h, ptr, _vp(arr), arr.nbytes))
 
     def status(self):
         L.check(L.load().rs_deal_trainer_status(self._h))

@@ -246,6 +246,72 @@ def test_deal_trainer_three_streets_from_a_flop_with_bucket_files():
     compare_trainer_tables(ctx)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world):
+    """`world` ranks x n deals on replicated tables, their i32 deltas summed between sweep and apply (what rs_comm_allreduce_deltas does
+    over xGMI; here the test adds them on the host), equal ONE trainer with world*n deals per batch, bit for bit: cards, tables, discount
+    ticks.  Ranks are emulated on one GPU, one trainer per rank."""
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)[::3]
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    n = 700
+    kw = dict(seed=21, discount_interval=2 * world * n - 100, discount_cap=10**9)
+    ranks = [rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, world=world, rank=r, **kw) for r in range(world)]
+    single = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, world * n, **kw)
+    for batch in range(4):
+        for tr in ranks:
+            tr.deal()
+        for player in (0, 1):
+            for tr in ranks:
+                tr.iterate_phase(player, 0)
+            parts = [tr.deltas() for tr in ranks]
+            dreg = np.sum([p[0].view(np.uint32) for p in parts], axis=0, dtype=np.uint32).view(np.int32)    # wrapping, like ncclInt32 sum
+            dssm = np.sum([p[1].view(np.uint32) for p in parts], axis=0, dtype=np.uint32).view(np.int32)
+            for tr in ranks:
+                tr.set_deltas(dreg, dssm)
+                tr.iterate_phase(player, 1)
+        for tr in ranks:
+            tr.finish_batch()
+        single.train(1)
+        assert (np.concatenate([tr.cards() for tr in ranks], axis=1) == single.cards()).all()
+        for nd in tree.action_nodes():
+            want = single.infosets.download_node(nd.index)
+            for tr in ranks:
+                got = tr.infosets.download_node(nd.index)
+                assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (batch, nd.index)
+    assert all(tr.iterations == single.iterations == 4 * world * n for tr in ranks)
+    for tr in ranks + [single]:
+        tr.status()
+
+
+def test_data_parallel_trainer_over_rccl_with_one_rank():
+    """the RCCL path itself (communicator, ncclAllReduce of the two delta arrays) with a 1-rank communicator: must equal the plain trainer"""
+    import ctypes as C2
+    from rustsolver_amd import _lib as L
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)[::5]
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    a = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 900, seed=4, world=1, rank=0)
+    b = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 900, seed=4)
+    ident = (C2.c_char * L.COMM_ID_BYTES)()
+    rc = L.load().rs_comm_unique_id(ident)
+    if rc == L.ERR_COMM:
+        pytest.skip("librccl.so cannot be loaded here")
+    L.check(rc)
+    comm = C2.c_void_p()
+    L.check(L.load().rs_comm_create(a.infosets._h, ident, 0, 1, C2.byref(comm)))
+    a.attach_comm(comm)
+    a.train(3)
+    b.train(3)
+    for nd in tree.action_nodes():
+        ga, gb = a.infosets.download_node(nd.index), b.infosets.download_node(nd.index)
+        assert (ga[0] == gb[0]).all() and (ga[1] == gb[1]).all()
+    a.attach_comm(None)
+    L.load().rs_comm_destroy(comm)
+
+
 def test_deal_trainer_rejects_bad_inputs():
     mask = ab.card_mask("4d5dAs3cKs")
     hands = ab.random_range(mask)
