@@ -93,7 +93,7 @@ class HandIndexerC(C.Structure):   # orc_hand_indexer (hand_index.h)
 
 
 DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
-                    ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t)]
+                    ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t), ("lane_base", C.c_size_t)]
 
 
 def build(force=False):
@@ -490,8 +490,8 @@ class OracleDealTable(OracleTable):
 class OracleDealSolver(OracleSolver):
     """Batch-synchronous deal sweeps (orc_iterate_deals)."""
 
-    def __init__(self, tree, table, leaves, cidx, n_deals, **kw):
-        """cidx: dict (round_idx, player) -> uint32 array [n_deals]"""
+    def __init__(self, tree, table, leaves, cidx, n_deals, lane_base=0, **kw):
+        """cidx: dict (round_idx, player) -> uint32 array [n_deals]; lane_base: global index of deal 0 (data-parallel batches)"""
         super().__init__(tree, table, leaves, chance_mode=CHANCE_PASS, **kw)
         self.delta = OracleDealTable(tree, table.sizes)
         self.n_deals = n_deals
@@ -499,6 +499,7 @@ class OracleDealSolver(OracleSolver):
         dc.ctx = C.pointer(self.ctx)
         dc.delta = C.pointer(self.delta.tb)
         dc.n_deals = n_deals
+        dc.lane_base = lane_base
         for (r, p), arr in cidx.items():
             a = np.ascontiguousarray(arr, dtype=np.uint32)
             self._keep.append(a)

@@ -792,7 +792,7 @@ float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t 
                     wrapping_add_i32(dinfo->strategy_sum[i], (int32_t)((uint32_t)s[i] - (uint32_t)infoset->strategy_sum[i]));
             }
         } else if (ctx->opp_mode == ORC_OPP_SAMPLE) { /* cfr.rs:467-476; the hash lane is the deal */
-            int a_idx = orc_weighted_index(strategy, n_actions, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, deal));
+            int a_idx = orc_weighted_index(strategy, n_actions, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, dc->lane_base + deal));
             util = orc_traverse_deal(dc, nd->children[a_idx], player, deal, cfr_reach * strategy[a_idx]);
         } else {
             for (i = 0; i < n_actions; i++) {

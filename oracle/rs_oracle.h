@@ -210,6 +210,7 @@ typedef struct {
     orc_table *delta;                    /* same shape as ctx->table, i32, zero at sweep start */
     const uint32_t *cidx[ORC_MAX_ROUNDS][ORC_MAX_PLAYERS];   /* [n_deals] each */
     size_t n_deals;
+    size_t lane_base;                    /* data-parallel batches: global index of deal 0 (opponent-sampling hash only) */
 } orc_deal_ctx;
 float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach);
 /* one traverser sweep over all deals, then table += delta (wrapping), delta = 0 */

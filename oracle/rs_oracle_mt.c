@@ -188,7 +188,7 @@ static float traverse_deal_mt(const orc_deal_ctx *dc, int node_id, int player, s
                 __atomic_fetch_add(&dinfo->strategy_sum[i], (int32_t)((uint32_t)s[i] - (uint32_t)infoset->strategy_sum[i]), __ATOMIC_RELAXED);
             }
         } else if (ctx->opp_mode == ORC_OPP_SAMPLE) {
-            int a = orc_weighted_index(strategy, n, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, deal));
+            int a = orc_weighted_index(strategy, n, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, dc->lane_base + deal));
             util = traverse_deal_mt(dc, nd->children[a], player, deal, cfr_reach * strategy[a]);
         } else {
             for (i = 0; i < n; i++) {

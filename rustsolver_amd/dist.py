@@ -2,6 +2,8 @@
 
 Pure host code (no GPU needed), so that the N > 1 path is testable with gloo on CPU:
   * shard_boards          contiguous board ranges per rank;
+  * deal_numbers          which deals of global batch b a rank of a data-parallel deal trainer samples (csrc/rs_trainer.cpp);
+  * apply_summed_deltas   the arithmetic between sweep and apply of a data-parallel deal batch: table + allreduce_sum(delta), wrapping i32;
   * replicated_allreduce  the arithmetic of rs_allreduce_replicated: x = snap + allreduce_sum(x - snap),
                           wrapping i32 (order-independent) or f32.
 """
@@ -28,3 +30,17 @@ def replicated_allreduce(x, snap, all_reduce_sum):
     restored = (x + neg_delta).astype(np.float32)
     total = np.asarray(all_reduce_sum(neg_delta), dtype=np.float32)
     return (restored - total).astype(np.float32)
+
+
+def deal_numbers(batch, rank, world, deals_per_batch):
+    """(first deal number, lane base of the sampling hash) of `rank` in global batch `batch`: mirrors rs_deal_trainer_deal and
+    rs_solver_params.deal_offset"""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return (batch * world + rank) * deals_per_batch, rank * deals_per_batch
+
+
+def apply_summed_deltas(table, delta, all_reduce_sum):
+    """table, delta: int32 arrays (delta = this rank's sweep result); all ranks end with table + sum of all deltas (wrapping)"""
+    total = np.asarray(all_reduce_sum(np.ascontiguousarray(delta, dtype=np.int32)), dtype=np.int32)
+    return (table.view(np.uint32) + total.view(np.uint32)).view(np.int32)

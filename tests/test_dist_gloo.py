@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from rustsolver_amd.dist import replicated_allreduce, shard_boards
+from rustsolver_amd.dist import apply_summed_deltas, deal_numbers, replicated_allreduce, shard_boards
 
 WORLD = 2
 C, B_TOTAL = 6, 5
@@ -118,6 +118,108 @@ def test_world2_board_sharding_and_replicated_allreduce():
     for r in range(WORLD):
         assert (res[r][2].view(np.uint32) == want).all()                # identical on every rank, = all deltas applied
         assert np.allclose(res[r][3], snap.astype(np.float32) + 3.0, rtol=1e-5)
+
+
+# ---- data-parallel deal batches: world 2 over gloo == one process with the union batch ------------------
+DP_N, DP_BATCHES, DP_SEED = 300, 3, 17
+DP_SIZES = [(13, 17)]
+
+
+def _dp_inputs():
+    rng = np.random.Generator(np.random.PCG64(99))
+    mask = 0b11111 << 10
+    hands = np.array([(a, b) for a in range(52) for b in range(a) if not ((mask >> a) & 1 or (mask >> b) & 1)], dtype=np.uint8)[::9]
+    tree = orc.OracleTree(orc.options_default_river())
+    init = {}
+    for d in tree.as_dicts():
+        if d["kind"] == orc.ACTION:
+            a, n = len(d["children"]), DP_SIZES[0][d["player"]]
+            init[d["index"]] = (rng.integers(-10**6, 10**6, size=(a, n)).astype(np.int32), rng.integers(0, 10**6, size=(a, n)).astype(np.int32))
+    return tree, init, mask, hands
+
+
+def _dp_run(tree, init, mask, hands, rank, world, all_reduce_sum):
+    """the CPU mirror of rs_deal_trainer_train with `world` ranks: deal this rank's numbers, sweep against the replicated table, sum the
+    i32 deltas over the ranks, apply"""
+    n = DP_N
+    tb = orc.OracleDealTable(tree, DP_SIZES)
+    for idx, (R, S) in init.items():
+        tb.set_node(idx, R, S)
+    cidx = {(0, p): np.zeros(n, dtype=np.uint32) for p in (0, 1)}
+    sign = np.zeros(n, dtype=np.float32)
+    leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in tree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    _, lane_base = deal_numbers(0, rank, world, n)
+    sol = orc.OracleDealSolver(tree, tb, leaves, cidx, n, lane_base=lane_base, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE,
+                               base_seed=DP_SEED)
+    for b in range(DP_BATCHES):
+        first, _ = deal_numbers(b, rank, world, n)
+        cards = orc.generate_hands(DP_SEED, first, mask, hands, hands, n)
+        for p in (0, 1):   # stand-in for get_cluster: any deterministic function of the cards will do for the host-path test
+            cidx[(0, p)][:] = (cards[5 + 2 * p].astype(np.uint32) * 52 + cards[6 + 2 * p]) % DP_SIZES[0][p]
+        sign[:] = orc.showdown_sign(cards)
+        for player in (0, 1):
+            before = {idx: tb.get_node(idx) for idx in init}
+            sol.iterate(player)                                   # sweep + local apply ...
+            for idx in init:                                      # ... turned back into (table, delta), reduced, applied
+                after = tb.get_node(idx)
+                new = [apply_summed_deltas(before[idx][k], (after[k].view(np.uint32) - before[idx][k].view(np.uint32)).view(np.int32), all_reduce_sum)
+                       for k in (0, 1)]
+                tb.set_node(idx, new[0], new[1])
+    return {idx: tb.get_node(idx) for idx in init}
+
+
+def _dp_worker(rank, port, q):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    try:
+        def allreduce(a):
+            t = torch.from_numpy(np.ascontiguousarray(a).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.numpy()
+        tree, init, mask, hands = _dp_inputs()
+        q.put((rank, _dp_run(tree, init, mask, hands, rank, WORLD, allreduce)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_data_parallel_deal_batches_equal_the_union_batch():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one process, world = 1, batches of WORLD * DP_N deals
+    global DP_N
+    tree, init, mask, hands = _dp_inputs()
+    DP_N *= WORLD
+    try:
+        want = _dp_run(tree, init, mask, hands, 0, 1, lambda a: a)
+    finally:
+        DP_N //= WORLD
+    for r in range(WORLD):
+        for idx in init:
+            assert (res[r][idx][0] == want[idx][0]).all() and (res[r][idx][1] == want[idx][1]).all(), (r, idx)
+
+
+def test_deal_numbers_tile_the_global_batches():
+    for world in (1, 2, 3, 8):
+        n = 5
+        seen = []
+        for b in range(3):
+            for r in range(world):
+                first, base = deal_numbers(b, r, world, n)
+                assert base == r * n
+                seen += list(range(first, first + n))
+        assert seen == list(range(3 * world * n))
+    with pytest.raises(ValueError):
+        deal_numbers(0, 2, 2, 4)
 
 
 def test_shard_boards_partitions():
