@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--boards3", default="1,49,2352", help="--tree three-street: boards per round (flop,turn,river)")
     ap.add_argument("--dtype", choices=["i32", "f32", "f16"], default="i32", help="table element type (f16 = BASELINE configs[4])")
     ap.add_argument("--opp", choices=["full", "sample"], default="full", help="opponent nodes: cfr() full width or mccfr() sampled")
+    ap.add_argument("--dp-deals", type=int, default=0,
+                    help="1: instead of the board-sharded sweep run the data-parallel deal trainer (replicated table, one ncclInt32 all-reduce of the "
+                         "delta tables per traverser sweep over RCCL); needs torch.distributed.run, works with one rank too")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -319,6 +322,75 @@ def kmeans_leg(rs, device, with_cpu, cpu_seconds):
     return out
 
 
+def dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout):
+    """--dp-deals 1: MCCFRTrainer::train as coded (see deal_trainer_leg), data-parallel: every rank deals and sweeps 4 M deals of each global
+    batch against its replica of the table; per traverser sweep the two i32 delta arrays are all-reduced over RCCL (xGMI) and every rank
+    applies the union.  WEAK scaling; `value` = deal-iterations/s of the whole job."""
+    import ctypes as C2
+    import torch
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd import abstraction as ab
+    if dist is None:
+        raise RuntimeError("--dp-deals needs a process group: launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --dp-deals 1")
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    n = 1 << 22
+    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=7, discount_interval=0, device=device, world=n_gpus, rank=rank)
+    tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))   # same seed on every rank: the replicas start identical
+    ident = (C2.c_char * L.COMM_ID_BYTES)()
+    if rank == 0:
+        L.check(L.load().rs_comm_unique_id(ident))
+    t_id = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda")
+    dist.broadcast(t_id, src=0)
+    ident = (C2.c_char * L.COMM_ID_BYTES).from_buffer_copy(bytes(t_id.cpu().tolist()))
+    comm = C2.c_void_p()
+    L.check(L.load().rs_comm_create(tr.infosets._h, ident, rank, n_gpus, C2.byref(comm)))
+    tr.attach_comm(comm)
+
+    def barrier():
+        tr.infosets.sync()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    tr.train(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    tr.train(a.steps)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    tr.status()
+    # the replicas must still be identical: compare a checksum of rank 0's table with everybody's
+    chk = 0
+    for nd in tree.action_nodes():
+        r_, s_ = tr.infosets.download_node(nd.index)
+        chk = (chk * 1000003 + int(r_.astype("int64").sum()) * 31 + int(s_.astype("int64").sum())) % (1 << 61)
+    c = torch.tensor([chk], dtype=torch.int64, device="cuda")
+    cmin, cmax = c.clone(), c.clone()
+    dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    tr.attach_comm(None)
+    L.load().rs_comm_destroy(comm)
+    if rank == 0:
+        out = {"metric": "mccfr_deal_iterations_per_sec", "value": n * n_gpus * a.steps / elapsed, "unit": "deal-iterations/s", "n_gpus": n_gpus,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+               "config": {"workload": "MCCFRTrainer::train as coded (default_flop board, random ranges, ISOMORPHIC river, 1081 clusters), data-parallel: "
+                                      "%d deals per rank and batch, 1 step = 1 global batch (both traversers), deltas all-reduced as ncclInt32" % n,
+                          "parallelism": "dp%d: replicated table, 2 all-reduces of %d i32 cells per traverser sweep" % (n_gpus, tr.infosets.cells),
+                          "replicas_identical": bool(cmin.item() == cmax.item())}}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(2, 1)
+    tr.destroy()
+    dist.destroy_process_group()
+
+
 def pmc_traffic(a, kernel):
     """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
     this exact workload; PMC counters cannot be read from inside the process."""
@@ -367,6 +439,10 @@ def main():
             dist.barrier()
             import torch
             torch.cuda.synchronize()
+
+    if a.dp_deals:
+        dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout)
+        return
 
     three = a.tree == "three-street"
     boards3 = [int(x) for x in a.boards3.split(",")]
