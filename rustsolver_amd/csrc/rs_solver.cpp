@@ -513,7 +513,8 @@ struct Builder {
                         leaf_buf[t2] = it->second;
                         leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
                     }
-                    // deal batches: privatise the deltas of a traverser node in LDS when [2][A][table pitch] ints fit in 64 KiB
+                    // deal batches: privatise the deltas of a traverser node in LDS when [2][A][table pitch] ints fit in what the device gives
+                    // ONE workgroup (MI355X: 160 KiB, launchable without any attribute -- probed; a 5 000-cluster node needs 121 KiB)
                     size_t lds_need = 0;
                     if (s->deal_mode) {
                         std::vector<int> stack{id};
@@ -527,7 +528,10 @@ struct Builder {
                         }
                     }
                     static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
-                    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= 64 * 1024 && !lds_off;
+                    int lds_limit = 0;
+                    if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device) != hipSuccess) lds_limit = 64 * 1024;
+                    if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+                    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off;
                     JitSubtree js;
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, js);

@@ -433,6 +433,25 @@ def test_deal_batches_vs_oracle(fuse, variant):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("sizes,lds_max", [([(5000, 4100)], None), ([(5000, 4100)], "65536"), ([(13000, 13000)], None)])
+def test_deal_batches_large_cluster_counts(sizes, lds_max, monkeypatch):
+    """5 000 clusters need a 121 KB LDS tile per traverser node (MI355X gives a workgroup 160 KB); capped at 64 KB, or with 13 000 clusters
+    (312 KB), the kernels fall back to direct global atomics.  Same bits either way."""
+    if lds_max:
+        monkeypatch.setenv("RS_JIT_LDS_MAX", lds_max)
+    n_deals = 6000
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), sizes, n_deals, 77)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=9)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=9)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_deal_batches_reject_bad_inputs():
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(5, 6)], 10, 3)
     with pytest.raises(rs.RsError):
