@@ -218,11 +218,16 @@ __global__ __launch_bounds__(kBlock) void k_hand_index(HandIndexView v, int upto
 
 // error word: bit 0 = a bucket without a dense id (Rust: unwrap on None, card_abstraction.rs:208), bit 1 = canonical index beyond the
 // bucket file (Rust: index out of bounds), bit 2 = the deal sampler gave up
-__global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJob *__restrict__ jobs, const uint8_t *__restrict__ cards, uint32_t n,
-                                                          uint32_t pitch, uint32_t *__restrict__ err) {
-    // read the job through its (wave-uniform) address: scalar loads.  A by-value copy would be indexed dynamically (rows.row[i],
-    // cards_per_round[r]) and therefore live in scratch: 168 B per lane, 700 MB of scratch writes per 4 M deals (profiles/r01e).
-    const ClusterJob *__restrict__ job = jobs + blockIdx.y;
+struct ClusterJobs {
+    ClusterJob j[2];   // one per player
+};
+__global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJobs jobs, const uint8_t *__restrict__ cards, uint32_t n, uint32_t pitch,
+                                                          uint32_t *__restrict__ err) {
+    // The descriptors are kernel ARGUMENTS (by value): the kernarg segment is ordinary memory, so jobs.j[blockIdx.y].rows.row[i] is a scalar
+    // load at a uniform address.  Two earlier forms were wrong: copying a descriptor from global memory into a local put the copy in scratch
+    // (168 B per lane, 700 MB of scratch writes per 4 M deals, profiles/r01e), and a descriptor slot in device memory shared by every user of
+    // the abstraction was rewritten under another stream's launch.
+    const ClusterJob *job = &jobs.j[blockIdx.y];
     const int n_cards = job->rows.n_cards;
     const uint32_t *__restrict__ arr = job->cluster_arr;
     const uint64_t arr_len = job->arr_len;
@@ -334,7 +339,6 @@ struct rs_card_abs {
         int device;
         uint32_t *cluster_arr;
         DenseSlot *slots[2];
-        ClusterJob *jobs;                       // [2], one per player
         uint32_t *err;
     };
     std::vector<Dev> devs;
@@ -360,7 +364,6 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
         e = hipMalloc(reinterpret_cast<void **>(&d.slots[p]), a->slots[p].size() * sizeof(DenseSlot));
         if (e == hipSuccess) e = hipMemcpyAsync(d.slots[p], a->slots[p].data(), a->slots[p].size() * sizeof(DenseSlot), hipMemcpyHostToDevice, t->stream);
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.jobs), 2 * sizeof(ClusterJob));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d.err, 0, sizeof(uint32_t), t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -368,7 +371,6 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
         (void)hipFree(d.cluster_arr);
         (void)hipFree(d.slots[0]);
         (void)hipFree(d.slots[1]);
-        (void)hipFree(d.jobs);
         (void)hipFree(d.err);
         return hip_fail(e, "rs_card_abs: device mirror");
     }
@@ -420,7 +422,10 @@ int rs_hand_indexer_create(int rounds, const uint8_t *cards_per_round, rs_hand_i
 void rs_hand_indexer_destroy(rs_hand_indexer *ix) {
     if (!ix) return;
     for (auto &d : ix->devs)
-        if (hipSetDevice(d.device) == hipSuccess) (void)hipFree(d.blob);
+        if (hipSetDevice(d.device) == hipSuccess) {
+            (void)hipDeviceSynchronize();   // a launch may still read the tables
+            (void)hipFree(d.blob);
+        }
     delete ix;
 }
 
@@ -550,7 +555,6 @@ void rs_card_abs_destroy(rs_card_abs *a) {
             (void)hipFree(d.cluster_arr);
             (void)hipFree(d.slots[0]);
             (void)hipFree(d.slots[1]);
-            (void)hipFree(d.jobs);
             (void)hipFree(d.err);
         }
     rs_hand_indexer_destroy(a->ix);
@@ -675,13 +679,13 @@ int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_ca
     rs_card_abs::Dev dev;
     if (int rc = abs_device(a, t, &dev)) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
-    ClusterJob jobs[2];
+    ClusterJobs jobs;
+    std::memset(&jobs, 0, sizeof(jobs));
     int n_jobs = 0;
     for (int p = 0; p < 2; ++p) {
         uint32_t *dst = p == 0 ? d_cluster_p0 : d_cluster_p1;
         if (!dst) continue;
-        ClusterJob &j = jobs[n_jobs++];
-        j = ClusterJob{};
+        ClusterJob &j = jobs.j[n_jobs++];
         j.view = v;
         j.upto = 1;
         j.rows.n_cards = 5 + a->round;
@@ -694,10 +698,8 @@ int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_ca
         j.mask = a->slots[p].size() - 1;
         j.out = dst;
     }
-    // the job slots are reused: stream order keeps an earlier launch's read ahead of this write
-    RS_HIP(hipMemcpyAsync(dev.jobs, jobs, size_t(n_jobs) * sizeof(ClusterJob), hipMemcpyHostToDevice, t->stream), "rs_card_abs_clusters_device: jobs");
     if (n_deals == 0) return RS_OK;
-    hipLaunchKernelGGL(k_deal_clusters, lane_grid(n_deals, uint32_t(n_jobs)), dim3(kBlock), 0, t->stream, dev.jobs, d_cards, n_deals,
+    hipLaunchKernelGGL(k_deal_clusters, lane_grid(n_deals, uint32_t(n_jobs)), dim3(kBlock), 0, t->stream, jobs, d_cards, n_deals,
                        uint32_t(round_up(n_deals, kLanePad)), dev.err);
     RS_HIP(hipGetLastError(), "k_deal_clusters");
     return RS_OK;
