@@ -137,6 +137,42 @@ __device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, c
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = p[idx[j]];
 }
+// AoS shadow of one action node for deal sweeps: record c = [regrets 0..H) [strategy_sum 0..H)], H = 4 ints (A <= 4) or 8 (A <= 8), built from
+// the SoA table at the start of every sweep (k_build_shadow).  A deal then reads a node with one or two 16-byte loads per array instead of
+// one 4-byte load per (action, array): the gathers of a wave touch 64 random cache lines EACH, and with the SoA rows they were what bounded
+// the deal kernels (about 250 gathers per 4 deals and tree walk).
+template <int A>
+__device__ __forceinline__ void gather_rec_half(const RS_GLOBAL int *rec, int (&out)[A][kVecD], int j) {
+    const i32x4 lo = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec);
+    out[0][j] = lo.x;
+    if (A > 1) out[1 < A ? 1 : 0][j] = lo.y;
+    if (A > 2) out[2 < A ? 2 : 0][j] = lo.z;
+    if (A > 3) out[3 < A ? 3 : 0][j] = lo.w;
+    if (A > 4) {
+        const i32x4 hi = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec + 4);
+        out[4 < A ? 4 : 0][j] = hi.x;
+        if (A > 5) out[5 < A ? 5 : 0][j] = hi.y;
+        if (A > 6) out[6 < A ? 6 : 0][j] = hi.z;
+        if (A > 7) out[7 < A ? 7 : 0][j] = hi.w;
+    }
+}
+template <int A>
+__device__ __forceinline__ void gather_rec(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {   // regrets only
+    constexpr int H = A <= 4 ? 4 : 8;
+    const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
+}
+template <int A>
+__device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
+    constexpr int H = A <= 4 ? 4 : 8;
+    const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
+        gather_rec_half<A>(p + (size_t)idx[j] * (2 * H) + H, s, j);
+    }
+}
 __device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, const unsigned (&idx)[kVecD], const int (&now)[kVecD],
                                                 const int (&before)[kVecD]) {
     RS_GLOBAL int *p = as_global<int>((int *)base + row_off);

@@ -85,6 +85,14 @@ hipError_t launch_node_util(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_ve
                             KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
 hipError_t launch_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, int n_actions,
                         KernelCfg cfg, const uint64_t *d_seed, hipStream_t stream);
+// deal sweeps: AoS shadow of the table nodes (rs_device.hpp gather_rec): one job per action node
+struct ShadowJob {
+    const int32_t *regrets;   // [A][pitch]
+    const int32_t *ssum;
+    int32_t *dst;             // [n_clusters][2 * half]
+    uint32_t pitch, n_clusters, n_actions, half;   // half = 4 (A <= 4) or 8
+};
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
@@ -113,6 +121,8 @@ struct JitSubtree {
     size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_seed = 0, off_cval = 0, off_nidx = 0,
            off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, args_size = 0;
     size_t off_dreg = 0, off_dssm = 0, off_cidx = 0, off_tpitch = 0, off_n_lanes = 0;   // deal batches only
+    size_t off_loff = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
+    size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,

@@ -373,6 +373,33 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
     }
 }
 
+// ---- deal batches: SoA table rows -> AoS records for the sweep's gathers (rs_device.hpp gather_rec); reads coalesce over clusters,
+// every thread writes its record with 16-byte stores (a wave covers 2-4 KB contiguous)
+__global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__restrict__ jobs) {
+    const ShadowJob *job = jobs + blockIdx.y;
+    const uint32_t n = job->n_clusters, pitch = job->pitch, A = job->n_actions, half = job->half;
+    const int32_t *__restrict__ reg = job->regrets, *__restrict__ ssm = job->ssum;
+    int32_t *__restrict__ dst = job->dst;
+    for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < n; c += gridDim.x * kBlock) {
+        int32_t rec[16];
+#pragma unroll
+        for (uint32_t a = 0; a < 8; ++a) {
+            rec[a] = a < A ? reg[(size_t)a * pitch + c] : 0;
+            rec[8 + a] = a < A ? ssm[(size_t)a * pitch + c] : 0;
+        }
+        i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * 2 * half);
+        if (half == 4) {
+            out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
+            out[1] = i32x4{rec[8], rec[9], rec[10], rec[11]};
+        } else {
+            out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
+            out[1] = i32x4{rec[4], rec[5], rec[6], rec[7]};
+            out[2] = i32x4{rec[8], rec[9], rec[10], rec[11]};
+            out[3] = i32x4{rec[12], rec[13], rec[14], rec[15]};
+        }
+    }
+}
+
 // ---- deal batches: table += delta (wrapping), delta = 0; 32 bytes per cell, whole table, end of every sweep ------
 __global__ __launch_bounds__(kBlock) void k_apply_delta(int32_t *__restrict__ regrets, int32_t *__restrict__ dregrets,
                                                         int32_t *__restrict__ ssum, int32_t *__restrict__ dssum, size_t n_vec) {
@@ -612,6 +639,12 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_
 }
 
 
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs);
+    return hipGetLastError();
+}
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream) {
     const size_t n_vec = n_cells / kVec;
     dim3 grid(grid_for(n_vec)), block(kBlock);

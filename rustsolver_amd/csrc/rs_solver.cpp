@@ -21,7 +21,7 @@ using namespace rs;
 
 namespace {
 
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW };
 
 struct Launch {
     int kind;
@@ -49,6 +49,7 @@ struct JitLaunch {
     double bytes = 0.0;
     int threads = 256;
     size_t lds_bytes = 0;
+    bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
 };
 
 struct Plan {
@@ -88,6 +89,13 @@ struct rs_solver {
     float *d_exchange = nullptr;        // [world][n_boundary][slot_lanes]
     size_t exchange_floats_per_rank = 0;
     rs_comm *comm = nullptr;
+    int n_cus = 256;                    // multiprocessors of the device (grid of the persistent deal kernels)
+    // deal sweeps through tree-specialised kernels read the table from an AoS shadow rebuilt at the start of every sweep
+    int32_t *d_shadow = nullptr;
+    std::vector<size_t> shadow_off;     // per table node, in ints
+    ShadowJob *d_shadow_jobs = nullptr;
+    int n_shadow_jobs = 0;
+    uint32_t shadow_max_clusters = 0;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -375,6 +383,12 @@ struct Builder {
                     util_override[nodes[id].children[0]] =
                         s->d_exchange + (size_t(s->params.shard_rank) * plan.n_boundary + boundary_k[id]) * s->slot_lanes;
 
+        if (s->d_shadow) {   // the table as of sweep start, transposed for the deal kernels' gathers
+            Launch L;
+            L.kind = L_SHADOW;
+            L.bytes = double(t->n_cells) * 16.0;
+            plan.launches.push_back(L);
+        }
         if (s->params.opp_mode == RS_OPP_SAMPLE) {   // advance the sweep seed (part of the plan, hence of the hipGraph)
             Launch L;
             L.kind = L_SEED;
@@ -531,6 +545,7 @@ struct Builder {
                     int lds_limit = 0;
                     if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device) != hipSuccess) lds_limit = 64 * 1024;
                     if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+                    if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
                     const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off;
                     JitSubtree js;
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
@@ -582,6 +597,7 @@ struct Builder {
                             const rs_tree_node &an = nodes[js.node_ids[k]];
                             put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
                             put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
+                            put_ptr(js.off_shd + 8 * k, s->d_shadow + s->shadow_off[an.index]);
                             tp[an.player] = uint32_t(t->pitch[an.index]);
                         }
                         for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
@@ -590,10 +606,40 @@ struct Builder {
                         put_u32(js.off_tpitch + 4, tp[1]);
                         put_u32(js.off_n_lanes, s->deals.n_deals);
                         put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
+                        // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
+                        // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
+                        size_t lds_total = 0;
+                        for (size_t k = 0; k < js.node_ids.size(); ++k) put_u32(js.off_loff + 4 * k, 0xffffffffu);
+                        if (use_lds) {
+                            static const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
+                            std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
+                            for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                                const rs_tree_node &an = nodes[js.node_ids[k]];
+                                if (an.player == p && an.n_children > 0) tiles.emplace_back(size_t(2) * an.n_children * t->pitch[an.index], k);
+                            }
+                            std::sort(tiles.begin(), tiles.end());
+                            const size_t limit = size_t(lds_limit) / 4;
+                            size_t resident = 0, n_res = 0;
+                            while (!resident_off && n_res < tiles.size()) {
+                                const size_t rest = n_res + 1 < tiles.size() ? tiles.back().first : 0;   // largest tile that would stay transient
+                                if (resident + tiles[n_res].first + rest > limit) break;
+                                resident += tiles[n_res].first;
+                                ++n_res;
+                            }
+                            size_t at = 0;
+                            for (size_t i = 0; i < n_res; ++i) {
+                                put_u32(js.off_loff + 4 * tiles[i].second, uint32_t(at));
+                                at += tiles[i].first;
+                            }
+                            put_u32(js.off_resident, uint32_t(resident));
+                            put_u32(js.off_trans, uint32_t(resident));
+                            lds_total = (resident + (n_res < tiles.size() ? tiles.back().first : 0)) * 4;
+                            if (n_res) JL.persistent = true;
+                        }
+                        if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_total);
                     }
                     JL.n_jobs += 1;
                     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
-                    if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_need);
                     JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
                 }
                 for (auto &kv : by_fn) {
@@ -662,6 +708,13 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         RS_HIP(launch_next_seed(s->d_seed_state, t->stream), "k_next_seed");
         return RS_OK;
     }
+    if (L.kind == L_SHADOW) {
+        prof_begin(t, RS_K_STRATEGY, L.bytes);
+        hipError_t es = launch_build_shadow(s->d_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream);
+        prof_end(t);
+        RS_HIP(es, "k_build_shadow");
+        return RS_OK;
+    }
     prof_begin(t, prof_kind[L.kind], L.bytes);
     hipError_t e = hipSuccess;
     const NodeJob *jobs = plan.d_jobs + L.first_job;
@@ -681,6 +734,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         const JitLaunch &JL = plan.jit[L.first_job];
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
         blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
+        if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));
+        if (const char *cap = getenv("RS_JIT_MAX_BLOCKS")) blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(atoi(cap))));   // tests: force several trips per workgroup   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
@@ -766,6 +821,10 @@ void rs::solver_release_device(rs_solver *s) {
         pl = Plan{};
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
+    if (s->d_shadow) (void)hipFree(s->d_shadow);
+    if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
+    s->d_shadow = nullptr;
+    s->d_shadow_jobs = nullptr;
     if (s->d_seed_state) (void)hipFree(s->d_seed_state);
     if (s->d_exchange) (void)hipFree(s->d_exchange);
     s->d_exchange = nullptr;
@@ -839,6 +898,40 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         if ((e = hipMalloc((void **)&s->d_seed_state, sizeof(init))) != hipSuccess ||
             (e = hipMemcpy(s->d_seed_state, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) {
             rc = hip_fail(e, "rs_solver_create: seed state");
+            rs_solver_destroy(s);
+            return rc;
+        }
+    }
+    if (s->deal_mode && s->params.fuse_subtrees) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
+        std::vector<ShadowJob> jobs;
+        size_t ints = 0;
+        s->shadow_off.assign(table->nodes.size(), 0);
+        for (size_t i = 0; i < table->nodes.size(); ++i) {
+            const rs_node_desc &d = table->nodes[i];
+            if (d.n_actions == 0) continue;
+            const uint32_t half = d.n_actions <= 4 ? 4 : 8;
+            s->shadow_off[i] = ints;
+            ShadowJob j{};
+            j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+            j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+            j.pitch = uint32_t(table->pitch[i]);
+            j.n_clusters = d.n_clusters;
+            j.n_actions = d.n_actions;
+            j.half = half;
+            jobs.push_back(j);
+            ints += round_up(size_t(d.n_clusters) * 2 * half, 64);
+            s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
+        }
+        e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
+        size_t k = 0;
+        for (size_t i = 0; i < table->nodes.size(); ++i)
+            if (table->nodes[i].n_actions) jobs[k++].dst = s->d_shadow + s->shadow_off[i];
+        s->n_shadow_jobs = int(jobs.size());
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
+        if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: table shadow");
             rs_solver_destroy(s);
             return rc;
         }

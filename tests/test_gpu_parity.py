@@ -452,6 +452,26 @@ def test_deal_batches_large_cluster_counts(sizes, lds_max, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("blocks,resident", [("1", True), ("2", True), ("1", False)])
+def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
+    """resident LDS tiles hold the sums of ALL trips of a workgroup and are flushed once at the end: force 1-2 workgroups over 7 000
+    deals (4+ trips of 2 048 deals, the last one partial) and compare with the oracle; also with resident tiles switched off"""
+    monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
+    if not resident:
+        monkeypatch.setenv("RS_JIT_NO_RESIDENT", "1")
+    n_deals = 7000
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(1081, 700)], n_deals, 78)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=3)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=3)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_deal_batches_reject_bad_inputs():
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(5, 6)], 10, 3)
     with pytest.raises(rs.RsError):
