@@ -49,7 +49,8 @@ per_kernel = collections.defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace)):
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        if g >= FULL and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_")):
+        # the persistent deal kernels (resident LDS tiles) run ONE 512-thread workgroup per CU: 131 072 work-items for a 4 M-deal batch
+        if (g >= FULL or ("_deals" in r["Kernel_Name"] and g >= (1 << 16))) and r["Kernel_Name"].startswith(("void rs::", "rs::", "rs_tree_")):
             per_kernel[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     lines += ["## full-size dispatches (>= 512K work-items), kernel trace", "",
               "| kernel | dispatches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
@@ -70,7 +71,7 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if int(r["Grid_Size"]) >= FULL and r["Counter_Name"] == counter and ("rs::" in r["Kernel_Name"] or "rs_tree_" in r["Kernel_Name"]):
+        if (int(r["Grid_Size"]) >= FULL or ("_deals" in r["Kernel_Name"] and int(r["Grid_Size"]) >= (1 << 16))) and r["Counter_Name"] == counter and ("rs::" in r["Kernel_Name"] or "rs_tree_" in r["Kernel_Name"]):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     traffic[counter] = agg
 if traffic:

@@ -205,6 +205,7 @@ struct ClusterJob {
     const DenseSlot *slots;        // cluster_map[player]
     uint64_t mask;
     uint32_t *out;                 // [pitch] dense cluster ids
+    const uint32_t *lut;           // [52 * 52] get_cluster by hole cards when the abstraction's whole board is the initial board, else nullptr
 };
 
 __global__ __launch_bounds__(kBlock) void k_hand_index(HandIndexView v, int upto, CardRows rows, const uint8_t *__restrict__ cards, uint32_t n,
@@ -234,6 +235,20 @@ __global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJobs jobs
     const DenseSlot *__restrict__ slots = job->slots;
     const uint64_t mask = job->mask;
     uint32_t *__restrict__ dst = job->out;
+    const uint32_t *__restrict__ lut = job->lut;
+    if (lut) {   // the board of this round is fixed: get_cluster is a function of the two hole cards, tabulated at init
+        const uint32_t r0 = job->rows.row[0], r1 = job->rows.row[1];
+        for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
+            const uint32_t a = cards[(size_t)r0 * pitch + l], b = cards[(size_t)r1 * pitch + l];
+            uint32_t dense = a < 52u && b < 52u ? lut[a * 52u + b] : kDenseMissing;
+            if (dense == kDenseMissing) {
+                atomicOr(err, 1u);
+                dense = 0;
+            }
+            dst[l] = dense;
+        }
+        return;
+    }
     for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
         uint8_t c[7];
 #pragma unroll
@@ -335,10 +350,12 @@ struct rs_card_abs {
     bool has_arr = false;
     std::vector<DenseSlot> slots[2];            // cluster_map[player]
     std::vector<uint64_t> keys[2];              // dense id -> bucket
+    std::vector<uint32_t> lut[2];               // [52 * 52] get_cluster by hole cards, when the round's board IS the initial board (else empty)
     struct Dev {                                // mirror on one GPU, created on first use
         int device;
         uint32_t *cluster_arr;
         DenseSlot *slots[2];
+        uint32_t *lut[2];
         uint32_t *err;
     };
     std::vector<Dev> devs;
@@ -364,6 +381,11 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
         e = hipMalloc(reinterpret_cast<void **>(&d.slots[p]), a->slots[p].size() * sizeof(DenseSlot));
         if (e == hipSuccess) e = hipMemcpyAsync(d.slots[p], a->slots[p].data(), a->slots[p].size() * sizeof(DenseSlot), hipMemcpyHostToDevice, t->stream);
     }
+    for (int p = 0; e == hipSuccess && p < 2; ++p) {
+        if (a->lut[p].empty()) continue;
+        e = hipMalloc(reinterpret_cast<void **>(&d.lut[p]), a->lut[p].size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(d.lut[p], a->lut[p].data(), a->lut[p].size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream);
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d.err, 0, sizeof(uint32_t), t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -371,6 +393,8 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
         (void)hipFree(d.cluster_arr);
         (void)hipFree(d.slots[0]);
         (void)hipFree(d.slots[1]);
+        (void)hipFree(d.lut[0]);
+        (void)hipFree(d.lut[1]);
         (void)hipFree(d.err);
         return hip_fail(e, "rs_card_abs: device mirror");
     }
@@ -555,6 +579,8 @@ void rs_card_abs_destroy(rs_card_abs *a) {
             (void)hipFree(d.cluster_arr);
             (void)hipFree(d.slots[0]);
             (void)hipFree(d.slots[1]);
+            (void)hipFree(d.lut[0]);
+            (void)hipFree(d.lut[1]);
             (void)hipFree(d.err);
         }
     rs_hand_indexer_destroy(a->ix);
@@ -628,6 +654,18 @@ int rs_card_abs_create(int betting_round, const uint8_t *hands_p0, size_t n_hand
             }
         }
         if (rc == RS_OK && a->slots[p].empty()) a->slots[p].assign(64, DenseSlot{0, 0});
+        if (rc == RS_OK && cards_left == 0) {   // the round's board is the initial board: tabulate get_cluster over the hole cards (memoisation only)
+            a->lut[p].assign(52 * 52, kDenseMissing);
+            for (int x = 0; x < 52; ++x)
+                for (int y = 0; y < 52; ++y) {
+                    if (x == y || ((1ull << x | 1ull << y) & initial_board_mask)) continue;
+                    cards[0] = uint8_t(x);
+                    cards[1] = uint8_t(y);
+                    uint64_t bucket = hand_index(v, 1, cards);
+                    if (a->has_arr) bucket = bucket < a->cluster_arr.size() ? a->cluster_arr[bucket] : ~0ull - 1;
+                    a->lut[p][size_t(x) * 52 + y] = dense_lookup(a->slots[p].data(), a->slots[p].size() - 1, bucket);
+                }
+        }
     }
     if (rc != RS_OK) {
         rs_card_abs_destroy(a);
@@ -695,6 +733,7 @@ int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_ca
         j.cluster_arr = dev.cluster_arr;
         j.arr_len = a->cluster_arr.size();
         j.slots = dev.slots[p];
+        j.lut = dev.lut[p];
         j.mask = a->slots[p].size() - 1;
         j.out = dst;
     }

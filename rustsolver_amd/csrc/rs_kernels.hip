@@ -443,21 +443,14 @@ __device__ __forceinline__ uint32_t top_bits(uint32_t mask, int n) {   // the n 
     }
     return out;
 }
-__device__ __forceinline__ uint32_t evaluate7(const uint8_t (&c)[7]) {
-    uint32_t suit_mask[4] = {0, 0, 0, 0};
-    uint32_t cnt[13];
-#pragma unroll
-    for (int r = 0; r < 13; r++) cnt[r] = 0;
-    uint32_t ranks = 0;
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const uint32_t r = c[i] >> 2, su = c[i] & 3;
-        ranks |= 1u << r;
-        uint32_t m0 = su == 0, m1 = su == 1, m2 = su == 2, m3 = su == 3;
-        suit_mask[0] |= m0 << r; suit_mask[1] |= m1 << r; suit_mask[2] |= m2 << r; suit_mask[3] |= m3 << r;
-#pragma unroll
-        for (int q = 0; q < 13; q++) cnt[q] += (r == (uint32_t)q);
-    }
+// score of the seven cards given as four 13-bit rank masks, one per suit.  Rank multiplicities come from the suit masks directly:
+// a rank held in >= 2 suits is in some pairwise AND, in >= 3 suits in some triple AND, in all four in the full AND.
+__device__ __forceinline__ uint32_t evaluate_suits(const uint32_t (&suit_mask)[4]) {
+    const uint32_t s0 = suit_mask[0], s1 = suit_mask[1], s2 = suit_mask[2], s3 = suit_mask[3];
+    const uint32_t ranks = s0 | s1 | s2 | s3;
+    const uint32_t ge2 = (s0 & s1) | (s0 & s2) | (s0 & s3) | (s1 & s2) | (s1 & s3) | (s2 & s3);
+    const uint32_t ge3 = (s0 & s1 & s2) | (s0 & s1 & s3) | (s0 & s2 & s3) | (s1 & s2 & s3);
+    const uint32_t quads = s0 & s1 & s2 & s3, trips = ge3 & ~quads, pairs = ge2 & ~ge3;
     uint32_t flush = 0;
 #pragma unroll
     for (int su = 0; su < 4; su++)
@@ -465,13 +458,6 @@ __device__ __forceinline__ uint32_t evaluate7(const uint8_t (&c)[7]) {
     if (flush) {
         const int sf = straight_high(flush);
         if (sf >= 0) return (8u << 20) | (uint32_t)sf;                       // straight flush
-    }
-    uint32_t quads = 0, trips = 0, pairs = 0;
-#pragma unroll
-    for (int q = 0; q < 13; q++) {
-        quads |= (uint32_t)(cnt[q] == 4) << q;
-        trips |= (uint32_t)(cnt[q] == 3) << q;
-        pairs |= (uint32_t)(cnt[q] == 2) << q;
     }
     if (quads) {
         const int qr = 31 - __builtin_clz(quads);
@@ -502,18 +488,24 @@ __device__ __forceinline__ uint32_t evaluate7(const uint8_t (&c)[7]) {
     return top_bits(ranks, 5);
 }
 
+__device__ __forceinline__ void add_card(uint32_t (&suit_mask)[4], uint32_t card) {
+    const uint32_t bit = (card >> 2) < 13u ? 1u << (card >> 2) : 0u, su = card & 3u;   // a byte that is no card adds nothing
+#pragma unroll
+    for (int q = 0; q < 4; q++) suit_mask[q] |= su == (uint32_t)q ? bit : 0u;
+}
 // cards[9][pitch] u8: rows 0-4 board, 5-6 player 0 hole cards, 7-8 player 1 hole cards; sign[lane] = sign(score0 - score1)
 __global__ __launch_bounds__(kBlock) void k_showdown_sign(const uint8_t *__restrict__ cards, float *__restrict__ sign, uint32_t n,
                                                           uint32_t pitch) {
     for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
-        uint8_t h0[7], h1[7];
+        uint32_t m0[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 5; i++) h0[i + 2] = h1[i + 2] = cards[(size_t)i * pitch + l];   // TrainHand.board[2..7], cfr.rs:42-44
-        h0[0] = cards[(size_t)5 * pitch + l];
-        h0[1] = cards[(size_t)6 * pitch + l];
-        h1[0] = cards[(size_t)7 * pitch + l];
-        h1[1] = cards[(size_t)8 * pitch + l];
-        const uint32_t s0 = evaluate7(h0), s1 = evaluate7(h1);
+        for (int i = 0; i < 5; i++) add_card(m0, cards[(size_t)i * pitch + l]);   // TrainHand.board[2..7], cfr.rs:42-44: shared by both hands
+        uint32_t m1[4] = {m0[0], m0[1], m0[2], m0[3]};
+        add_card(m0, cards[(size_t)5 * pitch + l]);
+        add_card(m0, cards[(size_t)6 * pitch + l]);
+        add_card(m1, cards[(size_t)7 * pitch + l]);
+        add_card(m1, cards[(size_t)8 * pitch + l]);
+        const uint32_t s0 = evaluate_suits(m0), s1 = evaluate_suits(m1);
         sign[l] = s0 == s1 ? 0.0f : (s0 > s1 ? 1.0f : -1.0f);                   // cfr.rs:326-333
     }
 }
