@@ -734,8 +734,9 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         const JitLaunch &JL = plan.jit[L.first_job];
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
         blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
-        if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));
-        if (const char *cap = getenv("RS_JIT_MAX_BLOCKS")) blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(atoi(cap))));   // tests: force several trips per workgroup   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
+        if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
+        if (const char *cap = getenv("RS_JIT_MAX_BLOCKS"))   // tests: force several trips per workgroup
+            blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(atoi(cap))));
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
