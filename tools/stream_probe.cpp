@@ -1,0 +1,49 @@
+// tools/stream_probe.cpp -- micro-benchmark behind DESIGN.md section 5: bytes/s of a streaming kernel as a function of how the same bytes are
+// split into streams.  Build: hipcc --offload-arch=gfx950 -O3 tools/stream_probe.cpp -o _ab/stream_probe ; run it on the GPU box.  Not part of the library.
+//   R read streams + W write streams, each thread moves CH x 16 B per stream (CH consecutive float4: AoSoA-style chunk)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int R, int W, int CH>
+__global__ __launch_bounds__(256) void k(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n_vec /* per stream, in units of CH float4 */) {
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * 256) {
+        f4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc += __builtin_nontemporal_load(in + ((size_t)r * n_vec + v) * CH + c);
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) __builtin_nontemporal_store(acc + (float)(w + c), out + ((size_t)w * n_vec + v) * CH + c);
+    }
+}
+template <int R, int W, int CH>
+double run(const f4 *in, f4 *out, size_t bytes_per_dir_read, int reps) {
+    const size_t n_vec = bytes_per_dir_read / 16 / R / CH;   // read bytes fixed; write bytes = read * W / R
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int grid = 4096;
+    hipLaunchKernelGGL((k<R, W, CH>), dim3(grid), dim3(256), 0, 0, in, out, n_vec);
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<R, W, CH>), dim3(grid), dim3(256), 0, 0, in, out, n_vec);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double bytes = double(n_vec) * CH * 16 * (R + W) * reps;
+    return bytes / (ms * 1e-3) / 1e12;
+}
+int main() {
+    const size_t rd = size_t(2200) << 20;   // ~2.2 GB read per launch like the tree kernel (2.14 GB), writes scaled 2:3.. by W/R
+    f4 *in, *out; hipMalloc(&in, rd + (64 << 20)); hipMalloc(&out, rd + (64 << 20));
+    hipMemset(in, 0, rd); hipMemset(out, 0, rd);
+    printf("copy        R1  W1  CH1 : %.2f TB/s\n", run<1, 1, 1>(in, out, rd, 10));
+    printf("copy        R1  W1  CH4 : %.2f TB/s\n", run<1, 1, 4>(in, out, rd, 10));
+    printf("3:2         R3  W2  CH1 : %.2f TB/s\n", run<3, 2, 1>(in, out, rd, 10));
+    printf("many        R12 W8  CH1 : %.2f TB/s\n", run<12, 8, 1>(in, out, rd, 10));
+    printf("many        R30 W20 CH1 : %.2f TB/s\n", run<30, 20, 1>(in, out, rd, 10));
+    printf("tree-like   R57 W38 CH1 : %.2f TB/s\n", run<57, 38, 1>(in, out, rd, 10));
+    printf("AoSoA-like  R19 W13 CH3 : %.2f TB/s\n", run<19, 13, 3>(in, out, rd, 10));
+    printf("AoSoA-like  R10 W7  CH6 : %.2f TB/s\n", run<10, 7, 6>(in, out, rd, 10));
+
+    return 0;
+}
