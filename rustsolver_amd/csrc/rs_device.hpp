@@ -337,6 +337,36 @@ __device__ __forceinline__ void lanes_sample(const float (&sig)[A][kVecD], unsig
     }
 }
 
+// sparse deal sweeps: the 4 lanes of a thread are entries of a compacted list of live deals; the hash must see the deal itself
+template <int A>
+__device__ __forceinline__ void lanes_sample_ids(const float (&sig)[A][kVecD], unsigned long long seed, unsigned node_index,
+                                                 const unsigned (&ids)[kVecD], int (&a_s)[kVecD], unsigned lane_base) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        float w[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) w[a] = sig[a][j];
+        a_s[j] = weighted_index<A>(w, sample_bits(seed, node_index, (unsigned long long)lane_base + ids[j]));
+    }
+}
+// per-deal rows read / written through the list (ids[j] valid only where real[j])
+__device__ __forceinline__ void gather_f32_ids(const float *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], float (&out)[kVecD], float pad) {
+    const RS_GLOBAL float *p = as_global<float>(base);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) out[j] = real[j] ? p[ids[j]] : pad;
+}
+__device__ __forceinline__ void gather_u32_ids(const unsigned *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], unsigned (&out)[kVecD]) {
+    const RS_GLOBAL unsigned *p = as_global<unsigned>(base);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) out[j] = real[j] ? p[ids[j]] : 0u;
+}
+__device__ __forceinline__ void scatter_f32_ids(float *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], const float (&in)[kVecD]) {
+    RS_GLOBAL float *p = as_global<float>(base);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++)
+        if (real[j]) p[ids[j]] = in[j];
+}
+
 // ---- 4-lane wrappers used by the tree-specialised (hipRTC) kernels ------------------------------------------
 template <int A, int DT>
 __device__ __forceinline__ void lanes_regret_match(const typename Row<DT>::val (&r)[A][kVecD], float (&sig)[A][kVecD]) {

@@ -92,6 +92,14 @@ struct ShadowJob {
     int32_t *dst;             // [n_clusters][2 * half]
     uint32_t pitch, n_clusters, n_actions, half;   // half = 4 (A <= 4) or 8
 };
+// sparse deal sweeps: live deals (reach not NaN) of one subtree root, compacted (order irrelevant: every use commutes)
+struct CompactJob {
+    const float *reach;   // [n_lanes]
+    uint32_t *list;       // [n_lanes]
+    uint32_t *count;
+    uint32_t n_lanes;
+};
+hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
@@ -123,10 +131,11 @@ struct JitSubtree {
     size_t off_dreg = 0, off_dssm = 0, off_cidx = 0, off_tpitch = 0, off_n_lanes = 0;   // deal batches only
     size_t off_loff = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
+    size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, JitSubtree &out);
+                      bool deals, bool lds, bool sparse, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

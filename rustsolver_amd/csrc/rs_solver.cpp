@@ -21,7 +21,8 @@ using namespace rs;
 
 namespace {
 
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW };
+constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT };
 
 struct Launch {
     int kind;
@@ -59,6 +60,12 @@ struct Plan {
     std::vector<NodeJob> jobs;
     NodeJob *d_jobs = nullptr;
     std::vector<Launch> launches;
+    // sparse deal sweeps: per subtree root the list of live deals (reach not NaN), rebuilt by k_compact_live after the top-down pass
+    uint32_t *d_lists = nullptr;        // [n_compact][pitch]
+    uint32_t *d_counts = nullptr;       // [n_compact]
+    CompactJob *d_compact_jobs = nullptr;
+    std::vector<CompactJob> compact_jobs;
+    uint32_t compact_max_lanes = 0;
     size_t split = 0;                   // sharded sweeps: launches [0, split) = phase 0, [split, end) = phase 1
     int n_boundary = 0;                 // chance nodes entering the sharded round
     size_t arena_bytes = 0;
@@ -469,6 +476,47 @@ struct Builder {
                 }
             }
         }
+        // ---- sparse deal sweeps: which subtree roots get a compacted list of their live deals ---------------------------------
+        // mccfr() follows ONE opponent action per node (cfr.rs:467-476): below a sampled node most deals are off their path (NaN reach).  A
+        // subtree kernel that walks every deal would compute nothing for them; instead the live ones are compacted and only they are walked.
+        std::vector<int> sparse_slot(n, -1);
+        {
+            static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr;
+            size_t n_sparse = 0, list_elems = 0;
+            if (s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off)
+                for (size_t id = 0; id < n; ++id)
+                    if (fused_root[id] && !inside[id] && !dead_end(int(id)) && reach[id].ptr) {
+                        sparse_slot[id] = int(n_sparse++);
+                        list_elems += s->pitch[lane_round[id]];
+                    }
+            if (n_sparse) {
+                hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
+                if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_sparse * kCountStride * sizeof(uint32_t));
+                if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_sparse * kCountStride * sizeof(uint32_t), t->stream);
+                if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
+                if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+                plan.compact_jobs.resize(n_sparse);
+                size_t at = 0;
+                double bytes = 0.0;
+                for (size_t id = 0; id < n; ++id) {
+                    if (sparse_slot[id] < 0) continue;
+                    CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
+                    cj.reach = reach[id].ptr;
+                    cj.list = plan.d_lists + at;
+                    cj.count = plan.d_counts + size_t(sparse_slot[id]) * kCountStride;   // one cache line each: atomics on neighbours would serialise
+                    cj.n_lanes = s->deals.n_deals;
+                    at += s->pitch[lane_round[id]];
+                    plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
+                    bytes += 8.0 * cj.n_lanes;
+                }
+                ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
+                if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+                Launch L;
+                L.kind = L_COMPACT;
+                L.bytes = bytes;
+                plan.launches.push_back(L);
+            }
+        }
         // ---- bottom-up -----------------------------------------------------------------------------
         // sharded sweeps: pass 0 = everything inside the sharded rounds (phase 0, before the exchange), pass 1 = the
         // replicated rounds including the boundary reduces (phase 1); unsharded: one pass
@@ -548,8 +596,9 @@ struct Builder {
                     if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
                     const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off;
                     JitSubtree js;
+                    const bool sparse = sparse_slot[id] >= 0;
                     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, js);
+                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, js);
                     hipFunction_t fn = nullptr;
                     if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
                     auto bi = by_fn.find(fn);
@@ -606,6 +655,10 @@ struct Builder {
                         put_u32(js.off_tpitch + 4, tp[1]);
                         put_u32(js.off_n_lanes, s->deals.n_deals);
                         put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
+                        if (sparse) {   // the subtree walks only its live deals
+                            put_ptr(js.off_list, plan.compact_jobs[size_t(sparse_slot[id])].list);
+                            put_ptr(js.off_count, plan.compact_jobs[size_t(sparse_slot[id])].count);
+                        }
                         // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
                         // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
                         size_t lds_total = 0;
@@ -706,6 +759,14 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     }
     if (L.kind == L_SEED) {
         RS_HIP(launch_next_seed(s->d_seed_state, t->stream), "k_next_seed");
+        return RS_OK;
+    }
+    if (L.kind == L_COMPACT) {
+        prof_begin(t, RS_K_REACH, L.bytes);
+        hipError_t ec = hipMemsetAsync(plan.d_counts, 0, plan.compact_jobs.size() * kCountStride * sizeof(uint32_t), t->stream);
+        if (ec == hipSuccess) ec = launch_compact_live(plan.d_compact_jobs, int(plan.compact_jobs.size()), plan.compact_max_lanes, t->stream);
+        prof_end(t);
+        RS_HIP(ec, "k_compact_live");
         return RS_OK;
     }
     if (L.kind == L_SHADOW) {
@@ -817,6 +878,9 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.graph) (void)hipGraphDestroy(pl.graph);
         if (pl.d_jobs) (void)hipFree(pl.d_jobs);
         if (pl.d_chance_jobs) (void)hipFree(pl.d_chance_jobs);
+        if (pl.d_lists) (void)hipFree(pl.d_lists);
+        if (pl.d_counts) (void)hipFree(pl.d_counts);
+        if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
         for (JitLaunch &JL : pl.jit)
             if (JL.d_blob) (void)hipFree(JL.d_blob);
         pl = Plan{};
@@ -1118,7 +1182,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;
