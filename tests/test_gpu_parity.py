@@ -472,6 +472,29 @@ def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("blocks", [None, "2"])
+@pytest.mark.parametrize("sparse", [True, False])
+def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypatch):
+    """sampled three-street sweeps over 40 000 deals: every river subtree walks only the compacted list of its live deals (several trips per
+    workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked.  Same bits, and
+    equal to the oracle."""
+    if blocks:
+        monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
+    if not sparse:
+        monkeypatch.setenv("RS_JIT_NO_SPARSE", "1")
+    n_deals = 40000
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (11, 8), (13, 17)], n_deals, 91)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=12)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=12)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_deal_batches_reject_bad_inputs():
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(5, 6)], 10, 3)
     with pytest.raises(rs.RsError):
