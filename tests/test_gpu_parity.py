@@ -521,6 +521,28 @@ def test_wide_nodes_through_both_plans(fuse):
     compare_tables(tree, table, otab)
 
 
+@pytest.mark.parametrize("sampled", [True, False])
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_wide_nodes_in_deal_batches(fuse, sampled):
+    """nodes with 5-6 actions in deal mode: the AoS shadow's wide records (8 + 8 ints), LDS tiles of 2 * 6 rows, the sampled hash"""
+    opts_g = rs.Options((800, 800), 40, 5, [[0.25, 0.5, 1.0, 2.0]], [[2.0, 3.0]])
+    opts_o = orc.make_options((800, 800), 40, 5, [[0.25, 0.5, 1.0, 2.0]], [[2.0, 3.0]])
+    n_deals = 5000
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(opts_g, opts_o, [(97, 61)], n_deals, 55)
+    assert max(nd.n_children for nd in tree.action_nodes()) >= 5
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=fuse, deals=cidx,
+                         opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=8)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64,
+                                opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=8)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_randomised_differential(seed):
     """random game options x engine modes, GPU vs oracle, bit for bit"""
