@@ -132,10 +132,12 @@ struct JitSubtree {
     size_t off_loff = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
     size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
+    size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
+    std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, JitSubtree &out);
+                      bool deals, bool lds, bool sparse, bool down, const std::vector<char> *cut, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -22,7 +22,7 @@ using namespace rs;
 namespace {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL };
 
 struct Launch {
     int kind;
@@ -66,6 +66,8 @@ struct Plan {
     CompactJob *d_compact_jobs = nullptr;
     std::vector<CompactJob> compact_jobs;
     uint32_t compact_max_lanes = 0;
+    float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep
+    size_t reach_nan_bytes = 0;
     size_t split = 0;                   // sharded sweeps: launches [0, split) = phase 0, [split, end) = phase 1
     int n_boundary = 0;                 // chance nodes entering the sharded round
     size_t arena_bytes = 0;
@@ -206,6 +208,13 @@ struct Builder {
     size_t arena = 0;
     int max_depth = 0;
     std::map<const float *, int> leaf_ids;   // leaf buffer -> id, so that kernels see the sharing pattern, not pointers
+    // deal batches: ONE generated subtree per betting round, cut at the chance nodes (a deal has one run-out, cfr.rs:306-313).  A round
+    // subtree has a DOWN kernel (reach for the next round's roots) and the usual kernel that walks back up and updates the table.
+    bool round_mode = false;
+    std::vector<std::vector<int>> bnd;       // per round root: the next-round roots below it
+    std::vector<int> nan_slot;               // per round root (except the first): slot of its reach buffer in the NaN-prefilled arena
+    int n_nan = 0;
+    int first_root = -1;
 
     Builder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
 
@@ -218,6 +227,7 @@ struct Builder {
     std::vector<float *> util_override;   // sharded: the utility rows of boundary children live in the exchange buffer
     std::vector<int> boundary_k;          // chance node id -> index among the boundary nodes, -1 otherwise
     float *uptr(int id) const { return util_override[id] ? util_override[id] : aptr(util_off[id]); }
+    float *nan_ptr(int id) const { return plan.d_reach_nan + size_t(nan_slot[size_t(id)]) * s->pitch[0]; }   // round mode: a root's reach buffer
     // deals below a chance node: global count when its child round is the sharded one
     uint32_t fan_of(int chance_id) const {
         const int c = nodes[chance_id].children[0];
@@ -263,6 +273,40 @@ struct Builder {
             return;
         }
         for (int k = 0; k < nd.n_children; ++k) mark_fused(nd.children[k]);
+    }
+
+    int resolve(int c) const {
+        while (nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE) c = nodes[c].children[0];
+        return c;
+    }
+    void mark_round_inside(int root, int id) {
+        for (int k = 0; k < nodes[id].n_children; ++k) {
+            int c = nodes[id].children[k];
+            bool through_chance = false;
+            while (nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE) {
+                inside[c] = 1;   // nothing is launched for a pass-through chance node
+                through_chance = true;
+                c = nodes[c].children[0];
+            }
+            if (through_chance && nodes[c].kind == RS_NODE_ACTION && nodes[c].n_children > 0) {
+                bnd[size_t(root)].push_back(c);
+                mark_round(c);
+            } else {
+                inside[c] = 1;
+                if (nodes[c].kind == RS_NODE_ACTION) mark_round_inside(root, c);
+            }
+        }
+    }
+    void mark_round(int root) {
+        fused_root[root] = 1;
+        mark_round_inside(root, root);
+    }
+    void layout_round(int root) {
+        util_off[root] = alloc(lane_round[root]);
+        for (int b : bnd[size_t(root)]) {
+            nan_slot[size_t(b)] = n_nan++;
+            layout_round(b);
+        }
     }
 
     // an action node without valid actions (state.rs:125-157 can return none): worth 0, owns nothing, launches nothing
@@ -352,8 +396,22 @@ struct Builder {
         plan.n_boundary = 0;
         for (size_t id = 0; id < n; ++id)
             if (boundary(int(id))) boundary_k[id] = plan.n_boundary++;
-        mark_fused(0);
-        layout(0);
+        bnd.assign(n, {});
+        nan_slot.assign(n, -1);
+        {
+            static const bool round_off = getenv("RS_JIT_NO_ROUNDS") != nullptr;
+            const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
+            first_root = resolve(0);
+            round_mode = s->deal_mode && s->params.fuse_subtrees && !prune && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
+                         nodes[first_root].n_children > 0;
+        }
+        if (round_mode) {
+            mark_round(first_root);
+            layout_round(first_root);
+        } else {
+            mark_fused(0);
+            layout(0);
+        }
         // ENUM chance children: need their own reach buffer when the chance node's reach is a buffer.
         // Resolve top-down in id order (parents have smaller ids than children).
         std::vector<char> reach_is_buf(n, 0);
@@ -373,6 +431,153 @@ struct Builder {
             }
         }
         plan.arena_bytes = arena;
+        return RS_OK;
+    }
+
+    // one subtree job of a tree-specialised kernel: `down` = the top-down half of a round subtree (deal batches), else the walk that updates the table
+    int add_jit_job(int id, bool down, const std::vector<int> &sparse_slot, std::map<hipFunction_t, int> &by_fn) {
+        const size_t n = nodes.size();
+        const rs_table *t = s->table;
+        const double es = double(elem_size(t->dtype));
+        if (has_own[id] && !reach[id].valid) return fail(RS_ERR_INVALID, "rs_solver_create: internal: no reach for a fused subtree");
+        std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
+        for (size_t t2 = 0; t2 < n; ++t2) {
+            const rs_tree_node &tn = nodes[t2];
+            if (tn.kind != RS_NODE_TERMINAL || tn.ttype == RS_TERM_UNCONTESTED) continue;
+            const rs_leaf_desc &lf = s->leaves[p][t2];
+            auto it = leaf_ids.find(lf.d_buf);
+            if (it == leaf_ids.end()) it = leaf_ids.emplace(lf.d_buf, int(leaf_ids.size())).first;
+            leaf_buf[t2] = it->second;
+            leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
+        }
+        // deal batches: privatise the deltas of a traverser node in LDS when [2][A][table pitch] ints fit in what the device gives
+        // ONE workgroup (MI355X: 160 KiB, launchable without any attribute -- probed; a 5 000-cluster node needs 121 KiB)
+        size_t lds_need = 0;
+        if (s->deal_mode) {
+            std::vector<int> stack{id};
+            while (!stack.empty()) {
+                const int q = stack.back();
+                stack.pop_back();
+                const rs_tree_node &qn = nodes[q];
+                if (qn.kind == RS_NODE_ACTION && qn.player == p && qn.n_children > 0)
+                    lds_need = std::max(lds_need, size_t(2) * qn.n_children * t->pitch[qn.index] * 4);
+                for (int k = 0; k < qn.n_children; ++k) {
+                    const int c = qn.children[k];
+                    const bool chance = nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE;
+                    if (!(round_mode && chance)) stack.push_back(c);   // a round subtree ends at the chance nodes
+                }
+            }
+        }
+        static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
+        int lds_limit = 0;
+        if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device) != hipSuccess) lds_limit = 64 * 1024;
+        if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+        if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
+        const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down;
+        JitSubtree js;
+        const bool sparse = sparse_slot[id] >= 0;
+        jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
+                         s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, round_mode ? &fused_root : nullptr, js);
+        hipFunction_t fn = nullptr;
+        if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
+        auto bi = by_fn.find(fn);
+        if (bi == by_fn.end()) {
+            bi = by_fn.emplace(fn, int(plan.jit.size())).first;
+            plan.jit.emplace_back();
+            plan.jit.back().fn = fn;
+            plan.jit.back().stride = js.args_size;
+            plan.jit.back().threads = js.threads;
+        }
+        JitLaunch &JL = plan.jit[bi->second];
+        const size_t base = JL.blob.size();
+        JL.blob.resize(base + js.args_size, 0);
+        unsigned char *a = JL.blob.data() + base;
+        auto put_ptr = [&](size_t off, const void *ptr) { std::memcpy(a + off, &ptr, 8); };
+        auto put_f32 = [&](size_t off, float f) { std::memcpy(a + off, &f, 4); };
+        auto put_u32 = [&](size_t off, uint32_t u) { std::memcpy(a + off, &u, 4); };
+        double bytes = 0.0;
+        for (size_t k = 0; k < js.node_ids.size(); ++k) {
+            const rs_tree_node &an = nodes[js.node_ids[k]];
+            put_ptr(js.off_reg + 8 * k, t->regrets_ptr(an.index));
+            put_ptr(js.off_ssm + 8 * k, t->ssum_ptr(an.index));
+            put_u32(js.off_nidx + 4 * k, uint32_t(an.index));
+            bytes += lanes(js.node_ids[k]) * an.n_children * es * (an.player == p ? 4.0 : 1.0);
+        }
+        for (size_t k = 0; k < js.leaf_terms.size(); ++k) put_ptr(js.off_leaf + 8 * k, s->leaves[p][js.leaf_terms[k]].d_buf);
+        for (size_t k = 0; k < js.const_terms.size(); ++k) {
+            const rs_tree_node &tn = nodes[js.const_terms[k]];
+            const float pot = float(tn.value);   // `tn.value as f32`
+            put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
+        }
+        put_ptr(js.off_reach, reach[id].ptr);
+        put_ptr(js.off_out, uptr(id));
+        put_ptr(js.off_seed, s->d_seed());
+        put_f32(js.off_reach_const, reach[id].cst);
+        put_f32(js.off_scale, s->params.scale);
+        const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / kVec);
+        put_u32(js.off_n_vec, n_vec);
+        put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
+        if (s->deal_mode) {
+            const int r = nodes[id].round_idx;
+            const uint32_t *cx[2] = {s->deals.d_cluster[r][0], s->deals.d_cluster[r][1]};
+            uint32_t tp[2] = {0, 0};
+            for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                const rs_tree_node &an = nodes[js.node_ids[k]];
+                put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
+                put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
+                put_ptr(js.off_shd + 8 * k, s->d_shadow + s->shadow_off[an.index]);
+                tp[an.player] = uint32_t(t->pitch[an.index]);
+            }
+            for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
+                put_ptr(js.off_cidx + 8 * q, cx[q] ? cx[q] : cx[1 - q]);
+            put_u32(js.off_tpitch, tp[0]);
+            put_u32(js.off_tpitch + 4, tp[1]);
+            put_u32(js.off_n_lanes, s->deals.n_deals);
+            put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
+            for (size_t k = 0; k < js.boundary_roots.size(); ++k) {   // round subtrees: what the next round's roots return / are handed
+                const int b = js.boundary_roots[k];
+                put_ptr(js.off_butil + 8 * k, uptr(b));
+                put_ptr(js.off_breach + 8 * k, nan_ptr(b));
+            }
+            if (sparse) {   // the subtree walks only its live deals
+                put_ptr(js.off_list, plan.compact_jobs[size_t(sparse_slot[id])].list);
+                put_ptr(js.off_count, plan.compact_jobs[size_t(sparse_slot[id])].count);
+            }
+            // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
+            // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
+            size_t lds_total = 0;
+            for (size_t k = 0; k < js.node_ids.size(); ++k) put_u32(js.off_loff + 4 * k, 0xffffffffu);
+            if (use_lds) {
+                static const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
+                std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
+                for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                    const rs_tree_node &an = nodes[js.node_ids[k]];
+                    if (an.player == p && an.n_children > 0) tiles.emplace_back(size_t(2) * an.n_children * t->pitch[an.index], k);
+                }
+                std::sort(tiles.begin(), tiles.end());
+                const size_t limit = size_t(lds_limit) / 4;
+                size_t resident = 0, n_res = 0;
+                while (!resident_off && n_res < tiles.size()) {
+                    const size_t rest = n_res + 1 < tiles.size() ? tiles.back().first : 0;   // largest tile that would stay transient
+                    if (resident + tiles[n_res].first + rest > limit) break;
+                    resident += tiles[n_res].first;
+                    ++n_res;
+                }
+                size_t at = 0;
+                for (size_t i = 0; i < n_res; ++i) {
+                    put_u32(js.off_loff + 4 * tiles[i].second, uint32_t(at));
+                    at += tiles[i].first;
+                }
+                put_u32(js.off_resident, uint32_t(resident));
+                put_u32(js.off_trans, uint32_t(resident));
+                lds_total = (resident + (n_res < tiles.size() ? tiles.back().first : 0)) * 4;
+                if (n_res) JL.persistent = true;
+            }
+            if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_total);
+        }
+        JL.n_jobs += 1;
+        JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
+        JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
         return RS_OK;
     }
 
@@ -480,42 +685,94 @@ struct Builder {
         // mccfr() follows ONE opponent action per node (cfr.rs:467-476): below a sampled node most deals are off their path (NaN reach).  A
         // subtree kernel that walks every deal would compute nothing for them; instead the live ones are compacted and only they are walked.
         std::vector<int> sparse_slot(n, -1);
-        {
-            static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr;
-            size_t n_sparse = 0, list_elems = 0;
-            if (s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off)
-                for (size_t id = 0; id < n; ++id)
-                    if (fused_root[id] && !inside[id] && !dead_end(int(id)) && reach[id].ptr) {
-                        sparse_slot[id] = int(n_sparse++);
-                        list_elems += s->pitch[lane_round[id]];
+        static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr;
+        const bool want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
+        // the compact jobs of `ids` (in that order); reach_of(id) = the buffer whose non-NaN lanes are the live deals
+        auto make_lists = [&](const std::vector<int> &ids, auto reach_of) -> int {
+            const size_t n_sparse = ids.size();
+            if (!n_sparse) return RS_OK;
+            size_t list_elems = 0;
+            for (int id : ids) list_elems += s->pitch[lane_round[id]];
+            hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
+            if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_sparse * kCountStride * sizeof(uint32_t));
+            if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_sparse * kCountStride * sizeof(uint32_t), t->stream);
+            if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
+            if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+            plan.compact_jobs.resize(n_sparse);
+            size_t at = 0;
+            for (size_t k = 0; k < n_sparse; ++k) {
+                const int id = ids[k];
+                sparse_slot[id] = int(k);
+                CompactJob &cj = plan.compact_jobs[k];
+                cj.reach = reach_of(id);
+                cj.list = plan.d_lists + at;
+                cj.count = plan.d_counts + k * kCountStride;   // one cache line each: atomics on neighbours would serialise
+                cj.n_lanes = s->deals.n_deals;
+                at += s->pitch[lane_round[id]];
+                plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
+            }
+            ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
+            if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+            return RS_OK;
+        };
+        auto push_compact = [&](int first, int count) {
+            if (count <= 0) return;
+            Launch L;
+            L.kind = L_COMPACT;
+            L.first_job = first;
+            L.n_jobs = count;
+            L.bytes = 8.0 * double(s->deals.n_deals) * count;
+            plan.launches.push_back(L);
+        };
+        if (round_mode) {
+            // ---- round subtrees, top-down: NaN-fill every root's reach buffer, then round by round compact the live deals of the round's
+            // roots and let their DOWN kernels hand reach to the next round's roots
+            std::vector<std::vector<int>> roots_of_round(1, std::vector<int>{first_root});
+            for (size_t r = 0; r < roots_of_round.size(); ++r)
+                for (int root : roots_of_round[r])
+                    for (int b : bnd[size_t(root)]) {
+                        if (roots_of_round.size() <= r + 1) roots_of_round.emplace_back();
+                        roots_of_round[r + 1].push_back(b);
                     }
-            if (n_sparse) {
-                hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
-                if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_sparse * kCountStride * sizeof(uint32_t));
-                if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_sparse * kCountStride * sizeof(uint32_t), t->stream);
-                if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
-                if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
-                plan.compact_jobs.resize(n_sparse);
-                size_t at = 0;
-                double bytes = 0.0;
-                for (size_t id = 0; id < n; ++id) {
-                    if (sparse_slot[id] < 0) continue;
-                    CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
-                    cj.reach = reach[id].ptr;
-                    cj.list = plan.d_lists + at;
-                    cj.count = plan.d_counts + size_t(sparse_slot[id]) * kCountStride;   // one cache line each: atomics on neighbours would serialise
-                    cj.n_lanes = s->deals.n_deals;
-                    at += s->pitch[lane_round[id]];
-                    plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
-                    bytes += 8.0 * cj.n_lanes;
-                }
-                ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
-                if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+            if (n_nan) {
+                plan.reach_nan_bytes = size_t(n_nan) * s->pitch[0] * sizeof(float);
+                hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
+                if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
+                if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
                 Launch L;
-                L.kind = L_COMPACT;
-                L.bytes = bytes;
+                L.kind = L_NANFILL;
                 plan.launches.push_back(L);
             }
+            std::vector<int> listed;
+            std::vector<std::pair<int, int>> slots_of_round(roots_of_round.size(), {0, 0});   // (first compact job, count)
+            if (want_lists)
+                for (size_t r = 1; r < roots_of_round.size(); ++r) {
+                    slots_of_round[r] = {int(listed.size()), int(roots_of_round[r].size())};
+                    listed.insert(listed.end(), roots_of_round[r].begin(), roots_of_round[r].end());
+                }
+            if (int rc = make_lists(listed, [&](int id) { return (const float *)nan_ptr(id); })) return rc;
+            for (size_t r = 0; r < roots_of_round.size(); ++r) {
+                push_compact(slots_of_round[r].first, slots_of_round[r].second);
+                std::map<hipFunction_t, int> by_fn;
+                for (int root : roots_of_round[r]) {
+                    if (bnd[size_t(root)].empty()) continue;
+                    for (int b : bnd[size_t(root)]) reach[b] = ReachSrc{nan_ptr(b), 0.0f, true};
+                    if (int rc = add_jit_job(root, true, sparse_slot, by_fn)) return rc;
+                }
+                for (auto &kv : by_fn) {
+                    Launch L;
+                    L.kind = L_TREE;
+                    L.first_job = kv.second;
+                    L.bytes = plan.jit[kv.second].bytes;
+                    plan.launches.push_back(L);
+                }
+            }
+        } else if (want_lists) {
+            std::vector<int> listed;
+            for (size_t id = 0; id < n; ++id)
+                if (fused_root[id] && !inside[id] && !dead_end(int(id)) && reach[id].ptr) listed.push_back(int(id));
+            if (int rc = make_lists(listed, [&](int id) { return reach[id].ptr; })) return rc;
+            push_compact(0, int(listed.size()));
         }
         // ---- bottom-up -----------------------------------------------------------------------------
         // sharded sweeps: pass 0 = everything inside the sharded rounds (phase 0, before the exchange), pass 1 = the
@@ -563,138 +820,8 @@ struct Builder {
             if (!sub_roots.empty()) {
                 // tree-specialised kernels: subtrees of one shape share a kernel and a launch (blockIdx.y = subtree)
                 std::map<hipFunction_t, int> by_fn;
-                for (int id : sub_roots) {
-                    if (has_own[id] && !reach[id].valid) return fail(RS_ERR_INVALID, "rs_solver_create: internal: no reach for a fused subtree");
-                    std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
-                    for (size_t t2 = 0; t2 < n; ++t2) {
-                        const rs_tree_node &tn = nodes[t2];
-                        if (tn.kind != RS_NODE_TERMINAL || tn.ttype == RS_TERM_UNCONTESTED) continue;
-                        const rs_leaf_desc &lf = s->leaves[p][t2];
-                        auto it = leaf_ids.find(lf.d_buf);
-                        if (it == leaf_ids.end()) it = leaf_ids.emplace(lf.d_buf, int(leaf_ids.size())).first;
-                        leaf_buf[t2] = it->second;
-                        leaf_flags[t2] = lf.kind == RS_LEAF_UTIL ? 0 : 1;
-                    }
-                    // deal batches: privatise the deltas of a traverser node in LDS when [2][A][table pitch] ints fit in what the device gives
-                    // ONE workgroup (MI355X: 160 KiB, launchable without any attribute -- probed; a 5 000-cluster node needs 121 KiB)
-                    size_t lds_need = 0;
-                    if (s->deal_mode) {
-                        std::vector<int> stack{id};
-                        while (!stack.empty()) {
-                            const int q = stack.back();
-                            stack.pop_back();
-                            const rs_tree_node &qn = nodes[q];
-                            if (qn.kind == RS_NODE_ACTION && qn.player == p && qn.n_children > 0)
-                                lds_need = std::max(lds_need, size_t(2) * qn.n_children * t->pitch[qn.index] * 4);
-                            for (int k = 0; k < qn.n_children; ++k) stack.push_back(qn.children[k]);
-                        }
-                    }
-                    static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
-                    int lds_limit = 0;
-                    if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device) != hipSuccess) lds_limit = 64 * 1024;
-                    if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
-                    if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
-                    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off;
-                    JitSubtree js;
-                    const bool sparse = sparse_slot[id] >= 0;
-                    jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                                     s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, js);
-                    hipFunction_t fn = nullptr;
-                    if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
-                    auto bi = by_fn.find(fn);
-                    if (bi == by_fn.end()) {
-                        bi = by_fn.emplace(fn, int(plan.jit.size())).first;
-                        plan.jit.emplace_back();
-                        plan.jit.back().fn = fn;
-                        plan.jit.back().stride = js.args_size;
-                        plan.jit.back().threads = js.threads;
-                    }
-                    JitLaunch &JL = plan.jit[bi->second];
-                    const size_t base = JL.blob.size();
-                    JL.blob.resize(base + js.args_size, 0);
-                    unsigned char *a = JL.blob.data() + base;
-                    auto put_ptr = [&](size_t off, const void *ptr) { std::memcpy(a + off, &ptr, 8); };
-                    auto put_f32 = [&](size_t off, float f) { std::memcpy(a + off, &f, 4); };
-                    auto put_u32 = [&](size_t off, uint32_t u) { std::memcpy(a + off, &u, 4); };
-                    double bytes = 0.0;
-                    for (size_t k = 0; k < js.node_ids.size(); ++k) {
-                        const rs_tree_node &an = nodes[js.node_ids[k]];
-                        put_ptr(js.off_reg + 8 * k, t->regrets_ptr(an.index));
-                        put_ptr(js.off_ssm + 8 * k, t->ssum_ptr(an.index));
-                        put_u32(js.off_nidx + 4 * k, uint32_t(an.index));
-                        bytes += lanes(js.node_ids[k]) * an.n_children * es * (an.player == p ? 4.0 : 1.0);
-                    }
-                    for (size_t k = 0; k < js.leaf_terms.size(); ++k) put_ptr(js.off_leaf + 8 * k, s->leaves[p][js.leaf_terms[k]].d_buf);
-                    for (size_t k = 0; k < js.const_terms.size(); ++k) {
-                        const rs_tree_node &tn = nodes[js.const_terms[k]];
-                        const float pot = float(tn.value);   // `tn.value as f32`
-                        put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
-                    }
-                    put_ptr(js.off_reach, reach[id].ptr);
-                    put_ptr(js.off_out, uptr(id));
-                    put_ptr(js.off_seed, s->d_seed());
-                    put_f32(js.off_reach_const, reach[id].cst);
-                    put_f32(js.off_scale, s->params.scale);
-                    const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / kVec);
-                    put_u32(js.off_n_vec, n_vec);
-                    put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
-                    if (s->deal_mode) {
-                        const int r = nodes[id].round_idx;
-                        const uint32_t *cx[2] = {s->deals.d_cluster[r][0], s->deals.d_cluster[r][1]};
-                        uint32_t tp[2] = {0, 0};
-                        for (size_t k = 0; k < js.node_ids.size(); ++k) {
-                            const rs_tree_node &an = nodes[js.node_ids[k]];
-                            put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
-                            put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
-                            put_ptr(js.off_shd + 8 * k, s->d_shadow + s->shadow_off[an.index]);
-                            tp[an.player] = uint32_t(t->pitch[an.index]);
-                        }
-                        for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
-                            put_ptr(js.off_cidx + 8 * q, cx[q] ? cx[q] : cx[1 - q]);
-                        put_u32(js.off_tpitch, tp[0]);
-                        put_u32(js.off_tpitch + 4, tp[1]);
-                        put_u32(js.off_n_lanes, s->deals.n_deals);
-                        put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
-                        if (sparse) {   // the subtree walks only its live deals
-                            put_ptr(js.off_list, plan.compact_jobs[size_t(sparse_slot[id])].list);
-                            put_ptr(js.off_count, plan.compact_jobs[size_t(sparse_slot[id])].count);
-                        }
-                        // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
-                        // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
-                        size_t lds_total = 0;
-                        for (size_t k = 0; k < js.node_ids.size(); ++k) put_u32(js.off_loff + 4 * k, 0xffffffffu);
-                        if (use_lds) {
-                            static const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
-                            std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
-                            for (size_t k = 0; k < js.node_ids.size(); ++k) {
-                                const rs_tree_node &an = nodes[js.node_ids[k]];
-                                if (an.player == p && an.n_children > 0) tiles.emplace_back(size_t(2) * an.n_children * t->pitch[an.index], k);
-                            }
-                            std::sort(tiles.begin(), tiles.end());
-                            const size_t limit = size_t(lds_limit) / 4;
-                            size_t resident = 0, n_res = 0;
-                            while (!resident_off && n_res < tiles.size()) {
-                                const size_t rest = n_res + 1 < tiles.size() ? tiles.back().first : 0;   // largest tile that would stay transient
-                                if (resident + tiles[n_res].first + rest > limit) break;
-                                resident += tiles[n_res].first;
-                                ++n_res;
-                            }
-                            size_t at = 0;
-                            for (size_t i = 0; i < n_res; ++i) {
-                                put_u32(js.off_loff + 4 * tiles[i].second, uint32_t(at));
-                                at += tiles[i].first;
-                            }
-                            put_u32(js.off_resident, uint32_t(resident));
-                            put_u32(js.off_trans, uint32_t(resident));
-                            lds_total = (resident + (n_res < tiles.size() ? tiles.back().first : 0)) * 4;
-                            if (n_res) JL.persistent = true;
-                        }
-                        if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_total);
-                    }
-                    JL.n_jobs += 1;
-                    JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
-                    JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
-                }
+                for (int id : sub_roots)
+                    if (int rc = add_jit_job(id, false, sparse_slot, by_fn)) return rc;
                 for (auto &kv : by_fn) {
                     Launch L;
                     L.kind = L_TREE;
@@ -761,10 +888,14 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         RS_HIP(launch_next_seed(s->d_seed_state, t->stream), "k_next_seed");
         return RS_OK;
     }
-    if (L.kind == L_COMPACT) {
+    if (L.kind == L_NANFILL) {   // 0xffffffff is a NaN: lanes nobody hands a reach to stay off every path
+        RS_HIP(hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream), "reach NaN fill");
+        return RS_OK;
+    }
+    if (L.kind == L_COMPACT) {   // jobs [first_job, first_job + n_jobs)
         prof_begin(t, RS_K_REACH, L.bytes);
-        hipError_t ec = hipMemsetAsync(plan.d_counts, 0, plan.compact_jobs.size() * kCountStride * sizeof(uint32_t), t->stream);
-        if (ec == hipSuccess) ec = launch_compact_live(plan.d_compact_jobs, int(plan.compact_jobs.size()), plan.compact_max_lanes, t->stream);
+        hipError_t ec = hipMemsetAsync(plan.d_counts + size_t(L.first_job) * kCountStride, 0, size_t(L.n_jobs) * kCountStride * sizeof(uint32_t), t->stream);
+        if (ec == hipSuccess) ec = launch_compact_live(plan.d_compact_jobs + L.first_job, L.n_jobs, plan.compact_max_lanes, t->stream);
         prof_end(t);
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
@@ -878,6 +1009,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.graph) (void)hipGraphDestroy(pl.graph);
         if (pl.d_jobs) (void)hipFree(pl.d_jobs);
         if (pl.d_chance_jobs) (void)hipFree(pl.d_chance_jobs);
+        if (pl.d_reach_nan) (void)hipFree(pl.d_reach_nan);
         if (pl.d_lists) (void)hipFree(pl.d_lists);
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
@@ -1182,7 +1314,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, nullptr, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;
