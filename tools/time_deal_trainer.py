@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Times the device trainer on the reference's as-coded game (options::default_flop(): board 4d5dAs3cKs, random ranges, ISOMORPHIC river).
+Knobs are read once per process (RS_JIT_DISTANCE, RS_JIT_THREADS, RS_JIT_NO_RESIDENT, ...): run one setting per process.
+
+    TAG=default python tools/time_deal_trainer.py
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustsolver_amd as rs
+from rustsolver_amd import abstraction as ab
+mask = ab.card_mask("4d5dAs3cKs"); hands = ab.random_range(mask)
+n_actions, tree = rs.build_game_tree(rs.default_flop())
+card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0)
+tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
+tr.train(5); tr.infosets.sync()
+best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter(); tr.train(20); tr.infosets.sync(); best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+print(os.environ.get("TAG", ""), "best %.3f ms/batch" % best)
