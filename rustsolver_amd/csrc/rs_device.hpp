@@ -209,6 +209,24 @@ __device__ __forceinline__ void lds_flush(int *lds, unsigned n_cells, void *dreg
     __syncthreads();
 }
 
+// Tiles may cover only the cluster range [c0, c0 + rcount) of a node (cluster-partitioned workgroups: every deal of the job has its traverser
+// cluster in that range): tile row a starts at a * rp, cell (a, c - c0) belongs to table cell a * tpitch + c.
+__device__ __forceinline__ void lds_flush_part(int *tile, unsigned n_actions, unsigned rp, unsigned rcount, unsigned c0, unsigned tpitch, void *dreg,
+                                               void *dssm) {
+    __syncthreads();
+    RS_GLOBAL int *pr = as_global<int>(dreg), *ps = as_global<int>(dssm);
+    const unsigned half = n_actions * rp;
+    for (unsigned i = threadIdx.x; i < half; i += blockDim.x) {
+        const unsigned a = i / rp, c = i - a * rp;
+        if (c >= rcount) continue;
+        const int x = tile[i], y = tile[half + i];
+        const unsigned g = a * tpitch + c0 + c;
+        if (x != 0) __hip_atomic_fetch_add(pr + g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (y != 0) __hip_atomic_fetch_add(ps + g, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
 // lanes past the end of the batch (pitch padding) must not touch the table: mark them inactive
 __device__ __forceinline__ void mask_tail_lanes(float (&reach)[kVecD], unsigned v, unsigned n_lanes) {
 #pragma unroll

@@ -94,10 +94,13 @@ struct ShadowJob {
 };
 // sparse deal sweeps: live deals (reach not NaN) of one subtree root, compacted (order irrelevant: every use commutes)
 struct CompactJob {
-    const float *reach;   // [n_lanes]
-    uint32_t *list;       // [n_lanes]
-    uint32_t *count;
+    const float *reach;   // [n_lanes], or nullptr: every lane is live (the first root)
+    uint32_t *list;       // [n_parts][list_stride]
+    uint32_t *count;      // [n_parts], count_stride apart
     uint32_t n_lanes;
+    // cluster-partitioned workgroups: a live deal goes to the list of part key[lane] / part_size (key = its traverser cluster id)
+    const uint32_t *key;  // nullptr when n_parts == 1
+    uint32_t part_size, n_parts, list_stride, count_stride;
 };
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
@@ -133,6 +136,7 @@ struct JitSubtree {
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
     size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
+    size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,

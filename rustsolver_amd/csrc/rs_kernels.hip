@@ -377,30 +377,38 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
 // with four ballots, ONE atomic reserves the slots (a first version issued one returning atomic per wave on 72 adjacent counters: they share three
 // cache lines, the L2 serialised 1.2 M of them, 8.3 ms per launch; counters now sit 256 B apart).  The order of workgroups in the list is
 // arbitrary, which is fine because every consumer of the list commutes.
+constexpr uint32_t kMaxParts = 64;
 __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__restrict__ jobs) {
-    __shared__ uint32_t wave_count[kBlock / 64];
-    __shared__ uint32_t group_base;
+    __shared__ uint32_t wave_count[kBlock / 64][kMaxParts];   // live lanes of every wave, per cluster range
+    __shared__ uint32_t part_base[kMaxParts];                 // list slot reserved for this workgroup, per cluster range
     const CompactJob *job = jobs + blockIdx.y;
-    const uint32_t n = job->n_lanes;
+    const uint32_t n = job->n_lanes, n_parts = job->n_parts, part_size = job->part_size;
     const float *__restrict__ reach = job->reach;
-    uint32_t *__restrict__ list = job->list, *__restrict__ count = job->count;
+    const uint32_t *__restrict__ key = job->key;
     const uint32_t lane_in_wave = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {   // whole workgroups iterate together
         const uint32_t l = base + threadIdx.x;
-        const bool live = l < n && reach[l] == reach[l];
-        const unsigned long long ballot = __ballot(live);
-        if (lane_in_wave == 0) wave_count[wave] = (uint32_t)__popcll(ballot);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
-            for (int w = 0; w < kBlock / 64; ++w) total += wave_count[w];
-            group_base = total ? atomicAdd(count, total) : 0u;
+        const bool live = l < n && (!reach || reach[l] == reach[l]);
+        const uint32_t part = (live && key) ? min(key[l] / part_size, n_parts - 1u) : 0u;
+        uint32_t rank_in_wave = 0;   // among the live lanes of this wave with the same part
+        for (uint32_t q = 0; q < n_parts; ++q) {   // ballots only: no barrier inside
+            const unsigned long long ballot = __ballot(live && part == q);
+            if (lane_in_wave == 0) wave_count[wave][q] = (uint32_t)__popcll(ballot);
+            if (live && part == q) rank_in_wave = (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
         }
         __syncthreads();
-        uint32_t slot = group_base;
-        for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w];
-        if (live) list[slot + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull))] = l;
-        __syncthreads();   // wave_count / group_base are rewritten by the next iteration
+        if (threadIdx.x < n_parts) {   // ONE reservation per workgroup and part, issued by different threads
+            uint32_t total = 0;
+            for (int w = 0; w < kBlock / 64; ++w) total += wave_count[w][threadIdx.x];
+            part_base[threadIdx.x] = total ? atomicAdd(job->count + (size_t)threadIdx.x * job->count_stride, total) : 0u;
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t slot = part_base[part] + rank_in_wave;
+            for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part];
+            job->list[(size_t)part * job->list_stride + slot] = l;
+        }
+        __syncthreads();   // wave_count / part_base are rewritten by the next iteration
     }
 }
 

@@ -65,6 +65,7 @@ struct Plan {
     uint32_t *d_counts = nullptr;       // [n_compact]
     CompactJob *d_compact_jobs = nullptr;
     std::vector<CompactJob> compact_jobs;
+    std::vector<size_t> count_off;      // per compact job: index of its first counter (a job has one per cluster range)
     uint32_t compact_max_lanes = 0;
     float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep
     size_t reach_nan_bytes = 0;
@@ -215,6 +216,44 @@ struct Builder {
     std::vector<int> nan_slot;               // per round root (except the first): slot of its reach buffer in the NaN-prefilled arena
     int n_nan = 0;
     int first_root = -1;
+    int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
+    bool want_lists = false, want_parts = false;
+    // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
+    // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
+    // cluster and each (root, range) becomes its own kernel job whose tiles cover that range only -- all resident, zeroed and flushed once.
+    struct Parts {
+        uint32_t first, second;   // number of cluster ranges, clusters per range
+        uint32_t n_clusters, pitch;   // of the TRAVERSER's nodes in this round subtree (the root may be the opponent's)
+    };
+    Parts parts_of(int root) const {
+        const rs_table *t = s->table;
+        size_t sum_a = 0;
+        uint32_t n_cl = 0, pitch = 0;
+        std::vector<int> stack{root};
+        while (!stack.empty()) {
+            const int q = stack.back();
+            stack.pop_back();
+            const rs_tree_node &qn = nodes[q];
+            if (qn.kind == RS_NODE_ACTION && qn.player == p && qn.n_children > 0) {
+                sum_a += size_t(qn.n_children);
+                n_cl = t->nodes[size_t(qn.index)].n_clusters;
+                pitch = uint32_t(t->pitch[size_t(qn.index)]);
+            }
+            for (int k = 0; k < qn.n_children; ++k) {
+                const int c = qn.children[k];
+                if (nodes[c].kind != RS_NODE_PRIVATE_CHANCE && nodes[c].kind != RS_NODE_PUBLIC_CHANCE) stack.push_back(c);
+            }
+        }
+        const size_t limit = size_t(lds_limit) / 4;
+        if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit) return Parts{1u, pitch, n_cl, pitch};
+        // Partitioning costs list indirection (gathers instead of row loads, a bucketing pass).  When most tiles would be resident anyway --
+        // 1 081 clusters miss the budget by 1 % and keep 5 of 7 -- it loses (measured 1.33 against 0.84 ms per batch): only partition when
+        // fewer than half of the tile bytes fit.
+        if (limit * 2 >= 2 * sum_a * pitch) return Parts{1u, pitch, n_cl, pitch};
+        const uint32_t r = uint32_t(limit / (2 * sum_a)) / 64u * 64u;
+        if (r < 64u || (n_cl + r - 1) / r > 64u) return Parts{1u, pitch, n_cl, pitch};   // k_compact_live handles up to 64 ranges
+        return Parts{(n_cl + r - 1) / r, r, n_cl, pitch};
+    }
 
     Builder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
 
@@ -404,6 +443,12 @@ struct Builder {
             first_root = resolve(0);
             round_mode = s->deal_mode && s->params.fuse_subtrees && !prune && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
+            static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
+            want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
+            want_parts = round_mode && want_lists && !parts_off;
+            if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
+            if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+            if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
         }
         if (round_mode) {
             mark_round(first_root);
@@ -469,13 +514,11 @@ struct Builder {
             }
         }
         static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
-        int lds_limit = 0;
-        if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device) != hipSuccess) lds_limit = 64 * 1024;
-        if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
-        if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
+        const bool sparse = sparse_slot[id] >= 0;
+        const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
+        if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
         const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down;
         JitSubtree js;
-        const bool sparse = sparse_slot[id] >= 0;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, round_mode ? &fused_root : nullptr, js);
         hipFunction_t fn = nullptr;
@@ -489,6 +532,7 @@ struct Builder {
             plan.jit.back().threads = js.threads;
         }
         JitLaunch &JL = plan.jit[bi->second];
+        for (uint32_t part = 0; part < parts.first; ++part) {   // one job per cluster range (one in all unless the tiles had to be partitioned)
         const size_t base = JL.blob.size();
         JL.blob.resize(base + js.args_size, 0);
         unsigned char *a = JL.blob.data() + base;
@@ -540,19 +584,28 @@ struct Builder {
                 put_ptr(js.off_breach + 8 * k, nan_ptr(b));
             }
             if (sparse) {   // the subtree walks only its live deals
-                put_ptr(js.off_list, plan.compact_jobs[size_t(sparse_slot[id])].list);
-                put_ptr(js.off_count, plan.compact_jobs[size_t(sparse_slot[id])].count);
+                const CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
+                put_ptr(js.off_list, cj.list + size_t(part) * cj.list_stride);
+                put_ptr(js.off_count, cj.count + size_t(part) * cj.count_stride);
             }
             // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
             // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
             size_t lds_total = 0;
             for (size_t k = 0; k < js.node_ids.size(); ++k) put_u32(js.off_loff + 4 * k, 0xffffffffu);
+            // the cluster range the tiles of this job cover: everything (rows as far apart as the table's), or one part
+            const uint32_t own_pitch = tp[p] ? tp[p] : tp[1 - p];
+            const uint32_t rp = parts.first > 1 ? parts.second : own_pitch;
+            const uint32_t c0 = parts.first > 1 ? part * parts.second : 0u;
+            const uint32_t n_cl = parts.n_clusters;
+            put_u32(js.off_c0, c0);
+            put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
+            put_u32(js.off_rp, rp);
             if (use_lds) {
                 static const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
                 for (size_t k = 0; k < js.node_ids.size(); ++k) {
                     const rs_tree_node &an = nodes[js.node_ids[k]];
-                    if (an.player == p && an.n_children > 0) tiles.emplace_back(size_t(2) * an.n_children * t->pitch[an.index], k);
+                    if (an.player == p && an.n_children > 0) tiles.emplace_back(size_t(2) * an.n_children * rp, k);
                 }
                 std::sort(tiles.begin(), tiles.end());
                 const size_t limit = size_t(lds_limit) / 4;
@@ -577,7 +630,8 @@ struct Builder {
         }
         JL.n_jobs += 1;
         JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
-        JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0);
+        JL.bytes += (bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0)) / parts.first;
+        }   // parts
         return RS_OK;
     }
 
@@ -685,32 +739,47 @@ struct Builder {
         // mccfr() follows ONE opponent action per node (cfr.rs:467-476): below a sampled node most deals are off their path (NaN reach).  A
         // subtree kernel that walks every deal would compute nothing for them; instead the live ones are compacted and only they are walked.
         std::vector<int> sparse_slot(n, -1);
-        static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr;
-        const bool want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
         // the compact jobs of `ids` (in that order); reach_of(id) = the buffer whose non-NaN lanes are the live deals
         auto make_lists = [&](const std::vector<int> &ids, auto reach_of) -> int {
             const size_t n_sparse = ids.size();
             if (!n_sparse) return RS_OK;
-            size_t list_elems = 0;
-            for (int id : ids) list_elems += s->pitch[lane_round[id]];
+            size_t list_elems = 0, n_counts = 0;
+            std::vector<uint32_t> n_parts(n_sparse, 1), part_size(n_sparse, 0);
+            for (size_t k = 0; k < n_sparse; ++k) {
+                const Parts pr = parts_of(ids[k]);
+                n_parts[k] = pr.first;
+                part_size[k] = pr.second;
+                list_elems += size_t(pr.first) * s->pitch[lane_round[ids[k]]];
+                n_counts += pr.first;
+            }
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
-            if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_sparse * kCountStride * sizeof(uint32_t));
-            if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_sparse * kCountStride * sizeof(uint32_t), t->stream);
+            if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
+            if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
             plan.compact_jobs.resize(n_sparse);
-            size_t at = 0;
+            plan.count_off.assign(n_sparse + 1, 0);
+            size_t at = 0, cat = 0;
             for (size_t k = 0; k < n_sparse; ++k) {
                 const int id = ids[k];
                 sparse_slot[id] = int(k);
                 CompactJob &cj = plan.compact_jobs[k];
+                cj = CompactJob{};
                 cj.reach = reach_of(id);
                 cj.list = plan.d_lists + at;
-                cj.count = plan.d_counts + k * kCountStride;   // one cache line each: atomics on neighbours would serialise
+                cj.count = plan.d_counts + cat * kCountStride;   // one cache line each: atomics on neighbours would serialise
                 cj.n_lanes = s->deals.n_deals;
-                at += s->pitch[lane_round[id]];
+                cj.n_parts = n_parts[k];
+                cj.part_size = std::max<uint32_t>(1, part_size[k]);
+                cj.list_stride = uint32_t(s->pitch[lane_round[id]]);
+                cj.count_stride = uint32_t(kCountStride);
+                cj.key = n_parts[k] > 1 ? s->deals.d_cluster[nodes[id].round_idx][p] : nullptr;   // the traverser's cluster on this round
+                plan.count_off[k] = cat;
+                at += size_t(n_parts[k]) * s->pitch[lane_round[id]];
+                cat += n_parts[k];
                 plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
             }
+            plan.count_off[n_sparse] = cat;
             ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
             return RS_OK;
@@ -745,12 +814,16 @@ struct Builder {
             }
             std::vector<int> listed;
             std::vector<std::pair<int, int>> slots_of_round(roots_of_round.size(), {0, 0});   // (first compact job, count)
+            if (want_lists && parts_of(first_root).first > 1) {   // its tiles had to be partitioned: every deal is live, listed by cluster range
+                slots_of_round[0] = {0, 1};
+                listed.push_back(first_root);
+            }
             if (want_lists)
                 for (size_t r = 1; r < roots_of_round.size(); ++r) {
                     slots_of_round[r] = {int(listed.size()), int(roots_of_round[r].size())};
                     listed.insert(listed.end(), roots_of_round[r].begin(), roots_of_round[r].end());
                 }
-            if (int rc = make_lists(listed, [&](int id) { return (const float *)nan_ptr(id); })) return rc;
+            if (int rc = make_lists(listed, [&](int id) { return id == first_root ? (const float *)nullptr : (const float *)nan_ptr(id); })) return rc;
             for (size_t r = 0; r < roots_of_round.size(); ++r) {
                 push_compact(slots_of_round[r].first, slots_of_round[r].second);
                 std::map<hipFunction_t, int> by_fn;
@@ -894,7 +967,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
     }
     if (L.kind == L_COMPACT) {   // jobs [first_job, first_job + n_jobs)
         prof_begin(t, RS_K_REACH, L.bytes);
-        hipError_t ec = hipMemsetAsync(plan.d_counts + size_t(L.first_job) * kCountStride, 0, size_t(L.n_jobs) * kCountStride * sizeof(uint32_t), t->stream);
+        const size_t c_lo = plan.count_off[size_t(L.first_job)], c_hi = plan.count_off[size_t(L.first_job + L.n_jobs)];
+        hipError_t ec = hipMemsetAsync(plan.d_counts + c_lo * kCountStride, 0, (c_hi - c_lo) * kCountStride * sizeof(uint32_t), t->stream);
         if (ec == hipSuccess) ec = launch_compact_live(plan.d_compact_jobs + L.first_job, L.n_jobs, plan.compact_max_lanes, t->stream);
         prof_end(t);
         RS_HIP(ec, "k_compact_live");
