@@ -290,6 +290,9 @@ size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
 int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);
+/* the same for deal batches (rs_solver_create_deals): the kernels of every round subtree -- reach-down half and table-updating walk, dense and
+ * over a live-deal list, with and without LDS tiles */
+int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels);
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
 
 /* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------

@@ -20,7 +20,7 @@ if not _BUILDING:
 
 from .solver import (DealTrainer, DeviceBuffer, GameTree, Infoset, InfosetTable, MCCFRTrainer, Options,  # noqa: E402
                      build_game_tree, create_infosets, deal_buffer, deal_pitch, default_flop, device_count, discount_factor,
-                     jit_check_tree, showdown_sign,
+                     jit_check_tree, jit_check_tree_deals, showdown_sign,
                      three_street_options, tree_from_nodes)
 from . import synth  # noqa: E402
 from . import abstraction  # noqa: E402

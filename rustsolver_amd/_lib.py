@@ -138,6 +138,7 @@ SYMBOLS = {
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
     "rs_jit_available": (C.c_int, []),
     "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rs_jit_check_tree_deals": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rs_cluster_file_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]),
     "rs_cluster_file_write": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.c_size_t]),
     "rs_free_u32": (None, [C.POINTER(C.c_uint32)]),

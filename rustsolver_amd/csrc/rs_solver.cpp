@@ -1397,6 +1397,56 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }
+// the same for deal batches: every round subtree (cut at the chance nodes) in the forms rs_solver_create_deals can pick -- the DOWN half and the
+// table-updating walk, each dense and over a live-deal list, the walk with and without LDS tiles
+int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels) {
+    if (!tree || tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_jit_check_tree_deals: bad tree");
+    const std::vector<rs_tree_node> &nodes = tree->nodes;
+    const size_t n = nodes.size();
+    auto resolve = [&](int c) {
+        while (nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = nodes[size_t(c)].children[0];
+        return c;
+    };
+    std::vector<char> root(n, 0);   // first action node, and every action node reached through a chance node
+    const int first = resolve(0);
+    if (nodes[size_t(first)].kind == RS_NODE_ACTION && nodes[size_t(first)].n_children > 0) root[size_t(first)] = 1;
+    for (size_t i = 0; i < n; ++i)
+        if (i > 0 && (nodes[i].kind == RS_NODE_PRIVATE_CHANCE || nodes[i].kind == RS_NODE_PUBLIC_CHANCE)) {
+            const int c = resolve(int(i));
+            if (nodes[size_t(c)].kind == RS_NODE_ACTION && nodes[size_t(c)].n_children > 0) root[size_t(c)] = 1;
+        }
+    std::map<std::string, int> seen;
+    for (int p = 0; p < 2; ++p) {
+        std::vector<char> has_own(n, 0);
+        std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
+        for (size_t i = n; i-- > 0;) {   // children have larger ids than parents
+            const rs_tree_node &nd = nodes[i];
+            bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
+            for (int k = 0; k < nd.n_children; ++k) own = own || has_own[size_t(nd.children[k])];
+            has_own[i] = own;
+            if (nd.kind == RS_NODE_TERMINAL && nd.ttype != RS_TERM_UNCONTESTED) {
+                leaf_buf[i] = 0;
+                leaf_flags[i] = 1;
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (!root[i]) continue;
+            for (int form = 0; form < 6; ++form) {   // down dense / sparse, walk lds dense / sparse, walk direct dense / sparse
+                const bool down = form < 2, sparse = (form & 1) != 0, lds = form >= 2 && form < 4;
+                if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
+                JitSubtree js;
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down, &root,
+                                 js);
+                if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
+                if (seen.count(js.source)) continue;
+                seen[js.source] = 1;
+                if (int rc = jit_compile_only(js.source)) return rc;
+            }
+        }
+    }
+    if (n_kernels) *n_kernels = int(seen.size());
+    return RS_OK;
+}
 int rs_solver_n_launches(const rs_solver *s, int traverser) {
     if (!s || traverser < 0 || traverser > 1) return RS_ERR_INVALID;
     return int(s->plan[traverser].launches.size());

@@ -685,6 +685,13 @@ def jit_check_tree(tree, dtype=L.I32, mode=L.UPD_CLAMP_I64, opp_mode=L.OPP_FULL)
     return n.value
 
 
+def jit_check_tree_deals(tree, mode=L.UPD_CLAMP_I64, opp_mode=L.OPP_SAMPLE):
+    """compile (no GPU needed) every deal-batch kernel of `tree`: round subtrees, reach-down and walk, dense / listed, LDS / direct"""
+    n = C.c_int()
+    L.check(L.load().rs_jit_check_tree_deals(tree._h, mode, opp_mode, C.byref(n)))
+    return n.value
+
+
 def discount_factor(tc, interval=MCCFRTrainer.DISCOUNT_INTERVAL):
     """cfr.rs:248-249"""
     return np.float32(L.load().rs_discount_factor(tc, interval))
