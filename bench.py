@@ -322,6 +322,37 @@ def kmeans_leg(rs, device, with_cpu, cpu_seconds):
     return out
 
 
+def three_street_leg(rs, device):
+    """The reference's commented-out "real" configuration (options.rs:68-77): flop start, three betting rounds (706 action nodes), 5 000-bucket
+    files on every street (EMD / OCHS shape: index -> bucket file -> dense id), sampled mccfr over 1 M deals per batch, everything on the device.
+    Round subtrees with reach-down / walk-up kernels, live-deal lists, cluster-partitioned LDS tiles."""
+    import numpy as np
+    from rustsolver_amd import abstraction as ab
+    rng = np.random.Generator(np.random.PCG64(1))
+    mask = ab.card_mask("7h8hQc")
+    hands = ab.random_range(mask)
+    k, n = 5000, 1 << 20
+    files = [rng.integers(0, k, size=size, dtype=np.uint32) for size in (1286792, 13960050, 123156254)]   # hand_indexer sizes of [2,3] [2,4] [2,5]
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
+    t0 = time.perf_counter()
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, device=device)
+    create_s = time.perf_counter() - t0
+    tr.train(2)
+    tr.status()
+    reps = 5
+    t0 = time.perf_counter()
+    tr.train(reps)
+    tr.infosets.sync()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"what": "MCCFRTrainer::train on a flop-start three-street tree (%d action nodes), %d-bucket files on flop / turn / river, %d deals per batch, sampled "
+                   "opponents: deal sampling, hand indexing through the bucket files, showdowns and the sweep on the device" % (n_actions, k, n),
+           "value": n / dt, "unit": "deal-iterations/s", "ms_per_batch": dt * 1e3, "n_deals": n, "clusters": [a_.get_size(0) for a_ in card_abs],
+           "table_bytes": int(tr.infosets.nbytes if not callable(tr.infosets.nbytes) else tr.infosets.nbytes()), "trainer_create_s": create_s}
+    tr.destroy()
+    return out
+
+
 def dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout):
     """--dp-deals 1: MCCFRTrainer::train as coded (see deal_trainer_leg), data-parallel: every rank deals and sweeps 4 M deals of each global
     batch against its replica of the table; per traverser sweep the two i32 delta arrays are all-reduced over RCCL (xGMI) and every rank
@@ -639,6 +670,11 @@ def main():
         out["deal_trainer"] = deal_trainer_leg(rs, device, 1 << 22, not a.no_cpu, min(a.cpu_seconds, 6.0))
     except Exception as e:
         out["deal_trainer"] = {"error": str(e)}
+
+    try:
+        out["deal_trainer_three_street"] = three_street_leg(rs, device)
+    except Exception as e:
+        out["deal_trainer_three_street"] = {"error": str(e)}
 
     try:
         out["kmeans_predict"] = kmeans_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))
