@@ -246,20 +246,30 @@ def test_deal_trainer_three_streets_from_a_flop_with_bucket_files():
     compare_trainer_tables(ctx)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world):
+@pytest.mark.parametrize("world,streets", [(2, 1), (3, 1), (2, 3)])
+def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets):
     """`world` ranks x n deals on replicated tables, their i32 deltas summed between sweep and apply (what rs_comm_allreduce_deltas does
     over xGMI; here the test adds them on the host), equal ONE trainer with world*n deals per batch, bit for bit: cards, tables, discount
-    ticks.  Ranks are emulated on one GPU, one trainer per rank."""
-    mask = ab.card_mask("4d5dAs3cKs")
-    hands = ab.random_range(mask)[::3]
-    n_actions, tree = rs.build_game_tree(rs.default_flop())
-    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    ticks.  Ranks are emulated on one GPU, one trainer per rank.  streets = 3: a flop-start tree, i.e. round subtrees, live-deal lists and the
+    rank's lane base in the sampling hash together."""
+    if streets == 1:
+        mask = ab.card_mask("4d5dAs3cKs")
+        hands = ab.random_range(mask)[::3]
+        n_actions, tree = rs.build_game_tree(rs.default_flop())
+        card_abs = [ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)]
+    else:
+        rng = np.random.Generator(np.random.PCG64(4))
+        mask = ab.card_mask("2c9dKh")
+        allh = ab.random_range(mask)
+        hands = allh[rng.permutation(len(allh))[:35]]
+        n_actions, tree = rs.build_game_tree(rs.three_street_options())
+        files = [rng.integers(0, 23, size=1286792, dtype=np.uint32), rng.integers(0, 41, size=13960050, dtype=np.uint32), None]
+        card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
     n = 700
     kw = dict(seed=21, discount_interval=2 * world * n - 100, discount_cap=10**9)
-    ranks = [rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, world=world, rank=r, **kw) for r in range(world)]
-    single = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, world * n, **kw)
-    for batch in range(4):
+    ranks = [rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, world=world, rank=r, **kw) for r in range(world)]
+    single = rs.DealTrainer(tree, card_abs, [hands, hands], mask, world * n, **kw)
+    for batch in range(4 if streets == 1 else 2):
         for tr in ranks:
             tr.deal()
         for player in (0, 1):
@@ -280,7 +290,7 @@ def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world):
             for tr in ranks:
                 got = tr.infosets.download_node(nd.index)
                 assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (batch, nd.index)
-    assert all(tr.iterations == single.iterations == 4 * world * n for tr in ranks)
+    assert all(tr.iterations == single.iterations for tr in ranks)
     for tr in ranks + [single]:
         tr.status()
 
