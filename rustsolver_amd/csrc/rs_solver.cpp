@@ -438,12 +438,12 @@ struct Builder {
         bnd.assign(n, {});
         nan_slot.assign(n, -1);
         {
-            static const bool round_off = getenv("RS_JIT_NO_ROUNDS") != nullptr;
+            const bool round_off = getenv("RS_JIT_NO_ROUNDS") != nullptr;
             const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
             first_root = resolve(0);
             round_mode = s->deal_mode && s->params.fuse_subtrees && !prune && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
-            static const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
+            const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
             want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
             want_parts = round_mode && want_lists && !parts_off;
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
@@ -513,7 +513,7 @@ struct Builder {
                 }
             }
         }
-        static const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
+        const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
         const bool sparse = sparse_slot[id] >= 0;
         const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
         if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
@@ -601,7 +601,7 @@ struct Builder {
             put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
             put_u32(js.off_rp, rp);
             if (use_lds) {
-                static const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
+                const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
                 for (size_t k = 0; k < js.node_ids.size(); ++k) {
                     const rs_tree_node &an = nodes[js.node_ids[k]];

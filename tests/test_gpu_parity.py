@@ -473,15 +473,17 @@ def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
 
 
 @pytest.mark.parametrize("blocks", [None, "2"])
-@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("sparse", [True, False, "no-rounds", "no-rounds-no-sparse"])
 def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypatch):
     """sampled three-street sweeps over 40 000 deals: every river subtree walks only the compacted list of its live deals (several trips per
-    workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked.  Same bits, and
-    equal to the oracle."""
+    workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked; with RS_JIT_NO_ROUNDS the flop and
+    turn rounds run as level kernels again.  The knobs are read when a solver is created.  Same bits, and equal to the oracle."""
     if blocks:
         monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
-    if not sparse:
+    if sparse is False or sparse == "no-rounds-no-sparse":
         monkeypatch.setenv("RS_JIT_NO_SPARSE", "1")
+    if isinstance(sparse, str):   # the level plan for flop / turn and chance-free river subtrees, as before the round subtrees
+        monkeypatch.setenv("RS_JIT_NO_ROUNDS", "1")
     n_deals = 40000
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (11, 8), (13, 17)], n_deals, 91)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=12)
