@@ -195,6 +195,13 @@ int stage_centers(rs_table *t, const std::vector<float> &prepared, const std::ve
     return RS_OK;
 }
 
+// histograms are padded with empty bins to the next instantiated width (registers and LDS rows per thread)
+int padded_bins(int n_bins) {
+    for (int nb : {8, 16, 24, 32, 48, 64})
+        if (n_bins <= nb) return nb;
+    return 64;
+}
+
 dim3 km_grid(size_t n) { return dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + kKmBlock - 1) / kKmBlock, 16384))); }
 
 }  // namespace
@@ -262,7 +269,7 @@ int rs_kmeans_predict(rs_table *t, int dist, const float *d_dataset, size_t n, c
                       float *d_min_dist) {
     if (int rc = check_args("rs_kmeans_predict", t, dist, d_dataset, n, centers, n_centers, n_bins)) return rc;
     if (!d_clusters && !d_min_dist) return RS_OK;
-    const int nb = n_bins <= 32 ? 32 : 64;
+    const int nb = padded_bins(n_bins);
     std::vector<float> prepared;
     std::vector<unsigned char> zero;
     prepare_centers(dist, centers, n_centers, n_bins, nb, prepared, zero);
@@ -273,14 +280,17 @@ int rs_kmeans_predict(rs_table *t, int dist, const float *d_dataset, size_t n, c
     if (e == hipSuccess && n > 0) {
         const size_t lds = size_t(nb) * kKmBlock * sizeof(float);
         const dim3 grid = km_grid(n), block(kKmBlock);
-        if (nb == 32 && dist == RS_DIST_EMD)
-            hipLaunchKernelGGL((k_kmeans_predict<32, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers, d_clusters, d_min_dist);
-        else if (nb == 64 && dist == RS_DIST_EMD)
-            hipLaunchKernelGGL((k_kmeans_predict<64, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers, d_clusters, d_min_dist);
-        else if (nb == 32)
-            hipLaunchKernelGGL((k_kmeans_predict<32, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers, d_clusters, d_min_dist);
-        else
-            hipLaunchKernelGGL((k_kmeans_predict<64, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers, d_clusters, d_min_dist);
+#define RS_KM_PREDICT(NB_)                                                                                                                          \
+    if (nb == NB_) {                                                                                                                           \
+        if (dist == RS_DIST_EMD)                                                                                                               \
+            hipLaunchKernelGGL((k_kmeans_predict<NB_, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers, \
+                               d_clusters, d_min_dist);                                                                                        \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((k_kmeans_predict<NB_, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_centers, d_zero, n_centers,    \
+                               d_clusters, d_min_dist);                                                                                        \
+    }
+        RS_KM_PREDICT(8) RS_KM_PREDICT(16) RS_KM_PREDICT(24) RS_KM_PREDICT(32) RS_KM_PREDICT(48) RS_KM_PREDICT(64)
+#undef RS_KM_PREDICT
         e = hipGetLastError();
     }
     RS_HIP(e, "k_kmeans_predict");
@@ -291,7 +301,7 @@ int rs_kmeans_predict(rs_table *t, int dist, const float *d_dataset, size_t n, c
 int rs_update_min_dists(rs_table *t, int dist, float *d_min_dists, const float *d_dataset, size_t n, const float *new_center, int n_bins) {
     if (int rc = check_args("rs_update_min_dists", t, dist, d_dataset, n, new_center, 1, n_bins)) return rc;
     if (!d_min_dists && n) return fail(RS_ERR_INVALID, "rs_update_min_dists: NULL argument");
-    const int nb = n_bins <= 32 ? 32 : 64;
+    const int nb = padded_bins(n_bins);
     std::vector<float> prepared;
     std::vector<unsigned char> zero;
     prepare_centers(dist, new_center, 1, n_bins, nb, prepared, zero);
@@ -303,10 +313,15 @@ int rs_update_min_dists(rs_table *t, int dist, float *d_min_dists, const float *
         const size_t lds = size_t(nb) * kKmBlock * sizeof(float);
         const dim3 grid = km_grid(n), block(kKmBlock);
         const int z = zero[0];
-        if (nb == 32 && dist == RS_DIST_EMD) hipLaunchKernelGGL((k_update_min_dists<32, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);
-        else if (nb == 64 && dist == RS_DIST_EMD) hipLaunchKernelGGL((k_update_min_dists<64, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);
-        else if (nb == 32) hipLaunchKernelGGL((k_update_min_dists<32, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);
-        else hipLaunchKernelGGL((k_update_min_dists<64, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);
+#define RS_KM_MIND(NB_)                                                                                                                                 \
+    if (nb == NB_) {                                                                                                                              \
+        if (dist == RS_DIST_EMD)                                                                                                                  \
+            hipLaunchKernelGGL((k_update_min_dists<NB_, RS_DIST_EMD>), grid, block, lds, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);       \
+        else                                                                                                                                      \
+            hipLaunchKernelGGL((k_update_min_dists<NB_, RS_DIST_L2>), grid, block, 0, t->stream, d_dataset, n, n_bins, d_center, z, d_min_dists);          \
+    }
+        RS_KM_MIND(8) RS_KM_MIND(16) RS_KM_MIND(24) RS_KM_MIND(32) RS_KM_MIND(48) RS_KM_MIND(64)
+#undef RS_KM_MIND
         e = hipGetLastError();
     }
     RS_HIP(e, "k_update_min_dists");
