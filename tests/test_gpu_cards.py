@@ -325,6 +325,21 @@ def test_data_parallel_trainer_over_rccl_with_one_rank():
     L.load().rs_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("n_deals", [1, 3, 65, 257])
+def test_deal_trainer_ragged_batches(n_deals):
+    """batches that are not multiples of the 4-deal vector or the 64-lane pitch, ranges of two combos: against the oracle chain"""
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    ranges = [hands[[10, 700]], hands[[333, 20]]]
+    ctx = load_trainer_pair(rs.default_flop(), orc.options_default_river(), mask, ranges, 1, n_deals, seed=3, interval=0, cap=0)
+    for b in range(3):
+        ctx["tr"].train(1)
+        cards = oracle_batch(ctx)
+        assert (ctx["tr"].cards() == cards).all()
+    ctx["tr"].status()
+    compare_trainer_tables(ctx)
+
+
 def test_deal_trainer_rejects_bad_inputs():
     mask = ab.card_mask("4d5dAs3cKs")
     hands = ab.random_range(mask)
