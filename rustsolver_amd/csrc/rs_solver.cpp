@@ -25,6 +25,7 @@ constexpr size_t kCountStride = 64;   // u32 elements between two live-deal coun
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL };
 
 struct Launch {
+    int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
     int kind;
     int n_actions = 0;
     int first_job = 0, n_jobs = 0;
@@ -100,6 +101,10 @@ struct rs_solver {
     size_t exchange_floats_per_rank = 0;
     rs_comm *comm = nullptr;
     int n_cus = 256;                    // multiprocessors of the device (grid of the persistent deal kernels)
+    // round subtrees of one round are independent: their launches are spread over a few auxiliary streams (fork / join with events)
+    static constexpr int kAux = 4;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
     // deal sweeps through tree-specialised kernels read the table from an AoS shadow rebuilt at the start of every sweep
     int32_t *d_shadow = nullptr;
     std::vector<size_t> shadow_off;     // per table node, in ints
@@ -216,6 +221,8 @@ struct Builder {
     std::vector<int> nan_slot;               // per round root (except the first): slot of its reach buffer in the NaN-prefilled arena
     int n_nan = 0;
     int first_root = -1;
+    std::vector<std::vector<int>> roots_of_round;   // round subtrees by betting round
+    int next_group = 0;
     int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
     bool want_lists = false, want_parts = false;
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
@@ -796,7 +803,7 @@ struct Builder {
         if (round_mode) {
             // ---- round subtrees, top-down: NaN-fill every root's reach buffer, then round by round compact the live deals of the round's
             // roots and let their DOWN kernels hand reach to the next round's roots
-            std::vector<std::vector<int>> roots_of_round(1, std::vector<int>{first_root});
+            roots_of_round.assign(1, std::vector<int>{first_root});
             for (size_t r = 0; r < roots_of_round.size(); ++r)
                 for (int root : roots_of_round[r])
                     for (int b : bnd[size_t(root)]) {
@@ -832,9 +839,11 @@ struct Builder {
                     for (int b : bnd[size_t(root)]) reach[b] = ReachSrc{nan_ptr(b), 0.0f, true};
                     if (int rc = add_jit_job(root, true, sparse_slot, by_fn)) return rc;
                 }
+                const int group = ++next_group;   // the DOWN kernels of one round write different reach buffers
                 for (auto &kv : by_fn) {
                     Launch L;
                     L.kind = L_TREE;
+                    L.group = group;
                     L.first_job = kv.second;
                     L.bytes = plan.jit[kv.second].bytes;
                     plan.launches.push_back(L);
@@ -863,7 +872,7 @@ struct Builder {
                 const rs_tree_node &nd = nodes[id];
                 if (inside[id] || dead_end(id) || !in_pass(id)) continue;
                 if (fused_root[id]) {
-                    sub_roots.push_back(id);
+                    if (!round_mode) sub_roots.push_back(id);   // round subtrees walk back up round by round, below
                     continue;
                 }
                 if (nd.kind == RS_NODE_ACTION) (nd.player == p ? upd_groups : util_groups)[nd.n_children].push_back(id);
@@ -931,6 +940,21 @@ struct Builder {
             }
         }
         }   // pass
+        if (round_mode)   // ---- round subtrees, bottom-up: last round first; the subtrees of one round are independent of each other
+            for (size_t r = roots_of_round.size(); r-- > 0;) {
+                std::map<hipFunction_t, int> by_fn;
+                for (int root : roots_of_round[r])
+                    if (int rc = add_jit_job(root, false, sparse_slot, by_fn)) return rc;
+                const int group = ++next_group;
+                for (auto &kv : by_fn) {
+                    Launch L;
+                    L.kind = L_TREE;
+                    L.group = group;
+                    L.first_job = kv.second;
+                    L.bytes = plan.jit[kv.second].bytes;
+                    plan.launches.push_back(L);
+                }
+            }
         if (!s->sharded) plan.split = plan.launches.size();   // deal batches: phase 0 = the sweep, phase 1 = the apply below
         if (s->deal_mode) {   // table += delta, delta = 0
             Launch L;
@@ -947,8 +971,9 @@ struct Builder {
     }
 };
 
-int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
+int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree_stream = nullptr) {
     rs_table *t = s->table;
+    if (!tree_stream) tree_stream = t->stream;
     static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
     if (L.kind == L_APPLY) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
@@ -1006,12 +1031,40 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L) {
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         void *params[] = {&d_blob, &flags};
-        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, t->stream, params, nullptr);
+        e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, tree_stream, params, nullptr);
         break;
     }
     }
     prof_end(t);
     RS_HIP(e, "plan launch");
+    return RS_OK;
+}
+
+// launches [lo, hi) in order; consecutive launches of one group (independent round subtrees) are spread over the auxiliary streams:
+// the main stream records a fork event, every used stream waits for it, and the main stream waits for all of them afterwards.  The same
+// calls inside a stream capture become the forks and joins of the graph.
+int run_range(rs_solver *s, Plan &plan, size_t lo, size_t hi) {
+    rs_table *t = s->table;
+    for (size_t i = lo; i < hi;) {
+        size_t j = i + 1;
+        if (plan.launches[i].group > 0)
+            while (j < hi && plan.launches[j].group == plan.launches[i].group) ++j;
+        if (j - i < 2 || !s->ev_fork || t->prof.on) {
+            for (; i < j; ++i)
+                if (int rc = run_launch(s, plan, plan.launches[i])) return rc;
+            continue;
+        }
+        RS_HIP(hipEventRecord(s->ev_fork, t->stream), "fork");
+        const int used = int(std::min<size_t>(rs_solver::kAux, j - i));
+        for (int k = 0; k < used; ++k) RS_HIP(hipStreamWaitEvent(s->aux[k], s->ev_fork, 0), "fork wait");
+        for (size_t k = i; k < j; ++k)
+            if (int rc = run_launch(s, plan, plan.launches[k], s->aux[(k - i) % rs_solver::kAux])) return rc;
+        for (int k = 0; k < used; ++k) {
+            RS_HIP(hipEventRecord(s->ev_join[k], s->aux[k]), "join");
+            RS_HIP(hipStreamWaitEvent(t->stream, s->ev_join[k], 0), "join wait");
+        }
+        i = j;
+    }
     return RS_OK;
 }
 
@@ -1022,9 +1075,7 @@ int run_plan(rs_solver *s, int p, int phase = -1) {
     if (phase < 0 && s->params.use_graph && !t->prof.on && !s->sharded && !s->comm) {
         if (!plan.graph_exec) {
             RS_HIP(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-            int rc = RS_OK;
-            for (const Launch &L : plan.launches)
-                if ((rc = run_launch(s, plan, L)) != RS_OK) break;
+            const int rc = run_range(s, plan, 0, plan.launches.size());
             hipError_t e = hipStreamEndCapture(t->stream, &plan.graph);
             if (rc != RS_OK) return rc;
             RS_HIP(e, "hipStreamEndCapture");
@@ -1034,9 +1085,7 @@ int run_plan(rs_solver *s, int p, int phase = -1) {
         return RS_OK;
     }
     const size_t lo = phase == 1 ? plan.split : 0, hi = phase == 0 ? plan.split : plan.launches.size();
-    for (size_t i = lo; i < hi; ++i)
-        if (int rc = run_launch(s, plan, plan.launches[i])) return rc;
-    return RS_OK;
+    return run_range(s, plan, lo, hi);
 }
 
 }  // namespace
@@ -1092,6 +1141,14 @@ void rs::solver_release_device(rs_solver *s) {
         pl = Plan{};
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
+    for (int k = 0; k < rs_solver::kAux; ++k) {
+        if (s->aux[k]) (void)hipStreamDestroy(s->aux[k]);
+        if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
+        s->aux[k] = nullptr;
+        s->ev_join[k] = nullptr;
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    s->ev_fork = nullptr;
     if (s->d_shadow) (void)hipFree(s->d_shadow);
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
     s->d_shadow = nullptr;
@@ -1169,6 +1226,18 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         if ((e = hipMalloc((void **)&s->d_seed_state, sizeof(init))) != hipSuccess ||
             (e = hipMemcpy(s->d_seed_state, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) {
             rc = hip_fail(e, "rs_solver_create: seed state");
+            rs_solver_destroy(s);
+            return rc;
+        }
+    }
+    if (s->deal_mode && s->params.fuse_subtrees && !getenv("RS_JIT_NO_OVERLAP")) {   // streams for independent round subtrees
+        e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+        for (int k = 0; e == hipSuccess && k < rs_solver::kAux; ++k) {
+            e = hipStreamCreateWithFlags(&s->aux[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "rs_solver_create: auxiliary streams");
             rs_solver_destroy(s);
             return rc;
         }
