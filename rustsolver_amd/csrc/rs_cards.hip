@@ -710,6 +710,14 @@ int rs_card_abs_get_cluster(const rs_card_abs *a, const uint8_t *cards, size_t n
 // (the layout of rs_showdown_sign).  d_cluster_p0 / d_cluster_p1 [pitch] (either may be NULL).  Asynchronous; a deal whose bucket has no
 // dense id raises the abstraction's error word, reported by rs_card_abs_status.
 int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0, uint32_t *d_cluster_p1) {
+    return rs::card_abs_clusters_on(a, t, t ? t->stream : nullptr, d_cards, n_deals, d_cluster_p0, d_cluster_p1);
+}
+}  // extern "C" (interrupted: the stream-taking forms below are internal)
+
+namespace rs {
+// the same on a stream of the caller's choice (the trainer deals the NEXT batch beside the sweeps of the current one)
+int card_abs_clusters_on(rs_card_abs *a, rs_table *t, hipStream_t stream, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0,
+                         uint32_t *d_cluster_p1) {
     if (!a || !t || !d_cards) return fail(RS_ERR_INVALID, "rs_card_abs_clusters_device: NULL argument");
     if (!d_cluster_p0 && !d_cluster_p1) return RS_OK;
     HandIndexView v;
@@ -738,11 +746,14 @@ int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_ca
         j.out = dst;
     }
     if (n_deals == 0) return RS_OK;
-    hipLaunchKernelGGL(k_deal_clusters, lane_grid(n_deals, uint32_t(n_jobs)), dim3(kBlock), 0, t->stream, jobs, d_cards, n_deals,
+    hipLaunchKernelGGL(k_deal_clusters, lane_grid(n_deals, uint32_t(n_jobs)), dim3(kBlock), 0, stream, jobs, d_cards, n_deals,
                        uint32_t(round_up(n_deals, kLanePad)), dev.err);
     RS_HIP(hipGetLastError(), "k_deal_clusters");
     return RS_OK;
 }
+}  // namespace rs
+
+extern "C" {
 
 // synchronises and reports (then clears) what the device kernels flagged since the last call
 int rs_card_abs_status(rs_card_abs *a, rs_table *t) {
@@ -764,6 +775,13 @@ int rs_card_abs_status(rs_card_abs *a, rs_table *t) {
 // the counter hash (seed, first_deal + i).  d_cards[9][pitch] as above.  d_err (may be NULL): bit 2 raised when a deal found no valid combo.
 int rs_deals_sample(rs_table *t, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
                     const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err) {
+    return rs::deals_sample_on(t, t ? t->stream : nullptr, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1, n_hands_p1, n_deals, d_cards, d_err);
+}
+}  // extern "C"
+
+namespace rs {
+int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
+                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err) {
     if (!t || !d_hands_p0 || !d_hands_p1 || !d_cards) return fail(RS_ERR_INVALID, "rs_deals_sample: NULL argument");
     if (n_hands_p0 == 0 || n_hands_p1 == 0) return fail(RS_ERR_INVALID, "rs_deals_sample: empty hand range (Rust: choose().unwrap() on None, cfr.rs:129)");
     if (board_mask >> 52) return fail(RS_ERR_INVALID, "rs_deals_sample: board mask has bits beyond card 51");
@@ -775,10 +793,9 @@ int rs_deals_sample(rs_table *t, uint64_t seed, uint64_t first_deal, uint64_t bo
         d_err = t->d_err_sink;   // nobody reads it
     }
     if (n_deals == 0) return RS_OK;
-    hipLaunchKernelGGL(k_deal_sample, lane_grid(n_deals), dim3(kBlock), 0, t->stream, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1,
+    hipLaunchKernelGGL(k_deal_sample, lane_grid(n_deals), dim3(kBlock), 0, stream, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1,
                        n_hands_p1, n_deals, uint32_t(round_up(n_deals, kLanePad)), d_cards, d_err);
     RS_HIP(hipGetLastError(), "k_deal_sample");
     return RS_OK;
 }
-
-}  // extern "C"
+}  // namespace rs

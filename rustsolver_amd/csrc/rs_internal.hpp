@@ -203,7 +203,13 @@ struct rs_table {
     void *ssum_ptr(int node) const { return (char *)d_ssum + cell_off[node] * rs::elem_size(dtype); }
 };
 
+struct rs_card_abs;
 namespace rs {
+// card kernels on a stream of the caller's choice (rs_cards.hip); the C ABI forms use the table's stream
+int card_abs_clusters_on(rs_card_abs *abs, rs_table *t, hipStream_t stream, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0,
+                         uint32_t *d_cluster_p1);
+int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
+                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err);
 void solver_release_device(struct rs_solver *s);   // frees a solver's device state and detaches it from its table
 // profiling hooks used around launches
 void prof_begin(rs_table *t, int kind, double bytes);

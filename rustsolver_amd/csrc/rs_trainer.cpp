@@ -28,6 +28,15 @@ struct rs_deal_trainer {
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
     uint32_t world = 1, rank = 0;  // data-parallel training: this rank's share of every global batch
+    // The NEXT batch is dealt (sample -> clusters -> showdown) into staging buffers on a second stream while the current one is swept -- the
+    // sweep kernels leave most wave slots of a CU idle -- and swapped in with device-to-device copies.  Same deal numbers, same results.
+    hipStream_t deal_stream = nullptr;
+    hipEvent_t ev_dealt = nullptr, ev_taken = nullptr;
+    uint8_t *s_cards = nullptr;
+    uint32_t *s_cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS] = {};
+    float *s_sign = nullptr;
+    bool staged = false;           // the staging buffers hold the next batch (or will, once ev_dealt fires)
+    bool taken_recorded = false;
 };
 
 extern "C" {
@@ -41,6 +50,15 @@ void rs_deal_trainer_destroy(rs_deal_trainer *tr) {
         if (tr->d_cards) rs_dfree(tr->table, tr->d_cards);
         if (tr->d_sign) rs_dfree(tr->table, tr->d_sign);
         if (tr->d_err) rs_dfree(tr->table, tr->d_err);
+        if (tr->deal_stream) (void)hipStreamSynchronize(tr->deal_stream);
+        if (tr->s_cards) rs_dfree(tr->table, tr->s_cards);
+        if (tr->s_sign) rs_dfree(tr->table, tr->s_sign);
+        for (int r = 0; r < RS_MAX_ROUNDS; ++r)
+            for (int p = 0; p < RS_MAX_PLAYERS; ++p)
+                if (tr->s_cluster[r][p]) rs_dfree(tr->table, tr->s_cluster[r][p]);
+        if (tr->deal_stream) (void)hipStreamDestroy(tr->deal_stream);
+        if (tr->ev_dealt) (void)hipEventDestroy(tr->ev_dealt);
+        if (tr->ev_taken) (void)hipEventDestroy(tr->ev_taken);
         for (int r = 0; r < RS_MAX_ROUNDS; ++r)
             for (int p = 0; p < RS_MAX_PLAYERS; ++p)
                 if (tr->d_cluster[r][p]) rs_dfree(tr->table, tr->d_cluster[r][p]);
@@ -120,6 +138,25 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_sign, 0, pitch * sizeof(float));
     if (rc == RS_OK) rc = rs_dmalloc(tr->table, 256, reinterpret_cast<void **>(&tr->d_err));
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_err, 0, 256);
+    if (rc == RS_OK && !getenv("RS_TRAINER_NO_PREFETCH")) {   // staging for the batch dealt ahead
+        rc = rs_dmalloc(tr->table, 9 * pitch, reinterpret_cast<void **>(&tr->s_cards));
+        if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_cards, 0, 9 * pitch);
+        if (rc == RS_OK) rc = rs_dmalloc(tr->table, pitch * sizeof(float), reinterpret_cast<void **>(&tr->s_sign));
+        if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_sign, 0, pitch * sizeof(float));
+        for (int r = 0; rc == RS_OK && r < n_rounds; ++r)
+            for (int p = 0; rc == RS_OK && p < 2; ++p) {
+                rc = rs_dmalloc(tr->table, pitch * sizeof(uint32_t), reinterpret_cast<void **>(&tr->s_cluster[r][p]));
+                if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_cluster[r][p], 0, pitch * sizeof(uint32_t));
+            }
+        if (rc == RS_OK) {
+            hipError_t e = hipSetDevice(device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&tr->deal_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&tr->ev_dealt, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&tr->ev_taken, hipEventDisableTiming);
+            if (e != hipSuccess) rc = hip_fail(e, "rs_deal_trainer_create: dealing stream");
+        }
+        if (rc == RS_OK) rc = rs_sync(tr->table);   // the memsets above ran on the table's stream
+    }
     rs_deal_batch batch{};
     batch.n_deals = params->deals_per_batch;
     for (int r = 0; rc == RS_OK && r < n_rounds; ++r)
@@ -158,18 +195,52 @@ const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *tr, int round_id
     return tr && round_idx >= 0 && round_idx < tr->n_rounds && (player == 0 || player == 1) ? tr->d_cluster[round_idx][player] : nullptr;
 }
 
+// sample -> clusters -> showdown of batch number `tr->batches` into (cards, cluster, sign) on `stream`
+static int deal_into(rs_deal_trainer *tr, hipStream_t stream, uint8_t *cards, uint32_t *cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], float *sign) {
+    const uint32_t n = tr->params.deals_per_batch;
+    const uint64_t first_deal = (tr->batches * tr->world + tr->rank) * uint64_t(n);   // global batch b = deals [b*world*n, (b+1)*world*n)
+    if (int rc = deals_sample_on(tr->table, stream, tr->params.seed, first_deal, tr->params.board_mask, tr->d_hands[0], tr->n_hands[0], tr->d_hands[1],
+                                 tr->n_hands[1], n, cards, tr->d_err))
+        return rc;
+    for (int r = 0; r < tr->n_rounds; ++r)
+        if (int rc = card_abs_clusters_on(tr->abs[r], tr->table, stream, cards, n, cluster[r][0], cluster[r][1])) return rc;
+    hipError_t e = launch_showdown_sign(cards, sign, n, uint32_t(round_up(n, kLanePad)), stream);
+    if (e != hipSuccess) return hip_fail(e, "k_showdown_sign");
+    tr->batches += 1;
+    return RS_OK;
+}
+
+// deal the batch after the one in the live buffers into the staging buffers, beside whatever the table's stream is doing
+static int prefetch(rs_deal_trainer *tr) {
+    if (!tr->deal_stream || tr->staged) return RS_OK;
+    hipError_t e = hipSetDevice(rs_table_device(tr->table));
+    if (e == hipSuccess && tr->taken_recorded) e = hipStreamWaitEvent(tr->deal_stream, tr->ev_taken, 0);   // the previous staged batch has been copied out
+    if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer: prefetch");
+    if (int rc = deal_into(tr, tr->deal_stream, tr->s_cards, tr->s_cluster, tr->s_sign)) return rc;
+    e = hipEventRecord(tr->ev_dealt, tr->deal_stream);
+    if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer: prefetch");
+    tr->staged = true;
+    return RS_OK;
+}
+
 // deal the next batch and derive everything the sweep reads from the cards (no table access)
 int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_deal: trainer is NULL");
-    const uint32_t n = tr->params.deals_per_batch;
-    const uint64_t first_deal = (tr->batches * tr->world + tr->rank) * uint64_t(n);   // global batch b = deals [b*world*n, (b+1)*world*n)
-    if (int rc = rs_deals_sample(tr->table, tr->params.seed, first_deal, tr->params.board_mask, tr->d_hands[0], tr->n_hands[0],
-                                 tr->d_hands[1], tr->n_hands[1], n, tr->d_cards, tr->d_err))
-        return rc;
-    for (int r = 0; r < tr->n_rounds; ++r)
-        if (int rc = rs_card_abs_clusters_device(tr->abs[r], tr->table, tr->d_cards, n, tr->d_cluster[r][0], tr->d_cluster[r][1])) return rc;
-    if (int rc = rs_showdown_sign(tr->table, tr->d_cards, n, tr->d_sign)) return rc;
-    tr->batches += 1;
+    if (!tr->staged) return deal_into(tr, (hipStream_t)rs_stream(tr->table), tr->d_cards, tr->d_cluster, tr->d_sign);
+    // the batch was dealt ahead: swap it in
+    hipStream_t main = (hipStream_t)rs_stream(tr->table);
+    const size_t pitch = round_up(tr->params.deals_per_batch, kLanePad);
+    hipError_t e = hipSetDevice(rs_table_device(tr->table));
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, tr->ev_dealt, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(tr->d_cards, tr->s_cards, 9 * pitch, hipMemcpyDeviceToDevice, main);
+    if (e == hipSuccess) e = hipMemcpyAsync(tr->d_sign, tr->s_sign, pitch * sizeof(float), hipMemcpyDeviceToDevice, main);
+    for (int r = 0; e == hipSuccess && r < tr->n_rounds; ++r)
+        for (int p = 0; e == hipSuccess && p < 2; ++p)
+            e = hipMemcpyAsync(tr->d_cluster[r][p], tr->s_cluster[r][p], pitch * sizeof(uint32_t), hipMemcpyDeviceToDevice, main);
+    if (e == hipSuccess) e = hipEventRecord(tr->ev_taken, main);
+    if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer_deal: swap");
+    tr->taken_recorded = true;
+    tr->staged = false;
     return RS_OK;
 }
 
@@ -195,6 +266,8 @@ int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_train: trainer is NULL");
     for (uint64_t b = 0; b < n_batches; ++b) {
         if (int rc = rs_deal_trainer_deal(tr)) return rc;
+        if (b + 1 < n_batches)   // deal the next batch beside this one's sweeps (never beyond what was asked for)
+            if (int rc = prefetch(tr)) return rc;
         for (int player = 0; player < 2; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
             if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
         if (int rc = rs_deal_trainer_finish_batch(tr)) return rc;
@@ -206,6 +279,7 @@ int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
 int rs_deal_trainer_status(rs_deal_trainer *tr) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_status: trainer is NULL");
     uint32_t err = 0;
+    if (tr->deal_stream && hipStreamSynchronize(tr->deal_stream) != hipSuccess) return fail(RS_ERR_HIP, "rs_deal_trainer_status: dealing stream");
     if (int rc = rs_d2h(tr->table, &err, tr->d_err, sizeof(err))) return rc;
     if (err) {
         rs_dmemset(tr->table, tr->d_err, 0, sizeof(err));
