@@ -14,7 +14,7 @@ from rustsolver_amd import abstraction as ab
 mask = ab.card_mask("4d5dAs3cKs"); hands = ab.random_range(mask)
 n_actions, tree = rs.build_game_tree(rs.default_flop())
 card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
-tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0)
+tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0, use_graph=bool(int(os.environ.get("GRAPH", "0"))))
 tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
 tr.train(5); tr.infosets.sync()
 best = 1e9
