@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
 // cache lines, the L2 serialised 1.2 M of them, 8.3 ms per launch; counters now sit 256 B apart).  The order of workgroups in the list is
 // arbitrary, which is fine because every consumer of the list commutes.
 constexpr uint32_t kMaxParts = 64;
+constexpr uint32_t kCompactPerThread = 4;   // lanes per thread and iteration: one slot reservation per workgroup covers 1 024 lanes
 __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__restrict__ jobs) {
     __shared__ uint32_t wave_count[kBlock / 64][kMaxParts];   // live lanes of every wave, per cluster range
     __shared__ uint32_t part_base[kMaxParts];                 // list slot reserved for this workgroup, per cluster range
@@ -386,15 +387,27 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
     const float *__restrict__ reach = job->reach;
     const uint32_t *__restrict__ key = job->key;
     const uint32_t lane_in_wave = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {   // whole workgroups iterate together
-        const uint32_t l = base + threadIdx.x;
-        const bool live = l < n && (!reach || reach[l] == reach[l]);
-        const uint32_t part = (live && key) ? min(key[l] / part_size, n_parts - 1u) : 0u;
-        uint32_t rank_in_wave = 0;   // among the live lanes of this wave with the same part
+    constexpr uint32_t kTile = kBlock * kCompactPerThread;
+    for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {   // whole workgroups iterate together
+        bool live[kCompactPerThread];
+        uint32_t part[kCompactPerThread], rank[kCompactPerThread];   // rank: among this wave's live lanes of the same part, over all sub-rounds
+#pragma unroll
+        for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers lanes base + i*256 .. +255: coalesced reads
+            const uint32_t l = base + i * kBlock + threadIdx.x;
+            live[i] = l < n && (!reach || reach[l] == reach[l]);
+            part[i] = (live[i] && key) ? min(key[l] / part_size, n_parts - 1u) : 0u;
+            rank[i] = 0;
+        }
         for (uint32_t q = 0; q < n_parts; ++q) {   // ballots only: no barrier inside
-            const unsigned long long ballot = __ballot(live && part == q);
-            if (lane_in_wave == 0) wave_count[wave][q] = (uint32_t)__popcll(ballot);
-            if (live && part == q) rank_in_wave = (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
+            uint32_t seen = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kCompactPerThread; ++i) {
+                const bool mine = live[i] && part[i] == q;
+                const unsigned long long ballot = __ballot(mine);
+                if (mine) rank[i] = seen + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
+                seen += (uint32_t)__popcll(ballot);
+            }
+            if (lane_in_wave == 0) wave_count[wave][q] = seen;
         }
         __syncthreads();
         if (threadIdx.x < n_parts) {   // ONE reservation per workgroup and part, issued by different threads
@@ -403,11 +416,13 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
             part_base[threadIdx.x] = total ? atomicAdd(job->count + (size_t)threadIdx.x * job->count_stride, total) : 0u;
         }
         __syncthreads();
-        if (live) {
-            uint32_t slot = part_base[part] + rank_in_wave;
-            for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part];
-            job->list[(size_t)part * job->list_stride + slot] = l;
-        }
+#pragma unroll
+        for (uint32_t i = 0; i < kCompactPerThread; ++i)
+            if (live[i]) {
+                uint32_t slot = part_base[part[i]] + rank[i];
+                for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part[i]];
+                job->list[(size_t)part[i] * job->list_stride + slot] = base + i * kBlock + threadIdx.x;
+            }
         __syncthreads();   // wave_count / part_base are rewritten by the next iteration
     }
 }
@@ -672,7 +687,8 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_
 
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
-    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_lanes) + kBlock - 1) / kBlock, 2048)), (unsigned)n_jobs), block(kBlock);
+    const size_t tile = size_t(kBlock) * kCompactPerThread;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_lanes) + tile - 1) / tile, 2048)), (unsigned)n_jobs), block(kBlock);
     hipLaunchKernelGGL(k_compact_live, grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
