@@ -32,6 +32,31 @@ double run(const f4 *in, f4 *out, size_t bytes_per_dir_read, int reps) {
     const double bytes = double(n_vec) * CH * 16 * (R + W) * reps;
     return bytes / (ms * 1e-3) / 1e12;
 }
+// a copy with U independent float4 in flight per thread (what a tuned streaming kernel looks like)
+template <int U>
+__global__ __launch_bounds__(256) void kcopy(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += stride * U) {
+        f4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = v + u * stride < n ? __builtin_nontemporal_load(in + v + u * stride) : f4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (v + u * stride < n) __builtin_nontemporal_store(x[u], out + v + u * stride);
+    }
+}
+template <int U>
+double run_copy(const f4 *in, f4 *out, size_t bytes, int grid, int reps) {
+    const size_t n = bytes / 16;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((kcopy<U>), dim3(grid), dim3(256), 0, 0, in, out, n);
+    (void)hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((kcopy<U>), dim3(grid), dim3(256), 0, 0, in, out, n);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    return 2.0 * double(n) * 16 * reps / (ms * 1e-3) / 1e12;
+}
+
 int main() {
     const size_t rd = size_t(2200) << 20;   // ~2.2 GB read per launch like the tree kernel (2.14 GB), writes scaled 2:3.. by W/R
     f4 *in, *out; hipMalloc(&in, rd + (64 << 20)); hipMalloc(&out, rd + (64 << 20));
@@ -45,5 +70,8 @@ int main() {
     printf("AoSoA-like  R19 W13 CH3 : %.2f TB/s\n", run<19, 13, 3>(in, out, rd, 10));
     printf("AoSoA-like  R10 W7  CH6 : %.2f TB/s\n", run<10, 7, 6>(in, out, rd, 10));
 
+    for (int grid : {1024, 4096, 16384})
+        printf("tuned copy grid %5d: U=1 %.2f  U=4 %.2f  U=8 %.2f TB/s\n", grid, run_copy<1>(in, out, rd, grid, 10), run_copy<4>(in, out, rd, grid, 10),
+               run_copy<8>(in, out, rd, grid, 10));
     return 0;
 }
