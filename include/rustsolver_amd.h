@@ -181,6 +181,22 @@ int rs_regret_match_node(rs_table *table, int node, float *d_strategy);
 int rs_final_strategy_node(rs_table *table, int node, float *d_strategy);
 /* every node: d_out[rs_table_cells()] with node blocks at rs_table_cell_offset() (calc_br's reader, cfr.rs:669-672) */
 int rs_final_strategy_all(rs_table *table, float *d_out);
+/* MCCFRTrainer::calc_br exactly AS CODED (cfr.rs:629-745): out[0], out[1] = the two numbers train() prints at every discount tick
+ * (cfr.rs:244-246).  Its op vectors have length 1 (cfr.rs:631), so only get_final_strategy() of bucket 0 of every action node
+ * enters (cfr.rs:677-679) and a terminal pays op * (+-)pot / op (cfr.rs:703-741): a placeholder, reproduced in its f32 operation
+ * order.  One gather kernel over the table, a few floats back.  Synchronises the table's stream. */
+int rs_calc_br(rs_table *table, const rs_tree *tree, float *out /*[2]*/);
+/* What that placeholder stands in for: out[p] = expected utility per deal, in the trainer's leaf
+ * utilities (cfr.rs:314-348), of player p against the opponent's AVERAGE strategy when p plays
+ *   RS_BR_MAX      a best response inside the abstraction (one action per info set = cluster), or
+ *   RS_BR_AVERAGE  its own average strategy (out[0] + out[1] = 0: the game is zero-sum),
+ * so (out[0] + out[1]) / 2 under RS_BR_MAX is the exploitability of the average strategy profile.  Vector form over both ranges
+ * of a single-round tree on a full board (the configuration main.rs runs): deals weigh as generate_hand draws them (cfr.rs:124-137),
+ * hands[n][2] hole cards, cluster[n] = get_cluster(hole cards + board, player) of every hand, board[5].  f64 on the device, every sum
+ * in a fixed order.  Host pointers; synchronises the table's stream.  RS_ERR_UNSUPPORTED for trees with public chance nodes. */
+enum { RS_BR_MAX = 0, RS_BR_AVERAGE = 1 };
+int rs_best_response(rs_table *table, const rs_tree *tree, const uint8_t *board, const uint8_t *hands_p0, size_t n_hands_p0, const uint32_t *cluster_p0,
+                     const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *cluster_p1, int mode, double *out /*[2]*/);
 
 /* One traverser visit of every lane of `node` (cfr.rs:370-466 / :571-623):
  *   sigma = get_strategy(); util = sum_a utils[a]*sigma[a]; regrets / strategy_sum updated with
@@ -401,6 +417,14 @@ int rs_deal_trainer_finish_batch(rs_deal_trainer *trainer);
 int rs_deal_trainer_deal(rs_deal_trainer *trainer);             /* only the dealing half of a batch (cards, cluster ids, signs) */
 int rs_deal_trainer_status(rs_deal_trainer *trainer);           /* synchronises; error if a deal could not be sampled / addressed */
 uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *trainer);   /* t of cfr.rs:200 */
+/* calc_br at the discount ticks (cfr.rs:244-246 runs it before the sweep and prints the two numbers): enable != 0 makes every tick
+ * call rs_calc_br first; rs_deal_trainer_last_br returns the latest pair and the iteration count it was taken at (RS_ERR_INVALID
+ * before the first tick).  rs_deal_trainer_calc_br / _best_response run the two readers on the trainer's own tree, ranges and
+ * abstraction at any time (best response: single-round trainers on a full board). */
+int rs_deal_trainer_set_tick_br(rs_deal_trainer *trainer, int enable);
+int rs_deal_trainer_last_br(const rs_deal_trainer *trainer, float *out /*[2]*/, uint64_t *iterations);
+int rs_deal_trainer_calc_br(rs_deal_trainer *trainer, float *out /*[2]*/);
+int rs_deal_trainer_best_response(rs_deal_trainer *trainer, int mode, double *out /*[2]*/);
 const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *trainer);  /* device: the current batch's d_cards[9][pitch] */
 const float *rs_deal_trainer_signs(const rs_deal_trainer *trainer);    /* device: its showdown signs [pitch] */
 const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *trainer, int round_idx, int player);   /* device: its cluster ids [pitch] */

@@ -1,0 +1,234 @@
+/*
+ * best_response.c -- CPU restatement of MCCFRTrainer::calc_br (cfr.rs:629-745), the reader of the average strategy that
+ * train() runs at every discount tick (cfr.rs:244-246), and of the real best response it stands in for.
+ *
+ * TEST INFRASTRUCTURE ONLY (see rs_oracle.h): loaded by tests/, smoke() and bench.py's cpu_baseline leg, never by the product.
+ * PARITY UNPINNED: the reference holds no test or fixture for calc_br and cannot be built here; pinned by hand-derived known
+ * answers (tests/golden/known_answers_br.json) and an independent Python restatement (oracle/np_restate.py).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rs_oracle.h"
+
+/* get_final_strategy of one info set whatever the table's element type (infoset.rs:104-123) */
+static void final_strategy_of(const orc_table *tb, int row, size_t lane, float *out) {
+    const orc_infoset *is = &tb->rows[row][lane];
+    if (tb->dtype == ORC_T_I32) orc_get_final_strategy(is->strategy_sum, is->n_actions, out);
+    else orc_get_strategy_f32(is->fstrategy_sum, is->n_actions, out);   /* same formula over floats (extension dtypes) */
+}
+
+/* ---- calc_br AS CODED ------------------------------------------------------------------------------------------------
+ * `op` is vec![vec![1.0; 1]; 2] (cfr.rs:631): ONE "hand" per player, so of the n_buckets final strategies that
+ * abstract_br_infoset collects (cfr.rs:669-672) only probabilites[0] -- bucket 0 -- is ever used (cfr.rs:677-679), and the
+ * terminal "payoffs" are op[opp][0] * (+-)pot * (1 / op[opp][0]) (cfr.rs:703-741): a placeholder, not an exploitability.
+ * Restated with the vectors kept (H = 1) so that every f32 operation happens in the reference's order. */
+#define BR_H 1
+typedef struct { float v[2][BR_H]; } br_vec;       /* Vec<Vec<f32>>: [player][hand] */
+typedef struct { float v[2]; } br_res;             /* the [player][0] the callers read */
+
+static br_res abstract_br(const orc_tree *tree, const orc_table *tb, int node_id, br_vec op);
+
+/* cfr.rs:695-745 */
+static br_res abstract_br_terminal(const orc_node *tn, br_vec op) {
+    br_res res = {{0.0f, 0.0f}};
+    const float money_f = (float)tn->value;                          /* cfr.rs:701 */
+    float opp_ges_p[2] = {0.0f, 0.0f};
+    int p, g;
+    for (p = 0; p < 2; p++) {
+        const int opp = 1 - p;
+        for (g = 0; g < BR_H; g++) {
+            float payoff;
+            if (tn->ttype == ORC_UNCONTESTED)                        /* cfr.rs:712: (op * sign) * money */
+                payoff = op.v[opp][g] * (p == (int)tn->last_to_act ? -1.0f : 1.0f) * money_f;
+            else                                                     /* cfr.rs:726: SHOWDOWN and ALLIN alike, +pot for both players */
+                payoff = op.v[opp][g] * money_f;
+            res.v[p] += payoff;
+            opp_ges_p[p] += op.v[opp][g];
+        }
+        res.v[p] *= 1.0f / opp_ges_p[p];                             /* cfr.rs:716 / :730: 0 reach gives 0 * inf = NaN, as there */
+    }
+    return res;
+}
+
+/* cfr.rs:658-693 */
+static br_res abstract_br_infoset(const orc_tree *tree, const orc_table *tb, const orc_node *an, br_vec op) {
+    float prob[BR_H][ORC_MAX_ACTIONS];
+    br_res payoffs[ORC_MAX_ACTIONS], res = {{0.0f, 0.0f}};
+    const int player = an->player, opp = 1 - an->player;
+    int a, h, max_index = 0;
+    float max_val;
+    memset(payoffs, 0, sizeof payoffs);   /* an action node always has children (payoffs[0] would panic in Rust otherwise) */
+    for (h = 0; h < BR_H; h++) final_strategy_of(tb, an->index, (size_t)h, prob[h]);   /* cfr.rs:669-672, the buckets that are read */
+    for (a = 0; a < an->n_children; a++) {
+        br_vec newop = op;                                                               /* cfr.rs:676 */
+        for (h = 0; h < BR_H; h++) newop.v[player][h] *= prob[h][a];                     /* cfr.rs:677-679 */
+        payoffs[a] = abstract_br(tree, tb, an->children[a], newop);
+    }
+    max_val = payoffs[0].v[player];                                                      /* cfr.rs:684-691: strict <, first maximum */
+    for (a = 1; a < an->n_children; a++)
+        if (max_val < payoffs[a].v[player]) {
+            max_val = payoffs[a].v[player];
+            max_index = a;
+        }
+    res.v[player] = max_val;
+    res.v[opp] = payoffs[max_index].v[opp];
+    return res;
+}
+
+/* cfr.rs:640-656 */
+static br_res abstract_br(const orc_tree *tree, const orc_table *tb, int node_id, br_vec op) {
+    const orc_node *n = &tree->nodes[node_id];
+    switch (n->kind) {
+    case ORC_TERMINAL: return abstract_br_terminal(n, op);
+    case ORC_PUBLIC_CHANCE:
+    case ORC_PRIVATE_CHANCE: return abstract_br(tree, tb, n->children[0], op);
+    default: return abstract_br_infoset(tree, tb, n, op);
+    }
+}
+
+/* cfr.rs:629-638 */
+void orc_calc_br(const orc_tree *tree, const orc_table *tb, float out[2]) {
+    br_vec op;
+    br_res r;
+    int p, h;
+    for (p = 0; p < 2; p++)
+        for (h = 0; h < BR_H; h++) op.v[p][h] = 1.0f;
+    r = abstract_br(tree, tb, 0, op);
+    out[0] = r.v[0];
+    out[1] = r.v[1];
+}
+
+/* ---- the real best response (NOT in the reference, whose calc_br is the placeholder above) ----------
+ * Value per deal, in the trainer's leaf utilities (cfr.rs:314-348), of player p against the opponent's average strategy when p
+ * plays mode 0: a best response inside the abstraction (one action per cluster), mode 1: its own average strategy.  Vector form over
+ * both ranges of a single-round tree on a full board; deals weigh as generate_hand draws them on a full board (cfr.rs:124-137):
+ * P(h0, h1) = [no shared card] / (N0 * N1(h0)).  f64, every sum in ascending hand / action order (the product does the same). */
+uint32_t orc_evaluate7(const uint8_t *c7);
+
+typedef struct {
+    const orc_tree *tree;
+    const orc_table *tb;
+    int mode, p;
+    size_t n[2];
+    const uint32_t *cid[2];
+    uint64_t *mask[2];
+    uint32_t *score[2];
+    double *pw[2];
+} br_ctx;
+
+static void br_walk(const br_ctx *c, int node_id, const double *q, double *v) {
+    const orc_node *n = &c->tree->nodes[node_id];
+    const int p = c->p, o = 1 - c->p;
+    const size_t np = c->n[p], no = c->n[o];
+    size_t h, g;
+    int a;
+    if (n->kind == ORC_TERMINAL) {
+        const double pot = (double)(float)n->value;
+        for (h = 0; h < np; h++) {
+            double acc = 0.0;
+            for (g = 0; g < no; g++) {
+                double u;
+                if (c->mask[p][h] & c->mask[o][g]) continue;
+                if (n->ttype == ORC_UNCONTESTED) u = (p == (int)n->last_to_act) ? -pot : pot;          /* cfr.rs:316-322 */
+                else u = c->score[p][h] > c->score[o][g] ? pot : (c->score[p][h] < c->score[o][g] ? -pot : 0.0);   /* cfr.rs:323-347 */
+                acc += q[g] * u;
+            }
+            v[h] = c->pw[p][h] * acc;
+        }
+        return;
+    }
+    if (n->kind != ORC_ACTION) {
+        br_walk(c, n->children[0], q, v);
+        return;
+    }
+    {
+        const int A = n->n_children;
+        double *vch = (double *)malloc((size_t)A * np * sizeof(double));
+        float sig[ORC_MAX_ACTIONS];
+        if ((int)n->player == p) {
+            for (a = 0; a < A; a++) br_walk(c, n->children[a], q, vch + (size_t)a * np);
+            if (c->mode == 0) {
+                /* per cluster: sum the hands' values per action (ascending hand order), first maximum */
+                size_t n_clusters = c->tb->row_len[n->index], k;
+                double *s = (double *)calloc(n_clusters * (size_t)A, sizeof(double));
+                for (a = 0; a < A; a++)
+                    for (h = 0; h < np; h++) s[(size_t)c->cid[p][h] * A + a] += vch[(size_t)a * np + h];
+                for (h = 0; h < np; h++) {
+                    int best = 0;
+                    k = c->cid[p][h];
+                    for (a = 1; a < A; a++)
+                        if (s[k * A + best] < s[k * A + a]) best = a;
+                    v[h] = vch[(size_t)best * np + h];
+                }
+                free(s);
+            } else {
+                for (h = 0; h < np; h++) {
+                    double acc = 0.0;
+                    final_strategy_of(c->tb, n->index, c->cid[p][h], sig);
+                    for (a = 0; a < A; a++) acc += (double)sig[a] * vch[(size_t)a * np + h];
+                    v[h] = acc;
+                }
+            }
+        } else {
+            double *qch = (double *)malloc((size_t)A * no * sizeof(double));
+            for (g = 0; g < no; g++) {
+                final_strategy_of(c->tb, n->index, c->cid[o][g], sig);
+                for (a = 0; a < A; a++) qch[(size_t)a * no + g] = q[g] * (double)sig[a];
+            }
+            for (a = 0; a < A; a++) br_walk(c, n->children[a], qch + (size_t)a * no, vch + (size_t)a * np);
+            for (h = 0; h < np; h++) {
+                double acc = 0.0;
+                for (a = 0; a < A; a++) acc += vch[(size_t)a * np + h];
+                v[h] = acc;
+            }
+            free(qch);
+        }
+        free(vch);
+    }
+}
+
+int orc_best_response(const orc_tree *tree, const orc_table *tb, const uint8_t *board, const uint8_t *hands_p0, size_t n0, const uint32_t *cid_p0,
+                      const uint8_t *hands_p1, size_t n1, const uint32_t *cid_p1, int mode, double *out) {
+    br_ctx c;
+    const uint8_t *hands[2];
+    double *w0, *ones, *v;
+    size_t h, g;
+    int p, i;
+    memset(&c, 0, sizeof c);
+    c.tree = tree; c.tb = tb; c.mode = mode;
+    c.n[0] = n0; c.n[1] = n1; c.cid[0] = cid_p0; c.cid[1] = cid_p1;
+    hands[0] = hands_p0; hands[1] = hands_p1;
+    for (p = 0; p < 2; p++) {
+        c.mask[p] = (uint64_t *)malloc(c.n[p] * sizeof(uint64_t));
+        c.score[p] = (uint32_t *)malloc(c.n[p] * sizeof(uint32_t));
+        for (h = 0; h < c.n[p]; h++) {
+            uint8_t c7[7];
+            c7[0] = hands[p][2 * h]; c7[1] = hands[p][2 * h + 1];
+            for (i = 0; i < 5; i++) c7[2 + i] = board[i];
+            c.mask[p][h] = (1ull << c7[0]) | (1ull << c7[1]);
+            c.score[p][h] = orc_evaluate7(c7);
+        }
+    }
+    w0 = (double *)malloc(n0 * sizeof(double));
+    ones = (double *)malloc(n1 * sizeof(double));
+    for (h = 0; h < n0; h++) {
+        size_t cnt = 0;
+        for (g = 0; g < n1; g++) cnt += (c.mask[0][h] & c.mask[1][g]) == 0;
+        w0[h] = cnt ? 1.0 / ((double)n0 * (double)cnt) : 0.0;
+    }
+    for (g = 0; g < n1; g++) ones[g] = 1.0;
+    c.pw[0] = w0; c.pw[1] = ones;
+    v = (double *)malloc((n0 > n1 ? n0 : n1) * sizeof(double));
+    for (p = 0; p < 2; p++) {
+        double total = 0.0;
+        c.p = p;
+        br_walk(&c, 0, p == 0 ? ones : w0, v);   /* the opponent's initial reach carries its share of the deal probability */
+        for (h = 0; h < c.n[p]; h++) total += v[h];
+        out[p] = total;
+    }
+    free(v); free(w0); free(ones);
+    for (p = 0; p < 2; p++) { free(c.mask[p]); free(c.score[p]); }
+    return 0;
+}

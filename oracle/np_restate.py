@@ -298,3 +298,97 @@ def weighted_index(W, bits):
     for i, c in enumerate(cum):
         idx = np.where(c <= chosen, i + 1, idx)
     return idx
+
+
+# ---------------------------------------------------------------------------------------------------
+# calc_br as coded (cfr.rs:629-745) and the real best response, second opinions
+# ---------------------------------------------------------------------------------------------------
+def calc_br(nodes, final_strategy_bucket0):
+    """MCCFRTrainer::calc_br with its length-1 `op` vectors.  final_strategy_bucket0[index] = get_final_strategy() of bucket 0 of
+    the action node with that index (f32 array).  Written with explicit [player][hand] lists like the Rust."""
+    def terminal(n, op):  # cfr.rs:695-745
+        res = [[F32(0.0)], [F32(0.0)]]
+        money = F32(n["value"])
+        for p in range(2):
+            opp = 1 - p
+            ges = F32(0.0)
+            for g in range(len(op[0])):
+                if n["ttype"] == "UNCONTESTED":
+                    pay = F32(F32(op[opp][g] * (F32(-1.0) if p == n["last_to_act"] else F32(1.0))) * money)
+                else:
+                    pay = F32(op[opp][g] * money)
+                res[p][0] = F32(res[p][0] + pay)
+                ges = F32(ges + op[opp][g])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                res[p][0] = F32(res[p][0] * F32(F32(1.0) / ges))
+        return res
+
+    def walk(i, op):
+        n = nodes[i]
+        if n["kind"] == "terminal":
+            return terminal(n, op)
+        if n["kind"] != "action":
+            return walk(n["children"][0], op)  # cfr.rs:646-651
+        pl, opp = n["player"], 1 - n["player"]
+        probs = [final_strategy_bucket0[n["index"]]]  # only probabilites[h] for h < len(op[player]) == 1 is read (cfr.rs:677-679)
+        pay = []
+        for a, ch in enumerate(n["children"]):
+            newop = [list(op[0]), list(op[1])]
+            for h in range(len(newop[pl])):
+                newop[pl][h] = F32(newop[pl][h] * F32(probs[h][a]))
+            pay.append(walk(ch, newop))
+        max_val, max_index = pay[0][pl][0], 0
+        for a in range(1, len(pay)):
+            if max_val < pay[a][pl][0]:  # cfr.rs:686
+                max_val, max_index = pay[a][pl][0], a
+        res = [[F32(0.0)], [F32(0.0)]]
+        res[pl][0] = max_val
+        res[opp][0] = pay[max_index][opp][0]
+        return res
+
+    r = walk(0, [[F32(1.0)], [F32(1.0)]])
+    return np.array([r[0][0], r[1][0]], dtype=np.float32)
+
+
+def best_response(nodes, sigma_bar, masks, scores, cids, mode="max"):
+    """Value per deal of each player against the other's average strategy (matrix form, f64; sums in numpy's order, so equal to the C
+    oracle up to rounding).  sigma_bar(index) -> f32 [A][n_clusters of the acting player]; masks[p] u64 [n_p]; scores[p] [n_p];
+    cids[p] [n_p].  Deal probability as generate_hand draws on a full board (cfr.rs:124-137): uniform h0, then h1 uniform among the
+    combos of range 1 that avoid h0."""
+    n = [len(masks[0]), len(masks[1])]
+    compat = (masks[0][:, None] & masks[1][None, :]) == 0  # [n0][n1]
+    cnt = compat.sum(axis=1).astype(np.float64)
+    w0 = np.where(cnt > 0, 1.0 / (n[0] * np.maximum(cnt, 1.0)), 0.0)
+    prob = compat * w0[:, None]  # P(h0, h1)
+    s0, s1 = scores[0].astype(np.int64)[:, None], scores[1].astype(np.int64)[None, :]
+    cmp01 = np.sign(s0 - s1).astype(np.float64)  # +1: player 0's hand wins
+    out = np.zeros(2)
+    for p in range(2):
+        P = prob if p == 0 else prob.T           # [n_p][n_o]
+        sgn = cmp01 if p == 0 else -cmp01.T
+
+        def walk(i, q):  # q: opponent reach [n_o]; returns values [n_p]
+            nd = nodes[i]
+            if nd["kind"] == "terminal":
+                pot = float(np.float32(nd["value"]))
+                if nd["ttype"] == "UNCONTESTED":
+                    return (P * q[None, :]).sum(axis=1) * (-pot if p == nd["last_to_act"] else pot)
+                return (P * sgn * q[None, :]).sum(axis=1) * pot
+            if nd["kind"] != "action":
+                return walk(nd["children"][0], q)
+            sig = sigma_bar(nd["index"]).astype(np.float64)  # [A][C]
+            if nd["player"] == p:
+                vch = np.stack([walk(ch, q) for ch in nd["children"]])  # [A][n_p]
+                if mode == "max":
+                    C = sig.shape[1]
+                    per = np.zeros((len(vch), C))
+                    for a in range(len(vch)):
+                        np.add.at(per[a], cids[p], vch[a])
+                    best = per.argmax(axis=0)  # first maximum
+                    return vch[best[cids[p]], np.arange(n[p])]
+                return (sig[:, cids[p]] * vch).sum(axis=0)
+            o = 1 - p
+            return sum(walk(ch, q * sig[a, cids[o]]) for a, ch in enumerate(nd["children"]))
+
+        out[p] = walk(0, np.ones(n[1 - p])).sum()
+    return out

@@ -98,7 +98,7 @@ DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
 
 def build(force=False):
     """Compile oracle/librs_oracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "kmeans_emd.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "kmeans_emd.c", "best_response.c", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -143,6 +143,9 @@ def lib():
     L.orc_iterate.argtypes = [C.POINTER(Ctx), C.c_int, f32p]
     L.orc_iterate_range.argtypes = [C.POINTER(Ctx), C.c_int, C.c_size_t, C.c_size_t, f32p]
     L.orc_train.argtypes = [C.POINTER(Ctx), C.c_size_t, C.c_size_t, C.c_size_t]
+    L.orc_calc_br.argtypes = [C.POINTER(Tree), C.POINTER(Table), f32p]
+    L.orc_best_response.argtypes = [C.POINTER(Tree), C.POINTER(Table), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_int, C.c_void_p]
     L.orc_get_strategy_f32.argtypes = [f32p, C.c_int, f32p]
     L.orc_update_infoset_f32.argtypes = [f32p, f32p, C.c_int, f32p, C.c_float, C.c_float, C.c_int, C.c_int]
     L.orc_update_infoset_f32.restype = C.c_float
@@ -388,6 +391,22 @@ class OracleTable:
 
     def discount(self, d):
         lib().orc_discount_table(C.byref(self.tb), np.float32(d))
+
+    def calc_br(self):
+        """MCCFRTrainer::calc_br as coded (cfr.rs:629-638): the two numbers train() prints at a discount tick"""
+        out = np.zeros(2, dtype=np.float32)
+        lib().orc_calc_br(C.byref(self.tree.t), C.byref(self.tb), _f32(out))
+        return out
+
+    def best_response(self, board, hands0, cid0, hands1, cid1, mode=0):
+        """value per deal of each player against the other's average strategy (mode 0: best response, 1: own average strategy)"""
+        b = np.ascontiguousarray(board, dtype=np.uint8)
+        h0, h1 = np.ascontiguousarray(hands0, dtype=np.uint8), np.ascontiguousarray(hands1, dtype=np.uint8)
+        c0, c1 = np.ascontiguousarray(cid0, dtype=np.uint32), np.ascontiguousarray(cid1, dtype=np.uint32)
+        out = np.zeros(2, dtype=np.float64)
+        lib().orc_best_response(C.byref(self.tree.t), C.byref(self.tb), b.ctypes.data, h0.ctypes.data, len(c0), c0.ctypes.data, h1.ctypes.data, len(c1),
+                                c1.ctypes.data, mode, out.ctypes.data)
+        return out
 
     def __del__(self):
         try:

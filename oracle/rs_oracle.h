@@ -225,6 +225,15 @@ void orc_iterate_range(const orc_ctx *ctx, int player, size_t lane_lo, size_t la
  * traverse, t += 1, then the discount check `tc > threshold` (cfr.rs:239-263). */
 void orc_train(const orc_ctx *ctx, size_t iterations, size_t discount_interval, size_t discount_cap);
 
+/* ---- calc_br (best_response.c) -----------------------------------------------------------------------------
+ * MCCFRTrainer::calc_br AS CODED (cfr.rs:629-745): op vectors of length 1, so only bucket 0 of every action node is read
+ * and the terminal "payoff" is op * (+-)pot / op -- a placeholder.  out = {br[0], br[1]} of cfr.rs:245-246. */
+void orc_calc_br(const orc_tree *tree, const orc_table *tb, float out[2]);
+/* the real thing (not in the reference): value per deal of player p against the opponent's average strategy, p playing a best
+ * response inside the abstraction (mode 0) or its own average strategy (mode 1); single-round tree, five-card board */
+int orc_best_response(const orc_tree *tree, const orc_table *tb, const uint8_t *board, const uint8_t *hands_p0, size_t n0, const uint32_t *cid_p0,
+                      const uint8_t *hands_p1, size_t n1, const uint32_t *cid_p1, int mode, double *out);
+
 /* ---- extension modes (north_star variants; NOT reference semantics) -------------------- */
 enum { ORC_F_F32 = 0, ORC_F_F16 = 1 };
 /* float tables: r += (scale*reach)*(u-util), s += (scale*reach)*sigma in f32; RM+ floors r at 0;

@@ -17,6 +17,7 @@ UPD_CLAMP_I64, UPD_WRAP_I32, UPD_RMPLUS, UPD_PRUNE = 0, 1, 0x100, 0x200
 LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
 CHANCE_PASS, CHANCE_ENUM = 0, 1
 OPP_FULL, OPP_SAMPLE = 0, 1
+BR_MAX, BR_AVERAGE = 0, 1   # rs_best_response modes
 DIST_EMD, DIST_L2 = 0, 1
 K_UPDATE, K_NODE_UTIL, K_REACH, K_CHANCE, K_DISCOUNT, K_STRATEGY, K_TREE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -115,6 +116,8 @@ SYMBOLS = {
     "rs_regret_match_node": (C.c_int, [_P, C.c_int, _P]),
     "rs_final_strategy_node": (C.c_int, [_P, C.c_int, _P]),
     "rs_final_strategy_all": (C.c_int, [_P, _P]),
+    "rs_calc_br": (C.c_int, [_P, _P, _P]),
+    "rs_best_response": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P, C.c_int, _P]),
     "rs_update_node": (C.c_int, [_P, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rs_node_util": (C.c_int, [_P, C.c_int, _P, _P]),
     "rs_child_reach": (C.c_int, [_P, C.c_int, _P, _P]),
@@ -174,6 +177,10 @@ SYMBOLS = {
     "rs_deal_trainer_deal": (C.c_int, [_P]),
     "rs_deal_trainer_status": (C.c_int, [_P]),
     "rs_deal_trainer_iterations": (C.c_uint64, [_P]),
+    "rs_deal_trainer_set_tick_br": (C.c_int, [_P, C.c_int]),
+    "rs_deal_trainer_last_br": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
+    "rs_deal_trainer_calc_br": (C.c_int, [_P, _P]),
+    "rs_deal_trainer_best_response": (C.c_int, [_P, C.c_int, _P]),
     "rs_deal_trainer_cards": (C.c_void_p, [_P]),
     "rs_deal_trainer_signs": (C.c_void_p, [_P]),
     "rs_deal_trainer_clusters": (C.c_void_p, [_P, C.c_int, C.c_int]),

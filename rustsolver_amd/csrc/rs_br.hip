@@ -1,0 +1,470 @@
+// rs_br.hip -- the readers of the AVERAGE strategy.
+//
+//  * rs_calc_br: MCCFRTrainer::calc_br exactly as coded (cfr.rs:629-745), the two numbers train() prints at every discount
+//    tick (cfr.rs:244-246).  Its `op` vectors have length 1, so of the n_buckets final strategies abstract_br_infoset collects
+//    (cfr.rs:669-672) only bucket 0 of every action node is used: ONE kernel gathers get_final_strategy() of lane 0 of every node
+//    (the table stays in HBM, n_nodes x 8 floats come back), and the walk itself -- a handful of f32 operations per tree node -- runs
+//    on the host in the reference's operation order.
+//  * rs_best_response: what that placeholder stands in for: the value of a best response to the opponent's average strategy in the
+//    abstracted game (and, mode RS_BR_AVERAGE, the value of the average strategy profile itself), in vector form over the two hand
+//    ranges of a single-round game on a full board -- the configuration the reference ships (options::default_flop()).  Reach and
+//    value vectors live on the device as f64; every sum runs in a fixed order, so the CPU oracle reproduces the result bit for bit.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rs_internal.hpp"
+#include "rs_device.hpp"
+#include "rs_eval.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace rs;
+
+#define RS_HIP(call, what)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return rs::hip_fail(e_, what); \
+    } while (0)
+
+namespace rs {
+
+constexpr int kBrBlock = 256;
+
+template <int DT> struct Elem;
+template <> struct Elem<kDT_I32> {
+    using val = int;
+    static __device__ __forceinline__ val at(const void *base, size_t i) { return ((const int *)base)[i]; }
+};
+template <> struct Elem<kDT_F32> {
+    using val = float;
+    static __device__ __forceinline__ val at(const void *base, size_t i) { return ((const float *)base)[i]; }
+};
+template <> struct Elem<kDT_F16> {
+    using val = float;
+    static __device__ __forceinline__ val at(const void *base, size_t i) { return (float)((const _Float16 *)base)[i]; }
+};
+
+// Infoset::get_final_strategy (infoset.rs:104-123) of ONE lane of a node's strategy_sum rows [A][pitch]
+template <int DT>
+__device__ __forceinline__ void final_sigma(const void *ssum, size_t cell_off, uint32_t pitch, uint32_t n_actions, uint32_t lane,
+                                            float (&sig)[RS_MAX_ACTIONS]) {
+    using V = typename Elem<DT>::val;
+    V r[RS_MAX_ACTIONS];
+    float norm = 0.0f;
+    for (uint32_t a = 0; a < n_actions; a++) {
+        r[a] = Elem<DT>::at(ssum, cell_off + (size_t)a * pitch + lane);
+        if (r[a] > (V)0) norm += (float)r[a];
+    }
+    const float uni = 1.0f / (float)n_actions;
+    for (uint32_t a = 0; a < n_actions; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
+}
+
+struct BrNodeRow {   // one action node's strategy_sum block
+    uint64_t cell_off;
+    uint32_t pitch, n_actions;
+};
+
+// calc_br's reader: probabilites[0] of every action node (cfr.rs:669-672 with :677-679)
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_bucket0_final_strategy(const void *__restrict__ ssum, const BrNodeRow *__restrict__ rows, uint32_t n_nodes,
+                                                                      float *__restrict__ out /*[n_nodes][RS_MAX_ACTIONS]*/) {
+    const uint32_t n = blockIdx.x * kBrBlock + threadIdx.x;
+    if (n >= n_nodes) return;
+    const BrNodeRow row = rows[n];
+    float sig[RS_MAX_ACTIONS];
+    final_sigma<DT>(ssum, row.cell_off, row.pitch, row.n_actions, 0u, sig);
+    for (uint32_t a = 0; a < RS_MAX_ACTIONS; a++) out[(size_t)n * RS_MAX_ACTIONS + a] = a < row.n_actions ? sig[a] : 0.0f;
+}
+
+// ---- best response, vector form ------------------------------------------------------------------------------------------
+// score[h] of hole cards + the five board cards (the evaluator the showdown-sign kernel uses; only compared, cfr.rs:326-333)
+__global__ __launch_bounds__(kBrBlock) void k_hand_scores(const uint8_t *__restrict__ hands /*[n][2]*/, uint32_t n, uint32_t b0, uint32_t b1, uint32_t b2,
+                                                          uint32_t b3, uint32_t b4, uint32_t *__restrict__ score) {
+    const uint32_t h = blockIdx.x * kBrBlock + threadIdx.x;
+    if (h >= n) return;
+    uint32_t m[4] = {0, 0, 0, 0};
+    add_card(m, b0); add_card(m, b1); add_card(m, b2); add_card(m, b3); add_card(m, b4);
+    add_card(m, hands[2 * h]);
+    add_card(m, hands[2 * h + 1]);
+    score[h] = evaluate_suits(m);
+}
+
+// opponent node: q_a[h] = q[h] * sigma_bar(cluster(h), a) for every action (cfr.rs:585's reach product, over the whole range at once)
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n,
+                                                           uint32_t n_pad, const double *__restrict__ q, double *__restrict__ q_out /*[A][n_pad]*/) {
+    const uint32_t h = blockIdx.x * kBrBlock + threadIdx.x;
+    if (h >= n) return;
+    float sig[RS_MAX_ACTIONS];
+    final_sigma<DT>(ssum, row.cell_off, row.pitch, row.n_actions, cid[h], sig);
+    const double qh = q[h];
+    for (uint32_t a = 0; a < row.n_actions; a++) q_out[(size_t)a * n_pad + h] = qh * (double)sig[a];
+}
+
+// terminal: v[hp] = pw[hp] * sum over the opponent's hands ho that share no card with hp, ascending, of q[ho] * u(hp, ho);
+// u as the trainer's leaves (cfr.rs:314-348): UNCONTESTED -pot for the folder / +pot for the other, SHOWDOWN and ALLIN +-pot by score, 0 on a tie
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
+                                                          uint32_t n_p, const uint64_t *__restrict__ mask_o, const uint32_t *__restrict__ score_o,
+                                                          const double *__restrict__ q, uint32_t n_o, int uncontested, double value, double *__restrict__ v) {
+    const uint32_t hp = blockIdx.x * kBrBlock + threadIdx.x;
+    if (hp >= n_p) return;
+    const uint64_t mp = mask_p[hp];
+    const uint32_t sp = score_p[hp];
+    double acc = 0.0;
+    for (uint32_t ho = 0; ho < n_o; ho++) {
+        if (mp & mask_o[ho]) continue;
+        const uint32_t so = score_o[ho];
+        const double u = uncontested ? value : (sp > so ? value : (sp < so ? -value : 0.0));
+        acc += q[ho] * u;
+    }
+    v[hp] = pw[hp] * acc;
+}
+
+// opponent node, on the way up: v[h] = v_0[h] + v_1[h] + ... in action order
+__global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ vch /*[A][n_pad]*/, uint32_t n_actions, uint32_t n, uint32_t n_pad,
+                                                     double *__restrict__ v) {
+    const uint32_t h = blockIdx.x * kBrBlock + threadIdx.x;
+    if (h >= n) return;
+    double acc = 0.0;
+    for (uint32_t a = 0; a < n_actions; a++) acc += vch[(size_t)a * n_pad + h];
+    v[h] = acc;
+}
+
+// own node: one thread per info set (cluster).  RS_BR_MAX: the action with the largest value summed over the cluster's hands
+// (ascending hand order; first maximum, strict < as cfr.rs:684-690) is played by every hand of the cluster; RS_BR_AVERAGE: sigma_bar.
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 1]*/,
+                                                     const uint32_t *__restrict__ order, uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch,
+                                                     int mode, double *__restrict__ v) {
+    const uint32_t c = blockIdx.x * kBrBlock + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t lo = start[c], hi = start[c + 1];
+    if (lo == hi) return;
+    if (mode == RS_BR_MAX) {
+        double s[RS_MAX_ACTIONS];
+        for (uint32_t a = 0; a < row.n_actions; a++) {
+            double acc = 0.0;
+            for (uint32_t i = lo; i < hi; i++) acc += vch[(size_t)a * n_pad + order[i]];
+            s[a] = acc;
+        }
+        uint32_t best = 0;
+        for (uint32_t a = 1; a < row.n_actions; a++)
+            if (s[best] < s[a]) best = a;
+        for (uint32_t i = lo; i < hi; i++) v[order[i]] = vch[(size_t)best * n_pad + order[i]];
+    } else {
+        float sig[RS_MAX_ACTIONS];
+        final_sigma<DT>(ssum, row.cell_off, row.pitch, row.n_actions, c, sig);
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t h = order[i];
+            double acc = 0.0;
+            for (uint32_t a = 0; a < row.n_actions; a++) acc += (double)sig[a] * vch[(size_t)a * n_pad + h];
+            v[h] = acc;
+        }
+    }
+}
+
+static unsigned grid1(uint32_t n) { return (n + kBrBlock - 1) / kBrBlock ? (n + kBrBlock - 1) / kBrBlock : 1; }
+
+#define RS_BR_DT(dtype_, CALL)                 \
+    do {                                       \
+        if ((dtype_) == RS_I32) { CALL(kDT_I32); } \
+        else if ((dtype_) == RS_F32) { CALL(kDT_F32); } \
+        else { CALL(kDT_F16); }                \
+    } while (0)
+
+// ---- host side of calc_br: cfr.rs:640-745 over the gathered bucket-0 strategies -------------------------------------------------
+struct Pay { float v[2]; };   // res[player][0]
+struct AsCoded {
+    const std::vector<rs_tree_node> &nodes;
+    const std::vector<float> &prob;   // [index][RS_MAX_ACTIONS]
+    Pay terminal(const rs_tree_node &tn, const float (&op)[2]) const {   // cfr.rs:695-745
+        Pay res{{0.0f, 0.0f}};
+        const float money_f = float(tn.value);
+        for (int p = 0; p < 2; ++p) {
+            const int opp = 1 - p;
+            float opp_ges = 0.0f;
+            float payoff;
+            if (tn.ttype == RS_TERM_UNCONTESTED) payoff = op[opp] * (p == int(tn.last_to_act) ? -1.0f : 1.0f) * money_f;   // cfr.rs:712
+            else payoff = op[opp] * money_f;                                                                                // cfr.rs:726
+            res.v[p] += payoff;
+            opp_ges += op[opp];
+            res.v[p] *= 1.0f / opp_ges;                                                                                     // cfr.rs:716 / :730
+        }
+        return res;
+    }
+    Pay walk(int id, const float (&op)[2]) const {
+        const rs_tree_node &n = nodes[size_t(id)];
+        if (n.kind == RS_NODE_TERMINAL) return terminal(n, op);
+        if (n.kind != RS_NODE_ACTION) return walk(n.children[0], op);   // cfr.rs:646-651: both chance kinds go to child 0
+        Pay pay[RS_MAX_ACTIONS];
+        const int player = n.player, opp = 1 - n.player;
+        for (int a = 0; a < n.n_children; ++a) {
+            float newop[2] = {op[0], op[1]};
+            newop[player] *= prob[size_t(n.index) * RS_MAX_ACTIONS + size_t(a)];   // cfr.rs:677-679
+            pay[a] = walk(n.children[a], newop);
+        }
+        float max_val = pay[0].v[player];
+        int max_index = 0;
+        for (int a = 1; a < n.n_children; ++a)
+            if (max_val < pay[a].v[player]) {   // cfr.rs:686
+                max_val = pay[a].v[player];
+                max_index = a;
+            }
+        Pay res{{0.0f, 0.0f}};
+        res.v[player] = max_val;
+        res.v[opp] = pay[max_index].v[opp];
+        return res;
+    }
+};
+
+static int check_tree_against_table(const rs_table *t, const rs_tree *tree, const char *fn) {
+    for (const rs_tree_node &n : tree->nodes) {
+        if (n.kind != RS_NODE_ACTION) continue;
+        if (n.index < 0 || size_t(n.index) >= t->nodes.size()) return fail(RS_ERR_INVALID, std::string(fn) + ": the tree has an action node the table lacks");
+        const rs_node_desc &nd = t->nodes[size_t(n.index)];
+        if (int(nd.n_actions) != n.n_children || nd.n_actions == 0 || nd.n_actions > RS_MAX_ACTIONS)
+            return fail(RS_ERR_INVALID, std::string(fn) + ": action counts of tree and table differ at node " + std::to_string(n.index));
+        if (nd.n_clusters == 0) return fail(RS_ERR_OOB, std::string(fn) + ": node " + std::to_string(n.index) + " has no bucket 0 (Rust: index out of bounds)");
+    }
+    return RS_OK;
+}
+
+static BrNodeRow row_of(const rs_table *t, int index) {
+    return BrNodeRow{uint64_t(t->cell_off[size_t(index)]), uint32_t(t->pitch[size_t(index)]), t->nodes[size_t(index)].n_actions};
+}
+
+}  // namespace rs
+
+extern "C" {
+
+int rs_calc_br(rs_table *t, const rs_tree *tree, float *out) {
+    if (!t || !tree || !out) return fail(RS_ERR_INVALID, "rs_calc_br: NULL argument");
+    if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_calc_br: empty tree");
+    if (int rc = check_tree_against_table(t, tree, "rs_calc_br")) return rc;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const uint32_t n_nodes = uint32_t(t->nodes.size());
+    std::vector<BrNodeRow> rows(n_nodes);
+    for (uint32_t n = 0; n < n_nodes; ++n) rows[n] = row_of(t, int(n));
+    std::vector<float> prob(size_t(n_nodes) * RS_MAX_ACTIONS);
+    if (n_nodes) {
+        BrNodeRow *d_rows = nullptr;
+        float *d_prob = nullptr;
+        RS_HIP(hipMalloc(&d_rows, rows.size() * sizeof(BrNodeRow)), "hipMalloc(calc_br rows)");
+        hipError_t e = hipMalloc(&d_prob, prob.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_rows, rows.data(), rows.size() * sizeof(BrNodeRow), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+#define RS_B0(DT_) hipLaunchKernelGGL((k_bucket0_final_strategy<DT_>), dim3(grid1(n_nodes)), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_rows, n_nodes, d_prob)
+            RS_BR_DT(t->dtype, RS_B0);
+#undef RS_B0
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(prob.data(), d_prob, prob.size() * sizeof(float), hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+        (void)hipFree(d_rows);
+        if (d_prob) (void)hipFree(d_prob);
+        if (e != hipSuccess) return hip_fail(e, "rs_calc_br");
+    }
+    const AsCoded walk{tree->nodes, prob};
+    const float op[2] = {1.0f, 1.0f};   // cfr.rs:631
+    const Pay r = walk.walk(0, op);
+    out[0] = r.v[0];                    // cfr.rs:633-636
+    out[1] = r.v[1];
+    return RS_OK;
+}
+
+}  // extern "C"
+
+// ---- best response proper -----------------------------------------------------------------------------------------------
+namespace rs {
+
+struct BrSide {
+    uint32_t n = 0, n_pad = 0, n_clusters = 0;
+    uint8_t *d_hands = nullptr;
+    uint64_t *d_mask = nullptr;
+    uint32_t *d_score = nullptr, *d_cid = nullptr, *d_start = nullptr, *d_order = nullptr;
+    double *d_init_q = nullptr;   // this side's hands as the OPPONENT's initial reach (its share of the deal probability)
+    double *d_pw = nullptr;       // this side's hands as the TRAVERSER's weight
+};
+
+struct BrRun {
+    rs_table *t = nullptr;
+    const rs_tree *tree = nullptr;
+    int mode = RS_BR_MAX;
+    int p = 0;
+    BrSide side[2];
+    std::vector<void *> allocs;
+    std::vector<double *> q_level, v_level;   // per tree depth: [RS_MAX_ACTIONS][n_pad] children buffers
+    hipError_t err = hipSuccess;
+
+    template <typename T> T *dalloc(size_t n) {
+        void *ptr = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&ptr, (n ? n : 1) * sizeof(T));
+        if (err == hipSuccess) allocs.push_back(ptr);
+        return static_cast<T *>(ptr);
+    }
+    template <typename T> T *upload(const std::vector<T> &h) {
+        T *d = dalloc<T>(h.size());
+        if (err == hipSuccess && !h.empty()) err = hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);   // blocking: h may be a temporary
+        return d;
+    }
+    ~BrRun() {
+        for (void *ptr : allocs) (void)hipFree(ptr);
+    }
+
+    void walk(int id, const double *q, double *v_out, int level) {
+        if (err != hipSuccess) return;
+        const rs_tree_node &n = tree->nodes[size_t(id)];
+        const BrSide &me = side[p], &op = side[1 - p];
+        if (n.kind == RS_NODE_TERMINAL) {
+            const int unc = n.ttype == RS_TERM_UNCONTESTED;
+            const double pot = double(float(n.value));   // tn.value as f32 (cfr.rs:316)
+            const double value = unc ? (p == int(n.last_to_act) ? -pot : pot) : pot;
+            hipLaunchKernelGGL(k_br_terminal, dim3(grid1(me.n)), dim3(kBrBlock), 0, t->stream, me.d_mask, me.d_score, me.d_pw, me.n, op.d_mask, op.d_score, q, op.n,
+                               unc, value, v_out);
+            err = hipGetLastError();
+            return;
+        }
+        if (n.kind != RS_NODE_ACTION) return walk(n.children[0], q, v_out, level);   // the private-chance root
+        const BrNodeRow row = row_of(t, n.index);
+        double *vch = v_level[size_t(level)];
+        if (int(n.player) == p) {
+            for (int a = 0; a < n.n_children; ++a) walk(n.children[a], q, vch + size_t(a) * me.n_pad, level + 1);
+            if (err != hipSuccess) return;
+#define RS_OWN(DT_)                                                                                                                                      \
+    hipLaunchKernelGGL((k_br_own<DT_>), dim3(grid1(me.n_clusters)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, me.d_start, me.d_order, me.n_clusters, \
+                       me.n_pad, vch, mode, v_out)
+            RS_BR_DT(t->dtype, RS_OWN);
+#undef RS_OWN
+        } else {
+            double *qch = q_level[size_t(level)];
+#define RS_OPP(DT_) hipLaunchKernelGGL((k_br_opp_reach<DT_>), dim3(grid1(op.n)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, op.d_cid, op.n, op.n_pad, q, qch)
+            RS_BR_DT(t->dtype, RS_OPP);
+#undef RS_OPP
+            err = hipGetLastError();
+            for (int a = 0; a < n.n_children; ++a) walk(n.children[a], qch + size_t(a) * op.n_pad, vch + size_t(a) * me.n_pad, level + 1);
+            if (err != hipSuccess) return;
+            hipLaunchKernelGGL(k_br_sum, dim3(grid1(me.n)), dim3(kBrBlock), 0, t->stream, vch, uint32_t(n.n_children), me.n, me.n_pad, v_out);
+        }
+        err = hipGetLastError();
+    }
+};
+
+static int tree_depth(const std::vector<rs_tree_node> &nodes, int id) {
+    const rs_tree_node &n = nodes[size_t(id)];
+    int d = 0;
+    for (int a = 0; a < n.n_children; ++a) d = std::max(d, tree_depth(nodes, n.children[a]));
+    return d + 1;
+}
+
+}  // namespace rs
+
+extern "C" {
+
+int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, const uint8_t *hands_p0, size_t n_hands_p0, const uint32_t *cluster_p0,
+                     const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *cluster_p1, int mode, double *out) {
+    if (!t || !tree || !board || !hands_p0 || !hands_p1 || !cluster_p0 || !cluster_p1 || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE");
+    if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_best_response: empty tree");
+    if (n_hands_p0 == 0 || n_hands_p1 == 0 || n_hands_p0 > 1326 || n_hands_p1 > 1326) return fail(RS_ERR_INVALID, "rs_best_response: 1..1326 hands per range");
+    if (int rc = check_tree_against_table(t, tree, "rs_best_response")) return rc;
+    uint32_t n_clusters[2] = {0, 0};
+    for (const rs_tree_node &n : tree->nodes) {
+        if (n.kind == RS_NODE_PUBLIC_CHANCE)
+            return fail(RS_ERR_UNSUPPORTED, "rs_best_response: single-round trees only (a public chance node would need the run-outs enumerated)");
+        if (n.kind != RS_NODE_ACTION) continue;
+        const rs_node_desc &nd = t->nodes[size_t(n.index)];
+        if (n.round_idx != 0 || nd.n_boards != 1) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: one round, one board (the reference's table shape)");
+        if (n.player > 1) return fail(RS_ERR_INVALID, "rs_best_response: two players");
+        if (n_clusters[n.player] && n_clusters[n.player] != nd.n_clusters) return fail(RS_ERR_INVALID, "rs_best_response: a player's nodes differ in cluster count");
+        n_clusters[n.player] = nd.n_clusters;
+    }
+    uint64_t board_mask = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (board[i] >= 52 || (board_mask >> board[i] & 1)) return fail(RS_ERR_INVALID, "rs_best_response: the board is five distinct cards");
+        board_mask |= 1ull << board[i];
+    }
+    const uint8_t *hands[2] = {hands_p0, hands_p1};
+    const uint32_t *cluster[2] = {cluster_p0, cluster_p1};
+    const size_t n_hands[2] = {n_hands_p0, n_hands_p1};
+    std::vector<uint64_t> mask[2];
+    for (int p = 0; p < 2; ++p) {
+        mask[p].resize(n_hands[p]);
+        for (size_t h = 0; h < n_hands[p]; ++h) {
+            const uint8_t a = hands[p][2 * h], b = hands[p][2 * h + 1];
+            if (a >= 52 || b >= 52 || a == b) return fail(RS_ERR_INVALID, "rs_best_response: bad hole cards in a range");
+            mask[p][h] = 1ull << a | 1ull << b;
+            if (mask[p][h] & board_mask) return fail(RS_ERR_INVALID, "rs_best_response: a range combo uses a board card");
+            if (n_clusters[p] && cluster[p][h] >= n_clusters[p])
+                return fail(RS_ERR_OOB, "rs_best_response: cluster id " + std::to_string(cluster[p][h]) + " of player " + std::to_string(p) + " is outside the table");
+        }
+    }
+    // the deal distribution of generate_hand on a full board (cfr.rs:124-137): player 0's combo uniform over its range, then player 1's
+    // uniform over the combos of ITS range that avoid it: P(h0, h1) = [disjoint] / (N0 * N1(h0))
+    std::vector<double> w0(n_hands[0]), ones(n_hands[1], 1.0);
+    for (size_t h0 = 0; h0 < n_hands[0]; ++h0) {
+        size_t n1 = 0;
+        for (size_t h1 = 0; h1 < n_hands[1]; ++h1) n1 += (mask[0][h0] & mask[1][h1]) == 0;
+        w0[h0] = n1 ? 1.0 / (double(n_hands[0]) * double(n1)) : 0.0;   // n1 == 0: the reference would spin forever at cfr.rs:127; such a hand gets no weight
+    }
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    BrRun run;
+    run.t = t;
+    run.tree = tree;
+    run.mode = mode;
+    for (int p = 0; p < 2; ++p) {
+        BrSide &s = run.side[p];
+        s.n = uint32_t(n_hands[p]);
+        s.n_pad = uint32_t(round_up(n_hands[p], 64));
+        s.n_clusters = n_clusters[p];
+        std::vector<uint8_t> hv(hands[p], hands[p] + 2 * n_hands[p]);
+        std::vector<uint32_t> cv(cluster[p], cluster[p] + n_hands[p]);
+        // info set -> its hands, ascending (counting sort)
+        std::vector<uint32_t> start(size_t(s.n_clusters) + 1, 0), order(n_hands[p]);
+        for (size_t h = 0; h < n_hands[p]; ++h) start[size_t(cv[h]) + 1]++;
+        for (size_t c = 0; c < s.n_clusters; ++c) start[c + 1] += start[c];
+        {
+            std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+            for (size_t h = 0; h < n_hands[p]; ++h) order[fill[cv[h]]++] = uint32_t(h);
+        }
+        s.d_hands = run.upload(hv);
+        s.d_mask = run.upload(mask[p]);
+        s.d_cid = run.upload(cv);
+        s.d_start = run.upload(start);
+        s.d_order = run.upload(order);
+        s.d_score = run.dalloc<uint32_t>(n_hands[p]);
+        s.d_init_q = run.upload(p == 0 ? w0 : ones);
+        s.d_pw = run.upload(p == 0 ? w0 : ones);
+        if (run.err == hipSuccess) {
+            hipLaunchKernelGGL(k_hand_scores, dim3(grid1(s.n)), dim3(kBrBlock), 0, t->stream, s.d_hands, s.n, uint32_t(board[0]), uint32_t(board[1]), uint32_t(board[2]),
+                               uint32_t(board[3]), uint32_t(board[4]), s.d_score);
+            run.err = hipGetLastError();
+        }
+    }
+    const int depth = tree_depth(tree->nodes, 0);
+    const size_t n_pad_max = std::max(run.side[0].n_pad, run.side[1].n_pad);
+    for (int l = 0; l < depth; ++l) {
+        run.q_level.push_back(run.dalloc<double>(size_t(RS_MAX_ACTIONS) * n_pad_max));
+        run.v_level.push_back(run.dalloc<double>(size_t(RS_MAX_ACTIONS) * n_pad_max));
+    }
+    double *d_root = run.dalloc<double>(n_pad_max);
+    std::vector<double> root(n_pad_max);
+    for (int p = 0; p < 2 && run.err == hipSuccess; ++p) {
+        run.p = p;
+        run.walk(0, run.side[1 - p].d_init_q, d_root, 0);
+        if (run.err == hipSuccess) run.err = hipMemcpyAsync(root.data(), d_root, run.side[p].n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
+        if (run.err == hipSuccess) run.err = hipStreamSynchronize(t->stream);
+        double total = 0.0;
+        for (uint32_t h = 0; h < run.side[p].n; ++h) total += root[h];   // ascending, like the oracle
+        out[p] = total;
+    }
+    // on error drain the stream before ~BrRun frees what queued kernels may still touch
+    if (run.err != hipSuccess) {
+        (void)hipStreamSynchronize(t->stream);
+        return hip_fail(run.err, "rs_best_response");
+    }
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 // Host code only: it drives the C ABI of this library.
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "rs_internal.hpp"
 
@@ -27,6 +28,11 @@ struct rs_deal_trainer {
     uint64_t t = 0;                // iterations done (deals), the shared counter of cfr.rs:200
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
+    std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
+    int tick_br = 0;                   // calc_br at every discount tick (cfr.rs:244-246)
+    float last_br[2] = {0.0f, 0.0f};
+    uint64_t last_br_t = 0;
+    bool have_br = false;
     uint32_t world = 1, rank = 0;  // data-parallel training: this rank's share of every global batch
     // The NEXT batch is dealt (sample -> clusters -> showdown) into staging buffers on a second stream while the current one is swept -- the
     // sweep kernels leave most wave slots of a CU idle -- and swapped in with device-to-device copies.  Same deal numbers, same results.
@@ -123,6 +129,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     const uint8_t *hands[2] = {hands_p0, hands_p1};
     for (int p = 0; rc == RS_OK && p < 2; ++p) {
         tr->n_hands[p] = uint32_t(n_hands[p]);
+        tr->h_hands[p].assign(hands[p], hands[p] + 2 * n_hands[p]);
         for (size_t h = 0; rc == RS_OK && h < n_hands[p]; ++h) {
             const uint8_t a = hands[p][2 * h], b = hands[p][2 * h + 1];
             if (a >= 52 || b >= 52 || a == b) rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: bad hole cards in a range");
@@ -250,10 +257,58 @@ int rs_deal_trainer_finish_batch(rs_deal_trainer *tr) {
     tr->t += uint64_t(tr->world) * tr->params.deals_per_batch;   // cfr.rs:226, once per deal
     if (tr->params.discount_interval == 0 || tr->t > tr->params.discount_cap) return RS_OK;   // cfr.rs:240-242
     if (tr->t > tr->threshold) {                                  // cfr.rs:243
+        if (tr->tick_br) {                                        // cfr.rs:244-246: calc_br on the table as it is before the sweep
+            if (int rc = rs_calc_br(tr->table, tr->tree, tr->last_br)) return rc;
+            tr->last_br_t = tr->t;
+            tr->have_br = true;
+        }
         if (int rc = rs_discount(tr->table, rs_discount_factor(tr->t, tr->params.discount_interval))) return rc;   // cfr.rs:248-261
         tr->threshold = tr->t + tr->params.discount_interval;     // cfr.rs:262
     }
     return RS_OK;
+}
+
+int rs_deal_trainer_set_tick_br(rs_deal_trainer *tr, int enable) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_set_tick_br: trainer is NULL");
+    tr->tick_br = enable;
+    return RS_OK;
+}
+int rs_deal_trainer_last_br(const rs_deal_trainer *tr, float *out, uint64_t *iterations) {
+    if (!tr || !out) return fail(RS_ERR_INVALID, "rs_deal_trainer_last_br: NULL argument");
+    if (!tr->have_br) return fail(RS_ERR_INVALID, "rs_deal_trainer_last_br: no discount tick has run calc_br yet");
+    out[0] = tr->last_br[0];
+    out[1] = tr->last_br[1];
+    if (iterations) *iterations = tr->last_br_t;
+    return RS_OK;
+}
+int rs_deal_trainer_calc_br(rs_deal_trainer *tr, float *out) {
+    if (!tr || !out) return fail(RS_ERR_INVALID, "rs_deal_trainer_calc_br: NULL argument");
+    return rs_calc_br(tr->table, tr->tree, out);
+}
+// the trainer's own game: board = the cards of board_mask in ascending order (cfr.rs:108-115), cluster ids through get_cluster
+// (hole cards first, then the board: cfr.rs:357-365)
+int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
+    if (!tr || !out) return fail(RS_ERR_INVALID, "rs_deal_trainer_best_response: NULL argument");
+    if (tr->n_rounds != 1 || __builtin_popcountll(tr->params.board_mask) != 5)
+        return fail(RS_ERR_UNSUPPORTED, "rs_deal_trainer_best_response: single-round trainers on a five-card board");
+    uint8_t board[5];
+    int nb = 0;
+    for (int c = 0; c < 52; ++c)
+        if (tr->params.board_mask >> c & 1) board[nb++] = uint8_t(c);
+    std::vector<uint32_t> cluster[2];
+    for (int p = 0; p < 2; ++p) {
+        const size_t n = tr->n_hands[p];
+        std::vector<uint8_t> cards(n * 7);
+        for (size_t h = 0; h < n; ++h) {
+            cards[7 * h] = tr->h_hands[p][2 * h];
+            cards[7 * h + 1] = tr->h_hands[p][2 * h + 1];
+            std::memcpy(&cards[7 * h + 2], board, 5);
+        }
+        cluster[p].resize(n);
+        if (int rc = rs_card_abs_get_cluster(tr->abs[0], cards.data(), n, p, cluster[p].data())) return rc;
+    }
+    return rs_best_response(tr->table, tr->tree, board, tr->h_hands[0].data(), tr->n_hands[0], cluster[0].data(), tr->h_hands[1].data(), tr->n_hands[1],
+                            cluster[1].data(), mode, out);
 }
 
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {

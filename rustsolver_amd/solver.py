@@ -354,6 +354,25 @@ class InfosetTable:
             res.append(flat[off: off + a * p].reshape(a, p)[:, : self.lanes(n)])
         return res
 
+    def calc_br(self, tree):
+        """MCCFRTrainer::calc_br as coded (cfr.rs:629-638): the pair train() prints at a discount tick"""
+        out = np.zeros(2, dtype=np.float32)
+        L.check(L.load().rs_calc_br(self._h, tree._h, _vp(out)))
+        return out
+
+    def best_response(self, tree, board, hands0, cluster0, hands1, cluster1, mode=L.BR_MAX):
+        """value per deal of each player against the other's average strategy: mode BR_MAX a best response inside the abstraction,
+        BR_AVERAGE its own average strategy; exploitability = best_response(...).sum() / 2"""
+        b = np.ascontiguousarray(board, dtype=np.uint8)
+        h0 = np.ascontiguousarray(hands0, dtype=np.uint8).reshape(-1, 2)
+        h1 = np.ascontiguousarray(hands1, dtype=np.uint8).reshape(-1, 2)
+        c0, c1 = np.ascontiguousarray(cluster0, dtype=np.uint32), np.ascontiguousarray(cluster1, dtype=np.uint32)
+        if len(b) != 5 or len(c0) != len(h0) or len(c1) != len(h1):
+            raise ValueError("board[5], one cluster id per hand")
+        out = np.zeros(2, dtype=np.float64)
+        L.check(L.load().rs_best_response(self._h, tree._h, _vp(b), _vp(h0), len(h0), _vp(c0), _vp(h1), len(h1), _vp(c1), mode, _vp(out)))
+        return out
+
     def update_node(self, node, action_utils, reach=None, scale=100.0, mode=L.UPD_CLAMP_I64):
         """One traverser visit of every lane (cfr.rs:370-466 / :571-623).  Returns node util [lanes]."""
         a = self.node_desc(node).n_actions
@@ -622,6 +641,30 @@ class DealTrainer:
     @property
     def iterations(self):
         return int(L.load().rs_deal_trainer_iterations(self._h))
+
+    def set_tick_br(self, enable=True):
+        """calc_br at every discount tick, as train() does (cfr.rs:244-246)"""
+        L.check(L.load().rs_deal_trainer_set_tick_br(self._h, int(enable)))
+
+    def last_br(self):
+        """(pair of the latest tick, iteration count it was taken at)"""
+        out, t = np.zeros(2, dtype=np.float32), C.c_uint64()
+        L.check(L.load().rs_deal_trainer_last_br(self._h, _vp(out), C.byref(t)))
+        return out, int(t.value)
+
+    def calc_br(self):
+        out = np.zeros(2, dtype=np.float32)
+        L.check(L.load().rs_deal_trainer_calc_br(self._h, _vp(out)))
+        return out
+
+    def best_response(self, mode=L.BR_MAX):
+        out = np.zeros(2, dtype=np.float64)
+        L.check(L.load().rs_deal_trainer_best_response(self._h, mode, _vp(out)))
+        return out
+
+    def exploitability(self):
+        """(BR value of player 0 + BR value of player 1) / 2 against the current average strategies, per deal, in pot units of the leaves"""
+        return float(self.best_response(L.BR_MAX).sum() / 2.0)
 
     def _download(self, ptr, dtype, count):
         out = np.empty(count, dtype=dtype)

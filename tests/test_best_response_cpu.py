@@ -1,0 +1,134 @@
+"""CPU: the two readers of the average strategy in the oracle (oracle/best_response.c) -- calc_br as coded (cfr.rs:629-745) and the real
+best response -- against hand-derived answers, the independent Python restatement (oracle/np_restate.py), the committed fixture
+(tests/golden/calc_br.json) and the properties a best response must have.  PARITY UNPINNED: the reference has no test for calc_br."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_restate as npr
+from oracle import orc
+
+BOARD = [4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3, 4 * 1 + 0, 4 * 11 + 3]   # 4d 5d As 3c Ks, options.rs:55
+
+
+def bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32).tolist()
+
+
+def fill(table, tree, rng, sparse=0.0, lo=0, hi=1000):
+    """random strategy sums; `sparse` = share of cells forced to 0 (zero-probability actions make the as-coded walk produce NaN)"""
+    fs = {}
+    for d in tree.as_dicts():
+        if d["kind"] != orc.ACTION:
+            continue
+        a, n = table.node_shape(d["index"])
+        S = rng.integers(lo, hi, (a, n))
+        S[rng.random((a, n)) < sparse] = 0
+        table.set_node(d["index"], rng.integers(-1000, 1000, (a, n)), S)
+        fs[d["index"]] = npr.get_strategy(S.astype(np.int32))
+    return fs
+
+
+def test_calc_br_hand_derived():
+    """no bet sizes: P0 check, P1 check, showdown of the 35 pot.  op stays 1.0, a SHOWDOWN pays +pot to BOTH players (cfr.rs:726):
+    (1 * 35) * (1 / 1) = 35 for each.  With bets, a zero table: every strategy is uniform and both players' maxima are the largest
+    showdown pot (1035 after Bet1.0-Raise3-Raise3-Call) up to the rounding of op * pot * (1 / op)."""
+    ot = orc.OracleTree(orc.make_options(bet_sizes=((),), raise_sizes=((),)))
+    assert ot.n_action_nodes == 2
+    tb = orc.OracleTable(ot, [1], 3)
+    assert tb.calc_br().tolist() == [35.0, 35.0]
+    ot = orc.OracleTree(orc.options_default_river())
+    tb = orc.OracleTable(ot, [1], 3)
+    got = tb.calc_br()
+    assert np.allclose(got, [1035.0, 1035.0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tree_name", ["river", "three_street"])
+@pytest.mark.parametrize("sparse", [0.0, 0.4, 1.0])
+def test_calc_br_c_oracle_equals_python_restatement(tree_name, sparse):
+    if tree_name == "river":
+        ot, (nodes, _) = orc.OracleTree(orc.options_default_river()), npr.build_tree()
+        n_boards = [1]
+    else:
+        ot = orc.OracleTree(orc.options_three_street())
+        nodes, _ = npr.build_tree(n_board_cards=3, bet_sizes=((0.5, 1.0),) * 3, raise_sizes=((3.0,),) * 3)
+        n_boards = [1, 1, 1]
+    assert len(nodes) == ot.n_nodes
+    for seed in range(4):
+        rng = np.random.Generator(np.random.PCG64(900 + seed))
+        tb = orc.OracleTable(ot, n_boards, 4)
+        fs = fill(tb, ot, rng, sparse=sparse)
+        want = npr.calc_br(nodes, {k: v[:, 0] for k, v in fs.items()})
+        assert bits(tb.calc_br()) == bits(want)
+
+
+def test_calc_br_fixture(golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "calc_br.json")))
+    for case in fx["cases"]:
+        ot = orc.OracleTree(orc.options_default_river() if case["tree"] == "river" else orc.options_three_street())
+        tb = orc.OracleTable(ot, [1, 1, 1][: 1 if case["tree"] == "river" else 3], case["n_clusters"])
+        fill(tb, ot, np.random.Generator(np.random.PCG64(case["seed"])), sparse=case["sparse"])
+        assert bits(tb.calc_br()) == case["br_bits"], case
+
+
+def river_game(rng, n0, n1, coarse):
+    """two ranges on the default board, cluster ids either one per hand or `coarse` hands per cluster"""
+    free = [c for c in range(52) if c not in BOARD]
+    combos = np.array([(a, b) for i, a in enumerate(free) for b in free[i + 1:]], dtype=np.uint8)
+    h = [combos[np.sort(rng.choice(len(combos), n, replace=False))] for n in (n0, n1)]
+    cid = [np.arange(len(x), dtype=np.uint32) // coarse for x in h]
+    return h, cid
+
+
+def oracle_game(rng, n0, n1, coarse, sparse=0.1):
+    h, cid = river_game(rng, n0, n1, coarse)
+    ot = orc.OracleTree(orc.options_default_river())
+    tb = orc.OracleDealTable(ot, [(int(cid[0].max()) + 1, int(cid[1].max()) + 1)])
+    fs = fill(tb, ot, rng, sparse=sparse)
+    return ot, tb, fs, h, cid
+
+
+@pytest.mark.parametrize("n0,n1,coarse", [(40, 40, 1), (55, 30, 1), (60, 60, 7), (1, 50, 1), (1081, 300, 3)])
+def test_best_response_c_oracle_equals_numpy_restatement(n0, n1, coarse):
+    rng = np.random.Generator(np.random.PCG64(n0 * 7 + n1))
+    ot, tb, fs, h, cid = oracle_game(rng, n0, n1, coarse)
+    nodes, _ = npr.build_tree()
+    masks = [(np.uint64(1) << x[:, 0].astype(np.uint64)) | (np.uint64(1) << x[:, 1].astype(np.uint64)) for x in h]
+    scores = [np.array([orc.evaluate7(list(x) + BOARD) for x in hp]) for hp in h]
+    for mode, name in ((0, "max"), (1, "avg")):
+        got = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], mode)
+        want = npr.best_response(nodes, lambda i: fs[i], masks, scores, cid, name)
+        assert np.allclose(got, want, rtol=1e-11, atol=1e-12), (mode, got, want)
+
+
+@pytest.mark.parametrize("coarse", [1, 5])
+def test_best_response_properties(coarse):
+    """zero-sum: the average profile's values cancel; a best response is worth at least the average strategy; exploitability >= 0"""
+    rng = np.random.Generator(np.random.PCG64(77 + coarse))
+    ot, tb, fs, h, cid = oracle_game(rng, 120, 90, coarse)
+    ev = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], 1)
+    br = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], 0)
+    assert abs(ev.sum()) < 1e-9
+    assert (br >= ev - 1e-12).all()
+    assert br.sum() / 2 > 0
+
+
+def test_best_response_folding_everything_loses_the_pot():
+    """hand-derived: player 0's average strategy is all-in on action 0 (Check) and, facing a bet, Fold (action 1 of Call / Fold / Raise):
+    player 1's best response is worth at least the 35 pot of an UNCONTESTED leaf per deal -- betting wins it outright"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    h, cid = river_game(rng, 80, 80, 1)
+    ot = orc.OracleTree(orc.options_default_river())
+    tb = orc.OracleDealTable(ot, [(80, 80)])
+    for d in ot.as_dicts():
+        if d["kind"] != orc.ACTION:
+            continue
+        a, n = tb.node_shape(d["index"])
+        S = np.zeros((a, n), dtype=np.int64)
+        kinds = [k for k, _ in d["actions"]]
+        S[kinds.index(orc.ACT_FOLD) if orc.ACT_FOLD in kinds else 0] = 100
+        tb.set_node(d["index"], np.zeros((a, n)), S)
+    br = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], 0)
+    assert br[1] >= 35.0 - 1e-9

@@ -1,0 +1,159 @@
+"""GPU (-m gpu): the readers of the average strategy through the C ABI -- rs_calc_br (MCCFRTrainer::calc_br as coded, cfr.rs:629-745) bit
+for bit against the CPU oracle and the committed fixture, rs_best_response (the real thing) bit for bit (f64, fixed summation
+order) against the oracle, and the domain properties on the device trainer: the average profile is zero-sum, a best response is worth at
+least the average strategy, and the exploitability of the trained average strategy falls as training goes on."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustsolver_amd as rs
+from oracle import orc
+from rustsolver_amd import _lib as L
+from rustsolver_amd import abstraction as ab
+from test_best_response_cpu import BOARD, bits, river_game
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if rs.device_count() < 1:
+        pytest.fail("no HIP device visible: GPU parity tests need a real MI355X (there is no CPU fallback)")
+
+
+def fill_both(table, otab, tree, rng, sparse, dtype=L.I32):
+    """the fill rule of tests/golden/make_calc_br_golden.py on the device table and the oracle table alike"""
+    for nd in tree.action_nodes():
+        a, n = otab.node_shape(nd.index)
+        S = rng.integers(0, 1000, (a, n))
+        S[rng.random((a, n)) < sparse] = 0
+        R = rng.integers(-1000, 1000, (a, n))
+        if dtype == L.I32:
+            table.upload_node(nd.index, R.astype(np.int32), S.astype(np.int32))
+        else:
+            table.upload_node(nd.index, R.astype(np.float32), S.astype(np.float32))
+        otab.set_node(nd.index, R, S)
+
+
+def test_calc_br_fixture_through_the_abi(golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "calc_br.json")))
+    for case in fx["cases"]:
+        river = case["tree"] == "river"
+        n_actions, tree = rs.build_game_tree(rs.default_flop() if river else rs.three_street_options())
+        rounds = 1 if river else 3
+        table = rs.create_infosets(n_actions, tree, [case["n_clusters"]] * rounds, [1] * rounds)
+        ot = orc.OracleTree(orc.options_default_river() if river else orc.options_three_street())
+        otab = orc.OracleTable(ot, [1] * rounds, case["n_clusters"])
+        fill_both(table, otab, tree, np.random.Generator(np.random.PCG64(case["seed"])), case["sparse"])
+        got = table.calc_br(tree)
+        assert bits(got) == case["br_bits"] == bits(otab.calc_br()), case
+
+
+@pytest.mark.parametrize("dtype,odtype", [(L.I32, orc.T_I32), (L.F32, orc.T_F32), (L.F16, orc.T_F16)])
+@pytest.mark.parametrize("river", [True, False])
+def test_calc_br_equals_oracle(dtype, odtype, river):
+    """every table element type, both trees, dense and sparse average strategies (zero-probability actions give NaN, as in the reference),
+    a zero table (uniform strategies) and values beyond 2^24 (i32 -> f32 rounds)"""
+    n_actions, tree = rs.build_game_tree(rs.default_flop() if river else rs.three_street_options())
+    rounds = 1 if river else 3
+    ot = orc.OracleTree(orc.options_default_river() if river else orc.options_three_street())
+    for seed, sparse, n_clusters in [(1, 0.0, 70), (2, 0.5, 3), (3, 0.9, 1)]:
+        table = rs.create_infosets(n_actions, tree, [n_clusters] * rounds, [1] * rounds, dtype=dtype)
+        otab = orc.OracleTable(ot, [1] * rounds, n_clusters, odtype)
+        assert bits(table.calc_br(tree)) == bits(otab.calc_br())   # zero table
+        fill_both(table, otab, tree, np.random.Generator(np.random.PCG64(seed)), sparse, dtype)
+        assert bits(table.calc_br(tree)) == bits(otab.calc_br())
+    if dtype == L.I32:
+        table = rs.create_infosets(n_actions, tree, [2] * rounds, [1] * rounds)
+        otab = orc.OracleTable(ot, [1] * rounds, 2)
+        rng = np.random.Generator(np.random.PCG64(9))
+        for nd in tree.action_nodes():
+            a, n = otab.node_shape(nd.index)
+            S = rng.integers(0, 2**31 - 1, (a, n))
+            table.upload_node(nd.index, np.zeros((a, n), np.int32), S.astype(np.int32))
+            otab.set_node(nd.index, np.zeros((a, n)), S)
+        assert bits(table.calc_br(tree)) == bits(otab.calc_br())
+
+
+def device_and_oracle_game(rng, n0, n1, coarse, sparse=0.1):
+    h, cid = river_game(rng, n0, n1, coarse)
+    sizes = (int(cid[0].max()) + 1, int(cid[1].max()) + 1)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, [sizes], [1])
+    ot = orc.OracleTree(orc.options_default_river())
+    otab = orc.OracleDealTable(ot, [sizes])
+    fill_both(table, otab, tree, rng, sparse)
+    return tree, table, otab, h, cid
+
+
+@pytest.mark.parametrize("n0,n1,coarse", [(1081, 1081, 1), (700, 1081, 1), (300, 257, 4), (1, 64, 1), (65, 1, 1), (1081, 1081, 40)])
+def test_best_response_equals_oracle_bit_for_bit(n0, n1, coarse):
+    rng = np.random.Generator(np.random.PCG64(n0 + 3 * n1 + coarse))
+    tree, table, otab, h, cid = device_and_oracle_game(rng, n0, n1, coarse)
+    for mode in (L.BR_MAX, L.BR_AVERAGE):
+        got = table.best_response(tree, BOARD, h[0], cid[0], h[1], cid[1], mode)
+        want = otab.best_response(BOARD, h[0], cid[0], h[1], cid[1], mode)
+        assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist(), (mode, got, want)
+    ev = table.best_response(tree, BOARD, h[0], cid[0], h[1], cid[1], L.BR_AVERAGE)
+    br = table.best_response(tree, BOARD, h[0], cid[0], h[1], cid[1], L.BR_MAX)
+    assert abs(ev.sum()) < 1e-9 and (br >= ev - 1e-12).all()
+
+
+def test_best_response_rejects_what_it_cannot_do():
+    rng = np.random.Generator(np.random.PCG64(3))
+    tree, table, otab, h, cid = device_and_oracle_game(rng, 30, 30, 1)
+    bad = cid[0].copy()
+    bad[7] = 30
+    with pytest.raises(rs.RsError, match="outside the table"):
+        table.best_response(tree, BOARD, h[0], bad, h[1], cid[1])
+    with pytest.raises(rs.RsError, match="five distinct cards"):
+        table.best_response(tree, [0, 0, 1, 2, 3], h[0], cid[0], h[1], cid[1])
+    hb = h[0].copy()
+    hb[0] = [BOARD[0], hb[0][1]]
+    with pytest.raises(rs.RsError, match="board card"):
+        table.best_response(tree, BOARD, hb, cid[0], h[1], cid[1])
+    n_actions, tree3 = rs.build_game_tree(rs.three_street_options())
+    table3 = rs.create_infosets(n_actions, tree3, [30, 30, 30], [1, 1, 1])
+    with pytest.raises(rs.RsError, match="single-round"):
+        table3.best_response(tree3, BOARD, h[0], cid[0], h[1], cid[1])
+
+
+def test_trainer_ticks_run_calc_br_and_exploitability_falls():
+    """the reference's own configuration (default_flop board, random ranges, ISOMORPHIC river abstraction) on the device trainer:
+    * with tick_br on, every discount tick stores calc_br of the table as it was BEFORE the discount (cfr.rs:244-247);
+    * zero table: every strategy uniform -- exploitable; after training the average strategy is much less so, and keeps improving."""
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, 2, None)]
+    n = 1 << 16
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=5, discount_interval=4 * n, discount_cap=10**12)
+    tr.set_tick_br(True)
+    with pytest.raises(rs.RsError, match="no discount tick"):
+        tr.last_br()
+    ev0, br0 = tr.best_response(L.BR_AVERAGE), tr.best_response(L.BR_MAX)
+    assert abs(ev0.sum()) < 1e-9 and (br0 >= ev0 - 1e-12).all()
+    e0 = tr.exploitability()
+    assert e0 > 1.0
+    tr.train(4)            # t = 4n: not yet beyond the threshold (cfr.rs:243 is a strict >)
+    with pytest.raises(rs.RsError, match="no discount tick"):
+        tr.last_br()
+    before_tick = None
+    tr.deal()
+    for player in (0, 1):
+        tr.iterate_phase(player, 0)
+        tr.iterate_phase(player, 1)
+    before_tick = tr.calc_br()
+    tr.finish_batch()      # t = 5n > 4n: calc_br, then the discount
+    pair, t = tr.last_br()
+    assert t == 5 * n and bits(pair) == bits(before_tick)
+    tr.train(60)
+    e1 = tr.exploitability()
+    tr.train(400)
+    e2 = tr.exploitability()
+    tr.status()
+    ev = tr.best_response(L.BR_AVERAGE)
+    assert abs(ev.sum()) < 1e-9
+    assert e1 < 0.5 * e0 and e2 < e1, (e0, e1, e2)
