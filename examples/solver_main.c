@@ -72,6 +72,7 @@ int main(int argc, char **argv) {
     params.rank = 0;
     rs_card_abs *abstractions[1] = {river};
     CHECK(rs_deal_trainer_create(tree, abstractions, 1, &hands[0][0], n_hands, &hands[0][0], n_hands, &params, 0, &trainer));
+    CHECK(rs_deal_trainer_set_tick_br(trainer, 1));   /* "calc br" at every discount tick (cfr.rs:244-246) */
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     CHECK(rs_deal_trainer_train(trainer, (iterations + deals_per_batch - 1) / deals_per_batch));   /* trainer.train(10_000_000) */
@@ -80,6 +81,14 @@ int main(int argc, char **argv) {
     const double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     printf("%llu iterations in %.3f ms (%.3g iterations/s)\n", (unsigned long long)rs_deal_trainer_iterations(trainer), s * 1e3,
            (double)rs_deal_trainer_iterations(trainer) / s);
+    float br[2];
+    uint64_t br_t = 0;
+    if (rs_deal_trainer_last_br(trainer, br, &br_t) == RS_OK) printf("calc br (as coded, last tick at %llu)\n%g %g\n", (unsigned long long)br_t, br[0], br[1]);
+    double brv[2], ev[2];
+    CHECK(rs_deal_trainer_best_response(trainer, RS_BR_MAX, brv));
+    CHECK(rs_deal_trainer_best_response(trainer, RS_BR_AVERAGE, ev));
+    printf("average strategy: value %.4f / %.4f per deal, best responses %.4f / %.4f, exploitability %.4f\n", ev[0], ev[1], brv[0], brv[1],
+           (brv[0] + brv[1]) / 2.0);
     float sigma[RS_MAX_ACTIONS];
     CHECK(rs_get_final_strategy(rs_deal_trainer_table(trainer), 0, 0, 0, sigma));   /* Infoset::get_final_strategy of the root, cluster 0 */
     printf("root, cluster 0: average strategy %.3f %.3f %.3f\n", sigma[0], sigma[1], sigma[2]);

@@ -100,6 +100,15 @@ extern "C" {
     pub fn rs_deal_trainer_table(trainer: *mut rs_deal_trainer) -> *mut rs_table;
     pub fn rs_deal_trainer_train(trainer: *mut rs_deal_trainer, n_batches: u64) -> c_int;
     pub fn rs_deal_trainer_status(trainer: *mut rs_deal_trainer) -> c_int;
+    // calc_br as coded (cfr.rs:629-745; printed at every discount tick, cfr.rs:244-246) and the best response it stands in for
+    pub fn rs_calc_br(table: *mut rs_table, tree: *const rs_tree, out: *mut f32) -> c_int;
+    pub fn rs_best_response(table: *mut rs_table, tree: *const rs_tree, board: *const u8, hands_p0: *const u8, n_hands_p0: usize,
+                            cluster_p0: *const u32, hands_p1: *const u8, n_hands_p1: usize, cluster_p1: *const u32, mode: c_int,
+                            out: *mut f64) -> c_int;
+    pub fn rs_deal_trainer_set_tick_br(trainer: *mut rs_deal_trainer, enable: c_int) -> c_int;
+    pub fn rs_deal_trainer_last_br(trainer: *const rs_deal_trainer, out: *mut f32, iterations: *mut u64) -> c_int;
+    pub fn rs_deal_trainer_calc_br(trainer: *mut rs_deal_trainer, out: *mut f32) -> c_int;
+    pub fn rs_deal_trainer_best_response(trainer: *mut rs_deal_trainer, mode: c_int, out: *mut f64) -> c_int;
 }
 
 #[repr(C)] pub struct rs_hand_indexer { _private: [u8; 0] }
