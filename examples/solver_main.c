@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
     params.solver.deal_offset = 0;
     params.world = 1;
     params.rank = 0;
+    params.prune_threshold = 10000000;   /* cfr.rs:190 */
     rs_card_abs *abstractions[1] = {river};
     CHECK(rs_deal_trainer_create(tree, abstractions, 1, &hands[0][0], n_hands, &hands[0][0], n_hands, &params, 0, &trainer));
     CHECK(rs_deal_trainer_set_tick_br(trainer, 1));   /* "calc br" at every discount tick (cfr.rs:244-246) */

@@ -279,6 +279,8 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
 typedef struct rs_deal_batch {
     uint32_t n_deals;
     const uint32_t *d_cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS];   /* device; [round_idx][player] */
+    const uint8_t *d_prune;   /* RS_UPD_PRUNE only: device [pitch] bytes, 1 = this deal is traversed with prune = true.  In train() pruning is a
+                                 property of the DEAL (cfr.rs:213-221: t > PRUNE_THRESHOLD && q > 0.05); NULL = every deal */
 } rs_deal_batch;
 int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                            const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out);
@@ -384,6 +386,11 @@ int rs_card_abs_status(rs_card_abs *abs, rs_table *table);   /* synchronises; RS
 int rs_deals_sample(rs_table *table, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0,
                     uint32_t n_hands_p0, const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err);
 
+/* train()'s per-deal prune decision (cfr.rs:213-221): d_flags[pitch] u8, 1 where deal number first_deal + i exceeds prune_threshold
+ * (PRUNE_THRESHOLD = 10 000 000, cfr.rs:190) AND its `q: f32 = rng.gen()` -- counter 4096 of the deal's hash, after everything
+ * generate_hand can draw -- is > 0.05.  Ready to be an rs_deal_batch.d_prune.  Asynchronous on the table's stream. */
+int rs_deals_prune_flags(rs_table *table, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags);
+
 /* ---- MCCFRTrainer on the GPU: init + train over sampled deals (cfr.rs:159-297) -----------------------------------------------------
  * Per batch, all on the table's stream: rs_deals_sample -> rs_card_abs_clusters_device for every round -> rs_showdown_sign -> one
  * sampled-opponent sweep per traverser (rs_solver_create_deals).  One deal = one reference iteration (cfr.rs:209-226). */
@@ -398,6 +405,9 @@ typedef struct rs_deal_trainer_params {
                                       deal_offset is set from rank */
     uint32_t world, rank;          /* data-parallel training on replicated tables: this rank deals numbers (b*world + rank)*n .. + n of
                                       global batch b; 0 / 0 or 1 / 0 = single GPU.  t advances by world * deals_per_batch per batch */
+    uint64_t prune_threshold;      /* cfr.rs:190 PRUNE_THRESHOLD (10 000 000): deals numbered beyond it are traversed with prune = true when their
+                                      q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  Batches that contain such deals run on
+                                      a second solver (level plan, RS_UPD_PRUNE with per-deal flags) created when the first one is reached */
 } rs_deal_trainer_params;
 /* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
  * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */
@@ -427,6 +437,7 @@ int rs_deal_trainer_calc_br(rs_deal_trainer *trainer, float *out /*[2]*/);
 int rs_deal_trainer_best_response(rs_deal_trainer *trainer, int mode, double *out /*[2]*/);
 const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *trainer);  /* device: the current batch's d_cards[9][pitch] */
 const float *rs_deal_trainer_signs(const rs_deal_trainer *trainer);    /* device: its showdown signs [pitch] */
+const uint8_t *rs_deal_trainer_prune_flags(const rs_deal_trainer *trainer);   /* device: its per-deal prune flags [pitch] (all 0 before the threshold) */
 const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *trainer, int round_idx, int player);   /* device: its cluster ids [pitch] */
 
 /* ---- abstraction generator's distance sweep: gen_abstraction/kmeans.rs, emd.rs -----------------------------

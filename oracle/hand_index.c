@@ -538,6 +538,14 @@ uint64_t orc_deal_bits(uint64_t seed, uint64_t deal, uint32_t k) {
     return mix64(mix64(seed ^ (deal + 1) * 0xD1B54A32D192ED03ull) + (uint64_t)k * 0x632BE59BD9B4E019ull);
 }
 
+/* train()'s per-deal prune decision (cfr.rs:213-221): `let q: f32 = rng.gen()` after generate_hand -- rand 0.7 Standard: the 24 high bits of a
+ * u32 times 2^-24 -- drawn as counter 4096 of the deal's hash (generate_hand stops before it); prune = t > PRUNE_THRESHOLD && q > 0.05 with
+ * t = the deal's global number */
+int orc_deal_prune(uint64_t seed, uint64_t deal, uint64_t prune_threshold) {
+    const float q = (float)((uint32_t)orc_deal_bits(seed, deal, 4096) >> 8) * (1.0f / 16777216.0f);
+    return deal > prune_threshold && q > 0.05f;
+}
+
 /* rand 0.7 UniformInt<u8>::sample for Uniform::from(0..52) (cfr.rs:106,:116): u32 draws, widening multiply, reject the low half above
  * `zone`; returns the card or -1 when the draw is rejected */
 static int uniform52(uint32_t draw) {

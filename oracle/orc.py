@@ -93,7 +93,8 @@ class HandIndexerC(C.Structure):   # orc_hand_indexer (hand_index.h)
 
 
 DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
-                    ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t), ("lane_base", C.c_size_t)]
+                    ("cidx", (C.POINTER(C.c_uint32) * 2) * MAX_ROUNDS), ("n_deals", C.c_size_t), ("lane_base", C.c_size_t),
+                    ("prune_deal", C.c_void_p)]
 
 
 def build(force=False):
@@ -196,6 +197,7 @@ def lib():
     L.orc_generate_map.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     L.orc_generate_map.restype = C.c_size_t
     L.orc_deal_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    L.orc_deal_prune.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     L.orc_deal_bits.restype = C.c_uint64
     L.orc_generate_hand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_emd_1d.argtypes = [f32p, f32p, C.c_int]
@@ -509,8 +511,9 @@ class OracleDealTable(OracleTable):
 class OracleDealSolver(OracleSolver):
     """Batch-synchronous deal sweeps (orc_iterate_deals)."""
 
-    def __init__(self, tree, table, leaves, cidx, n_deals, lane_base=0, **kw):
-        """cidx: dict (round_idx, player) -> uint32 array [n_deals]; lane_base: global index of deal 0 (data-parallel batches)"""
+    def __init__(self, tree, table, leaves, cidx, n_deals, lane_base=0, prune_deal=None, **kw):
+        """cidx: dict (round_idx, player) -> uint32 array [n_deals]; lane_base: global index of deal 0 (data-parallel batches);
+        prune_deal: uint8 [n_deals] read at every sweep, 1 = the deal is traversed with prune = true (needs prune=True; cfr.rs:213-221)"""
         super().__init__(tree, table, leaves, chance_mode=CHANCE_PASS, **kw)
         self.delta = OracleDealTable(tree, table.sizes)
         self.n_deals = n_deals
@@ -523,6 +526,11 @@ class OracleDealSolver(OracleSolver):
             a = np.ascontiguousarray(arr, dtype=np.uint32)
             self._keep.append(a)
             dc.cidx[r][p] = a.ctypes.data_as(C.POINTER(C.c_uint32))
+        if prune_deal is not None:
+            if prune_deal.dtype != np.uint8 or len(prune_deal) != n_deals or not prune_deal.flags.c_contiguous:
+                raise ValueError("prune_deal: contiguous uint8 [n_deals]")
+            self._keep.append(prune_deal)
+            dc.prune_deal = prune_deal.ctypes.data
         self.dc = dc
 
     def iterate(self, player, threads=1, seed=None):
@@ -658,6 +666,11 @@ class HandIndexer:
             lib().orc_hand_indexer_free(C.byref(self.ix))
         except Exception:
             pass
+
+
+def deal_prune_flags(seed, first_deal, prune_threshold, n_deals):
+    """train()'s per-deal prune decision (cfr.rs:213-221) for deals first_deal .. first_deal + n_deals - 1 -> uint8 [n_deals]"""
+    return np.array([lib().orc_deal_prune(seed, first_deal + i, prune_threshold) for i in range(n_deals)], dtype=np.uint8)
 
 
 def generate_hands(seed, first_deal, board_mask, hands0, hands1, n_deals):

@@ -772,11 +772,12 @@ float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t 
         const orc_infoset *infoset = &ctx->table->rows[nd->index][cluster_idx];
         orc_infoset *dinfo = &dc->delta->rows[nd->index][cluster_idx];
         float utils[ORC_MAX_ACTIONS], strategy[ORC_MAX_ACTIONS], util = 0.0f;
+        const int prune = ctx->prune && (!dc->prune_deal || dc->prune_deal[deal]);   /* the `prune` argument of mccfr(), cfr.rs:219-221 */
         orc_get_strategy(infoset->regrets, n_actions, strategy);
         if (nd->player == player) {
             int32_t r[ORC_MAX_ACTIONS], s[ORC_MAX_ACTIONS];
             for (i = 0; i < n_actions; i++) {
-                if (ctx->prune && !(infoset->regrets[i] > ORC_PRUNE_THRESHOLD)) {
+                if (prune && !(infoset->regrets[i] > ORC_PRUNE_THRESHOLD)) {
                     utils[i] = 0.0f;
                     continue;
                 }
@@ -785,7 +786,7 @@ float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t 
             memcpy(r, infoset->regrets, (size_t)n_actions * sizeof(int32_t));
             memcpy(s, infoset->strategy_sum, (size_t)n_actions * sizeof(int32_t));
             if (ctx->rmplus) util = orc_update_infoset_rmplus(r, s, n_actions, utils, cfr_reach, ctx->scale);
-            else util = orc_update_infoset(r, s, n_actions, utils, cfr_reach, ctx->scale, ctx->mode, ctx->prune);
+            else util = orc_update_infoset(r, s, n_actions, utils, cfr_reach, ctx->scale, ctx->mode, prune);
             for (i = 0; i < n_actions; i++) { /* delta against the snapshot value, accumulated with wrapping adds */
                 dinfo->regrets[i] = wrapping_add_i32(dinfo->regrets[i], (int32_t)((uint32_t)r[i] - (uint32_t)infoset->regrets[i]));
                 dinfo->strategy_sum[i] =

@@ -211,6 +211,8 @@ typedef struct {
     const uint32_t *cidx[ORC_MAX_ROUNDS][ORC_MAX_PLAYERS];   /* [n_deals] each */
     size_t n_deals;
     size_t lane_base;                    /* data-parallel batches: global index of deal 0 (opponent-sampling hash only) */
+    const uint8_t *prune_deal;           /* ctx->prune only: [n_deals] 1 = this deal is traversed with prune = true (in train() pruning is a
+                                            property of the deal: t > PRUNE_THRESHOLD && q > 0.05, cfr.rs:213-221); NULL = every deal */
 } orc_deal_ctx;
 float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t deal, float cfr_reach);
 /* one traverser sweep over all deals, then table += delta (wrapping), delta = 0 */

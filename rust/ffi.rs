@@ -31,7 +31,7 @@ pub struct rs_solver_params { pub scale: f32, pub mode: i32, pub chance_mode: i3
                                pub deal_offset: u32 }
 
 #[repr(C)] #[derive(Clone, Copy)]
-pub struct rs_deal_batch { pub n_deals: u32, pub d_cluster: [[*const u32; 2]; RS_MAX_ROUNDS] }
+pub struct rs_deal_batch { pub n_deals: u32, pub d_cluster: [[*const u32; 2]; RS_MAX_ROUNDS], pub d_prune: *const u8 /* per-deal prune flags, cfr.rs:213-221 */ }
 
 pub const RS_I32: c_int = 0;
 pub const RS_UPD_CLAMP_I64: c_int = 0;   // cfr.rs:413-464
@@ -93,6 +93,7 @@ extern "C" {
     // generate_hand (cfr.rs:100-143) and the whole MCCFRTrainer loop (cfr.rs:159-297) on the device
     pub fn rs_deals_sample(table: *mut rs_table, seed: u64, first_deal: u64, board_mask: u64, d_hands_p0: *const u8, n_hands_p0: u32,
                            d_hands_p1: *const u8, n_hands_p1: u32, n_deals: u32, d_cards: *mut u8, d_err: *mut u32) -> c_int;
+    pub fn rs_deals_prune_flags(table: *mut rs_table, seed: u64, first_deal: u64, prune_threshold: u64, n_deals: u32, d_flags: *mut u8) -> c_int;
     pub fn rs_deal_trainer_create(tree: *const rs_tree, card_abs: *const *mut rs_card_abs, n_rounds: c_int, hands_p0: *const u8,
                                   n_hands_p0: usize, hands_p1: *const u8, n_hands_p1: usize, params: *const rs_deal_trainer_params,
                                   device: c_int, out: *mut *mut rs_deal_trainer) -> c_int;
@@ -124,6 +125,7 @@ pub struct rs_deal_trainer_params {
     pub solver: rs_solver_params,
     pub world: u32,               // data-parallel training on replicated tables
     pub rank: u32,
+    pub prune_threshold: u64,     // cfr.rs:190 PRUNE_THRESHOLD; u64::MAX = never
 }
 
 /// Flatten `Tree<GameTreeNode>` (tree.rs:14-17, nodes.rs:46-52) into the ABI's node array.

@@ -51,7 +51,7 @@ class LeafDesc(C.Structure):
 
 
 class DealBatch(C.Structure):
-    _fields_ = [("n_deals", C.c_uint32), ("d_cluster", (C.c_void_p * MAX_PLAYERS) * MAX_ROUNDS)]
+    _fields_ = [("n_deals", C.c_uint32), ("d_cluster", (C.c_void_p * MAX_PLAYERS) * MAX_ROUNDS), ("d_prune", C.c_void_p)]
 
 
 class SolverParams(C.Structure):
@@ -63,7 +63,8 @@ class SolverParams(C.Structure):
 
 class DealTrainerParams(C.Structure):
     _fields_ = [("board_mask", C.c_uint64), ("deals_per_batch", C.c_uint32), ("seed", C.c_uint64), ("discount_interval", C.c_uint64),
-                ("discount_cap", C.c_uint64), ("solver", SolverParams), ("world", C.c_uint32), ("rank", C.c_uint32)]
+                ("discount_cap", C.c_uint64), ("solver", SolverParams), ("world", C.c_uint32), ("rank", C.c_uint32),
+                ("prune_threshold", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -169,6 +170,7 @@ SYMBOLS = {
     "rs_card_abs_clusters_device": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     "rs_card_abs_status": (C.c_int, [_P, _P]),
     "rs_deals_sample": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "rs_deals_prune_flags": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "rs_deal_trainer_create": (C.c_int, [_P, _PP, C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(DealTrainerParams), C.c_int, _PP]),
     "rs_deal_trainer_destroy": (None, [_P]),
     "rs_deal_trainer_table": (C.c_void_p, [_P]),
@@ -183,6 +185,7 @@ SYMBOLS = {
     "rs_deal_trainer_best_response": (C.c_int, [_P, C.c_int, _P]),
     "rs_deal_trainer_cards": (C.c_void_p, [_P]),
     "rs_deal_trainer_signs": (C.c_void_p, [_P]),
+    "rs_deal_trainer_prune_flags": (C.c_void_p, [_P]),
     "rs_deal_trainer_clusters": (C.c_void_p, [_P, C.c_int, C.c_int]),
     "rs_histogram_distance": (C.c_int, [C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "rs_kmeans_predict": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),

@@ -770,6 +770,14 @@ int rs_card_abs_status(rs_card_abs *a, rs_table *t) {
     return fail(RS_ERR_OOB, "get_cluster: a deal's bucket has no cluster id for its player (Rust: unwrap on None, card_abstraction.rs:208)");
 }
 
+// ---- train()'s per-deal prune flag (cfr.rs:213-221) --------------------------------------------------------------------------
+// `let q: f32 = rng.gen()` right after generate_hand, then prune = t.load() > PRUNE_THRESHOLD && q > 0.05 for BOTH traversals of the deal.
+// rand 0.7 Standard for f32: 24 high bits of a u32 times 2^-24.  The draw is counter kSampleMaxDraws of the deal's hash (generate_hand never
+// gets that far); t = the deal's global number (iterations completed before it in the sequential reading).
+int rs_deals_prune_flags(rs_table *t, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags) {
+    return rs::deal_prune_flags_on(t, t ? t->stream : nullptr, seed, first_deal, prune_threshold, n_deals, d_flags);
+}
+
 // ---- generate_hand for a batch (cfr.rs:100-143) ------------------------------------------------------------------------------
 // d_hands_p*: device arrays of (u8, u8) combos = HandRange.hands after remove_invalid_combos (cfr.rs:161-163).  Deal i of the call draws from
 // the counter hash (seed, first_deal + i).  d_cards[9][pitch] as above.  d_err (may be NULL): bit 2 raised when a deal found no valid combo.
@@ -780,6 +788,22 @@ int rs_deals_sample(rs_table *t, uint64_t seed, uint64_t first_deal, uint64_t bo
 }  // extern "C"
 
 namespace rs {
+__global__ __launch_bounds__(kBlock) void k_deal_prune_flags(uint64_t seed, uint64_t first_deal, uint64_t threshold, uint32_t n, uint32_t pitch,
+                                                             uint8_t *__restrict__ flags) {
+    for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < pitch; l += gridDim.x * kBlock) {
+        const uint64_t deal = first_deal + l;
+        const float q = (float)((uint32_t)deal_bits(seed, deal, kSampleMaxDraws) >> 8) * 5.9604644775390625e-08f;   // 2^-24
+        flags[l] = (l < n && deal > threshold && q > 0.05f) ? 1 : 0;
+    }
+}
+int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags) {
+    if (!t || !d_flags) return fail(RS_ERR_INVALID, "rs_deals_prune_flags: NULL argument");
+    if (n_deals == 0) return RS_OK;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    hipLaunchKernelGGL(k_deal_prune_flags, lane_grid(n_deals), dim3(kBlock), 0, stream, seed, first_deal, prune_threshold, n_deals, uint32_t(round_up(n_deals, kLanePad)), d_flags);
+    RS_HIP(hipGetLastError(), "k_deal_prune_flags");
+    return RS_OK;
+}
 int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
                     const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err) {
     if (!t || !d_hands_p0 || !d_hands_p1 || !d_cards) return fail(RS_ERR_INVALID, "rs_deals_sample: NULL argument");

@@ -52,6 +52,14 @@ __device__ __forceinline__ void finish_child(const ChildSrc &c, uint32_t v, floa
     }
 }
 
+// prune = true is a property of the DEAL in train() (cfr.rs:219: t > PRUNE_THRESHOLD && q > 0.05): deal batches carry one flag byte per lane
+__device__ __forceinline__ void lane_prune_flags(const NodeJob &job, bool prune, uint32_t v, bool (&out)[kVec]) {
+    uint32_t w = 0x01010101u;
+    if (prune && job.prune_lane) w = reinterpret_cast<const uint32_t *>(job.prune_lane)[v];
+#pragma unroll
+    for (int j = 0; j < kVec; j++) out[j] = prune && ((w >> (8 * j)) & 0xffu) != 0;
+}
+
 // table row of a node for the thread's 4 lanes: vector access (lane model) or gather through cluster ids (deal batches)
 template <int DT>
 __device__ __forceinline__ void load_table_row(const NodeJob &job, const void *base, uint32_t row_off, uint32_t v,
@@ -95,6 +103,8 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
 #pragma unroll
         for (int a = 0; a < A; a++) finish_child(job.child[a], v, u[a]);
         if (job.cidx) mask_tail_lanes(reach, v, job.n_lanes);
+        bool prune_l[kVec];
+        lane_prune_flags(job, prune, v, prune_l);
         V r0[A][kVec], s0[A][kVec];   // values before the visit (deal batches turn the update into a delta)
 #pragma unroll
         for (int a = 0; a < A; a++)
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
             float ul[A];
 #pragma unroll
             for (int a = 0; a < A; a++) { rl[a] = r[a][j]; sl[a] = s[a][j]; ul[a] = u[a][j]; }
-            if constexpr (DT == RS_I32) util[j] = visit_i32<A, ARITH>(rl, sl, ul, reach[j], job.scale, rmplus, prune);
+            if constexpr (DT == RS_I32) util[j] = visit_i32<A, ARITH>(rl, sl, ul, reach[j], job.scale, rmplus, prune_l[j]);
             else util[j] = visit_f32<A>(rl, sl, ul, reach[j], job.scale, rmplus);
 #pragma unroll
             for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
@@ -236,12 +246,14 @@ __global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restric
 #pragma unroll
             for (int j = 0; j < kVec; j++) reach[j] = job.reach_const;
         }
+        bool prune_l[kVec];
+        lane_prune_flags(job, true, v, prune_l);
 #pragma unroll
         for (int a = 0; a < A; a++) {
             if (!job.out_reach[a]) continue;
             float out[kVec];
 #pragma unroll
-            for (int j = 0; j < kVec; j++) out[j] = (r[a][j] > kPruneThreshold) ? reach[j] : __builtin_nanf("");
+            for (int j = 0; j < kVec; j++) out[j] = (!prune_l[j] || r[a][j] > kPruneThreshold) ? reach[j] : __builtin_nanf("");
             store_f32_row(job.out_reach[a], v, out);
         }
     }

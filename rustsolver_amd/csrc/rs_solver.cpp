@@ -114,6 +114,7 @@ struct rs_solver {
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
+    bool seed_shared = false;           // d_seed_state belongs to another solver of the same table (the trainer's pruning solver continues its sweep count)
     const uint64_t *d_seed() const { return d_seed_state ? d_seed_state + 2 : nullptr; }
 };
 
@@ -420,6 +421,7 @@ struct Builder {
             job.dssm = (char *)t->d_dssum + t->cell_off[nd.index] * 4;
             job.n_lanes = s->deals.n_deals;
             job.lane_base = s->params.deal_offset;
+            if (s->params.mode & RS_UPD_PRUNE) job.prune_lane = s->deals.d_prune;
         }
     }
 
@@ -1093,11 +1095,11 @@ int run_plan(rs_solver *s, int p, int phase = -1) {
 extern "C" {
 
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out);
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out, rs_solver *seed_owner);
 
 int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
                      const rs_solver_params *params, rs_solver **out) {
-    return solver_create_impl(table, tree, nullptr, leaves_p0, leaves_p1, params, out);
+    return solver_create_impl(table, tree, nullptr, leaves_p0, leaves_p1, params, out, nullptr);
 }
 
 int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
@@ -1116,10 +1118,19 @@ int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_b
         if (e == hipSuccess) e = hipMemsetAsync(table->d_dssum, 0, bytes, table->stream);
         if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: delta tables");
     }
-    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out);
+    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out, nullptr);
 }
 
 }  // extern "C"
+
+namespace rs {
+// a second deal solver on the same table that continues `seed_owner`'s count of sampled sweeps (the trainer's pruning solver)
+int solver_create_deals_sharing_seed(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
+                                     const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver *seed_owner, rs_solver **out) {
+    if (!deals || deals->n_deals == 0 || !table || !table->d_dregrets) return fail(RS_ERR_INVALID, "solver_create_deals_sharing_seed: needs a deal table");
+    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out, seed_owner);
+}
+}  // namespace rs
 
 void rs::solver_release_device(rs_solver *s) {
     if (!s || !s->table) return;   // already detached (its table was destroyed first)
@@ -1153,7 +1164,7 @@ void rs::solver_release_device(rs_solver *s) {
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
     s->d_shadow = nullptr;
     s->d_shadow_jobs = nullptr;
-    if (s->d_seed_state) (void)hipFree(s->d_seed_state);
+    if (s->d_seed_state && !s->seed_shared) (void)hipFree(s->d_seed_state);
     if (s->d_exchange) (void)hipFree(s->d_exchange);
     s->d_exchange = nullptr;
     s->d_arena = nullptr;
@@ -1163,7 +1174,7 @@ void rs::solver_release_device(rs_solver *s) {
 }
 
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out, rs_solver *seed_owner) {
     if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
         return fail(RS_ERR_INVALID, "rs_solver_create: NULL argument");
     const int arith = params->mode & RS_UPD_ARITH_MASK;
@@ -1221,7 +1232,10 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         rs_solver_destroy(s);
         return hip_fail(e, "hipSetDevice");
     }
-    if (params->opp_mode == RS_OPP_SAMPLE) {
+    if (params->opp_mode == RS_OPP_SAMPLE && seed_owner && seed_owner->d_seed_state && seed_owner->table == table) {
+        s->d_seed_state = seed_owner->d_seed_state;
+        s->seed_shared = true;
+    } else if (params->opp_mode == RS_OPP_SAMPLE) {
         const uint64_t init[3] = {params->sample_seed, 0, 0};
         if ((e = hipMalloc((void **)&s->d_seed_state, sizeof(init))) != hipSuccess ||
             (e = hipMemcpy(s->d_seed_state, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) {

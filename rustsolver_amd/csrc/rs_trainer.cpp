@@ -29,6 +29,15 @@ struct rs_deal_trainer {
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
+    // train()'s prune schedule (cfr.rs:213-221): batches holding deals numbered beyond prune_threshold run on a second solver whose
+    // traverser visits honour a per-deal flag (level plan, RS_UPD_PRUNE); it continues the first solver's count of sampled sweeps
+    rs_solver *solver_prune = nullptr;
+    uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
+    bool live_prune = false;           // the live batch has deals beyond the threshold
+    uint64_t live_first = 0, staged_first = 0;   // global number of deal 0 of the live / staged batch
+    rs_deal_batch batch{};
+    std::vector<rs_leaf_desc> leaves;
+    rs_comm *comm = nullptr;
     int tick_br = 0;                   // calc_br at every discount tick (cfr.rs:244-246)
     float last_br[2] = {0.0f, 0.0f};
     uint64_t last_br_t = 0;
@@ -49,8 +58,10 @@ extern "C" {
 
 void rs_deal_trainer_destroy(rs_deal_trainer *tr) {
     if (!tr) return;
+    if (tr->solver_prune) rs_solver_destroy(tr->solver_prune);
     if (tr->solver) rs_solver_destroy(tr->solver);
     if (tr->table) {
+        if (tr->d_prune) rs_dfree(tr->table, tr->d_prune);
         for (int p = 0; p < 2; ++p)
             if (tr->d_hands[p]) rs_dfree(tr->table, tr->d_hands[p]);
         if (tr->d_cards) rs_dfree(tr->table, tr->d_cards);
@@ -164,8 +175,11 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         }
         if (rc == RS_OK) rc = rs_sync(tr->table);   // the memsets above ran on the table's stream
     }
-    rs_deal_batch batch{};
+    if (rc == RS_OK) rc = rs_dmalloc(tr->table, pitch, reinterpret_cast<void **>(&tr->d_prune));
+    if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_prune, 0, pitch);
+    rs_deal_batch &batch = tr->batch;
     batch.n_deals = params->deals_per_batch;
+    batch.d_prune = tr->d_prune;
     for (int r = 0; rc == RS_OK && r < n_rounds; ++r)
         for (int p = 0; rc == RS_OK && p < 2; ++p) {
             rc = rs_dmalloc(tr->table, pitch * sizeof(uint32_t), reinterpret_cast<void **>(&tr->d_cluster[r][p]));
@@ -174,7 +188,8 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         }
     if (rc == RS_OK) {
         const int n = rs_tree_n_nodes(tr->tree);
-        std::vector<rs_leaf_desc> leaves(size_t(n), rs_leaf_desc{RS_LEAF_UNCONTESTED, nullptr});
+        std::vector<rs_leaf_desc> &leaves = tr->leaves;
+        leaves.assign(size_t(n), rs_leaf_desc{RS_LEAF_UNCONTESTED, nullptr});
         for (int i = 0; i < n; ++i) {
             rs_tree_node nd;
             rs_tree_get_node(tr->tree, i, &nd);
@@ -194,18 +209,42 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
 }
 
 rs_table *rs_deal_trainer_table(rs_deal_trainer *tr) { return tr ? tr->table : nullptr; }
-rs_solver *rs_deal_trainer_solver(rs_deal_trainer *tr) { return tr ? tr->solver : nullptr; }
+// the solver of the LIVE batch: the pruning one once the batch reaches beyond prune_threshold (created on first use)
+static int current_solver(rs_deal_trainer *tr, rs_solver **out) {
+    *out = tr->solver;
+    if (!tr->live_prune) return RS_OK;
+    if (!tr->solver_prune) {
+        rs_solver_params sp = tr->params.solver;
+        sp.chance_mode = RS_CHANCE_PASS;
+        sp.deal_offset = tr->rank * tr->params.deals_per_batch;
+        sp.mode |= RS_UPD_PRUNE;     // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune
+        sp.fuse_subtrees = 0;        // the generated subtree kernels have no pruned form: level plan
+        if (int rc = solver_create_deals_sharing_seed(tr->table, tr->tree, &tr->batch, tr->leaves.data(), tr->leaves.data(), &sp, tr->solver, &tr->solver_prune))
+            return rc;
+        if (tr->comm)
+            if (int rc = rs_solver_attach_comm(tr->solver_prune, tr->comm)) return rc;
+    }
+    *out = tr->solver_prune;
+    return RS_OK;
+}
+rs_solver *rs_deal_trainer_solver(rs_deal_trainer *tr) {
+    rs_solver *s = nullptr;
+    if (!tr || current_solver(tr, &s) != RS_OK) return nullptr;
+    return s;
+}
 uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *tr) { return tr ? tr->t : 0; }
 const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *tr) { return tr ? tr->d_cards : nullptr; }
 const float *rs_deal_trainer_signs(const rs_deal_trainer *tr) { return tr ? tr->d_sign : nullptr; }
+const uint8_t *rs_deal_trainer_prune_flags(const rs_deal_trainer *tr) { return tr ? tr->d_prune : nullptr; }
 const uint32_t *rs_deal_trainer_clusters(const rs_deal_trainer *tr, int round_idx, int player) {
     return tr && round_idx >= 0 && round_idx < tr->n_rounds && (player == 0 || player == 1) ? tr->d_cluster[round_idx][player] : nullptr;
 }
 
 // sample -> clusters -> showdown of batch number `tr->batches` into (cards, cluster, sign) on `stream`
-static int deal_into(rs_deal_trainer *tr, hipStream_t stream, uint8_t *cards, uint32_t *cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], float *sign) {
+static int deal_into(rs_deal_trainer *tr, hipStream_t stream, uint8_t *cards, uint32_t *cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], float *sign, uint64_t *first) {
     const uint32_t n = tr->params.deals_per_batch;
     const uint64_t first_deal = (tr->batches * tr->world + tr->rank) * uint64_t(n);   // global batch b = deals [b*world*n, (b+1)*world*n)
+    *first = first_deal;
     if (int rc = deals_sample_on(tr->table, stream, tr->params.seed, first_deal, tr->params.board_mask, tr->d_hands[0], tr->n_hands[0], tr->d_hands[1],
                                  tr->n_hands[1], n, cards, tr->d_err))
         return rc;
@@ -223,17 +262,28 @@ static int prefetch(rs_deal_trainer *tr) {
     hipError_t e = hipSetDevice(rs_table_device(tr->table));
     if (e == hipSuccess && tr->taken_recorded) e = hipStreamWaitEvent(tr->deal_stream, tr->ev_taken, 0);   // the previous staged batch has been copied out
     if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer: prefetch");
-    if (int rc = deal_into(tr, tr->deal_stream, tr->s_cards, tr->s_cluster, tr->s_sign)) return rc;
+    if (int rc = deal_into(tr, tr->deal_stream, tr->s_cards, tr->s_cluster, tr->s_sign, &tr->staged_first)) return rc;
     e = hipEventRecord(tr->ev_dealt, tr->deal_stream);
     if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer: prefetch");
     tr->staged = true;
     return RS_OK;
 }
 
+// the live batch's prune flags (cfr.rs:213-221), on the table's stream
+static int flag_live_batch(rs_deal_trainer *tr) {
+    const uint32_t n = tr->params.deals_per_batch;
+    tr->live_prune = tr->params.prune_threshold != UINT64_MAX && tr->live_first + n - 1 > tr->params.prune_threshold;
+    if (!tr->live_prune) return RS_OK;
+    return deal_prune_flags_on(tr->table, (hipStream_t)rs_stream(tr->table), tr->params.seed, tr->live_first, tr->params.prune_threshold, n, tr->d_prune);
+}
+
 // deal the next batch and derive everything the sweep reads from the cards (no table access)
 int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_deal: trainer is NULL");
-    if (!tr->staged) return deal_into(tr, (hipStream_t)rs_stream(tr->table), tr->d_cards, tr->d_cluster, tr->d_sign);
+    if (!tr->staged) {
+        if (int rc = deal_into(tr, (hipStream_t)rs_stream(tr->table), tr->d_cards, tr->d_cluster, tr->d_sign, &tr->live_first)) return rc;
+        return flag_live_batch(tr);
+    }
     // the batch was dealt ahead: swap it in
     hipStream_t main = (hipStream_t)rs_stream(tr->table);
     const size_t pitch = round_up(tr->params.deals_per_batch, kLanePad);
@@ -248,7 +298,8 @@ int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     if (e != hipSuccess) return hip_fail(e, "rs_deal_trainer_deal: swap");
     tr->taken_recorded = true;
     tr->staged = false;
-    return RS_OK;
+    tr->live_first = tr->staged_first;
+    return flag_live_batch(tr);
 }
 
 // the end of a batch: the shared iteration counter and the discount check of cfr.rs:240-262 (t counts deals over ALL ranks)
@@ -313,6 +364,9 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
 
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_attach_comm: trainer is NULL");
+    tr->comm = comm;
+    if (tr->solver_prune)
+        if (int rc = rs_solver_attach_comm(tr->solver_prune, comm)) return rc;
     return rs_solver_attach_comm(tr->solver, comm);
 }
 
@@ -323,8 +377,10 @@ int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
         if (int rc = rs_deal_trainer_deal(tr)) return rc;
         if (b + 1 < n_batches)   // deal the next batch beside this one's sweeps (never beyond what was asked for)
             if (int rc = prefetch(tr)) return rc;
+        rs_solver *solver = nullptr;
+        if (int rc = current_solver(tr, &solver)) return rc;
         for (int player = 0; player < 2; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
-            if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
+            if (int rc = rs_iterate(solver, player, nullptr)) return rc;
         if (int rc = rs_deal_trainer_finish_batch(tr)) return rc;
     }
     return RS_OK;

@@ -466,7 +466,7 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None, shard=None):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None, shard=None, prune_deal=None):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal.
         deals: None (lane model) or dict (round_idx, player) -> uint32 array of dense cluster ids, one per deal
         (what get_cluster() returned, cfr.rs:361-365): batch-synchronous deal sweeps on the reference-shaped table."""
@@ -488,6 +488,12 @@ class MCCFRTrainer:
                 buf = DeviceBuffer.from_numpy(infosets, host)
                 self._keep.append(buf)
                 batch.d_cluster[r][pl] = buf.ptr
+            if prune_deal is not None:   # UPD_PRUNE per deal (cfr.rs:213-221): uint8 flags, one per deal
+                host = np.zeros(pitch, dtype=np.uint8)
+                host[: self.n_deals] = np.asarray(prune_deal, dtype=np.uint8)
+                buf = DeviceBuffer.from_numpy(infosets, host)
+                self._keep.append(buf)
+                batch.d_prune = buf.ptr
             chance_mode = L.CHANCE_PASS
         arrs = []
         for lv in (leaves, leaves if leaves_p1 is None else leaves_p1):
@@ -582,8 +588,8 @@ class DealTrainer:
 
     def __init__(self, tree, card_abs, hand_ranges, board_mask, deals_per_batch, seed=0, scale=100.0, mode=L.UPD_CLAMP_I64,
                  opp_mode=L.OPP_SAMPLE, discount_interval=MCCFRTrainer.DISCOUNT_INTERVAL, discount_cap=MCCFRTrainer.DISCOUNT_CAP,
-                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0):
-        """world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
+                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0, prune_threshold=10_000_000):
+        """prune_threshold: cfr.rs:190 PRUNE_THRESHOLD (None = never prune).  world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
         batch; attach_comm() makes every rank apply the deltas of the union batch."""
         if fuse_subtrees is None:
             fuse_subtrees = bool(L.load().rs_jit_available())
@@ -591,6 +597,7 @@ class DealTrainer:
         p = L.DealTrainerParams()
         p.board_mask, p.deals_per_batch, p.seed = board_mask, deals_per_batch, seed
         p.world, p.rank = world, rank
+        p.prune_threshold = 2**64 - 1 if prune_threshold is None else prune_threshold
         p.discount_interval, p.discount_cap = discount_interval, discount_cap
         p.solver.scale, p.solver.mode, p.solver.chance_mode = scale, mode, L.CHANCE_PASS
         p.solver.use_graph, p.solver.fuse_subtrees = int(use_graph), int(bool(fuse_subtrees))
@@ -678,6 +685,11 @@ class DealTrainer:
 
     def signs(self):
         return self._download(L.load().rs_deal_trainer_signs(self._h), np.float32, deal_pitch(self.n_deals))[: self.n_deals]
+
+    def prune_flags(self):
+        """uint8 [n_deals]: the live batch's per-deal prune decision (cfr.rs:213-221); all zero before the threshold"""
+        ptr = L.load().rs_deal_trainer_prune_flags(self._h)
+        return self._download(ptr, np.uint8, deal_pitch(self.n_deals))[: self.n_deals]
 
     def clusters(self, round_idx, player):
         return self._download(L.load().rs_deal_trainer_clusters(self._h, round_idx, player), np.uint32, deal_pitch(self.n_deals))[: self.n_deals]

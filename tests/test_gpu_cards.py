@@ -156,20 +156,23 @@ def test_device_deal_sampler_gives_up_where_the_reference_would_spin(table):
         ab.sample_deals(table, 3, 0, 0b11, [[(10, 11)], [(12, 13)]], 64)      # invalid board mask (options.rs:41)
 
 
-def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None):
+def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None, prune_threshold=None):
     mask = ab.card_mask(board) if isinstance(board, str) else board
     n_actions, tree = rs.build_game_tree(options_rs)
     first = bin(mask).count("1") - 3
     card_abs = [ab.CardAbstraction.init(ranges, mask, first + r, None if bucket_files is None else bucket_files[r]) for r in range(rounds)]
-    tr = rs.DealTrainer(tree, card_abs, ranges, mask, n_deals, seed=seed, discount_interval=interval, discount_cap=cap, fuse_subtrees=fuse)
+    tr = rs.DealTrainer(tree, card_abs, ranges, mask, n_deals, seed=seed, discount_interval=interval, discount_cap=cap, fuse_subtrees=fuse,
+                        prune_threshold=prune_threshold)
     sizes = [(a.get_size(0), a.get_size(1)) for a in card_abs]
     otree = orc.OracleTree(options_orc)
     otab = orc.OracleDealTable(otree, sizes)
     cidx = {(r, p): np.zeros(n_deals, dtype=np.uint32) for r in range(rounds) for p in (0, 1)}
     sign = np.zeros(n_deals, dtype=np.float32)
     leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
-    osol = orc.OracleDealSolver(otree, otab, leaves, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed)
-    return dict(tr=tr, tree=tree, card_abs=card_abs, mask=mask, first=first, otab=otab, osol=osol, cidx=cidx, sign=sign, ranges=ranges,
+    prune = np.zeros(n_deals, dtype=np.uint8)   # all zero = every deal unpruned, whatever ctx.prune says
+    osol = orc.OracleDealSolver(otree, otab, leaves, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed,
+                                prune=True, prune_deal=prune)
+    return dict(prune=prune, prune_threshold=prune_threshold, tr=tr, tree=tree, card_abs=card_abs, mask=mask, first=first, otab=otab, osol=osol, cidx=cidx, sign=sign, ranges=ranges,
                 rounds=rounds, n_deals=n_deals, seed=seed, interval=interval, cap=cap, bucket_files=bucket_files, t=0, threshold=interval,
                 batches=0)
 
@@ -190,6 +193,8 @@ def oracle_batch(ctx):
             buckets = idx if arr is None else arr[idx.astype(np.int64)]
             ctx["cidx"][(r, p)][:] = [pos[int(b)] for b in buckets]
     ctx["sign"][:] = orc.showdown_sign(cards)
+    if ctx["prune_threshold"] is not None:   # cfr.rs:213-221: q per deal, prune = t > PRUNE_THRESHOLD && q > 0.05
+        ctx["prune"][:] = orc.deal_prune_flags(ctx["seed"], ctx["batches"] * n, ctx["prune_threshold"], n)
     for player in (0, 1):
         ctx["osol"].iterate(player)
     ctx["batches"] += 1
@@ -224,6 +229,48 @@ def test_deal_trainer_reference_as_coded(fuse):
         assert (ctx["tr"].signs() == ctx["sign"]).all()
     ctx["tr"].status()
     assert ctx["tr"].iterations == 15000 == ctx["t"]
+    compare_trainer_tables(ctx)
+
+
+@pytest.mark.parametrize("streets", [1, 3])
+def test_deal_trainer_prune_schedule(streets):
+    """train()'s prune flag (cfr.rs:213-221) with PRUNE_THRESHOLD moved into reach: deals numbered beyond it whose q > 0.05 are traversed
+    with prune = true (explored[] of cfr.rs:379-386, updates of :419-441).  The table starts with regrets on both sides of -10 000 000 so
+    that pruning bites; batches 0-1 run on the generated kernels, batch 1's tail and batches 2-4 on the pruning solver, which must continue
+    the same sweep-seed sequence.  Cards, flags and tables equal the oracle's."""
+    if streets == 1:
+        mask = ab.card_mask("4d5dAs3cKs")
+        hands = ab.random_range(mask)
+        ctx = load_trainer_pair(rs.default_flop(), orc.options_default_river(), mask, [hands, hands], 1, 3000, seed=21, interval=7000, cap=10**9,
+                                prune_threshold=4500)
+    else:
+        mask = ab.card_mask("7h8hQc")
+        hands = ab.random_range(mask)[:300]
+        rng = np.random.Generator(np.random.PCG64(12))
+        files = [rng.integers(0, 40, size=1286792, dtype=np.uint32), rng.integers(0, 30, size=13960050, dtype=np.uint32), None]
+        ctx = load_trainer_pair(rs.three_street_options(), orc.options_three_street(), mask, [hands, hands], 3, 1500, seed=22, interval=4000,
+                                cap=10**9, bucket_files=files, prune_threshold=2000)
+    rng = np.random.Generator(np.random.PCG64(99))
+    for nd in ctx["tree"].action_nodes():
+        a, n = ctx["otab"].node_shape(nd.index)
+        R = rng.integers(-10**6, 10**6, size=(a, n)).astype(np.int32)
+        R[rng.random((a, n)) < 0.3] = -10_000_001
+        R[rng.random((a, n)) < 0.05] = -10_000_000   # the threshold itself is NOT explored (cfr.rs:380 is a strict >)
+        S = rng.integers(0, 10**5, size=(a, n)).astype(np.int32)
+        ctx["tr"].infosets.upload_node(nd.index, R, S)
+        ctx["otab"].set_node(nd.index, R, S)
+    n = ctx["n_deals"]
+    seen = 0
+    for b in range(5):
+        ctx["tr"].train(1)
+        cards = oracle_batch(ctx)
+        assert (ctx["tr"].cards() == cards).all()
+        got = ctx["tr"].prune_flags()
+        assert (got == ctx["prune"]).all()
+        seen += int(got.sum())
+        assert int(got.sum()) == 0 if (b + 1) * n - 1 <= ctx["prune_threshold"] else got.sum() > 0
+    ctx["tr"].status()
+    assert seen > n
     compare_trainer_tables(ctx)
 
 

@@ -406,12 +406,16 @@ def setup_deals(options_rs, options_orc, sizes, n_deals, seed):
 
 @pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("variant", ["river-clamp", "river-wrap", "river-clamp+prune", "river-sampled", "three-street-sampled",
-                                     "three-street-full"])
+                                     "three-street-full", "river-sampled+prune-per-deal", "three-street-sampled+prune-per-deal"])
 def test_deal_batches_vs_oracle(fuse, variant):
-    """Many deals per info set (1000 deals on 13 / 17 clusters): collisions are the rule, results must still be exact."""
+    """Many deals per info set (1000 deals on 13 / 17 clusters): collisions are the rule, results must still be exact.
+    prune-per-deal: in train() `prune` is decided per deal (cfr.rs:213-221); a third of the deals carry the flag."""
     three = variant.startswith("three")
     sampled, prune, wrap = "sampled" in variant, "prune" in variant, "wrap" in variant
     n_deals = 1000 if not three else 300
+    flags = None
+    if "per-deal" in variant:
+        flags = (np.random.Generator(np.random.PCG64(5)).integers(0, 3, n_deals) == 0).astype(np.uint8)
     if three:
         tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(),
                                                              [(7, 9), (11, 8), (13, 17)], n_deals, 31)
@@ -419,8 +423,8 @@ def test_deal_batches_vs_oracle(fuse, variant):
         tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(13, 17)], n_deals, 32)
     scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if wrap else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), fuse_subtrees=fuse, deals=cidx,
-                         opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=777, use_graph=(variant == "river-clamp"))
-    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune,
+                         opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=777, use_graph=(variant == "river-clamp"), prune_deal=flags)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune, prune_deal=flags,
                                 opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=777)
     for it in range(3):
         for player in (0, 1):
