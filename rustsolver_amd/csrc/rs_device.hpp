@@ -420,4 +420,32 @@ __device__ __forceinline__ void lanes_visit(typename Row<DT>::val (&r)[A][kVecD]
     }
 }
 
+// the pruned visit (cfr.rs:379-386, :419-441) for the lanes whose deal is traversed with prune = true
+template <int A, int DT, int ARITH>
+__device__ __forceinline__ void lanes_visit_prune(typename Row<DT>::val (&r)[A][kVecD], typename Row<DT>::val (&s)[A][kVecD],
+                                                  const float (&u)[A][kVecD], const float (&reach)[kVecD], float scale, bool rmplus,
+                                                  const bool (&prune)[kVecD], float (&dest)[kVecD]) {
+    static_assert(DT == kDT_I32, "pruning compares i32 regrets with the threshold (cfr.rs:352)");
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        int rl[A], sl[A];
+        float ul[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) { rl[a] = r[a][j]; sl[a] = s[a][j]; ul[a] = u[a][j]; }
+        dest[j] = visit_i32<A, ARITH>(rl, sl, ul, reach[j], scale, rmplus, prune[j]);
+#pragma unroll
+        for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
+    }
+}
+// bit a*4+j: lane j explores action a (always when its deal is not pruned)
+template <int A>
+__device__ __forceinline__ unsigned lanes_explored(const int (&r)[A][kVecD], const bool (&prune)[kVecD]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int a = 0; a < A; a++)
+#pragma unroll
+        for (int j = 0; j < kVecD; j++) m |= (!prune[j] || r[a][j] > kPruneThresholdD) ? 1u << (a * 4 + j) : 0u;
+    return m;
+}
+
 }  // namespace rs

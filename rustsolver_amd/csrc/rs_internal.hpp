@@ -137,12 +137,13 @@ struct JitSubtree {
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
     size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
+    size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, const std::vector<char> *cut, JitSubtree &out);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, const std::vector<char> *cut, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -313,7 +313,7 @@ struct Builder {
     }
     void mark_fused(int id) {
         const rs_tree_node &nd = nodes[id];
-        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;   // prune keeps the level plan (NaN-reach bookkeeping)
+        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0 && !s->deal_mode;   // lane sweeps: prune keeps the level plan (NaN-reach bookkeeping); deal kernels have a pruned form
         if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
             fused_root[id] = 1;
             mark_inside(id);
@@ -448,9 +448,8 @@ struct Builder {
         nan_slot.assign(n, -1);
         {
             const bool round_off = getenv("RS_JIT_NO_ROUNDS") != nullptr;
-            const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
             first_root = resolve(0);
-            round_mode = s->deal_mode && s->params.fuse_subtrees && !prune && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
+            round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
             const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
             want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
@@ -529,7 +528,8 @@ struct Builder {
         const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down;
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                         s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, round_mode ? &fused_root : nullptr, js);
+                         s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
+                         round_mode ? &fused_root : nullptr, js);
         hipFunction_t fn = nullptr;
         if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
         auto bi = by_fn.find(fn);
@@ -609,6 +609,7 @@ struct Builder {
             put_u32(js.off_c0, c0);
             put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
             put_u32(js.off_rp, rp);
+            put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
             if (use_lds) {
                 const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
@@ -1471,7 +1472,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
             JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, nullptr, js);
+            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, false, nullptr, js);
             if (seen.count(js.source)) continue;
             seen[js.source] = 1;
             if (int rc = jit_compile_only(js.source)) return rc;
@@ -1518,8 +1519,8 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 const bool down = form < 2, sparse = (form & 1) != 0, lds = form >= 2 && form < 4;
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;
-                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down, &root,
-                                 js);
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
+                                 (mode & RS_UPD_PRUNE) != 0, &root, js);
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;

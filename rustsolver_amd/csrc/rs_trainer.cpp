@@ -30,7 +30,7 @@ struct rs_deal_trainer {
     uint64_t batches = 0;
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
     // train()'s prune schedule (cfr.rs:213-221): batches holding deals numbered beyond prune_threshold run on a second solver whose
-    // traverser visits honour a per-deal flag (level plan, RS_UPD_PRUNE); it continues the first solver's count of sampled sweeps
+    // traverser visits honour a per-deal flag (RS_UPD_PRUNE); it continues the first solver's count of sampled sweeps
     rs_solver *solver_prune = nullptr;
     uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
     bool live_prune = false;           // the live batch has deals beyond the threshold
@@ -217,8 +217,7 @@ static int current_solver(rs_deal_trainer *tr, rs_solver **out) {
         rs_solver_params sp = tr->params.solver;
         sp.chance_mode = RS_CHANCE_PASS;
         sp.deal_offset = tr->rank * tr->params.deals_per_batch;
-        sp.mode |= RS_UPD_PRUNE;     // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune
-        sp.fuse_subtrees = 0;        // the generated subtree kernels have no pruned form: level plan
+        sp.mode |= RS_UPD_PRUNE;     // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune (the `_prune` forms of the generated kernels)
         if (int rc = solver_create_deals_sharing_seed(tr->table, tr->tree, &tr->batch, tr->leaves.data(), tr->leaves.data(), &sp, tr->solver, &tr->solver_prune))
             return rc;
         if (tr->comm)

@@ -155,6 +155,9 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 8          # river tree: no reach-down half, 4 walks per traverser
     assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) > 8
     assert rs.jit_check_tree_deals(tree3, rs.UPD_WRAP_I32, rs.OPP_FULL) >= 4
+    # the pruned forms (cfr.rs:379-386 per deal) of the same kernels
+    assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) == 8
+    assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) > 8
 
 
 # ---- card-abstraction plumbing (card_abstraction.rs) --------------------------------------------------

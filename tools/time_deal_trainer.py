@@ -10,11 +10,13 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rustsolver_amd as rs
+# PRUNE=none: never prune; PRUNE=<t>: train()'s schedule with PRUNE_THRESHOLD = t (cfr.rs:190; default 10 000 000): batches beyond it run the `_prune` kernel forms
+PRUNE = None if os.environ.get("PRUNE", "10000000") == "none" else int(os.environ.get("PRUNE", "10000000"))
 from rustsolver_amd import abstraction as ab
 mask = ab.card_mask("4d5dAs3cKs"); hands = ab.random_range(mask)
 n_actions, tree = rs.build_game_tree(rs.default_flop())
 card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
-tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0, use_graph=bool(int(os.environ.get("GRAPH", "0"))))
+tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0, use_graph=bool(int(os.environ.get("GRAPH", "0"))), prune_threshold=PRUNE)
 tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
 tr.train(5); tr.infosets.sync()
 best = 1e9

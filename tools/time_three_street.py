@@ -12,6 +12,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rustsolver_amd as rs
+# PRUNE=none: never prune; PRUNE=<t>: train()'s schedule with PRUNE_THRESHOLD = t (cfr.rs:190; default 10 000 000): batches beyond it run the `_prune` kernel forms
+PRUNE = None if os.environ.get("PRUNE", "10000000") == "none" else int(os.environ.get("PRUNE", "10000000"))
 from rustsolver_amd import abstraction as ab
 rng = np.random.Generator(np.random.PCG64(1))
 mask = ab.card_mask("7h8hQc")
@@ -24,7 +26,7 @@ card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in 
 print("abstractions: %.1f s, sizes" % (time.perf_counter() - t0), [a.get_size(0) for a in card_abs], "action nodes", n_actions)
 n = int(os.environ.get("N", str(1 << 20)))
 t0 = time.perf_counter()
-tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0)
+tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE)
 print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.infosets.nbytes / 1e6 if not callable(tr.infosets.nbytes) else tr.infosets.nbytes() / 1e6))
 tr.train(2); tr.status()
 t0 = time.perf_counter(); tr.train(5); tr.infosets.sync(); dt = (time.perf_counter() - t0) / 5
