@@ -279,6 +279,40 @@ def deal_trainer_leg(rs, device, n_deals, with_cpu, cpu_seconds):
     return out
 
 
+def solve_leg(rs, device):
+    """Does the batched trainer SOLVE the game?  The reference's own configuration from a zero table, 65 536 deals per batch (the
+    time-to-quality sweet spot), the reference's discount and prune schedules; then the exploitability of the
+    average strategy (rs_best_response, both players) and calc_br as coded (cfr.rs:629-745) at the last tick."""
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd import abstraction as ab
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    n, batches = 1 << 16, 1024
+    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=1, use_graph=True, device=device)
+    tr.set_tick_br(True)
+    e0 = tr.exploitability()
+    tr.train(2)
+    tr.status()
+    t0 = time.perf_counter()
+    tr.train(batches - 2)
+    tr.status()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    br = tr.best_response(L.BR_MAX)
+    dt_br = time.perf_counter() - t0
+    ev = tr.best_response(L.BR_AVERAGE)
+    pair, tick = tr.last_br()
+    out = {"what": "options::default_flop() from a zero table: %d batches x %d deals (%.3g iterations), discount ticks and prune schedule as coded; "
+                   "exploitability = (BR value of player 0 + BR value of player 1) / 2 per deal against the average strategies, pot 35" % (batches, n, batches * n),
+           "exploitability_before": e0, "exploitability_after": float(br.sum() / 2), "seconds_training": dt * batches / (batches - 2),
+           "best_response_values": [float(x) for x in br], "average_profile_values": [float(x) for x in ev],
+           "ms_best_response_both_players": dt_br * 1e3, "calc_br_as_coded_last_tick": [float(x) for x in pair], "last_tick_iteration": tick}
+    tr.destroy()
+    return out
+
+
 def kmeans_leg(rs, device, with_cpu, cpu_seconds):
     """SURVEY N4 measured at the reference's own size: gen_emd(1, 500, 250, 20) (gen_abstraction/main.rs:384) = Kmeans::predict of the
     1 286 792 canonical flop histograms (20 bins, counts out of 250 samples) against 500 centers with emd_1d: the sweep whose output is
@@ -675,6 +709,11 @@ def main():
         out["deal_trainer_three_street"] = three_street_leg(rs, device)
     except Exception as e:
         out["deal_trainer_three_street"] = {"error": str(e)}
+
+    try:
+        out["solve"] = solve_leg(rs, device)
+    except Exception as e:
+        out["solve"] = {"error": str(e)}
 
     try:
         out["kmeans_predict"] = kmeans_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))

@@ -13,7 +13,10 @@ namespace rs {
 
 #ifndef RS_DEVICE_CONSTS
 #define RS_DEVICE_CONSTS
-constexpr int kVecD = 4;                       // lanes per thread
+#ifndef RS_LANES
+#define RS_LANES 4                             // lanes per thread; generated kernels for small deal batches define 1 (rs_jit.cpp)
+#endif
+constexpr int kVecD = RS_LANES;
 constexpr int kPruneThresholdD = -10000000;    // cfr.rs:352
 constexpr int kDT_I32 = 0, kDT_F32 = 1, kDT_F16 = 2;      // == RS_I32 / RS_F32 / RS_F16
 constexpr int kARITH_CLAMP = 0, kARITH_WRAP = 1;           // == RS_UPD_CLAMP_I64 / RS_UPD_WRAP_I32
@@ -74,44 +77,76 @@ template <int DT> struct Row;
 template <> struct Row<kDT_I32> {
     using val = int;
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+#if RS_LANES == 4
         i32x4 x = RS_LOADG(as_global<i32x4>((const int *)base + row_off) + v);
         out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+#else
+        for (int j = 0; j < kVecD; j++) out[j] = RS_LOADG(as_global<int>((const int *)base + row_off) + v * kVecD + j);
+#endif
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+#if RS_LANES == 4
         i32x4 x = {in[0], in[1], in[2], in[3]};
         RS_STOREG(x, as_global<i32x4>((int *)base + row_off) + v);
+#else
+        for (int j = 0; j < kVecD; j++) RS_STOREG(in[j], as_global<int>((int *)base + row_off) + v * kVecD + j);
+#endif
     }
 };
 template <> struct Row<kDT_F32> {
     using val = float;
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+#if RS_LANES == 4
         f32x4 x = RS_LOADG(as_global<f32x4>((const float *)base + row_off) + v);
         out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+#else
+        for (int j = 0; j < kVecD; j++) out[j] = RS_LOADG(as_global<float>((const float *)base + row_off) + v * kVecD + j);
+#endif
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+#if RS_LANES == 4
         f32x4 x = {in[0], in[1], in[2], in[3]};
         RS_STOREG(x, as_global<f32x4>((float *)base + row_off) + v);
+#else
+        for (int j = 0; j < kVecD; j++) RS_STOREG(in[j], as_global<float>((float *)base + row_off) + v * kVecD + j);
+#endif
     }
 };
 template <> struct Row<kDT_F16> {
     using val = float;  // binary16 in HBM, f32 in registers
     static __device__ __forceinline__ void load(const void *base, unsigned row_off, unsigned v, val (&out)[kVecD]) {
+#if RS_LANES == 4
         f16x4 x = RS_LOADG(as_global<f16x4>((const _Float16 *)base + row_off) + v);
         out[0] = (float)x.x; out[1] = (float)x.y; out[2] = (float)x.z; out[3] = (float)x.w;
+#else
+        for (int j = 0; j < kVecD; j++) out[j] = (float)RS_LOADG(as_global<_Float16>((const _Float16 *)base + row_off) + v * kVecD + j);
+#endif
     }
     static __device__ __forceinline__ void store(void *base, unsigned row_off, unsigned v, const val (&in)[kVecD]) {
+#if RS_LANES == 4
         f16x4 x = {(_Float16)in[0], (_Float16)in[1], (_Float16)in[2], (_Float16)in[3]};  // RNE
         RS_STOREG(x, as_global<f16x4>((_Float16 *)base + row_off) + v);
+#else
+        for (int j = 0; j < kVecD; j++) RS_STOREG((_Float16)in[j], as_global<_Float16>((_Float16 *)base + row_off) + v * kVecD + j);
+#endif
     }
 };
 
 __device__ __forceinline__ void load_f32_row(const float *base, unsigned v, float (&out)[kVecD]) {
+#if RS_LANES == 4
     f32x4 x = RS_LOADG(as_global<f32x4>(base) + v);
     out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+#else
+    for (int j = 0; j < kVecD; j++) out[j] = RS_LOADG(as_global<float>(base) + v * kVecD + j);
+#endif
 }
 __device__ __forceinline__ void store_f32_row(float *base, unsigned v, const float (&in)[kVecD]) {
+#if RS_LANES == 4
     f32x4 x = {in[0], in[1], in[2], in[3]};
     RS_STOREG(x, as_global<f32x4>(base) + v);
+#else
+    for (int j = 0; j < kVecD; j++) RS_STOREG(in[j], as_global<float>(base) + v * kVecD + j);
+#endif
 }
 
 // showdown / all-in leaf from a sign row: compare as evaluate() scores (cfr.rs:323-334); p1 flips the view
@@ -129,8 +164,12 @@ __device__ __forceinline__ void sign_to_util(float (&x)[kVecD], bool p1, float p
 // Reads gather from the table (i32 only), writes become atomic adds of (new - old) into a delta table that is
 // applied after the sweep: several deals may hit one info set, integer adds commute, so the result is deterministic.
 __device__ __forceinline__ void load_u32_row(const unsigned *base, unsigned v, unsigned (&out)[kVecD]) {
+#if RS_LANES == 4
     const i32x4 x = *(as_global<i32x4>(base) + v);
     out[0] = (unsigned)x.x; out[1] = (unsigned)x.y; out[2] = (unsigned)x.z; out[3] = (unsigned)x.w;
+#else
+    for (int j = 0; j < kVecD; j++) out[j] = *(as_global<unsigned>(base) + v * kVecD + j);
+#endif
 }
 __device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, const unsigned (&idx)[kVecD], int (&out)[kVecD]) {
     const RS_GLOBAL int *p = as_global<int>((const int *)base + row_off);
@@ -437,14 +476,14 @@ __device__ __forceinline__ void lanes_visit_prune(typename Row<DT>::val (&r)[A][
         for (int a = 0; a < A; a++) { r[a][j] = rl[a]; s[a][j] = sl[a]; }
     }
 }
-// bit a*4+j: lane j explores action a (always when its deal is not pruned)
+// bit a*kVecD+j: lane j explores action a (always when its deal is not pruned)
 template <int A>
 __device__ __forceinline__ unsigned lanes_explored(const int (&r)[A][kVecD], const bool (&prune)[kVecD]) {
     unsigned m = 0;
 #pragma unroll
     for (int a = 0; a < A; a++)
 #pragma unroll
-        for (int j = 0; j < kVecD; j++) m |= (!prune[j] || r[a][j] > kPruneThresholdD) ? 1u << (a * 4 + j) : 0u;
+        for (int j = 0; j < kVecD; j++) m |= (!prune[j] || r[a][j] > kPruneThresholdD) ? 1u << (a * kVecD + j) : 0u;
     return m;
 }
 

@@ -126,6 +126,7 @@ struct JitSubtree {
     std::string source;
     std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals|deals_lds}[_sampled]
     int threads = 256;             // workgroup size the kernel was generated for
+    int lanes = 4;                 // lanes (deals) per thread the kernel was generated for: n_vec = pitch / lanes
     std::vector<int> node_ids;     // tree node id of every action node, in the order the kernel indexes reg[] / ssm[]
     std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
     std::vector<int> const_terms;  // terminal ids in the order of cval[]
@@ -143,7 +144,7 @@ struct JitSubtree {
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, const std::vector<char> *cut, JitSubtree &out);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -16,10 +16,11 @@ from rustsolver_amd import abstraction as ab
 mask = ab.card_mask("4d5dAs3cKs"); hands = ab.random_range(mask)
 n_actions, tree = rs.build_game_tree(rs.default_flop())
 card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
-tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, 1 << 22, seed=7, discount_interval=0, use_graph=bool(int(os.environ.get("GRAPH", "0"))), prune_threshold=PRUNE)
+tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, int(os.environ.get("N", str(1 << 22))), seed=7, discount_interval=0, use_graph=bool(int(os.environ.get("GRAPH", "0"))), prune_threshold=PRUNE)
 tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
+K = int(os.environ.get("BATCHES", "20"))
 tr.train(5); tr.infosets.sync()
 best = 1e9
 for _ in range(5):
-    t0 = time.perf_counter(); tr.train(20); tr.infosets.sync(); best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+    t0 = time.perf_counter(); tr.train(K); tr.infosets.sync(); best = min(best, (time.perf_counter() - t0) / K * 1e3)
 print(os.environ.get("TAG", ""), "best %.3f ms/batch" % best)
