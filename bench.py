@@ -49,6 +49,8 @@ def parse():
                     help="1: instead of the board-sharded sweep run the data-parallel deal trainer (replicated table, one ncclInt32 all-reduce of the "
                          "delta tables per traverser sweep over RCCL); needs torch.distributed.run, works with one rank too")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (single board, deal batches, trainers, solve, k-means): "
+                    "the rocprofv3 --pmc passes only need the headline kernels, and counter collection serialises every dispatch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -674,10 +676,11 @@ def main():
         "lane_updates_per_sec": sum(table.lanes(n) for n in range(table.n_nodes)) * n_gpus * a.steps / elapsed,
     }
 
-    if n_gpus > 1:   # the extra legs (single board, deal batches, CPU baselines) are N = 1 material
+    if n_gpus > 1 or a.no_extra:   # the extra legs (single board, deal batches, CPU baselines) are N = 1 material
         emit(out)
         os.dup2(2, 1)
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
         return
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------

@@ -13,6 +13,7 @@
 
 #include "rs_hand_index.hpp"
 #include "rs_internal.hpp"
+#include "rs_eval.hpp"
 
 using namespace rs;
 
@@ -325,7 +326,8 @@ __device__ __forceinline__ void sample_deal(uint64_t seed, uint64_t deal, uint64
 
 __global__ __launch_bounds__(kBlock) void k_deal_sample(uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *__restrict__ hands0,
                                                         uint32_t n0, const uint8_t *__restrict__ hands1, uint32_t n1, uint32_t n, uint32_t pitch,
-                                                        uint8_t *__restrict__ cards, uint32_t *__restrict__ err) {
+                                                        uint8_t *__restrict__ cards, uint32_t *__restrict__ err, float *__restrict__ sign,
+                                                        uint8_t *__restrict__ flags, uint64_t prune_threshold) {
     for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
         uint8_t c[9];
         bool gave_up;
@@ -333,6 +335,24 @@ __global__ __launch_bounds__(kBlock) void k_deal_sample(uint64_t seed, uint64_t 
         if (gave_up) atomicOr(err, 4u);
 #pragma unroll
         for (int i = 0; i < 9; ++i) cards[(size_t)i * pitch + l] = c[i];
+        // the trainer's fused form: what k_showdown_sign and k_deal_prune_flags would compute from the same cards / deal number
+        if (sign) {
+            uint32_t m0[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 5; i++) add_card(m0, c[i]);
+            uint32_t m1[4] = {m0[0], m0[1], m0[2], m0[3]};
+            add_card(m0, c[5]);
+            add_card(m0, c[6]);
+            add_card(m1, c[7]);
+            add_card(m1, c[8]);
+            const uint32_t s0 = evaluate_suits(m0), s1 = evaluate_suits(m1);
+            sign[l] = s0 == s1 ? 0.0f : (s0 > s1 ? 1.0f : -1.0f);   // cfr.rs:326-333
+        }
+        if (flags) {
+            const uint64_t deal = first_deal + l;
+            const float q = (float)((uint32_t)deal_bits(seed, deal, kSampleMaxDraws) >> 8) * 5.9604644775390625e-08f;
+            flags[l] = (deal > prune_threshold && q > 0.05f) ? 1 : 0;   // cfr.rs:213-221
+        }
     }
 }
 
@@ -783,7 +803,8 @@ int rs_deals_prune_flags(rs_table *t, uint64_t seed, uint64_t first_deal, uint64
 // the counter hash (seed, first_deal + i).  d_cards[9][pitch] as above.  d_err (may be NULL): bit 2 raised when a deal found no valid combo.
 int rs_deals_sample(rs_table *t, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
                     const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err) {
-    return rs::deals_sample_on(t, t ? t->stream : nullptr, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1, n_hands_p1, n_deals, d_cards, d_err);
+    return rs::deals_sample_on(t, t ? t->stream : nullptr, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1, n_hands_p1, n_deals, d_cards, d_err,
+                               nullptr, nullptr, 0);
 }
 }  // extern "C"
 
@@ -805,7 +826,8 @@ int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t
     return RS_OK;
 }
 int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
-                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err) {
+                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err, float *d_sign, uint8_t *d_flags,
+                    uint64_t prune_threshold) {
     if (!t || !d_hands_p0 || !d_hands_p1 || !d_cards) return fail(RS_ERR_INVALID, "rs_deals_sample: NULL argument");
     if (n_hands_p0 == 0 || n_hands_p1 == 0) return fail(RS_ERR_INVALID, "rs_deals_sample: empty hand range (Rust: choose().unwrap() on None, cfr.rs:129)");
     if (board_mask >> 52) return fail(RS_ERR_INVALID, "rs_deals_sample: board mask has bits beyond card 51");
@@ -818,7 +840,7 @@ int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t fir
     }
     if (n_deals == 0) return RS_OK;
     hipLaunchKernelGGL(k_deal_sample, lane_grid(n_deals), dim3(kBlock), 0, stream, seed, first_deal, board_mask, d_hands_p0, n_hands_p0, d_hands_p1,
-                       n_hands_p1, n_deals, uint32_t(round_up(n_deals, kLanePad)), d_cards, d_err);
+                       n_hands_p1, n_deals, uint32_t(round_up(n_deals, kLanePad)), d_cards, d_err, d_sign, d_flags, prune_threshold);
     RS_HIP(hipGetLastError(), "k_deal_sample");
     return RS_OK;
 }

@@ -104,7 +104,8 @@ struct CompactJob {
     uint32_t part_size, n_parts, list_stride, count_stride;
 };
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
-hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
+// d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
@@ -212,7 +213,8 @@ namespace rs {
 int card_abs_clusters_on(rs_card_abs *abs, rs_table *t, hipStream_t stream, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0,
                          uint32_t *d_cluster_p1);
 int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
-                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err);
+                    const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err, float *d_sign /* fused showdown signs, may be null */,
+                    uint8_t *d_flags /* fused per-deal prune flags, may be null */, uint64_t prune_threshold);
 int solver_create_deals_sharing_seed(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                                      const rs_leaf_desc *leaves_p1, const rs_solver_params *params, struct rs_solver *seed_owner, struct rs_solver **out);
 int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags);

@@ -442,7 +442,11 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
 
 // ---- deal batches: SoA table rows -> AoS records for the sweep's gathers (rs_device.hpp gather_rec); reads coalesce over clusters,
 // every thread writes its record with 16-byte stores (a wave covers 2-4 KB contiguous)
-__global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__restrict__ jobs) {
+__global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__restrict__ jobs, uint64_t *__restrict__ seed_state) {
+    if (seed_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // k_next_seed folded in: the tree kernels read state[2] after this launch
+        seed_state[2] = sweep_seed(seed_state[0], seed_state[1]);
+        seed_state[1] += 1;
+    }
     const ShadowJob *job = jobs + blockIdx.y;
     const uint32_t n = job->n_clusters, pitch = job->pitch, A = job->n_actions, half = job->half;
     const int32_t *__restrict__ reg = job->regrets, *__restrict__ ssm = job->ssum;
@@ -636,10 +640,10 @@ hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t ma
     hipLaunchKernelGGL(k_compact_live, grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
-hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream) {
-    if (n_jobs <= 0) return hipSuccess;
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state) {
+    if (n_jobs <= 0) return d_seed_state ? launch_next_seed(d_seed_state, stream) : hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
-    hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs);
+    hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs, d_seed_state);
     return hipGetLastError();
 }
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream) {

@@ -665,13 +665,13 @@ struct Builder {
                     util_override[nodes[id].children[0]] =
                         s->d_exchange + (size_t(s->params.shard_rank) * plan.n_boundary + boundary_k[id]) * s->slot_lanes;
 
-        if (s->d_shadow) {   // the table as of sweep start, transposed for the deal kernels' gathers
+        if (s->d_shadow) {   // the table as of sweep start, transposed for the deal kernels' gathers; sampled sweeps: the same launch advances the seed
             Launch L;
             L.kind = L_SHADOW;
             L.bytes = double(t->n_cells) * 16.0;
+            L.n_jobs = s->params.opp_mode == RS_OPP_SAMPLE ? 1 : 0;   // 1 = with the seed
             plan.launches.push_back(L);
-        }
-        if (s->params.opp_mode == RS_OPP_SAMPLE) {   // advance the sweep seed (part of the plan, hence of the hipGraph)
+        } else if (s->params.opp_mode == RS_OPP_SAMPLE) {   // advance the sweep seed (part of the plan, hence of the hipGraph)
             Launch L;
             L.kind = L_SEED;
             plan.launches.push_back(L);
@@ -1010,7 +1010,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     }
     if (L.kind == L_SHADOW) {
         prof_begin(t, RS_K_STRATEGY, L.bytes);
-        hipError_t es = launch_build_shadow(s->d_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream);
+        hipError_t es = launch_build_shadow(s->d_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr);
         prof_end(t);
         RS_HIP(es, "k_build_shadow");
         return RS_OK;

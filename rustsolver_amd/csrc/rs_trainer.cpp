@@ -156,7 +156,9 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_sign, 0, pitch * sizeof(float));
     if (rc == RS_OK) rc = rs_dmalloc(tr->table, 256, reinterpret_cast<void **>(&tr->d_err));
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_err, 0, 256);
-    if (rc == RS_OK && !getenv("RS_TRAINER_NO_PREFETCH")) {   // staging for the batch dealt ahead
+    // staging for the batch dealt ahead; small batches are bound by the NUMBER of launches on the table's stream (about 5 us each), and swapping a
+    // staged batch in costs more of them (four copies + the flags) than dealing in place (two kernels): no staging up to 256 K deals
+    if (rc == RS_OK && !getenv("RS_TRAINER_NO_PREFETCH") && params->deals_per_batch > (1u << 18)) {
         rc = rs_dmalloc(tr->table, 9 * pitch, reinterpret_cast<void **>(&tr->s_cards));
         if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_cards, 0, 9 * pitch);
         if (rc == RS_OK) rc = rs_dmalloc(tr->table, pitch * sizeof(float), reinterpret_cast<void **>(&tr->s_sign));
@@ -244,13 +246,13 @@ static int deal_into(rs_deal_trainer *tr, hipStream_t stream, uint8_t *cards, ui
     const uint32_t n = tr->params.deals_per_batch;
     const uint64_t first_deal = (tr->batches * tr->world + tr->rank) * uint64_t(n);   // global batch b = deals [b*world*n, (b+1)*world*n)
     *first = first_deal;
+    // one launch deals the cards, compares the two hands (cfr.rs:323-333) and -- when dealing straight into the live buffers -- draws the prune flags
+    const bool live = cards == tr->d_cards;
     if (int rc = deals_sample_on(tr->table, stream, tr->params.seed, first_deal, tr->params.board_mask, tr->d_hands[0], tr->n_hands[0], tr->d_hands[1],
-                                 tr->n_hands[1], n, cards, tr->d_err))
+                                 tr->n_hands[1], n, cards, tr->d_err, sign, live ? tr->d_prune : nullptr, tr->params.prune_threshold))
         return rc;
     for (int r = 0; r < tr->n_rounds; ++r)
         if (int rc = card_abs_clusters_on(tr->abs[r], tr->table, stream, cards, n, cluster[r][0], cluster[r][1])) return rc;
-    hipError_t e = launch_showdown_sign(cards, sign, n, uint32_t(round_up(n, kLanePad)), stream);
-    if (e != hipSuccess) return hip_fail(e, "k_showdown_sign");
     tr->batches += 1;
     return RS_OK;
 }
@@ -268,11 +270,11 @@ static int prefetch(rs_deal_trainer *tr) {
     return RS_OK;
 }
 
-// the live batch's prune flags (cfr.rs:213-221), on the table's stream
-static int flag_live_batch(rs_deal_trainer *tr) {
+// the live batch's prune flags (cfr.rs:213-221), on the table's stream; a batch dealt straight into the live buffers already has them
+static int flag_live_batch(rs_deal_trainer *tr, bool have_flags) {
     const uint32_t n = tr->params.deals_per_batch;
     tr->live_prune = tr->params.prune_threshold != UINT64_MAX && tr->live_first + n - 1 > tr->params.prune_threshold;
-    if (!tr->live_prune) return RS_OK;
+    if (!tr->live_prune || have_flags) return RS_OK;
     return deal_prune_flags_on(tr->table, (hipStream_t)rs_stream(tr->table), tr->params.seed, tr->live_first, tr->params.prune_threshold, n, tr->d_prune);
 }
 
@@ -281,7 +283,7 @@ int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_deal: trainer is NULL");
     if (!tr->staged) {
         if (int rc = deal_into(tr, (hipStream_t)rs_stream(tr->table), tr->d_cards, tr->d_cluster, tr->d_sign, &tr->live_first)) return rc;
-        return flag_live_batch(tr);
+        return flag_live_batch(tr, true);
     }
     // the batch was dealt ahead: swap it in
     hipStream_t main = (hipStream_t)rs_stream(tr->table);
@@ -298,7 +300,7 @@ int rs_deal_trainer_deal(rs_deal_trainer *tr) {
     tr->taken_recorded = true;
     tr->staged = false;
     tr->live_first = tr->staged_first;
-    return flag_live_batch(tr);
+    return flag_live_batch(tr, false);
 }
 
 // the end of a batch: the shared iteration counter and the discount check of cfr.rs:240-262 (t counts deals over ALL ranks)

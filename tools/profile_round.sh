@@ -9,11 +9,14 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/prof"
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+( while sleep 60; do echo "profile_round: still running"; done ) &
+HEART=$!
+trap "kill $HEART 2>/dev/null" EXIT
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 50 --warmup 10 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 echo "trace pass done" && tail -c 400 "$OUT/trace_bench.json" | head -c 200 && echo
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu > "$OUT/pmc_fetch_bench.json" 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-extra > "$OUT/pmc_fetch_bench.json" 2> "$OUT/pmc_fetch.err"
 echo "fetch pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu > "$OUT/pmc_write_bench.json" 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-extra > "$OUT/pmc_write_bench.json" 2> "$OUT/pmc_write.err"
 echo "write pass done"
 # keep the merge small: the per-dispatch traces of the PMC passes are enough, drop the sqlite / agent dumps
 find "$OUT" -name "*.db" -delete
