@@ -406,8 +406,8 @@ typedef struct rs_deal_trainer_params {
     uint32_t world, rank;          /* data-parallel training on replicated tables: this rank deals numbers (b*world + rank)*n .. + n of
                                       global batch b; 0 / 0 or 1 / 0 = single GPU.  t advances by world * deals_per_batch per batch */
     uint64_t prune_threshold;      /* cfr.rs:190 PRUNE_THRESHOLD (10 000 000): deals numbered beyond it are traversed with prune = true when their
-                                      q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  Batches that contain such deals run on
-                                      a second solver (level plan, RS_UPD_PRUNE with per-deal flags) created when the first one is reached */
+                                      q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  With a finite threshold the solver runs
+                                      in RS_UPD_PRUNE mode with per-deal flags that stay zero (= unpruned, bit for bit) before it */
 } rs_deal_trainer_params;
 /* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
  * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */

@@ -215,8 +215,6 @@ int card_abs_clusters_on(rs_card_abs *abs, rs_table *t, hipStream_t stream, cons
 int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t board_mask, const uint8_t *d_hands_p0, uint32_t n_hands_p0,
                     const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err, float *d_sign /* fused showdown signs, may be null */,
                     uint8_t *d_flags /* fused per-deal prune flags, may be null */, uint64_t prune_threshold);
-int solver_create_deals_sharing_seed(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                                     const rs_leaf_desc *leaves_p1, const rs_solver_params *params, struct rs_solver *seed_owner, struct rs_solver **out);
 int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags);
 void solver_release_device(struct rs_solver *s);   // frees a solver's device state and detaches it from its table
 // profiling hooks used around launches

@@ -114,7 +114,6 @@ struct rs_solver {
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
-    bool seed_shared = false;           // d_seed_state belongs to another solver of the same table (the trainer's pruning solver continues its sweep count)
     const uint64_t *d_seed() const { return d_seed_state ? d_seed_state + 2 : nullptr; }
 };
 
@@ -218,7 +217,8 @@ struct Builder {
     // deal batches: ONE generated subtree per betting round, cut at the chance nodes (a deal has one run-out, cfr.rs:306-313).  A round
     // subtree has a DOWN kernel (reach for the next round's roots) and the usual kernel that walks back up and updates the table.
     bool round_mode = false;
-    int jit_lanes = 4;                   // deals per thread of the generated deal kernels (1 for small batches)
+    int jit_lanes = 4;                   // deals per thread of the generated deal kernels: the first round's subtree (1 for small batches) ...
+    int jit_lanes_below = 4;             // ... and the subtrees of later rounds, which walk short live-deal lists
     static constexpr uint32_t kSmallDealBatch = 1u << 18;   // measured on the river game: 64 K deals 0.161 -> 0.101 ms per batch, 256 K 0.175 -> 0.152, 1 M 0.295 -> 0.314
     std::vector<std::vector<int>> bnd;       // per round root: the next-round roots below it
     std::vector<int> nan_slot;               // per round root (except the first): slot of its reach buffer in the NaN-prefilled arena
@@ -453,8 +453,11 @@ struct Builder {
             first_root = resolve(0);
             // Small deal batches leave most SIMDs without a wave, and a generated kernel is a long dependent instruction stream: one deal per
             // thread puts four times as many waves on the chip, each walking a quarter of the code (RS_JIT_LANES = 1 / 4 overrides)
+            // Only the first round's subtree sees the whole batch; the subtrees behind chance nodes walk the live-deal lists of their roots, a small
+            // share of it each (three streets, 1 M deals per batch: 6.46 -> 5.87 ms with one deal per thread everywhere; 128 K deals: 3.81 -> 2.45)
             jit_lanes = (s->deal_mode && s->deals.n_deals <= kSmallDealBatch) ? 1 : 4;
-            if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = atoi(e) == 1 ? 1 : 4;
+            jit_lanes_below = s->deal_mode ? 1 : 4;
+            if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = jit_lanes_below = atoi(e) == 1 ? 1 : 4;
             round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
             const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
@@ -534,8 +537,8 @@ struct Builder {
         const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down;
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
-                         s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0, jit_lanes,
-                         round_mode ? &fused_root : nullptr, js);
+                         s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
+                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below, round_mode ? &fused_root : nullptr, js);
         hipFunction_t fn = nullptr;
         if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
         auto bi = by_fn.find(fn);
@@ -1102,11 +1105,11 @@ int run_plan(rs_solver *s, int p, int phase = -1) {
 extern "C" {
 
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out, rs_solver *seed_owner);
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out);
 
 int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *leaves_p0, const rs_leaf_desc *leaves_p1,
                      const rs_solver_params *params, rs_solver **out) {
-    return solver_create_impl(table, tree, nullptr, leaves_p0, leaves_p1, params, out, nullptr);
+    return solver_create_impl(table, tree, nullptr, leaves_p0, leaves_p1, params, out);
 }
 
 int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
@@ -1125,19 +1128,10 @@ int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_b
         if (e == hipSuccess) e = hipMemsetAsync(table->d_dssum, 0, bytes, table->stream);
         if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: delta tables");
     }
-    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out, nullptr);
+    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out);
 }
 
 }  // extern "C"
-
-namespace rs {
-// a second deal solver on the same table that continues `seed_owner`'s count of sampled sweeps (the trainer's pruning solver)
-int solver_create_deals_sharing_seed(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                                     const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver *seed_owner, rs_solver **out) {
-    if (!deals || deals->n_deals == 0 || !table || !table->d_dregrets) return fail(RS_ERR_INVALID, "solver_create_deals_sharing_seed: needs a deal table");
-    return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out, seed_owner);
-}
-}  // namespace rs
 
 void rs::solver_release_device(rs_solver *s) {
     if (!s || !s->table) return;   // already detached (its table was destroyed first)
@@ -1171,7 +1165,7 @@ void rs::solver_release_device(rs_solver *s) {
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
     s->d_shadow = nullptr;
     s->d_shadow_jobs = nullptr;
-    if (s->d_seed_state && !s->seed_shared) (void)hipFree(s->d_seed_state);
+    if (s->d_seed_state) (void)hipFree(s->d_seed_state);
     if (s->d_exchange) (void)hipFree(s->d_exchange);
     s->d_exchange = nullptr;
     s->d_arena = nullptr;
@@ -1181,7 +1175,7 @@ void rs::solver_release_device(rs_solver *s) {
 }
 
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
-                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out, rs_solver *seed_owner) {
+                              const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
         return fail(RS_ERR_INVALID, "rs_solver_create: NULL argument");
     const int arith = params->mode & RS_UPD_ARITH_MASK;
@@ -1239,10 +1233,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         rs_solver_destroy(s);
         return hip_fail(e, "hipSetDevice");
     }
-    if (params->opp_mode == RS_OPP_SAMPLE && seed_owner && seed_owner->d_seed_state && seed_owner->table == table) {
-        s->d_seed_state = seed_owner->d_seed_state;
-        s->seed_shared = true;
-    } else if (params->opp_mode == RS_OPP_SAMPLE) {
+    if (params->opp_mode == RS_OPP_SAMPLE) {
         const uint64_t init[3] = {params->sample_seed, 0, 0};
         if ((e = hipMalloc((void **)&s->d_seed_state, sizeof(init))) != hipSuccess ||
             (e = hipMemcpy(s->d_seed_state, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) {

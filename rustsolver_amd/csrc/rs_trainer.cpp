@@ -29,15 +29,11 @@ struct rs_deal_trainer {
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
-    // train()'s prune schedule (cfr.rs:213-221): batches holding deals numbered beyond prune_threshold run on a second solver whose
-    // traverser visits honour a per-deal flag (RS_UPD_PRUNE); it continues the first solver's count of sampled sweeps
-    rs_solver *solver_prune = nullptr;
+    // train()'s prune schedule (cfr.rs:213-221): with a finite prune_threshold the solver runs in RS_UPD_PRUNE mode from the start and every
+    // traverser visit honours the deal's flag byte -- all zero (= unpruned, bit for bit) until a batch reaches beyond the threshold
     uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
     bool live_prune = false;           // the live batch has deals beyond the threshold
     uint64_t live_first = 0, staged_first = 0;   // global number of deal 0 of the live / staged batch
-    rs_deal_batch batch{};
-    std::vector<rs_leaf_desc> leaves;
-    rs_comm *comm = nullptr;
     int tick_br = 0;                   // calc_br at every discount tick (cfr.rs:244-246)
     float last_br[2] = {0.0f, 0.0f};
     uint64_t last_br_t = 0;
@@ -58,7 +54,6 @@ extern "C" {
 
 void rs_deal_trainer_destroy(rs_deal_trainer *tr) {
     if (!tr) return;
-    if (tr->solver_prune) rs_solver_destroy(tr->solver_prune);
     if (tr->solver) rs_solver_destroy(tr->solver);
     if (tr->table) {
         if (tr->d_prune) rs_dfree(tr->table, tr->d_prune);
@@ -179,7 +174,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     }
     if (rc == RS_OK) rc = rs_dmalloc(tr->table, pitch, reinterpret_cast<void **>(&tr->d_prune));
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_prune, 0, pitch);
-    rs_deal_batch &batch = tr->batch;
+    rs_deal_batch batch{};
     batch.n_deals = params->deals_per_batch;
     batch.d_prune = tr->d_prune;
     for (int r = 0; rc == RS_OK && r < n_rounds; ++r)
@@ -190,8 +185,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         }
     if (rc == RS_OK) {
         const int n = rs_tree_n_nodes(tr->tree);
-        std::vector<rs_leaf_desc> &leaves = tr->leaves;
-        leaves.assign(size_t(n), rs_leaf_desc{RS_LEAF_UNCONTESTED, nullptr});
+        std::vector<rs_leaf_desc> leaves(size_t(n), rs_leaf_desc{RS_LEAF_UNCONTESTED, nullptr});
         for (int i = 0; i < n; ++i) {
             rs_tree_node nd;
             rs_tree_get_node(tr->tree, i, &nd);
@@ -200,6 +194,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         rs_solver_params sp = params->solver;
         sp.chance_mode = RS_CHANCE_PASS;   // one run-out per deal: the board is dealt up front (cfr.rs:115-122, :306-313)
         sp.deal_offset = tr->rank * params->deals_per_batch;
+        if (params->prune_threshold != UINT64_MAX) sp.mode |= RS_UPD_PRUNE;   // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune
         rc = rs_solver_create_deals(tr->table, tr->tree, &batch, leaves.data(), leaves.data(), &sp, &tr->solver);
     }
     if (rc != RS_OK) {
@@ -211,28 +206,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
 }
 
 rs_table *rs_deal_trainer_table(rs_deal_trainer *tr) { return tr ? tr->table : nullptr; }
-// the solver of the LIVE batch: the pruning one once the batch reaches beyond prune_threshold (created on first use)
-static int current_solver(rs_deal_trainer *tr, rs_solver **out) {
-    *out = tr->solver;
-    if (!tr->live_prune) return RS_OK;
-    if (!tr->solver_prune) {
-        rs_solver_params sp = tr->params.solver;
-        sp.chance_mode = RS_CHANCE_PASS;
-        sp.deal_offset = tr->rank * tr->params.deals_per_batch;
-        sp.mode |= RS_UPD_PRUNE;     // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune (the `_prune` forms of the generated kernels)
-        if (int rc = solver_create_deals_sharing_seed(tr->table, tr->tree, &tr->batch, tr->leaves.data(), tr->leaves.data(), &sp, tr->solver, &tr->solver_prune))
-            return rc;
-        if (tr->comm)
-            if (int rc = rs_solver_attach_comm(tr->solver_prune, tr->comm)) return rc;
-    }
-    *out = tr->solver_prune;
-    return RS_OK;
-}
-rs_solver *rs_deal_trainer_solver(rs_deal_trainer *tr) {
-    rs_solver *s = nullptr;
-    if (!tr || current_solver(tr, &s) != RS_OK) return nullptr;
-    return s;
-}
+rs_solver *rs_deal_trainer_solver(rs_deal_trainer *tr) { return tr ? tr->solver : nullptr; }
 uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *tr) { return tr ? tr->t : 0; }
 const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *tr) { return tr ? tr->d_cards : nullptr; }
 const float *rs_deal_trainer_signs(const rs_deal_trainer *tr) { return tr ? tr->d_sign : nullptr; }
@@ -365,9 +339,6 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
 
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_attach_comm: trainer is NULL");
-    tr->comm = comm;
-    if (tr->solver_prune)
-        if (int rc = rs_solver_attach_comm(tr->solver_prune, comm)) return rc;
     return rs_solver_attach_comm(tr->solver, comm);
 }
 
@@ -378,10 +349,8 @@ int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
         if (int rc = rs_deal_trainer_deal(tr)) return rc;
         if (b + 1 < n_batches)   // deal the next batch beside this one's sweeps (never beyond what was asked for)
             if (int rc = prefetch(tr)) return rc;
-        rs_solver *solver = nullptr;
-        if (int rc = current_solver(tr, &solver)) return rc;
         for (int player = 0; player < 2; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
-            if (int rc = rs_iterate(solver, player, nullptr)) return rc;
+            if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
         if (int rc = rs_deal_trainer_finish_batch(tr)) return rc;
     }
     return RS_OK;
