@@ -236,8 +236,8 @@ def test_deal_trainer_reference_as_coded(fuse):
 def test_deal_trainer_prune_schedule(streets):
     """train()'s prune flag (cfr.rs:213-221) with PRUNE_THRESHOLD moved into reach: deals numbered beyond it whose q > 0.05 are traversed
     with prune = true (explored[] of cfr.rs:379-386, updates of :419-441).  The table starts with regrets on both sides of -10 000 000 so
-    that pruning bites; batches 0-1 run on the generated kernels, batch 1's tail and batches 2-4 on the pruning solver, which must continue
-    the same sweep-seed sequence.  Cards, flags and tables equal the oracle's."""
+    that pruning bites; batch 0 carries no flag (its deals are numbered below the threshold), batch 1's tail and batches 2-4 do.  Cards, flags and
+    tables equal the oracle's."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
         hands = ab.random_range(mask)
