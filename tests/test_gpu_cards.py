@@ -296,15 +296,16 @@ def test_deal_trainer_three_streets_from_a_flop_with_bucket_files(parts, monkeyp
     compare_trainer_tables(ctx)
 
 
-@pytest.mark.parametrize("world,streets", [(2, 1), (3, 1), (2, 3)])
-def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets):
+@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (2, 3, 700), (2, 1, 1 << 21)])
+def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets, n):
     """`world` ranks x n deals on replicated tables, their i32 deltas summed between sweep and apply (what rs_comm_allreduce_deltas does
     over xGMI; here the test adds them on the host), equal ONE trainer with world*n deals per batch, bit for bit: cards, tables, discount
     ticks.  Ranks are emulated on one GPU, one trainer per rank.  streets = 3: a flop-start tree, i.e. round subtrees, live-deal lists and the
-    rank's lane base in the sampling hash together."""
+    rank's lane base in the sampling hash together.  n = 2 M: the property at bench.py's size (4 M deals per union batch, the whole range,
+    four deals per thread, staged dealing on the second stream)."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
-        hands = ab.random_range(mask)[::3]
+        hands = ab.random_range(mask)[:: (3 if n < 10000 else 1)]
         n_actions, tree = rs.build_game_tree(rs.default_flop())
         card_abs = [ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)]
     else:
@@ -315,7 +316,6 @@ def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets):
         n_actions, tree = rs.build_game_tree(rs.three_street_options())
         files = [rng.integers(0, 23, size=1286792, dtype=np.uint32), rng.integers(0, 41, size=13960050, dtype=np.uint32), None]
         card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
-    n = 700
     kw = dict(seed=21, discount_interval=2 * world * n - 100, discount_cap=10**9)
     ranks = [rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, world=world, rank=r, **kw) for r in range(world)]
     single = rs.DealTrainer(tree, card_abs, [hands, hands], mask, world * n, **kw)
