@@ -676,6 +676,17 @@ def main():
         "lane_updates_per_sec": sum(table.lanes(n) for n in range(table.n_nodes)) * n_gpus * a.steps / elapsed,
     }
 
+    try:   # the card's own streaming ceiling (cards of one pool differ by more than 10 %): a plain float4 copy, 2 x 2 GiB, on the same stream
+        import ctypes as C3
+        from rustsolver_amd import _lib as L3
+        g = C3.c_double()
+        L3.check(L3.load().rs_stream_probe(table._h, 2 << 30, 10, C3.byref(g)))
+        out["stream_probe"] = {"copy_GBps": g.value, "what": "nt float4 copy, 2 GiB read + 2 GiB written per launch, best of 1 024 / 4 096 / 16 384 workgroups, HIP events",
+                               "tree_kernel_over_copy": achieved / g.value if g.value > 0 else None}
+        out["roofline"]["frac_of_copy_on_this_card"] = out["stream_probe"]["tree_kernel_over_copy"]
+    except Exception as e:
+        out["stream_probe"] = {"error": str(e)}
+
     if n_gpus > 1 or a.no_extra:   # the extra legs (single board, deal batches, CPU baselines) are N = 1 material
         emit(out)
         os.dup2(2, 1)

@@ -477,6 +477,9 @@ typedef struct rs_profile {
     double ms[RS_K_COUNT];              /* sum of HIP-event durations on the table's stream */
     double algo_bytes[RS_K_COUNT];      /* sum of algorithmic bytes of those launches */
 } rs_profile;
+/* the rate (GB/s, read + write) a plain float4 copy of `bytes` reaches on this card, best of three grid sizes: the practical streaming ceiling
+ * beside the 8 TB/s specification.  Allocates 2 x bytes for the duration of the call; synchronises. */
+int rs_stream_probe(rs_table *table, size_t bytes, int reps, double *gbps);
 int rs_profile_enable(rs_table *table, int on); /* on: bracket every launch with hipEvents (adds host work) */
 int rs_profile_read(rs_table *table, rs_profile *out); /* synchronises, then accumulates pending events */
 int rs_profile_reset(rs_table *table);

@@ -117,6 +117,7 @@ SYMBOLS = {
     "rs_regret_match_node": (C.c_int, [_P, C.c_int, _P]),
     "rs_final_strategy_node": (C.c_int, [_P, C.c_int, _P]),
     "rs_final_strategy_all": (C.c_int, [_P, _P]),
+    "rs_stream_probe": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "rs_calc_br": (C.c_int, [_P, _P, _P]),
     "rs_best_response": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P, C.c_int, _P]),
     "rs_update_node": (C.c_int, [_P, C.c_int, _P, _P, C.c_float, C.c_int, _P]),

@@ -658,6 +658,16 @@ hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, u
     hipLaunchKernelGGL(k_showdown_sign, grid, block, 0, stream, cards, sign, n, pitch);
     return hipGetLastError();
 }
+// ---- what does a plain streaming copy reach on THIS card?  (bench.py prices the tree kernel against it beside the 8 TB/s spec) --------------
+__global__ __launch_bounds__(kBlock) void k_probe_copy(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, size_t n) {
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += (size_t)gridDim.x * kBlock)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + v), out + v);
+}
+hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(kBlock), 0, stream, (const f32x4 *)in, (f32x4 *)out, bytes / 16);
+    return hipGetLastError();
+}
+
 hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {
     hipLaunchKernelGGL(k_next_seed, dim3(1), dim3(64), 0, stream, d_state);
     return hipGetLastError();

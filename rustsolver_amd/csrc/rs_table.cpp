@@ -588,6 +588,40 @@ int rs_profile_read(rs_table *t, rs_profile *out) {
     *out = t->prof.acc;
     return RS_OK;
 }
+// The streaming rate this card reaches on a plain float4 copy (read `bytes`, write `bytes`), best of a few grid sizes: the practical ceiling
+// the update kernels are compared with beside the 8 TB/s specification (cards of one pool differ by more than 10 %).
+int rs_stream_probe(rs_table *t, size_t bytes, int reps, double *gbps) {
+    if (!t || !gbps) return fail(RS_ERR_INVALID, "rs_stream_probe: NULL argument");
+    if (bytes < (1u << 20) || reps < 1) return fail(RS_ERR_INVALID, "rs_stream_probe: at least 1 MiB and one repetition");
+    bytes &= ~size_t(4095);
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    void *in = nullptr, *out = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipMalloc(&in, bytes);
+    if (e == hipSuccess) e = hipMalloc(&out, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(in, 1, bytes, t->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(out, 0, bytes, t->stream);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    double best = 0.0;
+    for (unsigned blocks : {1024u, 4096u, 16384u}) {
+        if (e == hipSuccess) e = launch_probe_copy(in, out, bytes, blocks, t->stream);   // warm-up
+        if (e == hipSuccess) e = hipEventRecord(a, t->stream);
+        for (int r = 0; e == hipSuccess && r < reps; ++r) e = launch_probe_copy(in, out, bytes, blocks, t->stream);
+        if (e == hipSuccess) e = hipEventRecord(b, t->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess && ms > 0.0f) best = std::max(best, 2.0 * double(bytes) * reps / (double(ms) * 1e-3) / 1e9);
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (in) (void)hipFree(in);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) return hip_fail(e, "rs_stream_probe");
+    *gbps = best;
+    return RS_OK;
+}
 int rs_profile_reset(rs_table *t) {
     if (!t) return fail(RS_ERR_INVALID, "rs_profile_reset: table is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
