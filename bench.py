@@ -358,7 +358,7 @@ def kmeans_leg(rs, device, with_cpu, cpu_seconds):
     return out
 
 
-def three_street_leg(rs, device):
+def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     """The reference's commented-out "real" configuration (options.rs:68-77): flop start, three betting rounds (706 action nodes), 5 000-bucket
     files on every street (EMD / OCHS shape: index -> bucket file -> dense id), sampled mccfr over 1 M deals per batch, everything on the device.
     Round subtrees with reach-down / walk-up kernels, live-deal lists, cluster-partitioned LDS tiles."""
@@ -385,7 +385,30 @@ def three_street_leg(rs, device):
                    "opponents: deal sampling, hand indexing through the bucket files, showdowns and the sweep on the device" % (n_actions, k, n),
            "value": n / dt, "unit": "deal-iterations/s", "ms_per_batch": dt * 1e3, "n_deals": n, "clusters": [a_.get_size(0) for a_ in card_abs],
            "table_bytes": int(tr.infosets.nbytes if not callable(tr.infosets.nbytes) else tr.infosets.nbytes()), "trainer_create_s": create_s}
+    sizes = [(a_.get_size(0), a_.get_size(1)) for a_ in card_abs]
     tr.destroy()
+    if with_cpu:   # the same loop on the host cores: the oracle's train-from-cards (reference layout, per-visit allocations), 8 threads
+        from oracle import orc
+        threads = min(8, os.cpu_count() or 1)
+        nd_cpu = 50_000
+        otree = orc.OracleTree(orc.options_three_street())
+        otab = orc.OracleDealTable(otree, sizes)
+        cidx = {(r, p): np.zeros(nd_cpu, dtype=np.uint32) for r in range(3) for p in (0, 1)}
+        sign = np.zeros(nd_cpu, dtype=np.float32)
+        ol = {d["id"]: (orc.LEAF_SIGN, sign) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+        osol = orc.OracleDealSolver(otree, otab, ol, cidx, nd_cpu, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=1)
+        def run(k_):   # every call rebuilds the dense-id maps of all rounds (seconds): time DIFFERENCES between sweep counts
+            t0_ = time.perf_counter()
+            orc.run_train_from_cards(osol, cidx, sign, mask, [hands, hands], 7, k_, threads, bucket_files=files)
+            return time.perf_counter() - t0_
+        t_one, t_five = run(1), run(5)
+        per = max((t_five - t_one) / 4.0, 1e-4)
+        sweeps = max(4, int(cpu_seconds / per))
+        dtc = max(run(1 + sweeps) - t_one, 1e-6)
+        out["cpu_baseline"] = {"value": nd_cpu * sweeps / dtc, "unit": "deal-iterations/s", "cores": threads, "kind": "port",
+                               "sample": "%d sweeps x %d deals from cards through the same bucket files (generate_hand, hand index -> bucket -> dense id per round and "
+                                         "player, brute-force showdown, sampled mccfr with reference-style allocations), %d threads, %.1f s" % (sweeps, nd_cpu, threads, dtc)}
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
 
@@ -720,7 +743,7 @@ def main():
         out["deal_trainer"] = {"error": str(e)}
 
     try:
-        out["deal_trainer_three_street"] = three_street_leg(rs, device)
+        out["deal_trainer_three_street"] = three_street_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))
     except Exception as e:
         out["deal_trainer_three_street"] = {"error": str(e)}
 
