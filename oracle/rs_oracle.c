@@ -31,6 +31,9 @@ int32_t orc_f32_as_i32(float x) {
     return (int32_t)x;
 }
 
+/* `i64::from(r) + (x as i64)` (cfr.rs:445, :454): only an infinite delta (the cast saturates to i64::MIN / MAX) can overflow it; a release build
+ * wraps (overflow checks off), a debug build panics.  Restated as the wrap, in unsigned arithmetic so that it is defined C. */
+static int64_t wrapping_add_i64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 static int32_t wrapping_add_i32(int32_t a, int32_t b) {
     return (int32_t)((uint32_t)a + (uint32_t)b);
 }
@@ -445,9 +448,9 @@ float orc_update_infoset(int32_t *regrets, int32_t *ssum, int n, const float *ut
         for (i = 0; i < n; i++) {
             int64_t new_regret, new_ssum;
             if (!explored[i]) continue;
-            new_regret = (int64_t)regrets[i] + orc_f32_as_i64(scale * cfr_reach * (utils[i] - util));
+            new_regret = wrapping_add_i64((int64_t)regrets[i], orc_f32_as_i64(scale * cfr_reach * (utils[i] - util)));
             regrets[i] = (int32_t)clamp_i64_to_i32(new_regret);
-            new_ssum = (int64_t)ssum[i] + orc_f32_as_i64(scale * cfr_reach * strategy[i]);
+            new_ssum = wrapping_add_i64((int64_t)ssum[i], orc_f32_as_i64(scale * cfr_reach * strategy[i]));
             ssum[i] = (int32_t)clamp_i64_to_i32(new_ssum);
         }
     } else {
@@ -602,8 +605,8 @@ float orc_update_infoset_rmplus(int32_t *regrets, int32_t *ssum, int n, const fl
     orc_get_strategy(regrets, n, strategy);
     for (i = 0; i < n; i++) util += utils[i] * strategy[i];
     for (i = 0; i < n; i++) {
-        int64_t nr = (int64_t)regrets[i] + orc_f32_as_i64(scale * cfr_reach * (utils[i] - util));
-        int64_t ns = (int64_t)ssum[i] + orc_f32_as_i64(scale * cfr_reach * strategy[i]);
+        int64_t nr = wrapping_add_i64((int64_t)regrets[i], orc_f32_as_i64(scale * cfr_reach * (utils[i] - util)));
+        int64_t ns = wrapping_add_i64((int64_t)ssum[i], orc_f32_as_i64(scale * cfr_reach * strategy[i]));
         nr = clamp_i64_to_i32(nr);
         if (nr < 0) nr = 0;
         regrets[i] = (int32_t)nr;

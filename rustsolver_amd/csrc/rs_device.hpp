@@ -49,9 +49,13 @@ template <typename T> __device__ __forceinline__ RS_GLOBAL T *as_global(void *p)
 #endif
 
 // ---- Rust casts ---------------------------------------------------------------------------------
-// `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  |x| >= 2^32 saturates the
-// sum whatever r is, so x is first limited to +-2^32 (exact in f32) and the rest is exact i64 work.
+// `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  2^32 <= |x| < 2^63 saturates the sum whatever r is, so x is first
+// limited to +-2^32 (exact in f32) and the rest is exact i64 work.  |x| >= 2^63 (an infinite utility) is where the cast itself saturates, to
+// i64::MAX / i64::MIN, and adding an r of the same sign overflows the i64: a release build wraps (a debug build panics), so the clamp then
+// lands on the OPPOSITE limit -- reproduced, like the oracle does.
 __device__ __forceinline__ int add_clamp_i64(int r, float x) {
+    if (x >= 9223372036854775808.0f) return r > 0 ? -2147483647 - 1 : 2147483647;
+    if (x <= -9223372036854775808.0f) return r < 0 ? 2147483647 : -2147483647 - 1;
     if (x != x) x = 0.0f;                                  // NaN -> 0
     x = fminf(fmaxf(x, -4294967296.0f), 4294967296.0f);
     long long sum = (long long)r + (long long)x;            // trunc toward zero
@@ -301,19 +305,51 @@ __device__ __forceinline__ float visit_i32(int (&r)[A], int (&s)[A], const float
     }
     const bool active = !(reach != reach);           // NaN reach marks a lane whose subtree was pruned above
     const float k = scale * reach;                   // (100.0 * cfr_reach) first
+    if (ARITH == kARITH_CLAMP) {
+        // `f32 as i64`, 64-bit add, clamp (add_clamp_i64) is about 22 VALU instructions, and a sweep executes 2A of them per traverser node and lane:
+        // nearly half of a tree kernel's arithmetic.  Whenever |x| < 2^31 the same result is one conversion (v_cvt_i32_f32 truncates toward zero
+        // like the cast) and one SATURATING i32 add (the exact i64 sum clamped to i32 is what saturation means).  The test is made once per visit
+        // and for the whole wave, so both paths run unmasked; lanes whose adds are not executed anyway do not vote.
+        float dr[A], ds[A];
+        bool small = true;
 #pragma unroll
-    for (int a = 0; a < A; a++) {
-        if (ex[a] && active) {
-            const float dr = k * (u[a] - util);
-            const float ds = k * sig[a];
-            if (ARITH == kARITH_CLAMP) {
-                int nr = add_clamp_i64(r[a], dr);
+        for (int a = 0; a < A; a++) {
+            dr[a] = k * (u[a] - util);
+            ds[a] = k * sig[a];
+            small = small && (!ex[a] || (__builtin_fabsf(dr[a]) < 2147483648.0f && __builtin_fabsf(ds[a]) < 2147483648.0f));   // false for NaN
+        }
+        small = small || !active;
+#ifdef RS_NO_FAST_CLAMP   // A/B knob (RS_JIT_NO_FAST_CLAMP): the exact path for everybody
+        small = false;
+#endif
+        if (__builtin_amdgcn_ballot_w64(small) == __builtin_amdgcn_ballot_w64(true)) {
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                int nr = __builtin_elementwise_add_sat(r[a], (int)dr[a]);
                 if (rmplus && nr < 0) nr = 0;
-                r[a] = nr;
-                s[a] = add_clamp_i64(s[a], ds);
-            } else {
-                r[a] = add_wrap_i32(r[a], dr);
-                s[a] = add_wrap_i32(s[a], ds);
+                const int ns = __builtin_elementwise_add_sat(s[a], (int)ds[a]);
+                if (ex[a] && active) {
+                    r[a] = nr;
+                    s[a] = ns;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                if (ex[a] && active) {
+                    int nr = add_clamp_i64(r[a], dr[a]);
+                    if (rmplus && nr < 0) nr = 0;
+                    r[a] = nr;
+                    s[a] = add_clamp_i64(s[a], ds[a]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            if (ex[a] && active) {
+                r[a] = add_wrap_i32(r[a], k * (u[a] - util));
+                s[a] = add_wrap_i32(s[a], k * sig[a]);
             }
         }
     }

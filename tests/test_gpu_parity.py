@@ -132,6 +132,44 @@ def test_golden_extension_cases(rand):
 
 # ---- per-node kernels vs the oracle on seeded inputs ------------------------------------------------------
 
+@pytest.mark.parametrize("A", [2, 3, 6])
+def test_update_clamp_paths_agree_with_the_oracle_around_2_pow_31(A):
+    """The clamp update has two paths on the device: one conversion + one saturating add while every |scale * reach * (u - util)| and
+    |scale * reach * sigma| of a WAVE stays below 2^31, the i64 form otherwise (rs_device.hpp visit_i32).  Deltas here straddle 2^31 and
+    2^32, mixed per lane with ordinary ones, with NaN / inf utilities and regrets at the i32 limits: both paths and their boundary."""
+    rng = np.random.Generator(np.random.PCG64(77 + A))
+    n = 64 * 40                                                    # 40 waves: some all-small, some mixed, some all-large
+    R = rng.integers(-10**6, 10**6, size=(A, n)).astype(np.int32)
+    S = rng.integers(0, 10**6, size=(A, n)).astype(np.int32)
+    U = rng.uniform(-1035, 1035, size=(A, n)).astype(np.float32)
+    reach = rng.uniform(0, 1, size=n).astype(np.float32)
+    big = np.zeros(n, dtype=bool)
+    big[64 * 10: 64 * 20] = rng.random(640) < 0.1                  # mixed waves
+    big[64 * 20: 64 * 30] = True                                    # whole waves on the i64 path
+    nb = int(big.sum())
+    mag = rng.choice([2.0**31 / 100, 2.0**31 / 100 * 1.0000001, 2.0**32 / 100, 2.0**32 / 100 * 1.001, 1e9, 3e7, 2.1e7], size=(A, nb))
+    U[:, big] = (mag * rng.choice([-1.0, 1.0], size=(A, nb))).astype(np.float32)
+    reach[big] = 1.0
+    edge = np.flatnonzero(big)[:: 7]
+    R[:, edge] = rng.choice([2**31 - 1, -2**31, 2**31 - 2, -2**31 + 1, 0], size=(A, len(edge)))
+    S[:, edge] = rng.choice([2**31 - 1, 0, 2**31 - 5], size=(A, len(edge)))
+    U[0, 64 * 30 + 3] = np.nan                                      # Rust: NaN as i64 = 0
+    U[A - 1, 64 * 31 + 9] = np.inf
+    U[0, 64 * 32 + 1] = -np.inf
+    for rmplus in (False, True):
+        t = one_node_table(A, n, rs.I32, 1)
+        t.upload_node(0, R, S)
+        util = t.update_node(0, U, reach, 100.0, rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if rmplus else 0))
+        r, s = t.download_node(0)
+        for k in range(n):
+            if rmplus:
+                wu, rk, sk = orc.update_infoset_rmplus(R[:, k], S[:, k], U[:, k], reach[k], 100.0)
+            else:
+                wu, rk, sk = orc.update_infoset(R[:, k], S[:, k], U[:, k], reach[k], 100.0, orc.UPD_CLAMP_I64, False)
+            assert (r[:, k] == rk).all() and (s[:, k] == sk).all(), (A, rmplus, k, U[:, k], R[:, k], r[:, k], rk)
+            assert np.float32(util[k]).view(np.uint32) == np.float32(wu).view(np.uint32) or (np.isnan(util[k]) and np.isnan(wu))
+
+
 @pytest.mark.parametrize("A", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("C,B", [(1, 1), (5, 3), (169, 1), (1000, 2), (1081, 1)])
 def test_update_node_vs_oracle(A, C, B):
