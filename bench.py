@@ -677,6 +677,7 @@ def main():
                         % (a.dtype, "cfr.rs:413-464 clamp scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap scale 10000",
                            "full width (cfr.rs:576-589)" if a.opp == "full" else "sampled (mccfr, cfr.rs:467-476)"),
             "n_boards_per_gpu": a.boards, "n_clusters": a.clusters, "lanes_per_gpu": a.boards * a.clusters,
+            "lane_pitch": int(table.pitch(0)),
             "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
             "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
             "fused_subtrees": bool(trainer.fused),

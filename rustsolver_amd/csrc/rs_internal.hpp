@@ -109,6 +109,7 @@ hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
+hipError_t launch_probe_rows(void *reg, void *ssm, const uint64_t *d_off, int n_rows, size_t row_bytes, hipStream_t stream);   // rs_table_create's stride tuner
 hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned blocks, hipStream_t stream);   // rs_stream_probe
 hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);

@@ -668,6 +668,47 @@ hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned b
     return hipGetLastError();
 }
 
+// ---- which row stride suits THIS allocation?  (rs_table_create, big lane tables) ---------------------------------------------------------------
+// A tree kernel streams every row of every node at once -- ~95 rows [pitch] apart, read and written back 16 bytes per thread -- and how those streams fall on
+// the memory channels depends on the stride AND on where the allocation landed physically: the same binary measured 1.18 - 1.42 ms per iteration from
+// one process to the next, and for a given process the best of a handful of strides is 5 - 10 % faster than the worst.  This kernel walks the same
+// rows the same way (load a group of rows of both arrays, store them back), so that the candidates can be timed on the real buffers before the
+// table is zero-filled.
+__global__ __launch_bounds__(kBlock) void k_probe_rows(char *__restrict__ reg, char *__restrict__ ssm, const uint64_t *__restrict__ off, int n_rows, size_t n_vec,
+                                                       int traverser) {
+    // off[r] bit 0 = the row's node belongs to player 1.  Like a sweep of `traverser`: the regrets of every node are read, the traverser's own
+    // nodes are read in both arrays and written back
+    constexpr int G = 6;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * kBlock) {
+        float sink = 0.0f;
+        for (int r0 = 0; r0 < n_rows; r0 += G) {
+            f32x4 x[G], y[G];
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (r0 + i < n_rows) {
+                    const uint64_t o = off[r0 + i];
+                    x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reg + (o & ~1ull)) + v);
+                    if (int(o & 1) == traverser) y[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ssm + (o & ~1ull)) + v);
+                }
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (r0 + i < n_rows) {
+                    const uint64_t o = off[r0 + i];
+                    if (int(o & 1) == traverser) {
+                        __builtin_nontemporal_store(x[i], reinterpret_cast<f32x4 *>(reg + (o & ~1ull)) + v);
+                        __builtin_nontemporal_store(y[i], reinterpret_cast<f32x4 *>(ssm + (o & ~1ull)) + v);
+                    } else sink += x[i].x;
+                }
+        }
+        if (sink == 12345.678f) reg[0] = 1;   // keeps the read-only loads alive
+    }
+}
+hipError_t launch_probe_rows(void *reg, void *ssm, const uint64_t *d_off, int n_rows, size_t row_bytes, hipStream_t stream) {
+    for (int traverser = 0; traverser < 2; ++traverser)
+        hipLaunchKernelGGL(k_probe_rows, dim3(4096), dim3(kBlock), 0, stream, (char *)reg, (char *)ssm, d_off, n_rows, row_bytes / 16, traverser);
+    return hipGetLastError();
+}
+
 hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {
     hipLaunchKernelGGL(k_next_seed, dim3(1), dim3(64), 0, stream, d_state);
     return hipGetLastError();

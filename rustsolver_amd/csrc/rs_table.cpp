@@ -93,6 +93,12 @@ static float f16_bits_to_f32(uint16_t b) {
 }
 
 // copy a strided block between host [rows][row_len] (host element) and device rows at
+// Row stride of big lane tables.  A tree kernel streams ~95 rows of one node group at once, [action][pitch] apart, and how well that goes depends on the
+// stride and on where the allocation landed physically (rs_kernels.hip, k_probe_rows).  Tables whose widest node has at least kTuneMinLanes lanes get
+// their stride TUNED at creation: a few candidates are timed on the real buffers.  RS_TABLE_PITCH_TUNE=0 switches that off (rows back to back),
+// RS_TABLE_PITCH_SKEW=n fixes n extra 64-lane groups per row.  Only the widest nodes are ever skewed, and never below kSkewMinLanes lanes.
+static constexpr size_t kSkewMinLanes = size_t(1) << 16, kTuneMinLanes = size_t(1) << 20;
+
 // base + (r*row_stride + col0) elements.  dir: 0 = upload, 1 = download.
 static int copy_rows(rs_table *t, void *d_base, size_t row_stride, size_t col0, void *host, size_t rows, size_t row_len,
                      int dir) {
@@ -182,19 +188,78 @@ int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int devic
     t->nodes.assign(nodes, nodes + n_nodes);
     t->pitch.resize(n_nodes);
     t->cell_off.resize(n_nodes);
-    size_t off = 0;
-    for (int i = 0; i < n_nodes; ++i) {
-        t->pitch[i] = round_up(size_t(nodes[i].n_boards) * nodes[i].n_clusters, kLanePad);
-        t->cell_off[i] = off;
-        off += t->pitch[i] * nodes[i].n_actions;
-    }
-    t->n_cells = off;
-    const size_t bytes = off * elem_size(dtype);
+    size_t max_lanes = 0;
+    for (int i = 0; i < n_nodes; ++i) max_lanes = std::max(max_lanes, size_t(nodes[i].n_boards) * nodes[i].n_clusters);
+    // layout for a given row skew: extra 64-lane groups per row of the WIDEST nodes only (the last round's: what a tree kernel streams; the narrower
+    // rounds above keep the plain pitch, which sharded sweeps rely on when ranks exchange their rows)
+    auto layout = [&](size_t skew_groups) {
+        size_t off = 0;
+        for (int i = 0; i < n_nodes; ++i) {
+            const size_t lanes = size_t(nodes[i].n_boards) * nodes[i].n_clusters;
+            t->pitch[i] = round_up(lanes, kLanePad) + ((lanes == max_lanes && lanes >= kSkewMinLanes) ? skew_groups * kLanePad : 0);
+            t->cell_off[i] = off;
+            off += t->pitch[i] * nodes[i].n_actions;
+        }
+        t->n_cells = off;
+    };
+    const char *fixed = getenv("RS_TABLE_PITCH_SKEW"), *tune_env = getenv("RS_TABLE_PITCH_TUNE");
+    // candidates of the stride tuner: 0 = rows back to back; the others are odd-ish numbers of 256-byte groups, at most 0.5 MB per row
+    static const size_t kCand[] = {0, 32, 257, 825, 1000, 1849};
+    const bool tune = !fixed && max_lanes >= kTuneMinLanes && !(tune_env && atoi(tune_env) == 0);
+    layout(tune ? kCand[sizeof(kCand) / sizeof(kCand[0]) - 1] : (fixed ? size_t(atol(fixed) > 0 ? atol(fixed) : 0) : 0));
+    const size_t bytes = t->n_cells * elem_size(dtype);   // tuner: the largest candidate
     hipError_t er;
     if ((er = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (er = hipMalloc(&t->d_regrets, bytes)) != hipSuccess || (er = hipMalloc(&t->d_ssum, bytes)) != hipSuccess ||
-        (er = hipMemsetAsync(t->d_regrets, 0, bytes, t->stream)) != hipSuccess ||   // Infoset::init zero fill
-        (er = hipMemsetAsync(t->d_ssum, 0, bytes, t->stream)) != hipSuccess ||
+        (er = hipMalloc(&t->d_regrets, bytes)) != hipSuccess || (er = hipMalloc(&t->d_ssum, bytes)) != hipSuccess) {
+        int rc = hip_fail(er, "rs_table_create: device allocation");
+        rs_table_destroy(t);
+        return rc;
+    }
+    if (tune) {   // time the candidates on these very buffers (their content does not matter yet) and keep the fastest stride
+        size_t best = 0;
+        float best_ms = 0.0f;
+        uint64_t *d_off = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        er = hipMalloc(&d_off, sizeof(uint64_t) * size_t(n_nodes) * RS_MAX_ACTIONS);
+        if (er == hipSuccess) er = hipEventCreate(&a);
+        if (er == hipSuccess) er = hipEventCreate(&b);
+        for (size_t c = 0; er == hipSuccess && c < sizeof(kCand) / sizeof(kCand[0]); ++c) {
+            layout(kCand[c]);
+            std::vector<uint64_t> offs;   // the rows of the widest nodes: what one tree kernel streams together
+            size_t row_bytes = 0;
+            for (int i = 0; i < n_nodes; ++i)
+                if (size_t(nodes[i].n_boards) * nodes[i].n_clusters == max_lanes) {
+                    row_bytes = round_up(max_lanes, kLanePad) * elem_size(dtype);
+                    for (uint32_t k = 0; k < nodes[i].n_actions; ++k) offs.push_back((uint64_t(t->cell_off[i] + k * t->pitch[i]) * elem_size(dtype)) | uint64_t(nodes[i].player & 1));   // byte offsets are multiples of 128
+                }
+            if (offs.empty()) break;
+            er = hipMemcpy(d_off, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+            for (int rep = 0; er == hipSuccess && rep < 3; ++rep) {   // rep 0 warms up
+                if (rep == 1) er = hipEventRecord(a, t->stream);
+                if (er == hipSuccess) er = launch_probe_rows(t->d_regrets, t->d_ssum, d_off, int(offs.size()), row_bytes, t->stream);
+            }
+            if (er == hipSuccess) er = hipEventRecord(b, t->stream);
+            if (er == hipSuccess) er = hipEventSynchronize(b);
+            float ms = 0.0f;
+            if (er == hipSuccess) er = hipEventElapsedTime(&ms, a, b);
+            if (er == hipSuccess && (c == 0 || ms < best_ms)) {
+                best_ms = ms;
+                best = c;
+            }
+        }
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (d_off) (void)hipFree(d_off);
+        if (er != hipSuccess) {
+            int rc = hip_fail(er, "rs_table_create: stride tuner");
+            rs_table_destroy(t);
+            return rc;
+        }
+        layout(kCand[best]);
+    }
+    const size_t used = t->n_cells * elem_size(dtype);
+    if ((er = hipMemsetAsync(t->d_regrets, 0, used, t->stream)) != hipSuccess ||   // Infoset::init zero fill
+        (er = hipMemsetAsync(t->d_ssum, 0, used, t->stream)) != hipSuccess ||
         (er = hipStreamSynchronize(t->stream)) != hipSuccess) {
         int rc = hip_fail(er, "rs_table_create: device allocation");
         rs_table_destroy(t);

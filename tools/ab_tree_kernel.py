@@ -24,12 +24,19 @@ ap.add_argument("--steps", type=int, default=10)
 a = ap.parse_args()
 
 n_actions, tree = rs.build_game_tree(rs.default_flop())
-table = rs.create_infosets(n_actions, tree, [a.clusters], [a.boards])
-table.fill_random(1235, (-10**6, 10**6), (0, 10**6))
 root = tree.nodes[tree.nodes[0].children[0]]
-sign = table.lane_buffer(root.index, 1)
-L.check(L.load().rs_fill_uniform_f32(table._h, sign.ptr, table.pitch(root.index), 99, -1.0, 1.0))
-leaves = {i: (rs.LEAF_SIGN, sign) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+
+
+def make_table():
+    tb = rs.create_infosets(n_actions, tree, [a.clusters], [a.boards])
+    tb.fill_random(1235, (-10**6, 10**6), (0, 10**6))
+    sg = tb.lane_buffer(root.index, 1)
+    L.check(L.load().rs_fill_uniform_f32(tb._h, sg.ptr, tb.pitch(root.index), 99, -1.0, 1.0))
+    return tb, sg, {i: (rs.LEAF_SIGN, sg) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+
+
+table, sign, leaves = make_table()
+own = []   # variants with RS_TABLE_PITCH_SKEW get a table of their own (the knob is read once per PROCESS: only one skew value per run)
 trainers = []
 for v in a.variants:
     env = dict(kv.split("=") for kv in v.split()) if v.strip() else {}
@@ -60,3 +67,9 @@ for r in range(a.rounds):
 for v, ts in zip(a.variants, times):
     print("%-40s median %.3f ms  min %.3f  max %.3f   (%s)" % (v or "<default>", statistics.median(ts), min(ts), max(ts),
                                                             " ".join("%.3f" % t for t in ts)))
+import ctypes as C  # noqa: E402
+g = C.c_double()
+L.check(lib.rs_stream_probe(table._h, 2 << 30, 10, C.byref(g)))   # which kind of card was this?
+lanes = a.boards * a.clusters
+print("this card: plain copy %.0f GB/s; default variant moves %.0f GB/s (2 x 3.576 GB per iteration at 9216 x 1000 lanes)"
+      % (g.value, 2 * 3.576e9 * (lanes / 9.216e6) / (statistics.median(times[0]) * 1e-3) / 1e9))
