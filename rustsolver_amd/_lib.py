@@ -93,6 +93,7 @@ SYMBOLS = {
     "rs_table_node_desc": (C.c_int, [_P, C.c_int, C.POINTER(NodeDesc)]),
     "rs_table_dtype": (C.c_int, [_P]),
     "rs_table_device": (C.c_int, [_P]),
+    "rs_table_tile_lanes": (C.c_size_t, [_P, C.c_int]),
     "rs_table_lane_pitch": (C.c_size_t, [_P, C.c_int]),
     "rs_table_cells": (C.c_size_t, [_P]),
     "rs_table_cell_offset": (C.c_size_t, [_P, C.c_int]),

@@ -232,7 +232,8 @@ static int check_tree_against_table(const rs_table *t, const rs_tree *tree, cons
 }
 
 static BrNodeRow row_of(const rs_table *t, int index) {
-    return BrNodeRow{uint64_t(t->cell_off[size_t(index)]), uint32_t(t->pitch[size_t(index)]), t->nodes[size_t(index)].n_actions};
+    // rows are tile[] elements apart inside the first tile of a (possibly tiled) node block: all that bucket 0 / a one-board table ever touches
+    return BrNodeRow{uint64_t(t->cell_off[size_t(index)]), uint32_t(t->tile[size_t(index)]), t->nodes[size_t(index)].n_actions};
 }
 
 }  // namespace rs
@@ -375,7 +376,7 @@ int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, con
             return fail(RS_ERR_UNSUPPORTED, "rs_best_response: single-round trees only (a public chance node would need the run-outs enumerated)");
         if (n.kind != RS_NODE_ACTION) continue;
         const rs_node_desc &nd = t->nodes[size_t(n.index)];
-        if (n.round_idx != 0 || nd.n_boards != 1) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: one round, one board (the reference's table shape)");
+        if (n.round_idx != 0 || nd.n_boards != 1 || t->tiled(n.index)) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: one round, one board (the reference's table shape)");
         if (n.player > 1) return fail(RS_ERR_INVALID, "rs_best_response: two players");
         if (n_clusters[n.player] && n_clusters[n.player] != nd.n_clusters) return fail(RS_ERR_INVALID, "rs_best_response: a player's nodes differ in cluster count");
         n_clusters[n.player] = nd.n_clusters;

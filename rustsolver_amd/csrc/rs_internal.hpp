@@ -53,6 +53,11 @@ struct NodeJob {
     void *dssm;
     uint32_t n_lanes;         // deals in the batch (lanes beyond are padding)
     uint32_t lane_base;       // data-parallel deal batches: global index of this rank's first deal (opponent-sampling hash only)
+    // tiled node blocks (big lane tables, rs_table.cpp): the rows of a node are interleaved in tiles of row_stride lanes, [tile][action][row_stride]; the
+    // thread's vector v of row a sits at element a * row_stride + 4 * (((v >> tile_shift) * A << tile_shift) + (v & mask)).  Untiled: row_stride = pitch,
+    // tile_shift = 31 (one tile)
+    uint32_t row_stride;
+    uint32_t tile_shift;
     const uint8_t *prune_lane; // RS_UPD_PRUNE on deal batches: [lane pitch] 1 = this deal is traversed with prune = true (cfr.rs:219), nullptr = every lane
 };
 
@@ -109,12 +114,11 @@ hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
-hipError_t launch_probe_rows(void *reg, void *ssm, const uint64_t *d_off, int n_rows, size_t row_bytes, hipStream_t stream);   // rs_table_create's stride tuner
 hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned blocks, hipStream_t stream);   // rs_stream_probe
 hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec,
                               int n_actions, KernelCfg cfg, hipStream_t stream);
-hipError_t launch_strategy(const void *src /*[A][pitch]*/, float *dst, uint32_t pitch, int n_actions, int dtype,
-                           hipStream_t stream);
+hipError_t launch_strategy(const void *src /*[A][pitch], or tiled*/, float *dst /*[A][pitch]*/, uint32_t pitch, uint32_t row_stride, uint32_t tile_shift, int n_actions,
+                           int dtype, hipStream_t stream);
 hipError_t launch_chance_expand(const ChanceJob *d_jobs, int n_jobs, size_t max_child_lanes, bool vec4, hipStream_t stream);
 hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_parent_lanes, bool vec4, hipStream_t stream);
 hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream);
@@ -135,7 +139,7 @@ struct JitSubtree {
     std::vector<int> const_terms;  // terminal ids in the order of cval[]
     int max_actions = 0;
     size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_seed = 0, off_cval = 0, off_nidx = 0,
-           off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, args_size = 0;
+           off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, off_row_stride = 0, off_tile_shift = 0, args_size = 0;
     size_t off_dreg = 0, off_dssm = 0, off_cidx = 0, off_tpitch = 0, off_n_lanes = 0;   // deal batches only
     size_t off_loff = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
@@ -185,6 +189,7 @@ struct rs_table {
     hipStream_t stream = nullptr;
     std::vector<rs_node_desc> nodes;
     std::vector<size_t> pitch;        // per node, elements
+    std::vector<size_t> tile;         // per node: lanes per tile of its block [pitch / tile][A][tile]; == pitch: the plain [A][pitch] block
     std::vector<size_t> cell_off;     // per node, element offset of its [A][pitch] block
     size_t n_cells = 0;
     void *d_regrets = nullptr;        // n_cells elements
@@ -205,6 +210,18 @@ struct rs_table {
     rs::NodeJob *d_job = nullptr;     // one device job slot for the per-node ABI calls (stream-ordered reuse)
     rs::Profile prof;
 
+    bool tiled(int node) const { return tile[size_t(node)] != pitch[size_t(node)]; }
+    uint32_t tile_shift(int node) const {   // log2 of the VECTORS (4 lanes) per tile; 31 = one tile
+        if (!tiled(node)) return 31;
+        uint32_t sh = 0;
+        while ((size_t(rs::kVec) << sh) < tile[size_t(node)]) ++sh;
+        return sh;
+    }
+    // element offset inside the node's block of (action a, lane l)
+    size_t elem_index(int node, size_t a, size_t l) const {
+        const size_t T = tile[size_t(node)];
+        return ((l / T) * nodes[size_t(node)].n_actions + a) * T + l % T;
+    }
     void *regrets_ptr(int node) const { return (char *)d_regrets + cell_off[node] * rs::elem_size(dtype); }
     void *ssum_ptr(int node) const { return (char *)d_ssum + cell_off[node] * rs::elem_size(dtype); }
 };

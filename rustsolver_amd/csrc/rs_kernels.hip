@@ -52,6 +52,12 @@ __device__ __forceinline__ void finish_child(const ChildSrc &c, uint32_t v, floa
     }
 }
 
+// the thread's vector inside a (possibly tiled) node block of A rows: see NodeJob.row_stride
+template <int A>
+__device__ __forceinline__ uint32_t tiled_vec(uint32_t v, uint32_t tile_shift) {
+    return (((v >> tile_shift) * (uint32_t)A) << tile_shift) + (v & ((1u << tile_shift) - 1u));
+}
+
 // prune = true is a property of the DEAL in train() (cfr.rs:219: t > PRUNE_THRESHOLD && q > 0.05): deal batches carry one flag byte per lane
 __device__ __forceinline__ void lane_prune_flags(const NodeJob &job, bool prune, uint32_t v, bool (&out)[kVec]) {
     uint32_t w = 0x01010101u;
@@ -80,7 +86,7 @@ __device__ __forceinline__ void load_table_row(const NodeJob &job, const void *b
 template <int A, int DT, int ARITH>
 __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ jobs, int flags) {
     RS_JOB_DECL(NodeJob)
-    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    const uint32_t n_vec = job.n_vec, pitch = job.row_stride, tsh = job.tile_shift;
     const bool rmplus = (flags & RS_UPD_RMPLUS) != 0, prune = (flags & RS_UPD_PRUNE) != 0;
     using R = Row<DT>;
     using V = typename R::val;
@@ -90,9 +96,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
         unsigned idx[kVec] = {0, 0, 0, 0};
         if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, tiled_vec<A>(v, tsh), idx, r[a]);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.ssum, a * pitch, v, idx, s[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.ssum, a * pitch, tiled_vec<A>(v, tsh), idx, s[a]);
 #pragma unroll
         for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
@@ -134,9 +140,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const NodeJob *__restrict__ j
         }
         if (!scattered) {
 #pragma unroll
-            for (int a = 0; a < A; a++) R::store(job.regrets, a * pitch, v, r[a]);
+            for (int a = 0; a < A; a++) R::store(job.regrets, a * pitch, tiled_vec<A>(v, tsh), r[a]);
 #pragma unroll
-            for (int a = 0; a < A; a++) R::store(job.ssum, a * pitch, v, s[a]);
+            for (int a = 0; a < A; a++) R::store(job.ssum, a * pitch, tiled_vec<A>(v, tsh), s[a]);
         }
         if (job.out_util) store_f32_row(job.out_util, v, util);
     }
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
     const bool sampled = d_seed != nullptr;
     const unsigned long long seed = sampled ? *d_seed : 0ull;
     RS_JOB_DECL(NodeJob)
-    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    const uint32_t n_vec = job.n_vec, pitch = job.row_stride, tsh = job.tile_shift;
     using R = Row<DT>;
     using V = typename R::val;
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_node_util(const NodeJob *__restrict_
         unsigned idx[kVec] = {0, 0, 0, 0};
         if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, tiled_vec<A>(v, tsh), idx, r[a]);
 #pragma unroll
         for (int a = 0; a < A; a++) issue_child(job.child[a], v, u[a]);
 #pragma unroll
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
     const bool sampled = d_seed != nullptr;
     const unsigned long long seed = sampled ? *d_seed : 0ull;
     RS_JOB_DECL(NodeJob)
-    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    const uint32_t n_vec = job.n_vec, pitch = job.row_stride, tsh = job.tile_shift;
     using R = Row<DT>;
     using V = typename R::val;
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
         unsigned idx[kVec] = {0, 0, 0, 0};
         if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, v, idx, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<DT>(job, job.regrets, a * pitch, tiled_vec<A>(v, tsh), idx, r[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
         else {
 #pragma unroll
@@ -233,14 +239,14 @@ __global__ __launch_bounds__(kBlock) void k_reach(const NodeJob *__restrict__ jo
 template <int A>
 __global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restrict__ jobs) {
     RS_JOB_DECL(NodeJob)
-    const uint32_t n_vec = job.n_vec, pitch = job.pitch;
+    const uint32_t n_vec = job.n_vec, pitch = job.row_stride, tsh = job.tile_shift;
     for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += gridDim.x * kBlock) {
         int32_t r[A][kVec];
         float reach[kVec];
         unsigned idx[kVec] = {0, 0, 0, 0};
         if (job.cidx) load_u32_row(job.cidx, v, idx);
 #pragma unroll
-        for (int a = 0; a < A; a++) load_table_row<RS_I32>(job, job.regrets, a * pitch, v, idx, r[a]);
+        for (int a = 0; a < A; a++) load_table_row<RS_I32>(job, job.regrets, a * pitch, tiled_vec<A>(v, tsh), idx, r[a]);
         if (job.reach) load_f32_row(job.reach, v, reach);
         else {
 #pragma unroll
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_prune_reach(const NodeJob *__restric
 
 // bulk get_strategy / get_final_strategy over a node: src[A][pitch] -> dst[A][pitch] f32
 template <int A, int DT>
-__global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ src, float *__restrict__ dst, uint32_t pitch) {
+__global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ src, float *__restrict__ dst, uint32_t pitch, uint32_t row_stride, uint32_t tsh) {
     const uint32_t n_vec = pitch / kVec;
     using R = Row<DT>;
     using V = typename R::val;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_strategy(const void *__restrict__ sr
         V r[A][kVec];
         float out[A][kVec];
 #pragma unroll
-        for (int a = 0; a < A; a++) R::load(src, a * pitch, v, r[a]);
+        for (int a = 0; a < A; a++) R::load(src, a * row_stride, tiled_vec<A>(v, tsh), r[a]);
 #pragma unroll
         for (int j = 0; j < kVec; j++) {
             V rl[A];
@@ -668,58 +674,17 @@ hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned b
     return hipGetLastError();
 }
 
-// ---- which row stride suits THIS allocation?  (rs_table_create, big lane tables) ---------------------------------------------------------------
-// A tree kernel streams every row of every node at once -- ~95 rows [pitch] apart, read and written back 16 bytes per thread -- and how those streams fall on
-// the memory channels depends on the stride AND on where the allocation landed physically: the same binary measured 1.18 - 1.42 ms per iteration from
-// one process to the next, and for a given process the best of a handful of strides is 5 - 10 % faster than the worst.  This kernel walks the same
-// rows the same way (load a group of rows of both arrays, store them back), so that the candidates can be timed on the real buffers before the
-// table is zero-filled.
-__global__ __launch_bounds__(kBlock) void k_probe_rows(char *__restrict__ reg, char *__restrict__ ssm, const uint64_t *__restrict__ off, int n_rows, size_t n_vec,
-                                                       int traverser) {
-    // off[r] bit 0 = the row's node belongs to player 1.  Like a sweep of `traverser`: the regrets of every node are read, the traverser's own
-    // nodes are read in both arrays and written back
-    constexpr int G = 6;
-    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * kBlock) {
-        float sink = 0.0f;
-        for (int r0 = 0; r0 < n_rows; r0 += G) {
-            f32x4 x[G], y[G];
-#pragma unroll
-            for (int i = 0; i < G; i++)
-                if (r0 + i < n_rows) {
-                    const uint64_t o = off[r0 + i];
-                    x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reg + (o & ~1ull)) + v);
-                    if (int(o & 1) == traverser) y[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ssm + (o & ~1ull)) + v);
-                }
-#pragma unroll
-            for (int i = 0; i < G; i++)
-                if (r0 + i < n_rows) {
-                    const uint64_t o = off[r0 + i];
-                    if (int(o & 1) == traverser) {
-                        __builtin_nontemporal_store(x[i], reinterpret_cast<f32x4 *>(reg + (o & ~1ull)) + v);
-                        __builtin_nontemporal_store(y[i], reinterpret_cast<f32x4 *>(ssm + (o & ~1ull)) + v);
-                    } else sink += x[i].x;
-                }
-        }
-        if (sink == 12345.678f) reg[0] = 1;   // keeps the read-only loads alive
-    }
-}
-hipError_t launch_probe_rows(void *reg, void *ssm, const uint64_t *d_off, int n_rows, size_t row_bytes, hipStream_t stream) {
-    for (int traverser = 0; traverser < 2; ++traverser)
-        hipLaunchKernelGGL(k_probe_rows, dim3(4096), dim3(kBlock), 0, stream, (char *)reg, (char *)ssm, d_off, n_rows, row_bytes / 16, traverser);
-    return hipGetLastError();
-}
-
 hipError_t launch_next_seed(uint64_t *d_state, hipStream_t stream) {
     hipLaunchKernelGGL(k_next_seed, dim3(1), dim3(64), 0, stream, d_state);
     return hipGetLastError();
 }
 
-hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, int n_actions, int dtype, hipStream_t stream) {
+hipError_t launch_strategy(const void *src, float *dst, uint32_t pitch, uint32_t row_stride, uint32_t tile_shift, int n_actions, int dtype, hipStream_t stream) {
     dim3 grid(grid_for(pitch / kVec)), block(kBlock);
 #define RS_ST(A_)                                                                                     \
-    if (dtype == RS_I32) hipLaunchKernelGGL((k_strategy<A_, RS_I32>), grid, block, 0, stream, src, dst, pitch); \
-    else if (dtype == RS_F32) hipLaunchKernelGGL((k_strategy<A_, RS_F32>), grid, block, 0, stream, src, dst, pitch); \
-    else hipLaunchKernelGGL((k_strategy<A_, RS_F16>), grid, block, 0, stream, src, dst, pitch)
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_strategy<A_, RS_I32>), grid, block, 0, stream, src, dst, pitch, row_stride, tile_shift); \
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_strategy<A_, RS_F32>), grid, block, 0, stream, src, dst, pitch, row_stride, tile_shift); \
+    else hipLaunchKernelGGL((k_strategy<A_, RS_F16>), grid, block, 0, stream, src, dst, pitch, row_stride, tile_shift)
     RS_DISPATCH_A(n_actions, RS_ST)
 #undef RS_ST
     return hipGetLastError();

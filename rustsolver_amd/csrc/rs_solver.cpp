@@ -142,6 +142,9 @@ int derive_geometry(rs_solver *s) {
                 return fail(RS_ERR_INVALID, "rs_solver_create_deals: table row " + std::to_string(nd.index) + " does not match the tree");
             if (d.n_boards != 1)
                 return fail(RS_ERR_INVALID, "rs_solver_create_deals: the table must have n_boards = 1 (deals index clusters, not boards)");
+            if (t->tiled(nd.index))
+                return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: deal sweeps gather from plain [action][cluster] node blocks; this table's node " +
+                                                    std::to_string(nd.index) + " is tiled (RS_TABLE_TILE_LANES)");
             if (!s->deals.d_cluster[nd.round_idx][nd.player])
                 return fail(RS_ERR_INVALID, "rs_solver_create_deals: no cluster ids for round " + std::to_string(nd.round_idx) +
                                                 " player " + std::to_string(nd.player));
@@ -410,6 +413,8 @@ struct Builder {
         job.regrets = t->regrets_ptr(nd.index);
         job.ssum = t->ssum_ptr(nd.index);
         job.pitch = uint32_t(t->pitch[nd.index]);
+        job.row_stride = uint32_t(t->tile[size_t(nd.index)]);
+        job.tile_shift = t->tile_shift(nd.index);
         job.n_vec = job.pitch / kVec;
         job.n_actions = nd.n_children;
         job.scale = s->params.scale;
@@ -579,6 +584,11 @@ struct Builder {
         const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / size_t(js.lanes));
         put_u32(js.off_n_vec, n_vec);
         put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
+        {   // every node of a fused subtree lives on one round: same lanes, same tiling
+            const int n0 = nodes[size_t(js.node_ids.empty() ? id : js.node_ids[0])].index;
+            put_u32(js.off_row_stride, uint32_t(t->tile[size_t(n0)]));
+            put_u32(js.off_tile_shift, t->tile_shift(n0));
+        }
         if (s->deal_mode) {
             const int r = nodes[id].round_idx;
             const uint32_t *cx[2] = {s->deals.d_cluster[r][0], s->deals.d_cluster[r][1]};

@@ -92,48 +92,42 @@ static float f16_bits_to_f32(uint16_t b) {
     return (float)h;
 }
 
-// copy a strided block between host [rows][row_len] (host element) and device rows at
-// Row stride of big lane tables.  A tree kernel streams ~95 rows of one node group at once, [action][pitch] apart, and how well that goes depends on the
-// stride and on where the allocation landed physically (rs_kernels.hip, k_probe_rows).  Tables whose widest node has at least kTuneMinLanes lanes get
-// their stride TUNED at creation: a few candidates are timed on the real buffers.  RS_TABLE_PITCH_TUNE=0 switches that off (rows back to back),
-// RS_TABLE_PITCH_SKEW=n fixes n extra 64-lane groups per row.  Only the widest nodes are ever skewed, and never below kSkewMinLanes lanes.
-static constexpr size_t kSkewMinLanes = size_t(1) << 16, kTuneMinLanes = size_t(1) << 20;
+// Big lane tables keep the rows of a node INTERLEAVED in tiles: block = [pitch / T][A][T] instead of [A][pitch] (T = 16 384 lanes).  A sweep streams
+// every row of every node at once; with the rows tens of MB apart that is ~95 streams, each in its own DRAM pages and TLB entries, and the same bytes
+// move 22 - 35 % slower than when the rows of a node sit next to each other tile by tile (tools/stream_probe.cpp: 4.43 TB/s rows apart, 5.4 - 5.96 TB/s
+// grouped per node on the same card).  Nodes below kTileMinLanes lanes keep the plain block (T = pitch): everything a deal sweep gathers from.
+// RS_TABLE_TILE_LANES (a power of two >= 64; 0 = never tile) and RS_TABLE_TILE_MIN_LANES override, read at every table creation (tests tile small tables).
+static constexpr size_t kTileLanes = size_t(1) << 14, kTileMinLanes = size_t(1) << 20;
 
-// base + (r*row_stride + col0) elements.  dir: 0 = upload, 1 = download.
-static int copy_rows(rs_table *t, void *d_base, size_t row_stride, size_t col0, void *host, size_t rows, size_t row_len,
-                     int dir) {
-    const size_t es = elem_size(t->dtype);
+// copy between host [rows][row_len] (host element) and lanes [col0, col0 + row_len) of the first `rows` rows of `node`'s block at d_base.  dir: 0 = upload,
+// 1 = download.  One 2-D copy per tile the range touches (rows are T elements apart inside a tile).
+static int copy_rows(rs_table *t, void *d_base, int node, size_t col0, void *host, size_t rows, size_t row_len, int dir) {
+    const size_t es = elem_size(t->dtype), T = t->tile[size_t(node)], A = t->nodes[size_t(node)].n_actions;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
-    if (t->dtype != RS_F16) {
-        char *d = (char *)d_base + col0 * es;
-        if (dir == 0)
-            RS_HIP(hipMemcpy2DAsync(d, row_stride * es, host, row_len * es, row_len * es, rows, hipMemcpyHostToDevice,
-                                    t->stream),
-                   "hipMemcpy2DAsync(upload)");
-        else
-            RS_HIP(hipMemcpy2DAsync(host, row_len * es, d, row_stride * es, row_len * es, rows, hipMemcpyDeviceToHost,
-                                    t->stream),
-                   "hipMemcpy2DAsync(download)");
-        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
-        return RS_OK;
+    const bool f16 = t->dtype == RS_F16;
+    std::vector<uint16_t> tmp;   // F16: convert on the host through a temporary
+    char *h = (char *)host;
+    const size_t hes = f16 ? 2 : es;
+    if (f16) {
+        tmp.resize(rows * row_len);
+        h = (char *)tmp.data();
+        if (dir == 0) {
+            const float *src = (const float *)host;
+            for (size_t i = 0; i < rows * row_len; ++i) tmp[i] = f32_to_f16_bits(src[i]);
+        }
     }
-    // F16: convert on the host through a temporary
-    std::vector<uint16_t> tmp(rows * row_len);
-    char *d = (char *)d_base + col0 * 2;
-    if (dir == 0) {
-        const float *h = (const float *)host;
-        for (size_t i = 0; i < rows * row_len; ++i) tmp[i] = f32_to_f16_bits(h[i]);
-        RS_HIP(hipMemcpy2DAsync(d, row_stride * 2, tmp.data(), row_len * 2, row_len * 2, rows, hipMemcpyHostToDevice,
-                                t->stream),
-               "hipMemcpy2DAsync(upload f16)");
-        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
-    } else {
-        RS_HIP(hipMemcpy2DAsync(tmp.data(), row_len * 2, d, row_stride * 2, row_len * 2, rows, hipMemcpyDeviceToHost,
-                                t->stream),
-               "hipMemcpy2DAsync(download f16)");
-        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
-        float *h = (float *)host;
-        for (size_t i = 0; i < rows * row_len; ++i) h[i] = f16_bits_to_f32(tmp[i]);
+    for (size_t lo = col0; lo < col0 + row_len;) {
+        const size_t tile = lo / T, w = lo % T, len = std::min(T - w, col0 + row_len - lo);
+        char *d = (char *)d_base + ((tile * A) * T + w) * es;
+        char *hp = h + (lo - col0) * hes;
+        if (dir == 0) RS_HIP(hipMemcpy2DAsync(d, T * es, hp, row_len * hes, len * es, rows, hipMemcpyHostToDevice, t->stream), "hipMemcpy2DAsync(upload)");
+        else RS_HIP(hipMemcpy2DAsync(hp, row_len * hes, d, T * es, len * es, rows, hipMemcpyDeviceToHost, t->stream), "hipMemcpy2DAsync(download)");
+        lo += len;
+    }
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    if (f16 && dir == 1) {
+        float *dst = (float *)host;
+        for (size_t i = 0; i < rows * row_len; ++i) dst[i] = f16_bits_to_f32(tmp[i]);
     }
     return RS_OK;
 }
@@ -188,78 +182,29 @@ int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int devic
     t->nodes.assign(nodes, nodes + n_nodes);
     t->pitch.resize(n_nodes);
     t->cell_off.resize(n_nodes);
-    size_t max_lanes = 0;
-    for (int i = 0; i < n_nodes; ++i) max_lanes = std::max(max_lanes, size_t(nodes[i].n_boards) * nodes[i].n_clusters);
-    // layout for a given row skew: extra 64-lane groups per row of the WIDEST nodes only (the last round's: what a tree kernel streams; the narrower
-    // rounds above keep the plain pitch, which sharded sweeps rely on when ranks exchange their rows)
-    auto layout = [&](size_t skew_groups) {
-        size_t off = 0;
-        for (int i = 0; i < n_nodes; ++i) {
-            const size_t lanes = size_t(nodes[i].n_boards) * nodes[i].n_clusters;
-            t->pitch[i] = round_up(lanes, kLanePad) + ((lanes == max_lanes && lanes >= kSkewMinLanes) ? skew_groups * kLanePad : 0);
-            t->cell_off[i] = off;
-            off += t->pitch[i] * nodes[i].n_actions;
-        }
-        t->n_cells = off;
-    };
-    const char *fixed = getenv("RS_TABLE_PITCH_SKEW"), *tune_env = getenv("RS_TABLE_PITCH_TUNE");
-    // candidates of the stride tuner: 0 = rows back to back; the others are odd-ish numbers of 256-byte groups, at most 0.5 MB per row
-    static const size_t kCand[] = {0, 32, 257, 825, 1000, 1849};
-    const bool tune = !fixed && max_lanes >= kTuneMinLanes && !(tune_env && atoi(tune_env) == 0);
-    layout(tune ? kCand[sizeof(kCand) / sizeof(kCand[0]) - 1] : (fixed ? size_t(atol(fixed) > 0 ? atol(fixed) : 0) : 0));
-    const size_t bytes = t->n_cells * elem_size(dtype);   // tuner: the largest candidate
+    size_t tile_lanes = kTileLanes, tile_min = kTileMinLanes;
+    if (const char *e = getenv("RS_TABLE_TILE_LANES")) {
+        const long v = atol(e);
+        tile_lanes = (v >= long(kLanePad) && (v & (v - 1)) == 0) ? size_t(v) : 0;   // anything else: never tile
+    }
+    if (const char *e = getenv("RS_TABLE_TILE_MIN_LANES")) tile_min = size_t(std::max(0L, atol(e)));
+    t->tile.resize(size_t(n_nodes));
+    size_t off = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        const size_t lanes = size_t(nodes[i].n_boards) * nodes[i].n_clusters;
+        const bool tiled = tile_lanes != 0 && lanes >= tile_min && lanes > tile_lanes;
+        t->pitch[i] = round_up(lanes, tiled ? tile_lanes : size_t(kLanePad));
+        t->tile[i] = tiled ? tile_lanes : t->pitch[i];
+        t->cell_off[i] = off;
+        off += t->pitch[i] * nodes[i].n_actions;
+    }
+    t->n_cells = off;
+    const size_t bytes = off * elem_size(dtype);
     hipError_t er;
     if ((er = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (er = hipMalloc(&t->d_regrets, bytes)) != hipSuccess || (er = hipMalloc(&t->d_ssum, bytes)) != hipSuccess) {
-        int rc = hip_fail(er, "rs_table_create: device allocation");
-        rs_table_destroy(t);
-        return rc;
-    }
-    if (tune) {   // time the candidates on these very buffers (their content does not matter yet) and keep the fastest stride
-        size_t best = 0;
-        float best_ms = 0.0f;
-        uint64_t *d_off = nullptr;
-        hipEvent_t a = nullptr, b = nullptr;
-        er = hipMalloc(&d_off, sizeof(uint64_t) * size_t(n_nodes) * RS_MAX_ACTIONS);
-        if (er == hipSuccess) er = hipEventCreate(&a);
-        if (er == hipSuccess) er = hipEventCreate(&b);
-        for (size_t c = 0; er == hipSuccess && c < sizeof(kCand) / sizeof(kCand[0]); ++c) {
-            layout(kCand[c]);
-            std::vector<uint64_t> offs;   // the rows of the widest nodes: what one tree kernel streams together
-            size_t row_bytes = 0;
-            for (int i = 0; i < n_nodes; ++i)
-                if (size_t(nodes[i].n_boards) * nodes[i].n_clusters == max_lanes) {
-                    row_bytes = round_up(max_lanes, kLanePad) * elem_size(dtype);
-                    for (uint32_t k = 0; k < nodes[i].n_actions; ++k) offs.push_back((uint64_t(t->cell_off[i] + k * t->pitch[i]) * elem_size(dtype)) | uint64_t(nodes[i].player & 1));   // byte offsets are multiples of 128
-                }
-            if (offs.empty()) break;
-            er = hipMemcpy(d_off, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-            for (int rep = 0; er == hipSuccess && rep < 3; ++rep) {   // rep 0 warms up
-                if (rep == 1) er = hipEventRecord(a, t->stream);
-                if (er == hipSuccess) er = launch_probe_rows(t->d_regrets, t->d_ssum, d_off, int(offs.size()), row_bytes, t->stream);
-            }
-            if (er == hipSuccess) er = hipEventRecord(b, t->stream);
-            if (er == hipSuccess) er = hipEventSynchronize(b);
-            float ms = 0.0f;
-            if (er == hipSuccess) er = hipEventElapsedTime(&ms, a, b);
-            if (er == hipSuccess && (c == 0 || ms < best_ms)) {
-                best_ms = ms;
-                best = c;
-            }
-        }
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
-        if (d_off) (void)hipFree(d_off);
-        if (er != hipSuccess) {
-            int rc = hip_fail(er, "rs_table_create: stride tuner");
-            rs_table_destroy(t);
-            return rc;
-        }
-        layout(kCand[best]);
-    }
-    const size_t used = t->n_cells * elem_size(dtype);
-    if ((er = hipMemsetAsync(t->d_regrets, 0, used, t->stream)) != hipSuccess ||   // Infoset::init zero fill
-        (er = hipMemsetAsync(t->d_ssum, 0, used, t->stream)) != hipSuccess ||
+        (er = hipMalloc(&t->d_regrets, bytes)) != hipSuccess || (er = hipMalloc(&t->d_ssum, bytes)) != hipSuccess ||
+        (er = hipMemsetAsync(t->d_regrets, 0, bytes, t->stream)) != hipSuccess ||   // Infoset::init zero fill
+        (er = hipMemsetAsync(t->d_ssum, 0, bytes, t->stream)) != hipSuccess ||
         (er = hipStreamSynchronize(t->stream)) != hipSuccess) {
         int rc = hip_fail(er, "rs_table_create: device allocation");
         rs_table_destroy(t);
@@ -341,9 +286,9 @@ static int board_copy(rs_table *t, int node, int board, void *regrets, void *ssu
     if (board < 0 || uint32_t(board) >= nd.n_boards) return fail(RS_ERR_OOB, std::string(fn) + ": board out of bounds");
     const size_t col0 = size_t(board) * nd.n_clusters;
     if (regrets)
-        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], col0, regrets, nd.n_actions, nd.n_clusters, dir)) return rc;
+        if (int rc = copy_rows(t, t->regrets_ptr(node), node, col0, regrets, nd.n_actions, nd.n_clusters, dir)) return rc;
     if (ssum)
-        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], col0, ssum, nd.n_actions, nd.n_clusters, dir)) return rc;
+        if (int rc = copy_rows(t, t->ssum_ptr(node), node, col0, ssum, nd.n_actions, nd.n_clusters, dir)) return rc;
     return RS_OK;
 }
 int rs_table_upload(rs_table *t, int node, int board, const void *regrets, const void *ssum) {
@@ -358,9 +303,9 @@ static int node_copy(rs_table *t, int node, void *regrets, void *ssum, int dir, 
     if (nd.n_actions == 0) return RS_OK;   // nothing to copy
     const size_t lanes = size_t(nd.n_boards) * nd.n_clusters;
     if (regrets)
-        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], 0, regrets, nd.n_actions, lanes, dir)) return rc;
+        if (int rc = copy_rows(t, t->regrets_ptr(node), node, 0, regrets, nd.n_actions, lanes, dir)) return rc;
     if (ssum)
-        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], 0, ssum, nd.n_actions, lanes, dir)) return rc;
+        if (int rc = copy_rows(t, t->ssum_ptr(node), node, 0, ssum, nd.n_actions, lanes, dir)) return rc;
     return RS_OK;
 }
 int rs_table_upload_node(rs_table *t, int node, const void *regrets, const void *ssum) {
@@ -380,9 +325,9 @@ static int infoset_copy(rs_table *t, int node, int board, int cluster, void *reg
                                     " but the index is " + std::to_string(cluster));
     const size_t col0 = size_t(board) * nd.n_clusters + size_t(cluster);
     if (regrets)
-        if (int rc = copy_rows(t, t->regrets_ptr(node), t->pitch[node], col0, regrets, nd.n_actions, 1, dir)) return rc;
+        if (int rc = copy_rows(t, t->regrets_ptr(node), node, col0, regrets, nd.n_actions, 1, dir)) return rc;
     if (ssum)
-        if (int rc = copy_rows(t, t->ssum_ptr(node), t->pitch[node], col0, ssum, nd.n_actions, 1, dir)) return rc;
+        if (int rc = copy_rows(t, t->ssum_ptr(node), node, col0, ssum, nd.n_actions, 1, dir)) return rc;
     return RS_OK;
 }
 int rs_get_infoset(rs_table *t, int node, int board, int cluster, void *regrets, void *ssum) {
@@ -409,10 +354,11 @@ static int single_strategy(rs_table *t, int node, int board, int cluster, float 
     if (!t->d_query) RS_HIP(hipMalloc(&t->d_query, RS_MAX_ACTIONS * kLanePad * (4 + sizeof(float))), "hipMalloc(query scratch)");
     void *d_in = t->d_query;
     float *d_out = reinterpret_cast<float *>((char *)t->d_query + RS_MAX_ACTIONS * kLanePad * 4);
-    const char *src = (const char *)(final_ ? t->ssum_ptr(node) : t->regrets_ptr(node)) + g0 * es;
-    hipError_t e = hipMemcpy2DAsync(d_in, kLanePad * es, src, t->pitch[node] * es, kLanePad * es, nd.n_actions,
+    // the 64-lane group never straddles a tile (tiles are multiples of 64 lanes): rows are tile[node] elements apart from its first element on
+    const char *src = (const char *)(final_ ? t->ssum_ptr(node) : t->regrets_ptr(node)) + t->elem_index(node, 0, g0) * es;
+    hipError_t e = hipMemcpy2DAsync(d_in, kLanePad * es, src, t->tile[size_t(node)] * es, kLanePad * es, nd.n_actions,
                                     hipMemcpyDeviceToDevice, t->stream);
-    if (e == hipSuccess) e = launch_strategy(d_in, d_out, kLanePad, int(nd.n_actions), t->dtype, t->stream);
+    if (e == hipSuccess) e = launch_strategy(d_in, d_out, kLanePad, kLanePad, 31, int(nd.n_actions), t->dtype, t->stream);
     std::vector<float> host(nd.n_actions * kLanePad);
     if (e == hipSuccess)
         e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, t->stream);
@@ -420,6 +366,10 @@ static int single_strategy(rs_table *t, int node, int board, int cluster, float 
     if (e != hipSuccess) return hip_fail(e, fn);
     for (uint32_t a = 0; a < nd.n_actions; ++a) out[a] = host[a * kLanePad + (lane - g0)];
     return RS_OK;
+}
+size_t rs_table_tile_lanes(const rs_table *t, int node) {
+    if (!t || node < 0 || size_t(node) >= t->nodes.size()) return 0;
+    return t->tile[size_t(node)];
 }
 int rs_get_strategy(rs_table *t, int node, int board, int cluster, float *out) {
     return single_strategy(t, node, board, cluster, out, false, "rs_get_strategy");
@@ -506,6 +456,8 @@ static void base_job(const rs_table *t, int node, NodeJob &job) {
     job.regrets = t->regrets_ptr(node);
     job.ssum = t->ssum_ptr(node);
     job.pitch = uint32_t(t->pitch[node]);
+    job.row_stride = uint32_t(t->tile[size_t(node)]);
+    job.tile_shift = t->tile_shift(node);
     job.n_vec = uint32_t(t->pitch[node] / kVec);
     job.n_actions = int32_t(t->nodes[node].n_actions);
     job.reach_const = 1.0f;
@@ -519,7 +471,7 @@ int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_STRATEGY, double(nd.n_boards) * nd.n_clusters * nd.n_actions * (elem_size(t->dtype) + 4.0));
-    hipError_t e = launch_strategy(t->regrets_ptr(node), d_strategy, uint32_t(t->pitch[node]), int(nd.n_actions), t->dtype, t->stream);
+    hipError_t e = launch_strategy(t->regrets_ptr(node), d_strategy, uint32_t(t->pitch[node]), uint32_t(t->tile[size_t(node)]), t->tile_shift(node), int(nd.n_actions), t->dtype, t->stream);
     prof_end(t);
     RS_HIP(e, "k_strategy");
     return RS_OK;
@@ -531,7 +483,7 @@ int rs_final_strategy_node(rs_table *t, int node, float *d_strategy) {
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     const rs_node_desc &nd = t->nodes[node];
     prof_begin(t, RS_K_STRATEGY, double(nd.n_boards) * nd.n_clusters * nd.n_actions * (elem_size(t->dtype) + 4.0));
-    hipError_t e = launch_strategy(t->ssum_ptr(node), d_strategy, uint32_t(t->pitch[node]), int(nd.n_actions), t->dtype, t->stream);
+    hipError_t e = launch_strategy(t->ssum_ptr(node), d_strategy, uint32_t(t->pitch[node]), uint32_t(t->tile[size_t(node)]), t->tile_shift(node), int(nd.n_actions), t->dtype, t->stream);
     prof_end(t);
     RS_HIP(e, "k_strategy");
     return RS_OK;

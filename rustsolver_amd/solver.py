@@ -272,6 +272,10 @@ class InfosetTable:
     def pitch(self, node):
         return L.load().rs_table_lane_pitch(self._h, node)
 
+    def tile_lanes(self, node):
+        """lanes per tile of the node's block ([pitch / T][A][T]); == pitch(node): the plain [A][pitch] block"""
+        return int(L.load().rs_table_tile_lanes(self._h, node))
+
     @property
     def cells(self):
         return L.load().rs_table_cells(self._h)

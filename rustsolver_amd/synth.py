@@ -32,7 +32,10 @@ def table_node_values(table, node, seed, lo, hi, ssum=False):
     d = table.node_desc(node)
     pitch, off, lanes = table.pitch(node), table.cell_offset(node), table.lanes(node)
     s = (seed ^ 0x5353554D) if ssum else seed
-    idx = off + np.arange(d.n_actions, dtype=np.uint64)[:, None] * np.uint64(pitch) + np.arange(lanes, dtype=np.uint64)[None, :]
+    T = table.tile_lanes(node)   # block layout [pitch / T][A][T] (T == pitch: plain rows)
+    lane = np.arange(lanes, dtype=np.uint64)[None, :]
+    a = np.arange(d.n_actions, dtype=np.uint64)[:, None]
+    idx = off + ((lane // np.uint64(T)) * np.uint64(d.n_actions) + a) * np.uint64(T) + lane % np.uint64(T)
     return fill_values(s, idx, lo, hi)
 
 

@@ -28,7 +28,24 @@ DEALS_PER_THREAD_TESTS = {
 }
 
 
+# Lane tables of at least 2^20 lanes keep the rows of a node interleaved in 16 384-lane tiles (rs_table.cpp); the lane-model tests below run once
+# with the library's own choice (plain rows at their sizes) and once with 64-lane tiles forced on every node wider than that.
+TABLE_LAYOUT_TESTS = {
+    "test_known_answers_update_and_strategy", "test_known_answers_discount", "test_golden_random_update_cases", "test_golden_random_discount_cases",
+    "test_golden_extension_cases", "test_update_node_vs_oracle", "test_rmplus_i32_vs_oracle", "test_null_reach_means_one_and_per_board_copies",
+    "test_zero_init_and_fill_mirror", "test_iterate_river_tree_vs_oracle", "test_iterate_three_street_tree_vs_oracle",
+    "test_iterate_extension_dtypes_vs_oracle", "test_iterate_sampled_opponent_vs_oracle", "test_wide_nodes_through_both_plans",
+    "test_action_node_without_valid_actions", "test_train_with_discount_schedule_vs_oracle", "test_leaf_util_buffers_per_traverser",
+    "test_checkpoint_roundtrip", "test_sharded_enum_sweep_equals_single_gpu", "test_allreduce_replicated_single_rank_is_identity",
+    "test_calc_br_equals_oracle",
+}
+
+
 def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in TABLE_LAYOUT_TESTS:
+        if "table_layout" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("table_layout")
+        metafunc.parametrize("table_layout", ["plain", "tiled64"], indirect=True)
     if metafunc.function.__name__ in DEALS_PER_THREAD_TESTS:
         if "deals_per_thread" not in metafunc.fixturenames:
             metafunc.fixturenames.append("deals_per_thread")
@@ -39,4 +56,12 @@ def pytest_generate_tests(metafunc):
 def deals_per_thread(request, monkeypatch):
     if request.param != "auto":
         monkeypatch.setenv("RS_JIT_LANES", request.param)
+    return request.param
+
+
+@pytest.fixture
+def table_layout(request, monkeypatch):
+    if request.param == "tiled64":
+        monkeypatch.setenv("RS_TABLE_TILE_LANES", "64")
+        monkeypatch.setenv("RS_TABLE_TILE_MIN_LANES", "65")
     return request.param

@@ -41,11 +41,15 @@ trainers = []
 for v in a.variants:
     env = dict(kv.split("=") for kv in v.split()) if v.strip() else {}
     for k in list(os.environ):
-        if k.startswith("RS_JIT_") and k != "RS_JIT_CACHE":
+        if (k.startswith("RS_JIT_") and k != "RS_JIT_CACHE") or k.startswith("RS_TABLE_"):
             del os.environ[k]
     fuse = int(env.pop("FUSE", "1"))
     os.environ.update(env)
-    trainers.append(rs.MCCFRTrainer(tree, table, leaves, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse))
+    tb, lv = table, leaves
+    if any(k.startswith("RS_TABLE_") for k in env):   # a layout knob (read when a table is created): this variant gets a table of its own
+        tb, sg, lv = make_table()
+        own.append((tb, sg))
+    trainers.append(rs.MCCFRTrainer(tree, tb, lv, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=fuse))
 lib = L.load()
 
 
@@ -53,7 +57,7 @@ def run(tr, k):
     for _ in range(k):
         L.check(lib.rs_iterate(tr._h, 0, None))
         L.check(lib.rs_iterate(tr._h, 1, None))
-    table.sync()
+    tr.infosets.sync()
 
 
 for tr in trainers:

@@ -57,6 +57,60 @@ double run_copy(const f4 *in, f4 *out, size_t bytes, int grid, int reps) {
     return 2.0 * double(n) * 16 * reps / (ms * 1e-3) / 1e12;
 }
 
+// The same R + W streams, but interleaved at TILE bytes: tile t of stream s sits at (t * (R or W) + s) * TILE, so that the rows a workgroup walks together are
+// one contiguous region (a few pages) instead of R + W regions tens of MB apart.  A wave still reads 1 KB contiguous per stream.
+template <int R, int W, int TILE_VEC>
+__global__ __launch_bounds__(256) void ktiled(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n_vec) {
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * 256) {
+        const size_t tile = v / TILE_VEC, within = v % TILE_VEC;
+        f4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc += __builtin_nontemporal_load(in + (tile * R + r) * TILE_VEC + within);
+#pragma unroll
+        for (int w = 0; w < W; ++w) __builtin_nontemporal_store(acc + (float)w, out + (tile * W + w) * TILE_VEC + within);
+    }
+}
+template <int R, int W, int TILE_VEC>
+double run_tiled(const f4 *in, f4 *out, size_t bytes_read, int reps) {
+    const size_t n_vec = bytes_read / 16 / R / TILE_VEC * TILE_VEC;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((ktiled<R, W, TILE_VEC>), dim3(4096), dim3(256), 0, 0, in, out, n_vec);
+    (void)hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ktiled<R, W, TILE_VEC>), dim3(4096), dim3(256), 0, 0, in, out, n_vec);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    return double(n_vec) * 16 * (R + W) * reps / (ms * 1e-3) / 1e12;
+}
+
+// Per-NODE tiling: the streams come in NG groups (a node's rows of one array), each group a contiguous block [tile][rows of the group][TILE]; groups
+// stay tens of MB apart.  What the table would look like if only the inside of a node block were re-laid out.
+template <int NG, int RG, int WG, int TILE_VEC>
+__global__ __launch_bounds__(256) void kgrouped(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n_vec) {
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * 256) {
+        const size_t tile = v / TILE_VEC, within = v % TILE_VEC;
+        f4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < RG; ++r) acc += __builtin_nontemporal_load(in + (size_t)g * RG * n_vec + (tile * RG + r) * TILE_VEC + within);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int w = 0; w < WG; ++w) __builtin_nontemporal_store(acc + (float)w, out + (size_t)g * WG * n_vec + (tile * WG + w) * TILE_VEC + within);
+    }
+}
+template <int NG, int RG, int WG, int TILE_VEC>
+double run_grouped(const f4 *in, f4 *out, size_t bytes_read, int reps) {
+    const size_t n_vec = bytes_read / 16 / (NG * RG) / TILE_VEC * TILE_VEC;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((kgrouped<NG, RG, WG, TILE_VEC>), dim3(4096), dim3(256), 0, 0, in, out, n_vec);
+    (void)hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((kgrouped<NG, RG, WG, TILE_VEC>), dim3(4096), dim3(256), 0, 0, in, out, n_vec);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    return double(n_vec) * 16 * NG * (RG + WG) * reps / (ms * 1e-3) / 1e12;
+}
+
 int main() {
     const size_t rd = size_t(2200) << 20;   // ~2.2 GB read per launch like the tree kernel (2.14 GB), writes scaled 2:3.. by W/R
     f4 *in, *out; hipMalloc(&in, rd + (64 << 20)); hipMalloc(&out, rd + (64 << 20));
@@ -73,5 +127,9 @@ int main() {
     for (int grid : {1024, 4096, 16384})
         printf("tuned copy grid %5d: U=1 %.2f  U=4 %.2f  U=8 %.2f TB/s\n", grid, run_copy<1>(in, out, rd, grid, 10), run_copy<4>(in, out, rd, grid, 10),
                run_copy<8>(in, out, rd, grid, 10));
+    printf("tree-like R57 W38, rows interleaved in tiles of 4 KB: %.2f TB/s, 16 KB: %.2f TB/s, 64 KB: %.2f TB/s; rows apart (as the table is laid out): %.2f TB/s\n",
+           run_tiled<57, 38, 256>(in, out, rd, 10), run_tiled<57, 38, 1024>(in, out, rd, 10), run_tiled<57, 38, 4096>(in, out, rd, 10), run<57, 38, 1>(in, out, rd, 10));
+    printf("19 groups of 3 read + 2 written rows, tiled inside the group: 4 KB %.2f TB/s, 16 KB %.2f TB/s, 64 KB %.2f TB/s\n", run_grouped<19, 3, 2, 256>(in, out, rd, 10),
+           run_grouped<19, 3, 2, 1024>(in, out, rd, 10), run_grouped<19, 3, 2, 4096>(in, out, rd, 10));
     return 0;
 }
