@@ -137,7 +137,7 @@ size_t rs_table_lane_pitch(const rs_table *table, int node);  /* elements; 0 on 
  * a sweep streams all rows of a node together, and rows that sit next to each other move 22-35 % faster than rows tens of MB apart. */
 size_t rs_table_tile_lanes(const rs_table *table, int node);
 size_t rs_table_cells(const rs_table *table);                 /* sum over nodes of n_actions * pitch */
-size_t rs_table_cell_offset(const rs_table *table, int node); /* element offset of a node's [A][pitch] block */
+size_t rs_table_cell_offset(const rs_table *table, int node); /* element offset of a node's block (A * pitch elements) */
 size_t rs_table_bytes(const rs_table *table);                 /* device bytes of both arrays */
 
 /* Host <-> device copies.  Element type on the host: int32_t for RS_I32, float for RS_F32 and
@@ -184,7 +184,8 @@ enum {
 int rs_regret_match_node(rs_table *table, int node, float *d_strategy);
 /* bulk get_final_strategy (infoset.rs:104-123): d_strategy[A][pitch] */
 int rs_final_strategy_node(rs_table *table, int node, float *d_strategy);
-/* every node: d_out[rs_table_cells()] with node blocks at rs_table_cell_offset() (calc_br's reader, cfr.rs:669-672) */
+/* every node: d_out[rs_table_cells()] with node blocks at rs_table_cell_offset(), each a plain [A][pitch] block whatever the table's own tiling
+ * (calc_br's reader, cfr.rs:669-672) */
 int rs_final_strategy_all(rs_table *table, float *d_out);
 /* MCCFRTrainer::calc_br exactly AS CODED (cfr.rs:629-745): out[0], out[1] = the two numbers train() prints at every discount tick
  * (cfr.rs:244-246).  Its op vectors have length 1 (cfr.rs:631), so only get_final_strategy() of bucket 0 of every action node

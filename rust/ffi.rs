@@ -102,6 +102,7 @@ extern "C" {
     pub fn rs_deal_trainer_train(trainer: *mut rs_deal_trainer, n_batches: u64) -> c_int;
     pub fn rs_deal_trainer_status(trainer: *mut rs_deal_trainer) -> c_int;
     // calc_br as coded (cfr.rs:629-745; printed at every discount tick, cfr.rs:244-246) and the best response it stands in for
+    pub fn rs_table_tile_lanes(table: *const rs_table, node: c_int) -> usize;   // block layout [pitch / T][A][T]; T == pitch: plain rows
     pub fn rs_stream_probe(table: *mut rs_table, bytes: usize, reps: c_int, gbps: *mut f64) -> c_int;
     pub fn rs_calc_br(table: *mut rs_table, tree: *const rs_tree, out: *mut f32) -> c_int;
     pub fn rs_best_response(table: *mut rs_table, tree: *const rs_tree, board: *const u8, hands_p0: *const u8, n_hands_p0: usize,
