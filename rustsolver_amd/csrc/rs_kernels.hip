@@ -360,8 +360,11 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
     using V = typename R::val;
     constexpr size_t esize = (DT == RS_F16) ? 2 : 4;
     constexpr int U = 4;   // vectors per array per thread and trip: 8 x 16-byte loads in flight before the first use
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t v0 = (size_t)blockIdx.x * kBlock + threadIdx.x; v0 < n_vec; v0 += stride * U) {
+    // a workgroup's trip covers ONE contiguous 16 KB of each array (its U vectors are kBlock apart, not a whole grid apart): the same locality
+    // argument as the tiled node blocks
+    const size_t chunk = (size_t)kBlock * U;
+    for (size_t v0 = (size_t)blockIdx.x * chunk + threadIdx.x; v0 < n_vec; v0 += (size_t)gridDim.x * chunk) {
+        constexpr size_t stride = kBlock;
         V r[U][kVec], s[U][kVec];
 #pragma unroll
         for (int u = 0; u < U; u++) {
