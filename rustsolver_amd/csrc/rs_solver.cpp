@@ -1525,6 +1525,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
             for (int form = 0; form < 12; ++form) {   // down dense / sparse, walk lds dense / sparse, walk direct dense / sparse; four deals per thread, then one
                 const int lanes = form < 6 ? 4 : 1, f6 = form % 6;
                 const bool down = f6 < 2, sparse = (f6 & 1) != 0, lds = f6 >= 2 && f6 < 4;
+                if (lanes == 4 && nodes[i].round_idx != nodes[size_t(first)].round_idx) continue;   // later rounds always run one deal per thread
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
