@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 1
+#define RS_ABI_VERSION 2   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes) */
 #define RS_MAX_ACTIONS 8
 #define RS_MAX_ROUNDS 3
 #define RS_MAX_SIZES 4
