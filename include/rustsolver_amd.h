@@ -4,7 +4,10 @@
  * This is the drop-in boundary for RustSolver's hot path.  The reference has no FFI of its own
  * (it is a single Rust crate); every entry point below replaces a crate-internal Rust item and
  * cites it (paths relative to the reference repository root).  The Rust-side binding a
- * maintainer would add is shown in INTEGRATION.md and rust/ffi.rs.
+ * maintainer would add is shown in INTEGRATION.md and rust/ffi.rs (generated from this header by
+ * tools/gen_rust_ffi.py).  Bench / test diagnostics (synthetic fills, HIP-event profiling, the
+ * stream probe, compile-only checks of the generated kernels, table checksums) are NOT part of
+ * the drop-in surface: they live in rustsolver_amd_diag.h.
  *
  * Conventions
  *   - plain C: opaque handles, pointers and sizes only; no C++/torch types;
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 2   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes) */
+#define RS_ABI_VERSION 3   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h */
 #define RS_MAX_ACTIONS 8
 #define RS_MAX_ROUNDS 3
 #define RS_MAX_SIZES 4
@@ -155,12 +158,9 @@ int rs_set_infoset(rs_table *table, int node, int board, int cluster, const void
 int rs_get_strategy(rs_table *table, int node, int board, int cluster, float *out);       /* Infoset::get_strategy, infoset.rs:83-102 */
 int rs_get_final_strategy(rs_table *table, int node, int board, int cluster, float *out); /* Infoset::get_final_strategy, infoset.rs:104-123 */
 
-/* Synthetic fill on the device (bench / tests): cell value = lo + hash(seed, array, node, action,
- * lane) mod (hi - lo + 1), a pure function mirrored in rustsolver_amd/synth.py. */
-int rs_table_fill_random(rs_table *table, uint64_t seed, int64_t regret_lo, int64_t regret_hi, int64_t ssum_lo,
-                         int64_t ssum_hi);
-/* dst[i] = lo + (hi - lo) * u(seed, i), u in [0,1) from the same hash; i < n */
-int rs_fill_uniform_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi);
+/* get-infoset for a batch: the info sets of lanes[0..n) (lane = board * n_clusters + cluster, HOST array) of one node in one call -- what n calls of
+ * rs_get_infoset would return, host layout [A][n] per array (host type as above).  Either out pointer may be NULL. */
+int rs_get_infosets(rs_table *table, int node, const uint32_t *lanes, size_t n, void *regrets, void *strategy_sum);
 
 /* ---- device memory helpers (for hosts without their own HIP binding) ------------------------ */
 int rs_dmalloc(rs_table *table, size_t bytes, void **d_out);
@@ -312,11 +312,6 @@ int rs_comm_allreduce_deltas(rs_comm *comm, rs_table *table);   /* in-place nccl
 int rs_table_deltas(rs_table *table, int32_t **d_dregrets, int32_t **d_dstrategy_sum);
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
-/* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
-int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);
-/* the same for deal batches (rs_solver_create_deals): the kernels of every round subtree -- reach-down half and table-updating walk, dense and
- * over a live-deal list, with and without LDS tiles */
-int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels);
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
 
 /* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------
@@ -474,21 +469,6 @@ int rs_showdown_sign(rs_table *table, const uint8_t *d_cards, uint32_t n_deals, 
  * then a 64-bit FNV-1a checksum.  rs_table_load creates the table on `device`. */
 int rs_table_save(rs_table *table, const char *path);
 int rs_table_load(const char *path, int device, rs_table **out);
-
-/* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
-enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,
-       RS_K_TREE = 6, RS_K_COUNT = 7 };
-typedef struct rs_profile {
-    uint64_t launches[RS_K_COUNT];
-    double ms[RS_K_COUNT];              /* sum of HIP-event durations on the table's stream */
-    double algo_bytes[RS_K_COUNT];      /* sum of algorithmic bytes of those launches */
-} rs_profile;
-/* the rate (GB/s, read + write) a plain float4 copy of `bytes` reaches on this card, best of three grid sizes: the practical streaming ceiling
- * beside the 8 TB/s specification.  Allocates 2 x bytes for the duration of the call; synchronises. */
-int rs_stream_probe(rs_table *table, size_t bytes, int reps, double *gbps);
-int rs_profile_enable(rs_table *table, int on); /* on: bracket every launch with hipEvents (adds host work) */
-int rs_profile_read(rs_table *table, rs_profile *out); /* synchronises, then accumulates pending events */
-int rs_profile_reset(rs_table *table);
 
 /* ---- multi-GPU: boards shard across GPUs, one process per GPU -------------------------
  * Replicated tables (rounds whose boards are not sharded) accumulate rank-local deltas; one RCCL

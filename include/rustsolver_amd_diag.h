@@ -1,0 +1,54 @@
+/*
+ * rustsolver_amd_diag.h -- diagnostics of librustsolver_amd.so: what bench.py, the tests and the profiling tools call, NOT part of the
+ * drop-in surface that replaces the reference's items (that is rustsolver_amd.h).  Same conventions (status codes, d_* = device pointers,
+ * everything on the table's stream).
+ */
+#ifndef RUSTSOLVER_AMD_DIAG_H
+#define RUSTSOLVER_AMD_DIAG_H
+
+#include "rustsolver_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic inputs ---------------------------------------------------------------------------------------------------------- */
+/* Synthetic fill on the device (bench / tests): cell value = lo + hash(seed, array, node, action,
+ * lane) mod (hi - lo + 1), a pure function mirrored in rustsolver_amd/synth.py. */
+int rs_table_fill_random(rs_table *table, uint64_t seed, int64_t regret_lo, int64_t regret_hi, int64_t ssum_lo,
+                         int64_t ssum_hi);
+/* dst[i] = lo + (hi - lo) * u(seed, i), u in [0,1) from the same hash; i < n */
+int rs_fill_uniform_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi);
+
+/* ---- checks of the generated (hipRTC) kernels without a GPU ---------------------------------------------------------------------- */
+/* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
+int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);
+/* the same for deal batches (rs_solver_create_deals): the kernels of every round subtree -- reach-down half and table-updating walk, dense and
+ * over a live-deal list, with and without LDS tiles */
+int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels);
+
+/* ---- table checksum ----------------------------------------------------------------------------------------------------------------
+ * out[0] / out[1] = sum over the cells i of regrets / strategy_sum (pitch padding included: it stays zero) of splitmix64(i ^ bits(cell_i) * 0x9E3779B97F4A7C15)
+ * mod 2^64: order-independent, so two tables of the same shape and layout hold the same bits iff (with overwhelming probability) the sums agree.
+ * Synchronises.  Used to compare whole 135 GB tables (fused against level plan) without moving them to the host. */
+int rs_table_checksum(rs_table *table, uint64_t *out /*[2]*/);
+
+/* ---- profiling (bench.py roofline leg) ------------------------------------------------------------ */
+enum { RS_K_UPDATE = 0, RS_K_NODE_UTIL = 1, RS_K_REACH = 2, RS_K_CHANCE = 3, RS_K_DISCOUNT = 4, RS_K_STRATEGY = 5,
+       RS_K_TREE = 6, RS_K_COUNT = 7 };
+typedef struct rs_profile {
+    uint64_t launches[RS_K_COUNT];
+    double ms[RS_K_COUNT];              /* sum of HIP-event durations on the table's stream */
+    double algo_bytes[RS_K_COUNT];      /* sum of algorithmic bytes of those launches */
+} rs_profile;
+/* the rate (GB/s, read + write) a plain float4 copy of `bytes` reaches on this card, best of three grid sizes: the practical streaming ceiling
+ * beside the 8 TB/s specification.  Allocates 2 x bytes for the duration of the call; synchronises. */
+int rs_stream_probe(rs_table *table, size_t bytes, int reps, double *gbps);
+int rs_profile_enable(rs_table *table, int on); /* on: bracket every launch with hipEvents (adds host work) */
+int rs_profile_read(rs_table *table, rs_profile *out); /* synchronises, then accumulates pending events */
+int rs_profile_reset(rs_table *table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTSOLVER_AMD_DIAG_H */

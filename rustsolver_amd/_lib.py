@@ -1,4 +1,4 @@
-"""ctypes declarations for include/rustsolver_amd.h (the C ABI).  No torch, no CPU fallback."""
+"""ctypes declarations for include/rustsolver_amd.h (the C ABI) and include/rustsolver_amd_diag.h (diagnostics).  No torch, no CPU fallback."""
 import ctypes as C
 import os
 
@@ -103,6 +103,8 @@ SYMBOLS = {
     "rs_table_upload_node": (C.c_int, [_P, C.c_int, _P, _P]),
     "rs_table_download_node": (C.c_int, [_P, C.c_int, _P, _P]),
     "rs_get_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rs_get_infosets": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, _P]),
+    "rs_table_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rs_set_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rs_get_strategy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rs_get_final_strategy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -164,13 +164,9 @@ int rs_table_save(rs_table *t, const char *path) {
         const size_t lanes = size_t(d.n_boards) * d.n_clusters;
         buf.resize(lanes * d.n_actions * es);
         for (int which = 0; which < 2 && ok && rc == RS_OK; ++which) {
-            const void *src = which == 0 ? t->regrets_ptr(n) : t->ssum_ptr(n);
-            hipError_t e = hipSetDevice(t->device);
-            if (e == hipSuccess)
-                e = hipMemcpy2DAsync(buf.data(), lanes * es, src, t->pitch[n] * es, lanes * es, d.n_actions, hipMemcpyDeviceToHost, t->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
-            if (e != hipSuccess) rc = hip_fail(e, "rs_table_save: device read");
-            else ok = put(f, fnv, buf.data(), buf.size());
+            // tile-aware: the file holds plain [A][lanes] rows whatever the node's in-memory block looks like
+            rc = table_copy_node_raw(t, n, which, buf.data(), 1);
+            if (rc == RS_OK) ok = put(f, fnv, buf.data(), buf.size());
         }
     }
     const uint64_t sum = fnv.h;
@@ -219,10 +215,7 @@ int rs_table_load(const char *path, int device, rs_table **out) {
         for (int which = 0; which < 2 && ok && rc == RS_OK; ++which) {
             ok = get(f, fnv, buf.data(), buf.size());
             if (!ok) break;
-            void *dst = which == 0 ? t->regrets_ptr(n) : t->ssum_ptr(n);
-            hipError_t e = hipMemcpy2DAsync(dst, t->pitch[n] * es, buf.data(), lanes * es, lanes * es, d.n_actions, hipMemcpyHostToDevice, t->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
-            if (e != hipSuccess) rc = hip_fail(e, "rs_table_load: device write");
+            rc = table_copy_node_raw(t, n, which, buf.data(), 0);
         }
     }
     uint64_t want = 0;

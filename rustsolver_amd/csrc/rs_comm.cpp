@@ -155,7 +155,7 @@ int rs_replicated_begin(rs_table *t, uint32_t round_mask) {
     hipError_t e = hipSetDevice(t->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     if (t->rep_mask != round_mask || t->rep_nodes.empty()) {
-        t->rep_mask = round_mask;
+        t->rep_mask = 0;   // set again only once both snapshots exist: a failed allocation must not leave a state a retry would accept
         t->rep_nodes.clear();
         t->rep_off.clear();
         t->rep_cells = 0;
@@ -170,9 +170,17 @@ int rs_replicated_begin(rs_table *t, uint32_t round_mask) {
         t->d_snap_regrets = t->d_snap_ssum = nullptr;
         if (t->rep_cells) {
             if ((e = hipMalloc(&t->d_snap_regrets, t->rep_cells * 4)) != hipSuccess ||
-                (e = hipMalloc(&t->d_snap_ssum, t->rep_cells * 4)) != hipSuccess)
+                (e = hipMalloc(&t->d_snap_ssum, t->rep_cells * 4)) != hipSuccess) {
+                if (t->d_snap_regrets) (void)hipFree(t->d_snap_regrets);
+                if (t->d_snap_ssum) (void)hipFree(t->d_snap_ssum);
+                t->d_snap_regrets = t->d_snap_ssum = nullptr;
+                t->rep_nodes.clear();
+                t->rep_off.clear();
+                t->rep_cells = 0;
                 return hip_fail(e, "rs_replicated_begin: snapshot hipMalloc");
+            }
         }
+        t->rep_mask = round_mask;
     }
     for (size_t i = 0; i < t->rep_nodes.size(); ++i) {
         const int n = t->rep_nodes[i];
@@ -195,15 +203,14 @@ int rs_allreduce_replicated(rs_table *t, rs_comm *c, uint32_t round_mask) {
     hipError_t e = hipSetDevice(t->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     if (t->rep_cells == 0) return RS_OK;
-    // 1. snap := snap - x (= minus the rank's own delta, contiguous);  x := x + snap (= the snapshot again)
+    // 1. one fused pass per array: snap := snap - x (= minus the rank's own delta, contiguous) and x := the snapshot itself, bit for bit -- in f32
+    //    x + (snap - x) is not snap and its error depends on the rank's own x, which would let the replicated rounds drift apart across ranks
     for (size_t i = 0; i < t->rep_nodes.size(); ++i) {
         const int n = t->rep_nodes[i];
         const size_t cells = t->pitch[n] * t->nodes[n].n_actions;
         void *sr = (char *)t->d_snap_regrets + t->rep_off[i] * 4, *ss = (char *)t->d_snap_ssum + t->rep_off[i] * 4;
-        if ((e = launch_delta_sub(sr, t->regrets_ptr(n), cells, t->dtype, t->stream)) != hipSuccess ||  // snap = snap - x = -delta
-            (e = launch_delta_add(t->regrets_ptr(n), sr, cells, t->dtype, t->stream)) != hipSuccess ||  // x = x + (-delta) = snapshot
-            (e = launch_delta_sub(ss, t->ssum_ptr(n), cells, t->dtype, t->stream)) != hipSuccess ||
-            (e = launch_delta_add(t->ssum_ptr(n), ss, cells, t->dtype, t->stream)) != hipSuccess)
+        if ((e = launch_delta_swap(t->regrets_ptr(n), sr, cells, t->dtype, t->stream)) != hipSuccess ||
+            (e = launch_delta_swap(t->ssum_ptr(n), ss, cells, t->dtype, t->stream)) != hipSuccess)
             return hip_fail(e, "rs_allreduce_replicated: delta kernels");
     }
     // 2. one all-reduce per array over the contiguous (negated) deltas

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "rustsolver_amd.h"
+#include "rustsolver_amd_diag.h"
 
 namespace rs {
 
@@ -127,6 +128,9 @@ hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t 
 hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream);
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
+hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_t n, uint32_t A, size_t tile, size_t es, void *d_out, hipStream_t stream);
+hipError_t launch_checksum(const void *x, size_t n, size_t es, unsigned long long *d_out, hipStream_t stream);
+hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream);      // d = snap - x; x = snap; snap = d
 
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
 struct JitSubtree {
@@ -235,6 +239,7 @@ int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t fir
                     const uint8_t *d_hands_p1, uint32_t n_hands_p1, uint32_t n_deals, uint8_t *d_cards, uint32_t *d_err, float *d_sign /* fused showdown signs, may be null */,
                     uint8_t *d_flags /* fused per-deal prune flags, may be null */, uint64_t prune_threshold);
 int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags);
+int table_copy_node_raw(rs_table *t, int node, int which /* 0 regrets, 1 strategy_sum */, void *host /* [A][lanes], table element type */, int dir /* 0 up, 1 down */);
 void solver_release_device(struct rs_solver *s);   // frees a solver's device state and detaches it from its table
 // profiling hooks used around launches
 void prof_begin(rs_table *t, int kind, double bytes);

@@ -575,6 +575,42 @@ __global__ __launch_bounds__(kBlock) void k_delta(void *__restrict__ x, const vo
     }
 }
 
+// batched get-infoset (rs_get_infosets): out[a][k] = block cell (action a, lane lanes[k]) of a plain or tiled node block; raw elements (2 or 4 bytes)
+template <typename E>
+__global__ __launch_bounds__(kBlock) void k_gather_lanes(const E *__restrict__ block, const uint32_t *__restrict__ lanes, size_t n, uint32_t A, uint32_t T,
+                                                         E *__restrict__ out) {
+    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (size_t)gridDim.x * kBlock) {
+        const size_t l = lanes[k], base = (l / T) * A * T + l % T;
+        for (uint32_t a = 0; a < A; ++a) out[(size_t)a * n + k] = block[base + (size_t)a * T];
+    }
+}
+
+// order-independent checksum of an array of n cells (rs_table_checksum): sum of splitmix64(i ^ bits * GOLD)
+template <typename E>
+__global__ __launch_bounds__(kBlock) void k_checksum(const E *__restrict__ x, size_t n, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        acc += splitmix64((uint64_t)i ^ ((uint64_t)x[i] * 0x9E3779B97F4A7C15ull));
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+// d = snap - x;  x = snap;  snap = d: every rank restarts from the bit-identical snapshot (x + (snap - x) is NOT snap in f32, and its rounding error depends on the rank's own x)
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_delta_swap(void *__restrict__ x, void *__restrict__ snap, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if constexpr (DT == RS_I32) {
+            const uint32_t a = ((uint32_t *)x)[i], b = ((uint32_t *)snap)[i];
+            ((uint32_t *)x)[i] = b;
+            ((uint32_t *)snap)[i] = b - a;
+        } else {
+            const float a = ((float *)x)[i], b = ((float *)snap)[i];
+            ((float *)x)[i] = b;
+            ((float *)snap)[i] = b - a;
+        }
+    }
+}
+
 // =====================================================================================================
 // launchers
 // =====================================================================================================
@@ -744,6 +780,25 @@ hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipS
     dim3 grid(grid_for(n)), block(kBlock);
     if (dtype == RS_I32) hipLaunchKernelGGL((k_delta<RS_I32, -1>), grid, block, 0, stream, x, snap, n);
     else if (dtype == RS_F32) hipLaunchKernelGGL((k_delta<RS_F32, -1>), grid, block, 0, stream, x, snap, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_t n, uint32_t A, size_t tile, size_t es, void *d_out, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block_(kBlock);
+    if (es == 4) hipLaunchKernelGGL((k_gather_lanes<uint32_t>), grid, block_, 0, stream, (const uint32_t *)block, d_lanes, n, A, (uint32_t)tile, (uint32_t *)d_out);
+    else hipLaunchKernelGGL((k_gather_lanes<uint16_t>), grid, block_, 0, stream, (const uint16_t *)block, d_lanes, n, A, (uint32_t)tile, (uint16_t *)d_out);
+    return hipGetLastError();
+}
+hipError_t launch_checksum(const void *x, size_t n, size_t es, unsigned long long *d_out, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block_(kBlock);
+    if (es == 4) hipLaunchKernelGGL((k_checksum<uint32_t>), grid, block_, 0, stream, (const uint32_t *)x, n, d_out);
+    else hipLaunchKernelGGL((k_checksum<uint16_t>), grid, block_, 0, stream, (const uint16_t *)x, n, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_delta_swap<RS_I32>), grid, block, 0, stream, x, snap, n);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_delta_swap<RS_F32>), grid, block, 0, stream, x, snap, n);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -101,10 +101,11 @@ static constexpr size_t kTileLanes = size_t(1) << 14, kTileMinLanes = size_t(1) 
 
 // copy between host [rows][row_len] (host element) and lanes [col0, col0 + row_len) of the first `rows` rows of `node`'s block at d_base.  dir: 0 = upload,
 // 1 = download.  One 2-D copy per tile the range touches (rows are T elements apart inside a tile).
-static int copy_rows(rs_table *t, void *d_base, int node, size_t col0, void *host, size_t rows, size_t row_len, int dir) {
+// raw: the host side holds the table's own element type (binary16 bits for RS_F16 tables: checkpoints), no conversion.
+static int copy_rows(rs_table *t, void *d_base, int node, size_t col0, void *host, size_t rows, size_t row_len, int dir, bool raw = false) {
     const size_t es = elem_size(t->dtype), T = t->tile[size_t(node)], A = t->nodes[size_t(node)].n_actions;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
-    const bool f16 = t->dtype == RS_F16;
+    const bool f16 = t->dtype == RS_F16 && !raw;
     std::vector<uint16_t> tmp;   // F16: convert on the host through a temporary
     char *h = (char *)host;
     const size_t hes = f16 ? 2 : es;
@@ -130,6 +131,13 @@ static int copy_rows(rs_table *t, void *d_base, int node, size_t col0, void *hos
         for (size_t i = 0; i < rows * row_len; ++i) dst[i] = f16_bits_to_f32(tmp[i]);
     }
     return RS_OK;
+}
+
+// checkpoints (rs_abstraction.cpp): one array of one node as unpadded [A][lanes] rows of the TABLE's element type, whatever the in-memory tiling
+int table_copy_node_raw(rs_table *t, int node, int which, void *host, int dir) {
+    const rs_node_desc &nd = t->nodes[size_t(node)];
+    if (nd.n_actions == 0) return RS_OK;
+    return copy_rows(t, which == 0 ? t->regrets_ptr(node) : t->ssum_ptr(node), node, 0, host, nd.n_actions, size_t(nd.n_boards) * nd.n_clusters, dir, true);
 }
 
 }  // namespace rs
@@ -335,6 +343,55 @@ int rs_get_infoset(rs_table *t, int node, int board, int cluster, void *regrets,
 }
 int rs_set_infoset(rs_table *t, int node, int board, int cluster, const void *regrets, const void *ssum) {
     return infoset_copy(t, node, board, cluster, (void *)regrets, (void *)ssum, 0, "rs_set_infoset");
+}
+
+// get-infoset for a batch of lanes of one node: one gather kernel per array instead of n strided copies
+int rs_get_infosets(rs_table *t, int node, const uint32_t *lanes, size_t n, void *regrets, void *ssum) {
+    if (int rc = check_node(t, node, "rs_get_infosets")) return rc;
+    if (!lanes && n) return fail(RS_ERR_INVALID, "rs_get_infosets: lanes is NULL");
+    const rs_node_desc &nd = t->nodes[node];
+    if (nd.n_actions == 0 || n == 0) return RS_OK;
+    const size_t n_lanes = size_t(nd.n_boards) * nd.n_clusters;
+    for (size_t k = 0; k < n; ++k)
+        if (lanes[k] >= n_lanes)
+            return fail(RS_ERR_OOB, "rs_get_infosets: index out of bounds: the len is " + std::to_string(n_lanes) + " but the index is " + std::to_string(lanes[k]));
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const size_t es = elem_size(t->dtype), A = nd.n_actions;
+    uint32_t *d_lanes = nullptr;
+    void *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_lanes, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_out, A * n * es);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lanes, lanes, n * 4, hipMemcpyHostToDevice, t->stream);
+    std::vector<uint16_t> tmp(t->dtype == RS_F16 ? A * n : 0);
+    for (int which = 0; which < 2 && e == hipSuccess; ++which) {
+        void *host = which == 0 ? regrets : ssum;
+        if (!host) continue;
+        e = launch_gather_lanes(which == 0 ? t->regrets_ptr(node) : t->ssum_ptr(node), d_lanes, n, uint32_t(A), t->tile[size_t(node)], es, d_out, t->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(t->dtype == RS_F16 ? (void *)tmp.data() : host, d_out, A * n * es, hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+        if (e == hipSuccess && t->dtype == RS_F16)
+            for (size_t i = 0; i < A * n; ++i) ((float *)host)[i] = f16_bits_to_f32(tmp[i]);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (d_lanes) (void)hipFree(d_lanes);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, "rs_get_infosets");
+    return RS_OK;
+}
+
+int rs_table_checksum(rs_table *t, uint64_t *out) {
+    if (!t || !out) return fail(RS_ERR_INVALID, "rs_table_checksum: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, 16, t->stream);
+    if (e == hipSuccess) e = launch_checksum(t->d_regrets, t->n_cells, elem_size(t->dtype), d, t->stream);
+    if (e == hipSuccess) e = launch_checksum(t->d_ssum, t->n_cells, elem_size(t->dtype), d + 1, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (d) (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "rs_table_checksum");
+    return RS_OK;
 }
 
 // Infoset::get_strategy / get_final_strategy for ONE info set: the device kernel computes the whole

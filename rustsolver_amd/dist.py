@@ -27,9 +27,9 @@ def replicated_allreduce(x, snap, all_reduce_sum):
         total = all_reduce_sum(neg_delta)
         return (snap.view(np.uint32) - np.asarray(total, dtype=np.int32).view(np.uint32)).view(np.int32)
     neg_delta = (snap - x).astype(np.float32)
-    restored = (x + neg_delta).astype(np.float32)
     total = np.asarray(all_reduce_sum(neg_delta), dtype=np.float32)
-    return (restored - total).astype(np.float32)
+    # every rank restarts from the snapshot ITSELF (k_delta_swap), not from x + (snap - x): that is not snap in f32 and depends on the rank's own x
+    return (snap - total).astype(np.float32)
 
 
 def deal_numbers(batch, rank, world, deals_per_batch):

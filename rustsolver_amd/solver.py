@@ -400,6 +400,21 @@ class InfosetTable:
         L.check(L.load().rs_child_reach(self._h, node, None if r is None else r.ptr, out.ptr))
         return self.read_lane_buffer(out, node, a)
 
+    def get_infosets(self, node, lanes):
+        """batched get-infoset: (regrets[A][n], strategy_sum[A][n]) of lanes (= board * n_clusters + cluster) of one node"""
+        lanes = np.ascontiguousarray(lanes, dtype=np.uint32)
+        a = self.node_desc(node).n_actions
+        dt = np.int32 if self.dtype == L.I32 else np.float32
+        r, s = np.zeros((a, len(lanes)), dtype=dt), np.zeros((a, len(lanes)), dtype=dt)
+        L.check(L.load().rs_get_infosets(self._h, node, lanes.ctypes.data_as(C.c_void_p), len(lanes), r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
+        return r, s
+
+    def checksum(self):
+        """(regrets, strategy_sum) order-independent 64-bit checksums of the whole device arrays (diagnostics)"""
+        out = (C.c_uint64 * 2)()
+        L.check(L.load().rs_table_checksum(self._h, out))
+        return int(out[0]), int(out[1])
+
     def save(self, path):
         """checkpoint ("RSTB" v1)"""
         L.check(L.load().rs_table_save(self._h, path.encode()))

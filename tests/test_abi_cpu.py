@@ -16,10 +16,13 @@ from rustsolver_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "rustsolver_amd.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", src)))
+def header_functions(which=("rustsolver_amd.h", "rustsolver_amd_diag.h")):
+    names = set()
+    for h in which:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -29,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "librustsolver_amd.so does not export %s" % n
     assert sorted(L.SYMBOLS) == names, set(L.SYMBOLS) ^ set(names)
-    assert lib.rs_abi_version() == 2
+    assert lib.rs_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -225,3 +228,29 @@ def test_header_is_plain_c_and_the_example_driver_links(tmp_path):
         pytest.skip("a GPU is visible: the run itself is covered by the GPU tests")
     r = subprocess.run([exe, "1000"], capture_output=True, text=True)
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and "1081 / 1081 river clusters" in r.stdout
+
+
+def test_rust_binding_covers_every_export():
+    """rust/ffi.rs is generated from the headers (tools/gen_rust_ffi.py): it must be current, declare EVERY exported function with the header's arity,
+    and mirror every struct field by field (ctypes declares the same structs: their field names must agree too)."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"]) == 0
+    rust = open(os.path.join(ROOT, "rust", "ffi.rs")).read()
+    rfns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rs_\w+)\(([^)]*)\)", rust)}
+    assert sorted(rfns) == header_functions()
+    csrc = ""
+    for h in ("rustsolver_amd.h", "rustsolver_amd_diag.h"):
+        csrc += re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)
+    for name, rargs in rfns.items():
+        m = re.search(r"\b%s\s*\(([^)]*)\)\s*;" % name, csrc)
+        cargs = m.group(1).strip()
+        n_c = 0 if cargs in ("", "void") else cargs.count(",") + 1
+        n_r = 0 if not rargs.strip() else rargs.count(":")
+        assert n_c == n_r, "%s: %d arguments in the header, %d in rust/ffi.rs" % (name, n_c, n_r)
+        assert len(L.SYMBOLS[name][1]) == n_c, "%s: ctypes arity" % name
+    for cname, cls in (("rs_tree_node", L.TreeNode), ("rs_options", L.OptionsC), ("rs_node_desc", L.NodeDesc), ("rs_leaf_desc", L.LeafDesc),
+                       ("rs_deal_batch", L.DealBatch), ("rs_solver_params", L.SolverParams)):
+        m = re.search(r"pub struct %s \{(.*?)\n\}" % cname, rust, flags=re.S)
+        rfields = re.findall(r"pub (\w+):", m.group(1))
+        assert rfields == [f[0] for f in cls._fields_], cname

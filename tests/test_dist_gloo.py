@@ -77,7 +77,11 @@ def _worker(rank, port, q):
         x_new = replicated_allreduce(x, snap, allreduce)
         xf = snap.astype(np.float32) + np.float32(rank + 1)
         xf_new = replicated_allreduce(xf, snap.astype(np.float32), allreduce)
-        q.put((rank, gathered if rank == 0 else None, x_new, xf_new))
+        # f32 with rank-specific deltas much larger than the snapshot: x + (snap - x) != snap there, so a restore-by-addition would differ per rank
+        snap_small = rng.uniform(-1, 1, size=(3, 40)).astype(np.float32)
+        big = [rng.uniform(-1e4, 1e4, size=(3, 40)).astype(np.float32) for _ in range(WORLD)]
+        xg_new = replicated_allreduce((snap_small + big[rank]).astype(np.float32), snap_small, allreduce)
+        q.put((rank, gathered if rank == 0 else None, x_new, xf_new, xg_new))
     finally:
         dist.destroy_process_group()
 
@@ -118,6 +122,7 @@ def test_world2_board_sharding_and_replicated_allreduce():
     for r in range(WORLD):
         assert (res[r][2].view(np.uint32) == want).all()                # identical on every rank, = all deltas applied
         assert np.allclose(res[r][3], snap.astype(np.float32) + 3.0, rtol=1e-5)
+        assert res[r][4].tobytes() == res[0][4].tobytes(), "replicated f32 rounds must stay bit-identical across ranks"
 
 
 # ---- data-parallel deal batches: world 2 over gloo == one process with the union batch ------------------

@@ -812,18 +812,51 @@ def test_cards_to_iteration_pipeline():
         assert (r == ro).all() and (s == so).all()
 
 
-def test_checkpoint_roundtrip(tmp_path):
+def test_checkpoint_roundtrip(tmp_path, table_layout, monkeypatch):
+    """RSTB files hold unpadded [A][lanes] rows whatever the in-memory block looks like: a tiled table (lanes % tile != 0 on the turn) must come back bit for bit,
+    also when the file is loaded under a DIFFERENT tiling than it was saved under."""
+    C = 50                                                               # lanes 50 / 100 / 200: turn and river nodes are tiled in the tiled64 run, 100 % 64 != 0
     for dtype, odt in ((rs.I32, orc.T_I32), (rs.F16, orc.T_F16)):
-        tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [1, 2, 4], 7, 5, dtype, odt)
+        tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), [1, 2, 4], C, 5, dtype, odt)
+        n_tiled = sum(table.tile_lanes(nd.index) != table.pitch(nd.index) for nd in tree.action_nodes() if nd.n_children)
+        assert (n_tiled > 0) == (table_layout == "tiled64"), "the tiled64 run must really tile some nodes"
+        want = {nd.index: table.download_node(nd.index) for nd in tree.action_nodes()}
+        for nd in tree.action_nodes():                                   # ... and the bits are the oracle's, not merely self-consistent
+            ro, so = otab.get_node(nd.index)
+            assert want[nd.index][0].tobytes() == ro.tobytes() and want[nd.index][1].tobytes() == so.tobytes()
         path = str(tmp_path / ("t%d.rstb" % dtype))
         table.save(path)
-        t2 = rs.InfosetTable.load(path)
-        assert t2.n_nodes == table.n_nodes and t2.dtype == table.dtype
+        loads = [rs.InfosetTable.load(path)]
+        with monkeypatch.context() as m:                                 # the other layout: saved tiled -> loaded plain and the reverse
+            if table_layout == "tiled64":
+                m.setenv("RS_TABLE_TILE_LANES", "0")
+            else:
+                m.setenv("RS_TABLE_TILE_LANES", "64")
+                m.setenv("RS_TABLE_TILE_MIN_LANES", "65")
+            loads.append(rs.InfosetTable.load(path))
+            other_tiled = sum(loads[1].tile_lanes(nd.index) != loads[1].pitch(nd.index) for nd in tree.action_nodes() if nd.n_children)
+            assert (other_tiled > 0) == (table_layout != "tiled64")
+        for t2 in loads:
+            assert t2.n_nodes == table.n_nodes and t2.dtype == table.dtype
+            for nd in tree.action_nodes():
+                a, b = want[nd.index], t2.download_node(nd.index)
+                assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+                assert bytes(t2.node_desc(nd.index)) == bytes(table.node_desc(nd.index))
+        # the file itself: header 16 B + 16 B per node, then regrets[A][lanes] | strategy_sum[A][lanes] per node, unpadded
+        raw = open(path, "rb").read()
+        off = 16 + 16 * table.n_nodes
+        es = 4 if dtype == rs.I32 else 2
         for nd in tree.action_nodes():
-            a, b = table.download_node(nd.index), t2.download_node(nd.index)
-            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
-            assert bytes(t2.node_desc(nd.index)) == bytes(table.node_desc(nd.index))
-        raw = bytearray(open(path, "rb").read())
+            lanes = table.lanes(nd.index)
+            n = nd.n_children * lanes * es
+            if dtype == rs.I32:
+                assert raw[off:off + n] == want[nd.index][0].astype(np.int32).tobytes(), "file rows of node %d are not [A][lanes]" % nd.index
+                assert raw[off + n:off + 2 * n] == want[nd.index][1].astype(np.int32).tobytes()
+            else:
+                assert raw[off:off + n] == want[nd.index][0].astype(np.float16).tobytes()
+            off += 2 * n
+        assert off + 8 == len(raw)
+        raw = bytearray(raw)
         raw[len(raw) // 2] ^= 0x40                                   # corrupt one byte -> checksum mismatch
         open(path, "wb").write(bytes(raw))
         with pytest.raises(rs.RsError):
