@@ -9,10 +9,15 @@ options::default_flop() (options.rs:52-81), C = 1000 clusters, A in {2,3}, i32 t
 replicated to `--boards` per GPU so that one sweep streams >= 8 GB (>> the 256 MB Infinity Cache).
 One STEP = one CFR iteration = both traversers swept over every (board, cluster) lane of the tree
 (rs_iterate x 2).  `value` = board-iterations / second summed over all ranks, inputs resident in HBM.
-N > 1: boards shard across ranks (one process per GPU, no data-path collective for this river-only
-workload -- nothing is replicated), weak scaling.
+N > 1: `python bench.py --gpus N` STARTS ITS OWN N RANKS (one process per GPU, torch.distributed over RCCL) when it was not launched by
+torch.distributed.run -- the parent touches no GPU API, spawns N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, forwards
+rank 0's single JSON line and fails if any child fails (the reference's train() spawns its own 8 workers the same way, cfr.rs:195-229).
+The headline stays config 2 with boards sharded across ranks (no data-path collective: nothing is replicated in a river-only tree), weak
+scaling; beside it the N > 1 line carries `config4` (the 706-node flop+turn+river sweep with turn / river boards sharded over the ranks,
+one RCCL all-gather per traverser sweep, STRONG scaling, all-gather time split out) and `dp_deals` (data-parallel sampled training, one
+ncclInt32 all-reduce of the delta tables per sweep).  N = 1 carries `config3` (the same sweep on one GPU, 135 GB table) instead.
 
-The oracle (oracle/) is used ONLY for the `cpu_baseline` leg.
+The oracle (oracle/) is used ONLY for the `cpu_baseline` legs.
 """
 import argparse
 import ctypes as C
@@ -52,7 +57,80 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (single board, deal batches, trainers, solve, k-means): "
                     "the rocprofv3 --pmc passes only need the headline kernels, and counter collection serialises every dispatch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--config3-steps", type=int, default=5, help="timed iterations of the config 3 / config 4 leg (0 = skip the leg)")
     return ap.parse_args()
+
+
+# ---- self-launch: python bench.py --gpus N starts its own N ranks -----------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank run.  MUST NOT touch the GPU (no HIP call, no torch.cuda, no librustsolver_amd): it only starts N
+    fresh python processes of this file with the torch.distributed environment set, forwards rank 0's stdout (the single JSON line) and
+    returns non-zero as soon as any rank fails, ending the others (exactly the PIDs it started)."""
+    import subprocess
+    import threading
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RS_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
+        time.sleep(0.05)
+    for r in live:          # a rank failed: end exactly the children this process started
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    reader.join(timeout=20)
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    if rc == 0 and not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def probe_main(kind):
+    """RS_BENCH_PROBE (CPU tests of the launcher, no GPU): a child only proves the rendezvous -- gloo process group over the environment the
+    launcher set, all ranks gathered -- and rank 0 prints them.  'fail': rank 1 exits with code 3 before the rendezvous."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if kind == "fail" and rank == 1:
+        sys.exit(3)
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, int(os.environ["LOCAL_RANK"]), os.getpid()))
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "ranks": sorted(x[0] for x in seen), "local_ranks": sorted(x[1] for x in seen),
+                          "distinct_pids": len({x[2] for x in seen}), "master": os.environ["MASTER_ADDR"]}))
+    dist.destroy_process_group()
 
 
 def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full", shard=None):
@@ -135,30 +213,62 @@ def cpu_baseline(n_clusters, mode, seconds):
     }
 
 
-def cpu_baseline_tuned(n_clusters, mode, seconds):
-    """Non-strawman CPU number: the same per-lane arithmetic on a contiguous pooled layout, no per-visit
-    allocations, ALL host cores."""
+def cpu_soa(n_clusters, mode, seconds, boards=None, threads=None):
+    """The NON-strawman CPU number (BASELINE.md section 2 `cpu_soa`): the GPU's own SoA layout, the tree walked over blocks of 256 contiguous
+    lanes so that every inner loop vectorises (gcc -O3 -march=native, compiled on this host), persistent threads on ALL host cores with
+    first-touch placement (oracle/cpu_soa.c).  Before anything is timed the same code and the literal per-lane restatement (rs_oracle.c) are
+    run on the same seeded inputs and their tables compared bit for bit."""
     import numpy as np
     from oracle import orc
-    threads = os.cpu_count() or 1
-    boards = max(64, 4 * threads)
-    tree = orc.OracleTree(orc.options_default_river())
-    tb = orc.OracleFlatTable(tree, [boards], n_clusters, seed=7)
-    rng = np.random.Generator(np.random.PCG64(77))
-    sign = np.sign(rng.uniform(-1, 1, size=boards * n_clusters)).astype(np.float32)
-    leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in tree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    threads = threads or (os.cpu_count() or 1)
     scale, m = (100.0, orc.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, orc.UPD_WRAP_I32)
-    sol = orc.OracleSolver(tree, tb, leaves, scale=scale, mode=m, chance_mode=orc.CHANCE_PASS, ref_alloc=False)
+    tree = orc.OracleTree(orc.options_default_river())
+    rng = np.random.Generator(np.random.PCG64(1236))
+    # ---- identical outputs first (3 boards, 2 iterations, saturating ranges included) ----------------------------------------------
+    vb = 3
+    vsign = np.sign(rng.uniform(-1, 1, size=vb * n_clusters)).astype(np.float32)
+    vsign[::9] = 0.0
+    chk = orc.SoaSolver(tree, vb * n_clusters, vsign, scale, m)
+    chk.fill(11, (-2**31, 2**31 - 1), (0, 2**31 - 1), threads=min(threads, 4))
+    tb = orc.OracleTable(tree, [vb], n_clusters)
+    acts = [(d["index"], len(d["children"])) for d in tree.as_dicts() if d["kind"] == orc.ACTION]
+    for idx, na in acts:
+        r_, s_ = chk.get_node(idx, na)
+        tb.set_node(idx, r_, s_)
+    leaves = {d["id"]: (orc.LEAF_SIGN, vsign) for d in tree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
+    osol = orc.OracleSolver(tree, tb, leaves, scale=scale, mode=m, chance_mode=orc.CHANCE_PASS)
+    osol.run_iterations(2, min(threads, 4))
+    chk.run(2, min(threads, 4))
+    same = True
+    for idx, na in acts:
+        r_, s_ = chk.get_node(idx, na)
+        ro, so = tb.get_node(idx)
+        same = same and bool((r_ == ro).all() and (s_ == so).all())
+    chk.destroy()
+    if not same:
+        raise RuntimeError("cpu_soa and the per-lane oracle disagree: refusing to time it")
+    # ---- the timed sample: big enough to leave every cache (>= 1.2 GB of table for 1000 clusters) ----------------------------------------
+    boards = boards or max(4096, 16 * threads)
+    lanes = boards * n_clusters
+    sign = np.sign(rng.uniform(-1, 1, size=lanes)).astype(np.float32)
+    sol = orc.SoaSolver(tree, lanes, sign, scale, m)
+    sol.fill(7, (-10**6, 10**6), (0, 10**6), threads=threads)
     t0 = time.perf_counter()
-    sol.run_iterations(2, threads)
-    t1 = (time.perf_counter() - t0) / 2
+    sol.run(1, threads)
+    t1 = time.perf_counter() - t0
     iters = max(2, int(seconds / max(t1, 1e-6)))
     t0 = time.perf_counter()
-    sol.run_iterations(iters, threads)
+    sol.run(iters, threads)
     dt = time.perf_counter() - t0
-    return {"value": boards * iters / dt, "unit": "board-iterations/s", "cores": threads, "kind": "port",
-            "sample": "%d iterations x %d boards x %d clusters, pooled contiguous layout, no per-visit allocations, %d threads, %.1f s"
-                      % (iters, boards, n_clusters, threads, dt)}
+    # algorithmic bytes per lane and traverser as for the GPU tree kernel (DESIGN.md section 4): own nodes 16 A, opponent nodes 4 A, sign row 4
+    own = {p_: sum(len(d["children"]) for d in tree.as_dicts() if d["kind"] == orc.ACTION and d["player"] == p_) for p_ in (0, 1)}
+    per_lane = sum(16 * own[p_] + 4 * own[1 - p_] + 4 for p_ in (0, 1))
+    out = {"value": boards * iters / dt, "unit": "board-iterations/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+           "algo_GBps": lanes * per_lane * iters / dt / 1e9, "table_bytes": sol.table_bytes, "identical_to_per_lane_oracle": same,
+           "sample": "%d iterations x %d boards x %d clusters of the same river tree, SoA [A][lanes] rows, blocks of 256 lanes, gcc -O3 -march=native "
+                     "auto-vectorised, %d persistent threads (first touch), %.1f s" % (iters, boards, n_clusters, threads, dt)}
+    sol.destroy()
+    return out
 
 
 def deal_batch_leg(rs, device, n_deals, n_clusters, with_cpu, cpu_seconds):
@@ -412,23 +522,11 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     return out
 
 
-def dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout):
-    """--dp-deals 1: MCCFRTrainer::train as coded (see deal_trainer_leg), data-parallel: every rank deals and sweeps 4 M deals of each global
-    batch against its replica of the table; per traverser sweep the two i32 delta arrays are all-reduced over RCCL (xGMI) and every rank
-    applies the union.  WEAK scaling; `value` = deal-iterations/s of the whole job."""
+def make_comm(table, dist, rank, n_gpus):
+    """an RCCL communicator over the ranks of the torch process group (its unique id travels through one broadcast)"""
     import ctypes as C2
     import torch
     from rustsolver_amd import _lib as L
-    from rustsolver_amd import abstraction as ab
-    if dist is None:
-        raise RuntimeError("--dp-deals needs a process group: launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --dp-deals 1")
-    mask = ab.card_mask("4d5dAs3cKs")
-    hands = ab.random_range(mask)
-    n_actions, tree = rs.build_game_tree(rs.default_flop())
-    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
-    n = 1 << 22
-    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=7, discount_interval=0, device=device, world=n_gpus, rank=rank)
-    tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))   # same seed on every rank: the replicas start identical
     ident = (C2.c_char * L.COMM_ID_BYTES)()
     if rank == 0:
         L.check(L.load().rs_comm_unique_id(ident))
@@ -436,7 +534,40 @@ def dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout):
     dist.broadcast(t_id, src=0)
     ident = (C2.c_char * L.COMM_ID_BYTES).from_buffer_copy(bytes(t_id.cpu().tolist()))
     comm = C2.c_void_p()
-    L.check(L.load().rs_comm_create(tr.infosets._h, ident, rank, n_gpus, C2.byref(comm)))
+    L.check(L.load().rs_comm_create(table._h, ident, rank, n_gpus, C2.byref(comm)))
+    return comm
+
+
+def _step_stats(ms):
+    ms = sorted(ms)
+    if not ms:
+        return None
+    return {"min": ms[0], "median": ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]), "max": ms[-1], "n": len(ms)}
+
+
+def _max_over_ranks(dist, x):
+    if dist is None:
+        return x
+    import torch
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dp_deals_leg(rs, dist, rank, n_gpus, device, steps, warmup, n=1 << 22):
+    """MCCFRTrainer::train as coded (see deal_trainer_leg), data-parallel: every rank deals and sweeps n deals of each global batch against
+    its replica of the table; per traverser sweep the two i32 delta arrays are all-reduced over RCCL (xGMI) and every rank applies the union.
+    WEAK scaling; `value` = deal-iterations/s of the whole job."""
+    import torch
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd import abstraction as ab
+    mask = ab.card_mask("4d5dAs3cKs")
+    hands = ab.random_range(mask)
+    n_actions, tree = rs.build_game_tree(rs.default_flop())
+    card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
+    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=7, discount_interval=0, device=device, world=n_gpus, rank=rank)
+    tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))   # same seed on every rank: the replicas start identical
+    comm = make_comm(tr.infosets, dist, rank, n_gpus)
     tr.attach_comm(comm)
 
     def barrier():
@@ -444,60 +575,141 @@ def dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout):
         dist.barrier()
         torch.cuda.synchronize()
 
-    tr.train(a.warmup)
+    tr.train(warmup)
     barrier()
     t0 = time.perf_counter()
-    tr.train(a.steps)
+    tr.train(steps)
     barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = _max_over_ranks(dist, time.perf_counter() - t0)
     tr.status()
     # the replicas must still be identical: compare a checksum of rank 0's table with everybody's
-    chk = 0
-    for nd in tree.action_nodes():
-        r_, s_ = tr.infosets.download_node(nd.index)
-        chk = (chk * 1000003 + int(r_.astype("int64").sum()) * 31 + int(s_.astype("int64").sum())) % (1 << 61)
-    c = torch.tensor([chk], dtype=torch.int64, device="cuda")
+    cr, cs = tr.infosets.checksum()
+    c = torch.tensor([(cr ^ (cs * 1000003)) & ((1 << 62) - 1)], dtype=torch.int64, device="cuda")
     cmin, cmax = c.clone(), c.clone()
     dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
     dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    cells = tr.infosets.cells
     tr.attach_comm(None)
     L.load().rs_comm_destroy(comm)
-    if rank == 0:
-        out = {"metric": "mccfr_deal_iterations_per_sec", "value": n * n_gpus * a.steps / elapsed, "unit": "deal-iterations/s", "n_gpus": n_gpus,
-               "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-               "config": {"workload": "MCCFRTrainer::train as coded (default_flop board, random ranges, ISOMORPHIC river, 1081 clusters), data-parallel: "
-                                      "%d deals per rank and batch, 1 step = 1 global batch (both traversers), deltas all-reduced as ncclInt32" % n,
-                          "parallelism": "dp%d: replicated table, 2 all-reduces of %d i32 cells per traverser sweep" % (n_gpus, tr.infosets.cells),
-                          "replicas_identical": bool(cmin.item() == cmax.item())}}
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(out))
-        sys.stdout.flush()
-        os.dup2(2, 1)
     tr.destroy()
-    dist.destroy_process_group()
+    return {"metric": "mccfr_deal_iterations_per_sec", "value": n * n_gpus * steps / elapsed, "unit": "deal-iterations/s", "n_gpus": n_gpus,
+            "rccl_ranks": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "i32",
+            "workload": "MCCFRTrainer::train as coded (default_flop board, random ranges, ISOMORPHIC river, 1081 clusters), data-parallel: %d deals "
+                        "per rank and batch, 1 step = 1 global batch (both traversers), deltas all-reduced as ncclInt32" % n,
+            "parallelism": "dp%d: replicated table, 2 all-reduces of %d i32 cells per traverser sweep" % (n_gpus, cells),
+            "replicas_identical": bool(cmin.item() == cmax.item())}
+
+
+def three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, steps):
+    """BASELINE configs[2] (N = 1: `config3`) and configs[3] (N > 1: `config4`): the 706-action-node flop+turn+river tree, 5 000 clusters on every
+    round, boards 1 / 49 / 2 352, i32 tables (135 GB in all), full-width cfr() with ENUM chance nodes (cfr.rs:502-522).  N > 1: turn and river
+    boards sharded over the ranks, flop replicated, ONE RCCL all-gather of the turn-root utility rows per traverser sweep between phase 0
+    (> 99 % of the bytes) and phase 1: STRONG scaling, bit-identical to the single-GPU sweep for any rank count."""
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd.dist import shard_boards
+    C_, G = 5000, [1, 49, 2352]
+    boards3, shard = list(G), None
+    if n_gpus > 1:
+        tlo, thi = shard_boards(G[1], rank, n_gpus)
+        shard = (n_gpus, rank, 1, G[1])
+        boards3 = [G[0], thi - tlo, (thi - tlo) * (G[2] // G[1])]
+    t0 = time.perf_counter()
+    tr = make_trainer(rs, boards3, C_, a.mode, 0, device, 1234 + 2 + rank, a.fuse, "three-street", "i32", "full", shard)
+    create_s = time.perf_counter() - t0
+    table = tr.infosets
+    comm = None
+    if shard is not None:
+        comm = make_comm(table, dist, rank, n_gpus)
+        tr.attach_comm(comm)
+    lib = L.load()
+
+    def barrier():
+        table.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run_steps(tr, 2)
+    barrier()
+    table.profile_mark()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_steps(tr, 1)
+        table.profile_mark()
+    barrier()
+    elapsed = _max_over_ranks(dist, time.perf_counter() - t0)
+    step_ms = table.profile_marks()
+    out = {"workload": "config%d flop+turn+river: 706-action-node tree, %d clusters per round, boards %s%s, i32 tables, %s, "
+                       "full-width opponents, ENUM chance; 1 step = 1 CFR iteration (both traversers, all lanes)"
+                       % (3 if n_gpus == 1 else 4, C_, "/".join(str(b) for b in G), "" if n_gpus == 1 else " (global; turn and river boards sharded x%d)" % n_gpus,
+                          "cfr.rs:413-464 clamp update scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap update scale 10000"),
+           "n_gpus": n_gpus, "scaling": "strong", "steps": steps, "ms_per_iteration": elapsed / steps * 1e3, "step_ms_hip_events_rank0": _step_stats(step_ms),
+           "value": G[2] * steps / elapsed, "unit": "river-board-iterations/s (global)",
+           "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": tr.workspace_bytes, "launches_per_iteration": tr.n_launches(0) + tr.n_launches(1),
+           "fused_subtrees": bool(tr.fused), "trainer_create_s": create_s}
+    if shard is not None:   # the same iterations driven phase by phase, with the all-gather bracketed by events (rank 0's stream)
+        for _ in range(steps):
+            for p_ in (0, 1):
+                buf, nbytes = tr.exchange_info(p_)
+                table.profile_mark()
+                L.check(lib.rs_iterate_phase(tr._h, p_, 0, None))
+                table.profile_mark()
+                L.check(lib.rs_comm_allgather(comm, table._h, buf, nbytes))
+                table.profile_mark()
+                L.check(lib.rs_iterate_phase(tr._h, p_, 1, None))
+        table.profile_mark()
+        ms = table.profile_marks()
+        ph = [sum(ms[k::3]) / steps for k in range(3)]
+        out["phases_ms_per_iteration_rank0"] = {"phase0_sharded_rounds": ph[0], "allgather": ph[1], "phase1_replicated_rounds": ph[2]}
+        out["allgather_bytes_per_rank_and_sweep"] = int(nbytes)
+        out["rccl_ranks"] = n_gpus
+    # per-kernel rates: the same iterations with every launch bracketed by HIP events
+    barrier()
+    table.profile_reset()
+    table.profile_enable(True)
+    run_steps(tr, min(steps, 3))
+    prof = table.profile_read()
+    table.profile_enable(False)
+    k_ = min(steps, 3)
+    out["kernels"] = {k: {"launches_per_iteration": v["launches"] / k_, "ms_per_iteration": v["ms"] / k_,
+                          "algo_GBps": (v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None,
+                          "frac_of_8TBps": (v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v["ms"] > 0 else None}
+                      for k, v in prof.items() if v["launches"]}
+    tot_b, tot_ms = sum(v["algo_bytes"] for v in prof.values()), sum(v["ms"] for v in prof.values())
+    out["algo_GBps_all_kernels"] = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else None
+    out["table_checksum"] = ["%016x" % x for x in table.checksum()]
+    if comm is not None:
+        tr.attach_comm(None)
+        lib.rs_comm_destroy(comm)
+    tr.destroy()
+    table.destroy()
+    return out
 
 
 def pmc_traffic(a, kernel):
-    """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), if they were taken on
-    this exact workload; PMC counters cannot be read from inside the process."""
+    """(HBM bytes per launch, file) from the newest committed rocprofv3 PMC passes (profiles/), if they were taken on this exact workload.  PMC
+    counters cannot be read from inside the process, so this figure is CANNED: it comes from a tracked file, not from this run."""
     import glob
     if (a.boards, a.clusters, a.mode, a.tree, a.dtype, a.opp) != (9216, 1000, "clamp", "river", "i32", "full"):
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_traffic_%s.json" % kernel)))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def main():
     a = parse()
+    if os.environ.get("RS_BENCH_PROBE") and "RANK" in os.environ:
+        probe_main(os.environ["RS_BENCH_PROBE"])
+        return
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not under torch.distributed.run: start the N ranks ourselves, BEFORE anything in this process touches the GPU
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     # stdout carries exactly ONE JSON line: libraries that print banners there (RCCL's version block, hipRTC) are
     # sent to stderr until the result is ready
     sys.stdout.flush()
@@ -515,13 +727,21 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
-    if a.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (a.gpus, world, n_gpus), file=sys.stderr)
+    if a.gpus != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with matching values (or plain `python bench.py --gpus N`, which starts its own ranks)"
+                         % (a.gpus, world))
 
     import rustsolver_amd as rs  # raises if the HIP library is missing (no fallback)
     if rs.device_count() < 1:
         raise RuntimeError("bench.py needs a GPU: the engine has no CPU fallback")
     device = local_rank % max(1, rs.device_count())
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj))
+        sys.stdout.flush()
+        os.dup2(2, 1)
 
     def barrier():
         trainer.infosets.sync()
@@ -531,7 +751,13 @@ def main():
             torch.cuda.synchronize()
 
     if a.dp_deals:
-        dp_deals_main(a, rs, dist, rank, n_gpus, device, real_stdout)
+        if dist is None:
+            raise RuntimeError("--dp-deals needs a process group: python bench.py --gpus N --dp-deals 1 (N > 1 starts its own ranks), or torch.distributed.run")
+        leg = dp_deals_leg(rs, dist, rank, n_gpus, device, a.steps, a.warmup)
+        if rank == 0:
+            emit(dict(leg, higher_is_better=True, vs_baseline=None, data="synthetic",
+                      config={"workload": leg["workload"], "parallelism": leg["parallelism"], "replicas_identical": leg["replicas_identical"]}))
+        dist.destroy_process_group()
         return
 
     three = a.tree == "three-street"
@@ -541,7 +767,7 @@ def main():
     shard = None
     if three and n_gpus > 1 and a.opp == "full":
         # BASELINE configs[3]: turn and river boards sharded over the ranks, flop replicated, one RCCL all-gather per sweep
-        # (STRONG scaling: the global problem is fixed).  Not yet run on more than one physical GPU.
+        # (STRONG scaling: the global problem is fixed)
         from rustsolver_amd.dist import shard_boards
         tlo, thi = shard_boards(boards3[1], rank, n_gpus)
         fan = boards3[2] // boards3[1]
@@ -550,35 +776,27 @@ def main():
         boards3 = [boards3[0], thi - tlo, (thi - tlo) * fan]
     trainer = make_trainer(rs, boards3 if three else a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse,
                            a.tree, a.dtype, a.opp, shard)
+    comm = None
     if shard is not None:
-        import ctypes as C2
-        import torch
-        from rustsolver_amd import _lib as L
-        ident = (C2.c_char * L.COMM_ID_BYTES)()
-        if rank == 0:
-            L.check(L.load().rs_comm_unique_id(ident))
-        t_id = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda")
-        dist.broadcast(t_id, src=0)
-        ident = (C2.c_char * L.COMM_ID_BYTES).from_buffer_copy(bytes(t_id.cpu().tolist()))
-        comm = C2.c_void_p()
-        L.check(L.load().rs_comm_create(trainer.infosets._h, ident, rank, n_gpus, C2.byref(comm)))
+        comm = make_comm(trainer.infosets, dist, rank, n_gpus)
         trainer.attach_comm(comm)
     if three:
         a.boards = boards3[-1] if shard is None else global_river / n_gpus   # `value` counts river boards (global when sharded)
     table = trainer.infosets
 
-    # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides -------------
+    # ---- warmup, then the timed region: exactly K steps between barrier+sync on both sides.  One event per step boundary on the table's
+    # stream (rs_profile_mark: a hipEventRecord, no synchronisation) gives the per-step times of THIS pass ---------------------------------
     run_steps(trainer, a.warmup)
     barrier()
+    table.profile_mark()
     t0 = time.perf_counter()
-    run_steps(trainer, a.steps)
+    for _ in range(a.steps):
+        run_steps(trainer, 1)
+        table.profile_mark()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    step_ms = table.profile_marks()
+    elapsed = _max_over_ranks(dist, elapsed)
 
     # ---- roofline leg: the same K steps again with every launch bracketed by HIP events on the table's
     # stream (graph replay off so that single launches can be timed) ---------------------------------------
@@ -591,17 +809,6 @@ def main():
     prof = table.profile_read()
     table.profile_enable(False)
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    def emit(obj):
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(obj))
-        sys.stdout.flush()
-
     dom_name = "tree" if prof["tree"]["launches"] else "update"
     upd = prof[dom_name]
     achieved = upd["algo_bytes"] / (upd["ms"] * 1e-3) / 1e9 if upd["ms"] > 0 else 0.0
@@ -612,54 +819,56 @@ def main():
     # ---- the per-node river regret-update kernel on its own (20A+8 bytes per lane, all inputs
     # buffers): rs_update_node on the root node (A = 3), HIP-event timed ---------------------------------------
     upd_node = None
-    try:
-        import numpy as np  # noqa: F401
-        from rustsolver_amd import _lib as L
-        lib = L.load()
-        ubuf = table.lane_buffer(0, 3)
-        rbuf = table.lane_buffer(0, 1)
-        obuf = table.lane_buffer(0, 1)
-        L.check(lib.rs_fill_uniform_f32(table._h, ubuf.ptr, 3 * table.pitch(0), 5, -1035.0, 1035.0))
-        L.check(lib.rs_fill_uniform_f32(table._h, rbuf.ptr, table.pitch(0), 6, 0.0, 1.0))
-        mode_flag = rs.UPD_CLAMP_I64 if (a.mode == "clamp" or a.dtype != "i32") else rs.UPD_WRAP_I32
-        scale = (100.0 if a.mode == "clamp" else 10000.0) if a.dtype == "i32" else 1.0
-        for _ in range(3):
-            L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
-        table.profile_reset()
-        table.profile_enable(True)
-        for _ in range(20):
-            L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
-        pu = table.profile_read()["update"]
-        table.profile_enable(False)
-        gbs = pu["algo_bytes"] / (pu["ms"] * 1e-3) / 1e9
-        upd_node = {"kernel": "rs::k_update<3> via rs_update_node (%s per lane, all inputs buffers)" %
-                              ("20A+8 = 68 B" if a.dtype != "f16" else "12A+8 = 44 B"),
-                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "launches": pu["launches"], "avg_launch_ms": pu["ms"] / max(1, pu["launches"]),
-                    "algo_bytes_per_launch": pu["algo_bytes"] / max(1, pu["launches"])}
-        for b in (ubuf, rbuf, obuf):
-            b.free()
-    except Exception as e:
-        upd_node = {"error": str(e)}
+    if rank == 0:
+        try:
+            from rustsolver_amd import _lib as L
+            lib = L.load()
+            ubuf = table.lane_buffer(0, 3)
+            rbuf = table.lane_buffer(0, 1)
+            obuf = table.lane_buffer(0, 1)
+            L.check(lib.rs_fill_uniform_f32(table._h, ubuf.ptr, 3 * table.pitch(0), 5, -1035.0, 1035.0))
+            L.check(lib.rs_fill_uniform_f32(table._h, rbuf.ptr, table.pitch(0), 6, 0.0, 1.0))
+            mode_flag = rs.UPD_CLAMP_I64 if (a.mode == "clamp" or a.dtype != "i32") else rs.UPD_WRAP_I32
+            scale = (100.0 if a.mode == "clamp" else 10000.0) if a.dtype == "i32" else 1.0
+            for _ in range(3):
+                L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
+            table.profile_reset()
+            table.profile_enable(True)
+            for _ in range(20):
+                L.check(lib.rs_update_node(table._h, 0, ubuf.ptr, rbuf.ptr, scale, mode_flag, obuf.ptr))
+            pu = table.profile_read()["update"]
+            table.profile_enable(False)
+            gbs = pu["algo_bytes"] / (pu["ms"] * 1e-3) / 1e9
+            upd_node = {"kernel": "rs::k_update<3> via rs_update_node (%s per lane, all inputs buffers)" %
+                                  ("20A+8 = 68 B" if a.dtype != "f16" else "12A+8 = 44 B"),
+                        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "launches": pu["launches"], "avg_launch_ms": pu["ms"] / max(1, pu["launches"]),
+                        "algo_bytes_per_launch": pu["algo_bytes"] / max(1, pu["launches"])}
+            for b in (ubuf, rbuf, obuf):
+                b.free()
+        except Exception as e:
+            upd_node = {"error": str(e)}
 
     # ---- discount sweep (cfr.rs:250-261, row a8): 16 bytes per cell, whole table --------------------------------------
     disc = None
-    try:
-        table.profile_reset()
-        table.profile_enable(True)
-        for _ in range(10):
-            table.discount(0.999)
-        pd = table.profile_read()["discount"]
-        table.profile_enable(False)
-        gbs = pd["algo_bytes"] / (pd["ms"] * 1e-3) / 1e9
-        disc = {"kernel": "rs::k_discount (16 B per cell)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": pd["ms"] / max(1, pd["launches"])}
-    except Exception as e:
-        disc = {"error": str(e)}
+    if rank == 0:
+        try:
+            table.profile_reset()
+            table.profile_enable(True)
+            for _ in range(10):
+                table.discount(0.999)
+            pd = table.profile_read()["discount"]
+            table.profile_enable(False)
+            gbs = pd["algo_bytes"] / (pd["ms"] * 1e-3) / 1e9
+            disc = {"kernel": "rs::k_discount (16 B per cell)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": pd["ms"] / max(1, pd["launches"])}
+        except Exception as e:
+            disc = {"error": str(e)}
 
     dom_kernel = ("rs_tree_p{0,1}_lanes (tree-specialised, hipRTC: regret matching, reach, utilities and the regret / strategy_sum "
                   "update of all 14 river nodes in one launch per traverser)") if dom_name == "tree" else \
                  "rs::k_update (river regret/strategy_sum update, all action counts)"
+    traffic, traffic_file = pmc_traffic(a, dom_name)
     out = {
         "metric": "cfr_iterations_per_sec",
         "value": a.boards * n_gpus * a.steps / elapsed,
@@ -668,6 +877,7 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
+        "step_ms_hip_events": dict(_step_stats(step_ms) or {}, what="per-step durations of the TIMED pass itself, one event per step boundary on the table's stream (rank 0)"),
         "config": {
             "workload": ("config2 river-only: 14-action-node tree of options::default_flop(), %d clusters, A in {2,3}, "
                          "%d boards per GPU" % (a.clusters, a.boards) if not three else
@@ -681,18 +891,22 @@ def main():
             "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": trainer.workspace_bytes,
             "launches_per_step": trainer.n_launches(0) + trainer.n_launches(1), "hip_graph": bool(a.graph),
             "fused_subtrees": bool(trainer.fused),
-            "parallelism": "boards sharded x%d, no collective (nothing replicated in a river-only tree)" % n_gpus,
+            "parallelism": ("boards sharded x%d, no collective (nothing replicated in a river-only tree)" % n_gpus) if shard is None else
+                           ("turn / river boards sharded x%d, flop replicated, one RCCL all-gather per traverser sweep" % n_gpus),
+            "process_group_ranks": (dist.get_world_size() if dist is not None else 1),
+            "self_launched": bool(os.environ.get("RS_BENCH_SELF_LAUNCHED")),
         },
         "roofline": {
             "kernel": dom_kernel,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(a, dom_name),
-            "traffic_source": "profiles/r*_roofline_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % dom_name,
+            "traffic": traffic, "traffic_canned": traffic is not None,
+            "traffic_source": ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; NOT measured in this run" % traffic_file) if traffic_file else None,
             "launches": upd["launches"], "avg_launch_ms": upd["ms"] / max(1, upd["launches"]),
             "algo_bytes_per_launch": upd["algo_bytes"] / max(1, upd["launches"]),
-            "note": "achieved = algorithmic bytes (DESIGN.md) / HIP-event duration of every launch of this kernel in a second, "
-                    "event-bracketed pass over the same K steps (ms_per_step there: %.3f)" % (elapsed_prof / a.steps * 1e3),
+            "ms_per_step_timed_pass": elapsed / a.steps * 1e3, "ms_per_step_event_pass": elapsed_prof / a.steps * 1e3,
+            "note": "achieved = algorithmic bytes (DESIGN.md section 4) / HIP-event duration of every launch of this kernel in a second, event-bracketed pass "
+                    "over the same K steps right after the timed one; both passes' step times are given",
         },
         "roofline_update_node": upd_node,
         "roofline_discount": disc,
@@ -700,27 +914,63 @@ def main():
         "lane_updates_per_sec": sum(table.lanes(n) for n in range(table.n_nodes)) * n_gpus * a.steps / elapsed,
     }
 
-    try:   # the card's own streaming ceiling (cards of one pool differ by more than 10 %): a plain float4 copy, 2 x 2 GiB, on the same stream
-        import ctypes as C3
-        from rustsolver_amd import _lib as L3
-        g = C3.c_double()
-        L3.check(L3.load().rs_stream_probe(table._h, 2 << 30, 10, C3.byref(g)))
-        out["stream_probe"] = {"copy_GBps": g.value, "what": "nt float4 copy, 2 GiB read + 2 GiB written per launch, best of 1 024 / 4 096 / 16 384 workgroups, HIP events",
-                               "tree_kernel_over_copy": achieved / g.value if g.value > 0 else None}
-        out["roofline"]["frac_of_copy_on_this_card"] = out["stream_probe"]["tree_kernel_over_copy"]
-    except Exception as e:
-        out["stream_probe"] = {"error": str(e)}
+    if rank == 0:
+        try:   # the card's own streaming ceiling (cards of one pool differ by more than 10 %): a plain float4 copy, 2 x 2 GiB, on the same stream
+            import ctypes as C3
+            from rustsolver_amd import _lib as L3
+            g = C3.c_double()
+            L3.check(L3.load().rs_stream_probe(table._h, 2 << 30, 10, C3.byref(g)))
+            out["stream_probe"] = {"copy_GBps": g.value, "what": "nt float4 copy, 2 GiB read + 2 GiB written per launch, best of 1 024 / 4 096 / 16 384 workgroups, HIP events",
+                                   "tree_kernel_over_copy": achieved / g.value if g.value > 0 else None}
+            out["roofline"]["frac_of_copy_on_this_card"] = out["stream_probe"]["tree_kernel_over_copy"]
+        except Exception as e:
+            out["stream_probe"] = {"error": str(e)}
 
-    if n_gpus > 1 or a.no_extra:   # the extra legs (single board, deal batches, CPU baselines) are N = 1 material
-        emit(out)
-        os.dup2(2, 1)
+    # the headline's table is no longer needed: the legs below want the memory (config 3 / 4 is 135 GB on one GPU)
+    if comm is not None:
+        from rustsolver_amd import _lib as L4
+        trainer.attach_comm(None)
+        L4.load().rs_comm_destroy(comm)
+    trainer.destroy()
+    table.destroy()
+
+    if a.no_extra or three:
+        if rank == 0:
+            emit(out)
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    if n_gpus > 1 or dist is not None:
+        # ---- N ranks: the two RCCL paths beside the headline (every rank takes part, rank 0 reports) ------------------------------------
+        if a.config3_steps > 0:
+            try:
+                out["config4" if n_gpus > 1 else "config3"] = three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, a.config3_steps)
+            except Exception as e:
+                out["config4" if n_gpus > 1 else "config3"] = {"error": str(e)}
+                if n_gpus > 1:
+                    raise        # a rank that drops out of a collective leaves the others hanging: fail the whole job loudly
+        try:
+            out["dp_deals"] = dp_deals_leg(rs, dist, rank, n_gpus, device, 10, 3)
+        except Exception as e:
+            out["dp_deals"] = {"error": str(e)}
+            if n_gpus > 1:
+                raise
+        if rank == 0:
+            emit(out)
+        dist.destroy_process_group()
+        return
+
+    # ---- one GPU: config 3 at size, then the rows either side of the path ---------------------------------------------------------------
+    if a.config3_steps > 0:
+        try:
+            out["config3"] = three_street_sweep_leg(rs, None, 0, 1, device, a, a.config3_steps)
+        except Exception as e:
+            out["config3"] = {"error": str(e)}
+
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:
-        small = make_trainer(rs, [1, 1, 1] if three else 1, a.clusters, a.mode, 1, device, 99, a.fuse, a.tree, a.dtype, a.opp)
+        small = make_trainer(rs, 1, a.clusters, a.mode, 1, device, 99, a.fuse, a.tree, a.dtype, a.opp)
         run_steps(small, 20)
         small.infosets.sync()
         t0 = time.perf_counter()
@@ -762,14 +1012,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         try:
-            out["cpu_baseline_tuned"] = cpu_baseline_tuned(a.clusters, a.mode, min(a.cpu_seconds, 8.0))
-            out["gpu_over_cpu_tuned"] = out["value"] / out["cpu_baseline_tuned"]["value"]
+            out["cpu_soa"] = cpu_soa(a.clusters, a.mode, min(a.cpu_seconds, 10.0))
+            out["gpu_over_cpu_soa"] = out["value"] / out["cpu_soa"]["value"]
         except Exception as e:
-            out["cpu_baseline_tuned"] = {"error": str(e)}
+            out["cpu_soa"] = {"error": str(e)}
     emit(out)
-    if dist is not None:
-        os.dup2(2, 1)
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -47,6 +47,10 @@ int rs_stream_probe(rs_table *table, size_t bytes, int reps, double *gbps);
 int rs_profile_enable(rs_table *table, int on); /* on: bracket every launch with hipEvents (adds host work) */
 int rs_profile_read(rs_table *table, rs_profile *out); /* synchronises, then accumulates pending events */
 int rs_profile_reset(rs_table *table);
+/* step boundaries: rs_profile_mark records one event on the table's stream (asynchronous, independent of rs_profile_enable); rs_profile_marks synchronises,
+ * writes the min(cap, n) durations in ms between consecutive marks, sets *n_out = n = marks - 1 and forgets the marks */
+int rs_profile_mark(rs_table *table);
+int rs_profile_marks(rs_table *table, float *ms_out, size_t cap, size_t *n_out);
 
 #ifdef __cplusplus
 }

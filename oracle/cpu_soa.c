@@ -1,0 +1,251 @@
+/*
+ * cpu_soa.c -- the NON-strawman CPU baseline of bench.py (`cpu_soa`): the same lane-model CFR sweep as the
+ * GPU engine on the GPU's own SoA layout (per action node regrets[A][pitch], strategy_sum[A][pitch], lane axis fastest), walked
+ * block by block -- a block of SOA_BL consecutive lanes goes through the whole public tree with every per-lane quantity held as a
+ * short vector, so every inner loop runs over contiguous lanes and gcc vectorises it (-O3 -march=native) -- by persistent threads,
+ * one contiguous lane range each, first-touched by its owner.
+ *
+ * TEST / BENCH INFRASTRUCTURE ONLY, like the rest of oracle/: it is the thing bench.py's `cpu_baseline` leg times beside the GPU,
+ * never part of the product.  PARITY UNPINNED by the reference (it has no test for this path); bench.py asserts that
+ * this file and the literal per-lane restatement (rs_oracle.c: orc_traverse) leave bit-identical tables on the same seeded inputs
+ * before it times anything.
+ *
+ * Semantics followed (paths relative to the reference root):
+ *   regret matching          src/solver/infoset.rs:83-102
+ *   cfr() action block       src/solver/cfr.rs:559-625   (opponent: reach * strategy[i] :585, util += utils[i]*strategy[i] :588)
+ *   mccfr() clamp update     src/solver/cfr.rs:413-464   (i64 add, clamp to i32, scale 100)
+ *   cfr() wrapping update    src/solver/cfr.rs:612-621   (saturating `as i32`, wrapping +=, scale 10000)
+ *   terminals                src/solver/cfr.rs:314-348
+ * Full-width opponents, no pruning, pass-through chance nodes, i32 tables: the configuration bench.py's headline runs (config 2).
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rs_oracle.h"
+
+#define SOA_BL 256          /* lanes per block: 1 KiB per f32 row, the whole walk stays in L1/L2 */
+#define SOA_MAX_DEPTH 24
+
+typedef struct {
+    const orc_tree *tree;
+    int32_t **reg;          /* [action node index] -> [A][pitch] */
+    int32_t **ssm;
+    size_t pitch;           /* lanes rounded up to SOA_BL */
+    size_t n_lanes;
+    const float *sign;      /* [pitch]: > 0 player 0 wins a showdown, < 0 player 1, 0 tie */
+    float scale;
+    int mode;               /* ORC_UPD_CLAMP_I64 / ORC_UPD_WRAP_I32 */
+} soa_ctx;
+
+/* (scale * reach * x) as i64, added to an i32 and clamped to the i32 range: once |delta| >= 2^32 the clamp decides, so the delta is
+ * limited to +-2^32 first (exact in f32), which also makes the conversion defined in C; NaN -> 0 like Rust's `as i64` */
+static inline int32_t add_clamp(int32_t old, float delta) {
+    float d = delta != delta ? 0.0f : delta;
+    d = d > 4294967296.0f ? 4294967296.0f : d;
+    d = d < -4294967296.0f ? -4294967296.0f : d;
+    int64_t v = (int64_t)old + (int64_t)d;
+    v = v > INT32_MAX ? INT32_MAX : v;
+    v = v < INT32_MIN ? INT32_MIN : v;
+    return (int32_t)v;
+}
+/* Rust `x as i32` (truncate, saturate, NaN -> 0) then wrapping add */
+static inline int32_t add_wrap(int32_t old, float delta) {
+    float d = delta != delta ? 0.0f : delta;
+    int32_t di = d >= 2147483648.0f ? INT32_MAX : d <= -2147483648.0f ? INT32_MIN : (int32_t)d;
+    return (int32_t)((uint32_t)old + (uint32_t)di);
+}
+
+/* util[0..SOA_BL) of `node` for traverser p over lanes [l0, l0 + SOA_BL); reach == NULL means 1.0 for every lane */
+static void walk(const soa_ctx *c, int node, int p, const float *restrict reach, float *restrict util, size_t l0, int depth) {
+    const orc_node *nd = &c->tree->nodes[node];
+    if (nd->kind == ORC_PRIVATE_CHANCE || nd->kind == ORC_PUBLIC_CHANCE) {   /* cfr.rs:306-313 */
+        walk(c, nd->children[0], p, reach, util, l0, depth);
+        return;
+    }
+    if (nd->kind == ORC_TERMINAL) {
+        const float pot = (float)nd->value;
+        if (nd->ttype == ORC_UNCONTESTED) {                                   /* cfr.rs:316-322 */
+            const float v = (p == nd->last_to_act) ? -1.0f * pot : 1.0f * pot;
+            for (int i = 0; i < SOA_BL; i++) util[i] = v;
+        } else {                                                              /* cfr.rs:323-347 */
+            const float *s = c->sign + l0;
+            const float win0 = (p == 0) ? pot : -pot;
+            for (int i = 0; i < SOA_BL; i++) util[i] = s[i] == 0.0f ? 0.0f : (s[i] > 0.0f ? win0 : -win0);
+        }
+        return;
+    }
+    const int A = nd->n_children;
+    float sigma[ORC_MAX_ACTIONS][SOA_BL], u[ORC_MAX_ACTIONS][SOA_BL], norm[SOA_BL];
+    int32_t *restrict R = c->reg[nd->index] + l0, *restrict S = c->ssm[nd->index] + l0;
+    const size_t P = c->pitch;
+    /* get_strategy, infoset.rs:83-102 */
+    for (int i = 0; i < SOA_BL; i++) norm[i] = 0.0f;
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < SOA_BL; i++) {
+            const int32_t r = R[a * P + i];
+            norm[i] += r > 0 ? (float)r : 0.0f;
+        }
+    const float uni = 1.0f / (float)A;
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < SOA_BL; i++) {
+            const int32_t r = R[a * P + i];
+            sigma[a][i] = norm[i] > 0.0f ? (r > 0 ? (float)r / norm[i] : 0.0f) : uni;
+        }
+    if (nd->player == p) {
+        for (int a = 0; a < A; a++) walk(c, nd->children[a], p, reach, u[a], l0, depth + 1);   /* cfr.rs:578-581 */
+        for (int i = 0; i < SOA_BL; i++) util[i] = 0.0f;
+        for (int a = 0; a < A; a++)
+            for (int i = 0; i < SOA_BL; i++) util[i] += u[a][i] * sigma[a][i];                 /* cfr.rs:588 */
+        const float scale = c->scale;
+        if (c->mode == ORC_UPD_CLAMP_I64) {
+            for (int a = 0; a < A; a++)
+                for (int i = 0; i < SOA_BL; i++) {
+                    const float sr = scale * (reach ? reach[i] : 1.0f);
+                    R[a * P + i] = add_clamp(R[a * P + i], sr * (u[a][i] - util[i]));
+                    S[a * P + i] = add_clamp(S[a * P + i], sr * sigma[a][i]);
+                }
+        } else {
+            for (int a = 0; a < A; a++)
+                for (int i = 0; i < SOA_BL; i++) {
+                    const float sr = scale * (reach ? reach[i] : 1.0f);
+                    R[a * P + i] = add_wrap(R[a * P + i], sr * (u[a][i] - util[i]));
+                    S[a * P + i] = add_wrap(S[a * P + i], sr * sigma[a][i]);
+                }
+        }
+    } else {
+        float child_reach[SOA_BL];
+        for (int i = 0; i < SOA_BL; i++) util[i] = 0.0f;
+        for (int a = 0; a < A; a++) {
+            for (int i = 0; i < SOA_BL; i++) child_reach[i] = sigma[a][i] * (reach ? reach[i] : 1.0f);   /* cfr.rs:585 */
+            walk(c, nd->children[a], p, child_reach, u[a], l0, depth + 1);
+            for (int i = 0; i < SOA_BL; i++) util[i] += u[a][i] * sigma[a][i];
+        }
+    }
+}
+
+typedef struct {
+    soa_ctx *c;
+    size_t blk_lo, blk_hi;      /* this thread's blocks */
+    size_t iterations;
+    uint64_t seed;
+    int op;                     /* 0 = fill (first touch), 1 = iterate */
+    int64_t rlo, rhi, slo, shi;
+} soa_job;
+
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static void *soa_worker(void *arg) {
+    soa_job *j = (soa_job *)arg;
+    soa_ctx *c = j->c;
+    if (j->op == 0) {   /* every thread fills (= first-touches) its own lane range of every row */
+        const uint64_t rspan = (uint64_t)(j->rhi - j->rlo) + 1, sspan = (uint64_t)(j->shi - j->slo) + 1;
+        for (int n = 0; n < c->tree->n_nodes; n++) {
+            const orc_node *nd = &c->tree->nodes[n];
+            if (nd->kind != ORC_ACTION) continue;
+            for (int a = 0; a < nd->n_children; a++)
+                for (size_t l = j->blk_lo * SOA_BL; l < j->blk_hi * SOA_BL; l++) {
+                    const uint64_t key = ((uint64_t)nd->index << 40) ^ ((uint64_t)a << 32) ^ (uint64_t)l;
+                    const int live = l < c->n_lanes;
+                    c->reg[nd->index][(size_t)a * c->pitch + l] = live ? (int32_t)(j->rlo + (int64_t)(splitmix64(j->seed ^ key * 0x9E3779B97F4A7C15ull) % rspan)) : 0;
+                    c->ssm[nd->index][(size_t)a * c->pitch + l] = live ? (int32_t)(j->slo + (int64_t)(splitmix64((j->seed ^ 0x5353554Dull) ^ key * 0x9E3779B97F4A7C15ull) % sspan)) : 0;
+                }
+        }
+        return NULL;
+    }
+    float util[SOA_BL];
+    for (size_t it = 0; it < j->iterations; it++)   /* lanes never share cells, so a thread may run ahead of the others: no barrier per iteration */
+        for (int p = 0; p < 2; p++)
+            for (size_t b = j->blk_lo; b < j->blk_hi; b++) walk(c, 0, p, NULL, util, b * SOA_BL, 0);
+    return NULL;
+}
+
+static void run_threads(soa_ctx *c, soa_job proto, int n_threads) {
+    const size_t n_blk = c->pitch / SOA_BL;
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_blk) n_threads = (int)n_blk;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    soa_job *jobs = (soa_job *)malloc((size_t)n_threads * sizeof(soa_job));
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i] = proto;
+        jobs[i].c = c;
+        jobs[i].blk_lo = n_blk * (size_t)i / (size_t)n_threads;
+        jobs[i].blk_hi = n_blk * (size_t)(i + 1) / (size_t)n_threads;
+        pthread_create(&th[i], NULL, soa_worker, &jobs[i]);
+    }
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* ---- C entry points (ctypes: oracle/orc.py SoaSolver) ------------------------------------------------------------------------------ */
+soa_ctx *soa_create(const orc_tree *tree, size_t n_lanes, const float *sign, float scale, int mode) {
+    soa_ctx *c = (soa_ctx *)calloc(1, sizeof(soa_ctx));
+    if (!c) return NULL;
+    c->tree = tree;
+    c->n_lanes = n_lanes;
+    c->pitch = (n_lanes + SOA_BL - 1) / SOA_BL * SOA_BL;
+    c->scale = scale;
+    c->mode = mode;
+    c->reg = (int32_t **)calloc((size_t)tree->n_action_nodes, sizeof(int32_t *));
+    c->ssm = (int32_t **)calloc((size_t)tree->n_action_nodes, sizeof(int32_t *));
+    float *sg = NULL;
+    if (posix_memalign((void **)&sg, 64, c->pitch * sizeof(float))) return NULL;
+    memset(sg, 0, c->pitch * sizeof(float));
+    memcpy(sg, sign, n_lanes * sizeof(float));
+    c->sign = sg;
+    for (int n = 0; n < tree->n_nodes; n++) {
+        const orc_node *nd = &tree->nodes[n];
+        if (nd->kind != ORC_ACTION) continue;
+        /* malloc'ed, NOT zeroed here: the pages are first touched by the thread that owns the lanes (soa_fill / soa_set_node) */
+        if (posix_memalign((void **)&c->reg[nd->index], 64, (size_t)nd->n_children * c->pitch * 4) ||
+            posix_memalign((void **)&c->ssm[nd->index], 64, (size_t)nd->n_children * c->pitch * 4))
+            return NULL;
+    }
+    return c;
+}
+void soa_destroy(soa_ctx *c) {
+    if (!c) return;
+    for (int i = 0; i < c->tree->n_action_nodes; i++) {
+        free(c->reg[i]);
+        free(c->ssm[i]);
+    }
+    free(c->reg);
+    free(c->ssm);
+    free((void *)c->sign);
+    free(c);
+}
+/* seeded fill by the owning threads (NUMA first touch) */
+void soa_fill(soa_ctx *c, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, int n_threads) {
+    soa_job j;
+    memset(&j, 0, sizeof(j));
+    j.op = 0;
+    j.seed = seed;
+    j.rlo = rlo; j.rhi = rhi; j.slo = slo; j.shi = shi;
+    run_threads(c, j, n_threads);
+}
+void soa_get_node(const soa_ctx *c, int index, int n_actions, int32_t *regrets, int32_t *ssum) {   /* [A][n_lanes], unpadded */
+    for (int a = 0; a < n_actions; a++) {
+        memcpy(regrets + (size_t)a * c->n_lanes, c->reg[index] + (size_t)a * c->pitch, c->n_lanes * 4);
+        memcpy(ssum + (size_t)a * c->n_lanes, c->ssm[index] + (size_t)a * c->pitch, c->n_lanes * 4);
+    }
+}
+void soa_run(soa_ctx *c, size_t iterations, int n_threads) {
+    soa_job j;
+    memset(&j, 0, sizeof(j));
+    j.op = 1;
+    j.iterations = iterations;
+    run_threads(c, j, n_threads);
+}
+size_t soa_table_bytes(const soa_ctx *c) {
+    size_t cells = 0;
+    for (int n = 0; n < c->tree->n_nodes; n++)
+        if (c->tree->nodes[n].kind == ORC_ACTION) cells += (size_t)c->tree->nodes[n].n_children * c->pitch;
+    return cells * 8;
+}

@@ -716,3 +716,87 @@ def update_min_dists(min_dists, dataset, new_center, kind=DIST_EMD):
     assert min_dists.dtype == np.float32 and min_dists.flags.c_contiguous
     lib().orc_update_min_dists(kind, _f32(min_dists), _f32(d), len(d), _f32(c), d.shape[1])
     return min_dists
+
+
+# ---- cpu_soa: the non-strawman CPU baseline of bench.py (oracle/cpu_soa.c) -----------------------------------------------------------
+def _cpu_tag():
+    """a short hash of this host's CPU model + ISA flags: the SoA baseline is compiled -march=native, and the .so travels with the repository
+    snapshot to a GPU box with a different CPU, where it must be rebuilt rather than executed"""
+    import hashlib
+    txt = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith(("model name", "flags")):
+                txt += line
+                if line.startswith("flags"):
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1(txt.encode()).hexdigest()[:10]
+
+
+_soa_lib = None
+
+
+def soa_lib():
+    global _soa_lib
+    if _soa_lib is not None:
+        return _soa_lib
+    so = os.path.join(_HERE, "librs_soa_%s.so" % _cpu_tag())
+    srcs = [os.path.join(_HERE, f) for f in ("cpu_soa.c", "rs_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        tmp = so + ".%d.tmp" % os.getpid()
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-trapping-math", "-Wall", "-pthread",
+                               "-shared", "-o", tmp, os.path.join(_HERE, "cpu_soa.c"), "-lpthread"])
+        os.replace(tmp, so)
+    L = C.CDLL(so)
+    L.soa_create.argtypes = [C.POINTER(Tree), C.c_size_t, C.POINTER(C.c_float), C.c_float, C.c_int]
+    L.soa_create.restype = C.c_void_p
+    L.soa_destroy.argtypes = [C.c_void_p]
+    L.soa_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]
+    L.soa_get_node.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.soa_run.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.soa_table_bytes.argtypes = [C.c_void_p]
+    L.soa_table_bytes.restype = C.c_size_t
+    _soa_lib = L
+    return L
+
+
+class SoaSolver:
+    """The lane-model sweep (full-width opponents, pass-through chance, i32 tables) on the GPU's SoA layout, vectorised over blocks of lanes,
+    persistent threads with first-touch placement (oracle/cpu_soa.c).  Bench baseline only."""
+
+    def __init__(self, tree, n_lanes, sign, scale=100.0, mode=UPD_CLAMP_I64):
+        self.tree, self.n_lanes = tree, int(n_lanes)
+        self._sign = np.ascontiguousarray(sign, dtype=np.float32)
+        assert self._sign.size == self.n_lanes
+        self._h = soa_lib().soa_create(C.byref(tree.t), self.n_lanes, _f32(self._sign), scale, mode)
+        if not self._h:
+            raise MemoryError("soa_create")
+
+    def fill(self, seed, regret_range=(-10**6, 10**6), ssum_range=(0, 10**6), threads=1):
+        soa_lib().soa_fill(self._h, seed, regret_range[0], regret_range[1], ssum_range[0], ssum_range[1], threads)
+
+    def get_node(self, index, n_actions):
+        r = np.zeros((n_actions, self.n_lanes), dtype=np.int32)
+        s = np.zeros((n_actions, self.n_lanes), dtype=np.int32)
+        soa_lib().soa_get_node(self._h, index, n_actions, _i32(r), _i32(s))
+        return r, s
+
+    def run(self, iterations, threads):
+        soa_lib().soa_run(self._h, iterations, threads)
+
+    @property
+    def table_bytes(self):
+        return int(soa_lib().soa_table_bytes(self._h))
+
+    def destroy(self):
+        if self._h:
+            soa_lib().soa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -200,6 +200,8 @@ SYMBOLS = {
     "rs_profile_enable": (C.c_int, [_P, C.c_int]),
     "rs_profile_read": (C.c_int, [_P, C.POINTER(Profile)]),
     "rs_profile_reset": (C.c_int, [_P]),
+    "rs_profile_mark": (C.c_int, [_P]),
+    "rs_profile_marks": (C.c_int, [_P, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "rs_comm_unique_id": (C.c_int, [_P]),
     "rs_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, _PP]),
     "rs_comm_destroy": (None, [_P]),

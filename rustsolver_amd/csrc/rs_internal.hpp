@@ -177,6 +177,7 @@ struct Profile {
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
+    std::vector<hipEvent_t> marks;     // rs_profile_mark: events on the table's stream, read (and recycled) by rs_profile_marks
     rs_profile acc{};
 };
 

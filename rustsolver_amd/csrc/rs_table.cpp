@@ -250,6 +250,7 @@ void rs_table_destroy(rs_table *t) {
         (void)hipEventDestroy(p.b);
     }
     for (hipEvent_t e : t->prof.pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->prof.marks) (void)hipEventDestroy(e);
     if (t->d_regrets) (void)hipFree(t->d_regrets);
     if (t->d_ssum) (void)hipFree(t->d_ssum);
     if (t->d_snap_regrets) (void)hipFree(t->d_snap_regrets);
@@ -694,6 +695,29 @@ int rs_stream_probe(rs_table *t, size_t bytes, int reps, double *gbps) {
     if (out) (void)hipFree(out);
     if (e != hipSuccess) return hip_fail(e, "rs_stream_probe");
     *gbps = best;
+    return RS_OK;
+}
+// step boundaries of bench.py's timed region: one event per mark on the table's stream, durations between consecutive marks
+int rs_profile_mark(rs_table *t) {
+    if (!t) return fail(RS_ERR_INVALID, "rs_profile_mark: table is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    hipEvent_t e = prof_event(t);
+    if (!e) return fail(RS_ERR_HIP, "rs_profile_mark: hipEventCreate failed");
+    RS_HIP(hipEventRecord(e, t->stream), "hipEventRecord");
+    t->prof.marks.push_back(e);
+    return RS_OK;
+}
+int rs_profile_marks(rs_table *t, float *ms_out, size_t cap, size_t *n_out) {
+    if (!t || !n_out || (!ms_out && cap)) return fail(RS_ERR_INVALID, "rs_profile_marks: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    const size_t n = t->prof.marks.empty() ? 0 : t->prof.marks.size() - 1;
+    *n_out = n;
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < n && i < cap && e == hipSuccess; ++i) e = hipEventElapsedTime(&ms_out[i], t->prof.marks[i], t->prof.marks[i + 1]);
+    for (hipEvent_t ev : t->prof.marks) t->prof.pool.push_back(ev);
+    t->prof.marks.clear();
+    if (e != hipSuccess) return hip_fail(e, "rs_profile_marks");
     return RS_OK;
 }
 int rs_profile_reset(rs_table *t) {

@@ -436,6 +436,15 @@ class InfosetTable:
     def profile_enable(self, on=True):
         L.check(L.load().rs_profile_enable(self._h, int(on)))
 
+    def profile_mark(self):
+        L.check(L.load().rs_profile_mark(self._h))
+
+    def profile_marks(self, cap=65536):
+        """durations (ms) between consecutive profile_mark() events on the table's stream; synchronises and forgets the marks"""
+        buf, n = (C.c_float * cap)(), C.c_size_t()
+        L.check(L.load().rs_profile_marks(self._h, buf, cap, C.byref(n)))
+        return [float(buf[i]) for i in range(min(cap, n.value))]
+
     def profile_reset(self):
         L.check(L.load().rs_profile_reset(self._h))
 
