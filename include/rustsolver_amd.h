@@ -458,6 +458,22 @@ int rs_kmeans_predict(rs_table *table, int dist, const float *d_dataset, size_t 
 /* update_min_dists (kmeans.rs:603-619), the kmeans++ step: d_min_dists[i] = min(d_min_dists[i], dist(dataset[i], new_center)^2) */
 int rs_update_min_dists(rs_table *table, int dist, float *d_min_dists, const float *d_dataset, size_t n, const float *new_center, int n_bins);
 
+/* The training loops that produce the centers (kmeans.rs:213-601), Hamerly-bounded: d_clusters (u32 [n]) and d_bounds (float [n][2] = (lower, upper) per datum) are
+ * DEVICE arrays; centers and s live on the HOST; every f32 sum runs in the reference's order (means are summed in data order), so results are bit-identical to the
+ * sequential Rust loops (rayon only ever parallelises loops whose iterations write their own element).  All of them synchronise.
+ *   rs_kmeans_init_s        Kmeans::init_s (:267-285): s[i] = min(s[i], min_{j != i} dist(c_i, c_j)) / 2 -- s is IN/OUT, as coded (created once, :518)
+ *   rs_kmeans_reassign      Kmeans::reassign_clusters (:287-334) = assignment_with_bounds (:213-265); d_order (may be NULL): datum i = dataset[d_order[i]]
+ *   rs_kmeans_fit_regular   Kmeans::fit_regular (:497-600), `iterations` = 10 in the reference; centers in/out, d_clusters out, d_bounds / inertia out (may be NULL)
+ *   rs_kmeans_fit_growbatch Kmeans::fit_growbatch AS CODED (:336-495: one pass over the first `batch` shuffled items, then `break`); the shuffle (:352) is the
+ *                           caller's: d_order; stats (may be NULL) = {min_change, inertia as printed} */
+int rs_kmeans_init_s(rs_table *table, int dist, const float *centers, int n_centers, int n_bins, float *s);
+int rs_kmeans_reassign(rs_table *table, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, const float *centers, int n_centers, int n_bins,
+                       const float *s, uint32_t *d_clusters, float *d_bounds);
+int rs_kmeans_fit_regular(rs_table *table, int dist, const float *d_dataset, size_t n, float *centers, int n_centers, int n_bins, int iterations, uint32_t *d_clusters,
+                          float *d_bounds, float *inertia);
+int rs_kmeans_fit_growbatch(rs_table *table, int dist, const float *d_dataset, size_t n, const uint32_t *d_order, size_t batch, float *centers, int n_centers,
+                            int n_bins, uint32_t *d_clusters, float *d_bounds, float *stats);
+
 /* ---- showdown evaluation on the device ---------------------------------------------------------------
  * d_cards[9][pitch] (u8, pitch = round_up(n_deals, 64)): rows 0-4 the board, 5-6 player 0's hole cards, 7-8 player 1's;
  * card = 4*rank + suit, rank 0..12 = 2..A (cfr.rs:592).  d_sign[lane] = sign(evaluate(hand0) - evaluate(hand1)) exactly as

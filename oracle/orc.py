@@ -99,7 +99,7 @@ DealCtx._fields_ = [("ctx", C.POINTER(Ctx)), ("delta", C.POINTER(Table)),
 
 def build(force=False):
     """Compile oracle/librs_oracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "kmeans_emd.c", "best_response.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_oracle_mt.c", "rs_oracle.h", "hand_index.c", "hand_index.h", "kmeans_emd.c", "kmeans_fit.c", "best_response.c", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -716,6 +716,47 @@ def update_min_dists(min_dists, dataset, new_center, kind=DIST_EMD):
     assert min_dists.dtype == np.float32 and min_dists.flags.c_contiguous
     lib().orc_update_min_dists(kind, _f32(min_dists), _f32(d), len(d), _f32(c), d.shape[1])
     return min_dists
+
+
+# ---- k-means training loops (kmeans_fit.c) -----------------------------------------------------------------------------------------------
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def kmeans_init_s(centers, s, kind=DIST_EMD):
+    """Kmeans::init_s (kmeans.rs:267-285); s is updated in place (it is only ever lowered, then halved: see kmeans_fit.c)"""
+    c = np.ascontiguousarray(centers, dtype=np.float32)
+    assert s.dtype == np.float32 and s.flags.c_contiguous and len(s) == len(c)
+    lib().orc_kmeans_init_s(kind, _f32(c), len(c), c.shape[1], _f32(s))
+    return s
+
+
+def kmeans_reassign(dataset, centers, s, clusters, bounds, kind=DIST_EMD, order=None):
+    """Kmeans::reassign_clusters (kmeans.rs:287-334); clusters (uint32 [n]) and bounds (float32 [n][2] = lower, upper) in place"""
+    d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.ascontiguousarray(centers, dtype=np.float32)
+    assert clusters.dtype == np.uint32 and bounds.dtype == np.float32 and bounds.shape == (len(clusters), 2)
+    o = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+    lib().orc_kmeans_reassign(kind, _f32(d), None if o is None else _u32(o), len(clusters), _f32(c), len(c), d.shape[1], _f32(np.ascontiguousarray(s, dtype=np.float32)),
+                              _u32(clusters), _f32(bounds))
+
+
+def kmeans_fit_regular(dataset, centers, kind=DIST_EMD, iterations=10):
+    """Kmeans::fit_regular (kmeans.rs:497-600) -> (clusters, new centers, bounds, inertia)"""
+    d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.array(centers, dtype=np.float32, order="C")
+    clusters, bounds = np.zeros(len(d), dtype=np.uint32), np.zeros((len(d), 2), dtype=np.float32)
+    fn = lib().orc_kmeans_fit_regular
+    fn.restype = C.c_float
+    inertia = fn(kind, _f32(d), C.c_size_t(len(d)), _f32(c), len(c), d.shape[1], iterations, _u32(clusters), _f32(bounds))
+    return clusters, c, bounds, np.float32(inertia)
+
+
+def kmeans_fit_growbatch(dataset, order, batch, centers, kind=DIST_EMD):
+    """Kmeans::fit_growbatch as coded (one pass over the first `batch` shuffled items, kmeans.rs:336-495) -> (clusters, new centers, bounds, (p, inertia))"""
+    d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.array(centers, dtype=np.float32, order="C")
+    o = np.ascontiguousarray(order, dtype=np.uint32)
+    clusters, bounds, stats = np.zeros(batch, dtype=np.uint32), np.zeros((batch, 2), dtype=np.float32), np.zeros(2, dtype=np.float32)
+    lib().orc_kmeans_fit_growbatch(kind, _f32(d), C.c_size_t(len(d)), _u32(o), C.c_size_t(batch), _f32(c), len(c), d.shape[1], _u32(clusters), _f32(bounds), _f32(stats))
+    return clusters, c, bounds, stats
 
 
 # ---- cpu_soa: the non-strawman CPU baseline of bench.py (oracle/cpu_soa.c) -----------------------------------------------------------

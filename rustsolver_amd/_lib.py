@@ -195,6 +195,10 @@ SYMBOLS = {
     "rs_kmeans_predict": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
     "rs_update_min_dists": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     "rs_showdown_sign": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "rs_kmeans_init_s": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "rs_kmeans_reassign": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "rs_kmeans_fit_regular": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_float)]),
+    "rs_kmeans_fit_growbatch": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P, _P]),
     "rs_table_save": (C.c_int, [_P, C.c_char_p]),
     "rs_table_load": (C.c_int, [C.c_char_p, C.c_int, _PP]),
     "rs_profile_enable": (C.c_int, [_P, C.c_int]),

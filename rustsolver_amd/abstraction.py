@@ -294,3 +294,45 @@ class Kmeans:
         L.check(L.load().rs_update_min_dists(self.table._h, dist, dm.ptr if dm else None, self._data.ptr if self._data else None, self.n, c.ctypes.data,
                                              self.n_bins))
         return dm.download(np.float32, self.n) if self.n else m
+
+    # ---- the training loops (kmeans.rs:213-601) ------------------------------------------------------------------------------------------
+    def init_s(self, centers, s, dist=DIST_EMD):
+        """Kmeans::init_s (kmeans.rs:267-285): returns the updated s (float32 [k]); s is in/out in the reference"""
+        c = np.ascontiguousarray(centers, dtype=np.float32)
+        out = np.array(s, dtype=np.float32, order="C")
+        L.check(L.load().rs_kmeans_init_s(self.table._h, dist, c.ctypes.data, len(c), self.n_bins, out.ctypes.data))
+        return out
+
+    def reassign(self, centers, s, clusters, bounds, dist=DIST_EMD, order=None):
+        """Kmeans::reassign_clusters (kmeans.rs:287-334) -> (clusters uint32 [m], bounds float32 [m][2]); m = len(clusters) items, item i = dataset[order[i]]"""
+        c = np.ascontiguousarray(centers, dtype=np.float32)
+        s_ = np.ascontiguousarray(s, dtype=np.float32)
+        dc = self._DeviceBuffer.from_numpy(self.table, np.ascontiguousarray(clusters, dtype=np.uint32))
+        db = self._DeviceBuffer.from_numpy(self.table, np.ascontiguousarray(bounds, dtype=np.float32))
+        do = None if order is None else self._DeviceBuffer.from_numpy(self.table, np.ascontiguousarray(order, dtype=np.uint32))
+        m = len(clusters)
+        L.check(L.load().rs_kmeans_reassign(self.table._h, dist, self._data.ptr, do.ptr if do else None, m, c.ctypes.data, len(c), self.n_bins, s_.ctypes.data,
+                                            dc.ptr, db.ptr))
+        return dc.download(np.uint32, m), db.download(np.float32, 2 * m).reshape(m, 2)
+
+    def fit_regular(self, centers, dist=DIST_EMD, iterations=10):
+        """Kmeans::fit_regular (kmeans.rs:497-600) -> (clusters uint32 [n], new centers [k][n_bins], bounds [n][2], inertia)"""
+        import ctypes as C
+        c = np.array(centers, dtype=np.float32, order="C")
+        dc = self._DeviceBuffer(self.table, self.n * 4)
+        db = self._DeviceBuffer(self.table, self.n * 8)
+        inertia = C.c_float()
+        L.check(L.load().rs_kmeans_fit_regular(self.table._h, dist, self._data.ptr, self.n, c.ctypes.data, len(c), self.n_bins, iterations, dc.ptr, db.ptr,
+                                               C.byref(inertia)))
+        return dc.download(np.uint32, self.n), c, db.download(np.float32, 2 * self.n).reshape(self.n, 2), np.float32(inertia.value)
+
+    def fit_growbatch(self, order, batch, centers, dist=DIST_EMD):
+        """Kmeans::fit_growbatch as coded (kmeans.rs:336-495) -> (clusters [batch], new centers, bounds [batch][2], stats = (p, inertia))"""
+        c = np.array(centers, dtype=np.float32, order="C")
+        do = self._DeviceBuffer.from_numpy(self.table, np.ascontiguousarray(order, dtype=np.uint32))
+        dc = self._DeviceBuffer(self.table, batch * 4)
+        db = self._DeviceBuffer(self.table, batch * 8)
+        stats = np.zeros(2, dtype=np.float32)
+        L.check(L.load().rs_kmeans_fit_growbatch(self.table._h, dist, self._data.ptr, self.n, do.ptr, batch, c.ctypes.data, len(c), self.n_bins, dc.ptr, db.ptr,
+                                                 stats.ctypes.data))
+        return dc.download(np.uint32, batch), c, db.download(np.float32, 2 * batch).reshape(batch, 2), stats

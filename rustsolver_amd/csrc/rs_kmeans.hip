@@ -146,6 +146,130 @@ __global__ __launch_bounds__(kKmBlock) void k_update_min_dists(const float *__re
     }
 }
 
+// ---- the training loops (kmeans.rs:213-601): Hamerly-bounded assignment, center sums in data order, bound shifts -----------------------------------------
+// distance of a loaded datum to prepared center c, with emd_1d's zero-sum shortcut (emd.rs:59-61) on either side
+template <int NB, int DIST>
+__device__ __forceinline__ float datum_dist(bool live, const float (&p)[NB], const float *__restrict__ centers, const unsigned char *__restrict__ center_zero, int c,
+                                            int n_bins, float *r_col) {
+    if (DIST == RS_DIST_EMD) return (!live || center_zero[c]) ? 0.0f : emd_pair<NB>(p, centers + (size_t)c * NB, n_bins, r_col);
+    return l2_pair<NB>(p, centers + (size_t)c * NB);
+}
+
+// Kmeans::init_s (kmeans.rs:267-285): s[i] = min(s[i], min over j != i of dist(c_i, c_j)) / 2 -- s is IN/OUT: the reference creates it once with f32::MAX
+// (kmeans.rs:518) and init_s only ever lowers it before halving it again.  raw = the centers as Vec<Histogram> (the datum side), centers = prepared (q side)
+template <int NB, int DIST>
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_init_s(const float *__restrict__ raw, int n_bins, const float *__restrict__ centers,
+                                                            const unsigned char *__restrict__ center_zero, int k, float *__restrict__ s) {
+    extern __shared__ float lds[];
+    float *r_col = lds + threadIdx.x;
+    const int i = blockIdx.x * kKmBlock + threadIdx.x;
+    if (i >= k) return;
+    float p[NB];
+    const bool live = load_datum<NB, DIST>(raw, (size_t)i, n_bins, p);
+    float si = s[i];
+    for (int j = 0; j < k; ++j) {
+        if (j == i) continue;
+        const float d = datum_dist<NB, DIST>(live, p, centers, center_zero, j, n_bins, r_col);
+        if (d < si) si = d;
+    }
+    s[i] = si / 2.0f;
+}
+
+// Kmeans::reassign_clusters / assignment_with_bounds (kmeans.rs:287-334, :213-265): one thread per datum; order != nullptr: datum i is dataset[order[i]]
+// (fit_growbatch's shuffled_data).  bounds[i] = (lower, upper).
+template <int NB, int DIST>
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_reassign(const float *__restrict__ dataset, const unsigned *__restrict__ order, size_t n, int n_bins,
+                                                              const float *__restrict__ centers, const unsigned char *__restrict__ center_zero, int k,
+                                                              const float *__restrict__ s, unsigned *__restrict__ clusters, float *__restrict__ bounds) {
+    extern __shared__ float lds[];
+    float *r_col = lds + threadIdx.x;
+    for (size_t i = (size_t)blockIdx.x * kKmBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kKmBlock) {
+        const int ci = (int)clusters[i];
+        const float lb = bounds[2 * i], ub = bounds[2 * i + 1];
+        const float ucb = fmaxf(s[ci], lb);                      // s[min_cluster].max(bi.0)
+        if (ub <= ucb) continue;
+        float p[NB];
+        const bool live = load_datum<NB, DIST>(dataset, order ? (size_t)order[i] : i, n_bins, p);
+        float u2 = datum_dist<NB, DIST>(live, p, centers, center_zero, ci, n_bins, r_col);
+        bounds[2 * i + 1] = u2;                                  // bi.1 = u2
+        if (u2 <= ucb) continue;
+        float l2 = 3.40282347e+38f;                              // f32::MAX
+        int min_cluster = ci;
+        for (int j = 0; j < k; ++j) {
+            if (j == min_cluster) continue;                      // the CURRENT best, as coded (kmeans.rs:311)
+            const float d = datum_dist<NB, DIST>(live, p, centers, center_zero, j, n_bins, r_col);
+            if (d < u2) {
+                l2 = u2;
+                u2 = d;
+                min_cluster = j;
+            } else if (d < l2) {
+                l2 = d;
+            }
+        }
+        bounds[2 * i] = l2;
+        if (ci != min_cluster) {
+            bounds[2 * i + 1] = u2;
+            clusters[i] = (unsigned)min_cluster;
+        }
+    }
+}
+
+// Per-cluster sums of the member histograms, member counts and (growbatch) squared upper bounds, every sum in DATA ORDER like the reference's sequential
+// f32 `+=` (kmeans.rs:525-530, :393-400): ONE wave per cluster walks the assignment vector 256 entries at a time, a ballot per 64 marks its members, and they
+// are added one after the other -- lane b owns bin b.  Splitting a cluster's members over several waves would change the order of the f32 additions.
+__global__ __launch_bounds__(64) void k_kmeans_center_sums(const float *__restrict__ dataset, const unsigned *__restrict__ order, const unsigned *__restrict__ clusters,
+                                                           const float *__restrict__ bounds, size_t n, int n_bins, float *__restrict__ sums,
+                                                           float *__restrict__ counts, float *__restrict__ sq) {
+    const unsigned c = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.0f, cnt = 0.0f, sqa = 0.0f;
+    for (size_t j0 = 0; j0 < n; j0 += 256) {
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t j = j0 + (size_t)q * 64 + lane;
+            v[q] = j < n ? clusters[j] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned long long m = __ballot(v[q] == c);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const size_t jj = j0 + (size_t)q * 64 + (size_t)b;
+                const size_t row = order ? (size_t)order[jj] : jj;
+                if ((int)lane < n_bins) acc += dataset[row * (size_t)n_bins + lane];
+                cnt += 1.0f;                                     // f32 `+= 1.0` (sticks at 2^24 exactly like the reference)
+                if (sq) {
+                    const float u = bounds[2 * jj + 1];
+                    sqa += u * u;                                // bounds[i].1.powf(2.0)
+                }
+            }
+        }
+    }
+    if ((int)lane < n_bins) sums[(size_t)c * n_bins + lane] = acc;
+    if (lane == 0) {
+        counts[c] = cnt;
+        if (sq) sq[c] = sqa;
+    }
+}
+
+// bounds after the centers moved (kmeans.rs:571-578 = :445-452): upper += movement[own], lower -= the longest movement of any OTHER center
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_shift_bounds(const unsigned *__restrict__ clusters, size_t n, const float *__restrict__ movement, int longest_idx,
+                                                                  float longest, float second, float *__restrict__ bounds) {
+    for (size_t i = (size_t)blockIdx.x * kKmBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kKmBlock) {
+        const unsigned c = clusters[i];
+        bounds[2 * i + 1] += movement[c];
+        bounds[2 * i] -= ((int)c == longest_idx) ? second : longest;
+    }
+}
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_init_state(size_t n, unsigned *__restrict__ clusters, float *__restrict__ bounds) {
+    for (size_t i = (size_t)blockIdx.x * kKmBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kKmBlock) {
+        clusters[i] = 0;
+        bounds[2 * i] = 0.0f;
+        bounds[2 * i + 1] = 3.40282347e+38f;                     // (0f32, f32::MAX), kmeans.rs:520
+    }
+}
+
 }  // namespace rs
 
 namespace {
@@ -325,6 +449,268 @@ int rs_update_min_dists(rs_table *t, int dist, float *d_min_dists, const float *
         e = hipGetLastError();
     }
     RS_HIP(e, "k_update_min_dists");
+    return RS_OK;
+}
+
+}  // extern "C"
+
+// ---- Kmeans::init_s / reassign_clusters / fit_regular / fit_growbatch (kmeans.rs:213-601) --------------------------------------------------------------
+namespace {
+
+struct KmDevice {   // per-call device workspace of the training loops
+    float *raw = nullptr, *s = nullptr, *mv = nullptr, *sums = nullptr, *counts = nullptr, *sq = nullptr;
+    ~KmDevice() {
+        for (float *q : {raw, s, mv, sums, counts, sq})
+            if (q) (void)hipFree(q);
+    }
+    int alloc(int k, int n_bins) {
+        hipError_t e = hipMalloc((void **)&raw, size_t(k) * n_bins * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&s, size_t(k) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&mv, size_t(k) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&sums, size_t(k) * n_bins * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&counts, size_t(k) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&sq, size_t(k) * 4);
+        return e == hipSuccess ? RS_OK : hip_fail(e, "k-means workspace");
+    }
+};
+
+// stages the (prepared) centers for the distance kernels; returns the device pointers
+int stage_for(rs_table *t, int dist, const float *centers, int k, int n_bins, int nb, float **d_centers, unsigned char **d_zero) {
+    std::vector<float> prepared;
+    std::vector<unsigned char> zero;
+    prepare_centers(dist, centers, k, n_bins, nb, prepared, zero);
+    return stage_centers(t, prepared, zero, d_centers, d_zero);
+}
+
+#define RS_KM_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                                                   \
+    do {                                                                                                                            \
+        const size_t lds_ = dist == RS_DIST_EMD ? size_t(nb) * kKmBlock * sizeof(float) : 0;                                        \
+        if (dist == RS_DIST_EMD) {                                                                                                  \
+            if (nb == 8) hipLaunchKernelGGL((KERNEL<8, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);                   \
+            else if (nb == 16) hipLaunchKernelGGL((KERNEL<16, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);            \
+            else if (nb == 24) hipLaunchKernelGGL((KERNEL<24, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);            \
+            else if (nb == 32) hipLaunchKernelGGL((KERNEL<32, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);            \
+            else if (nb == 48) hipLaunchKernelGGL((KERNEL<48, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERNEL<64, RS_DIST_EMD>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);                          \
+        } else {                                                                                                                    \
+            if (nb == 8) hipLaunchKernelGGL((KERNEL<8, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);                    \
+            else if (nb == 16) hipLaunchKernelGGL((KERNEL<16, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);             \
+            else if (nb == 24) hipLaunchKernelGGL((KERNEL<24, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);             \
+            else if (nb == 32) hipLaunchKernelGGL((KERNEL<32, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);             \
+            else if (nb == 48) hipLaunchKernelGGL((KERNEL<48, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);             \
+            else hipLaunchKernelGGL((KERNEL<64, RS_DIST_L2>), GRID, BLOCK, lds_, t->stream, __VA_ARGS__);                           \
+        }                                                                                                                           \
+    } while (0)
+
+// init_s on the device: s (device, in/out) against `centers` (host); the raw centers go to w.raw (the datum side of dist_func(&centers[i], &centers[j]))
+int init_s_device(rs_table *t, int dist, const float *centers, int k, int n_bins, KmDevice &w) {
+    const int nb = padded_bins(n_bins);
+    float *d_centers = nullptr;
+    unsigned char *d_zero = nullptr;
+    if (int rc = stage_for(t, dist, centers, k, n_bins, nb, &d_centers, &d_zero)) return rc;
+    RS_HIP(hipMemcpy(w.raw, centers, size_t(k) * n_bins * 4, hipMemcpyHostToDevice), "k-means centers upload");
+    const dim3 grid((unsigned)((k + kKmBlock - 1) / kKmBlock)), block(kKmBlock);
+    RS_KM_DISPATCH(k_kmeans_init_s, grid, block, (const float *)w.raw, n_bins, (const float *)d_centers, (const unsigned char *)d_zero, k, w.s);
+    RS_HIP(hipGetLastError(), "k_kmeans_init_s");
+    return RS_OK;
+}
+
+int reassign_device(rs_table *t, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, int k, int n_bins, const float *d_s, uint32_t *d_clusters,
+                    float *d_bounds) {
+    // the centers were staged by init_s_device just before (same stream, same scratch): reuse them
+    const int nb = padded_bins(n_bins);
+    float *d_centers = reinterpret_cast<float *>(t->d_km_scratch);
+    unsigned char *d_zero = reinterpret_cast<unsigned char *>((char *)t->d_km_scratch + round_up(size_t(k) * nb * sizeof(float), 256));
+    if (n == 0) return RS_OK;
+    const dim3 grid = km_grid(n), block(kKmBlock);
+    RS_KM_DISPATCH(k_kmeans_reassign, grid, block, d_dataset, (const unsigned *)d_order, n, n_bins, (const float *)d_centers, (const unsigned char *)d_zero, k, d_s,
+                   (unsigned *)d_clusters, d_bounds);
+    RS_HIP(hipGetLastError(), "k_kmeans_reassign");
+    return RS_OK;
+}
+
+// kmeans.rs:552-569 (= :427-444)
+void two_longest(const std::vector<float> &mv, int *longest_idx, float *longest, float *second) {
+    *longest_idx = 0;
+    *longest = mv[0];
+    *second = mv[1];
+    if (*longest < *second) {
+        *longest = mv[1];
+        *second = mv[0];
+        *longest_idx = 1;
+    }
+    for (size_t i = 2; i < mv.size(); ++i) {
+        if (*longest < mv[i]) {
+            *second = *longest;
+            *longest = mv[i];
+            *longest_idx = int(i);
+        } else if (*second < mv[i]) {
+            *second = mv[i];
+        }
+    }
+}
+
+int fit_check(const char *who, const rs_table *t, int dist, const void *d_dataset, size_t n, const float *centers, int k, int n_bins) {
+    if (int rc = check_args(who, t, dist, d_dataset, n, centers, k, n_bins)) return rc;
+    if (k < 2) return fail(RS_ERR_INVALID, std::string(who) + ": at least two centers (Rust: index out of bounds on center_movement[1], kmeans.rs:554)");
+    if (n == 0) return fail(RS_ERR_INVALID, std::string(who) + ": empty dataset");
+    return RS_OK;
+}
+
+// one training step after the assignment: sums in data order on the device, means / movements on the host (k * n_bins numbers), bounds shifted on the device.
+// growbatch: the `&& count > 0` form of the mean and the squared upper bounds per cluster.  new_centers / counts / sq are host outputs.
+int update_step(rs_table *t, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, std::vector<float> &centers, int k, int n_bins, bool growbatch,
+                const uint32_t *d_clusters, float *d_bounds, KmDevice &w, std::vector<float> &mv, std::vector<float> &counts, std::vector<float> &sq) {
+    hipLaunchKernelGGL(k_kmeans_center_sums, dim3((unsigned)k), dim3(64), 0, t->stream, d_dataset, (const unsigned *)d_order, (const unsigned *)d_clusters,
+                       (const float *)d_bounds, n, n_bins, w.sums, w.counts, growbatch ? w.sq : (float *)nullptr);
+    RS_HIP(hipGetLastError(), "k_kmeans_center_sums");
+    std::vector<float> mass(size_t(k) * n_bins);
+    counts.assign(size_t(k), 0.0f);
+    sq.assign(size_t(k), 0.0f);
+    RS_HIP(hipMemcpyAsync(mass.data(), w.sums, mass.size() * 4, hipMemcpyDeviceToHost, t->stream), "k-means sums download");
+    RS_HIP(hipMemcpyAsync(counts.data(), w.counts, size_t(k) * 4, hipMemcpyDeviceToHost, t->stream), "k-means counts download");
+    if (growbatch) RS_HIP(hipMemcpyAsync(sq.data(), w.sq, size_t(k) * 4, hipMemcpyDeviceToHost, t->stream), "k-means squares download");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    for (int j = 0; j < k; ++j)        // kmeans.rs:531-543 / :402-414
+        for (int b = 0; b < n_bins; ++b) {
+            float &m = mass[size_t(j) * n_bins + b];
+            if (m > 0.0f && (!growbatch || counts[size_t(j)] > 0.0f)) m /= counts[size_t(j)];
+        }
+    mv.assign(size_t(k), 0.0f);
+    for (int j = 0; j < k; ++j)        // dist_func(&new_centers[j], &self.centers[j]), kmeans.rs:546-549
+        if (int rc = rs_histogram_distance(dist, mass.data() + size_t(j) * n_bins, centers.data() + size_t(j) * n_bins, n_bins, &mv[size_t(j)])) return rc;
+    int longest_idx;
+    float longest, second;
+    two_longest(mv, &longest_idx, &longest, &second);
+    RS_HIP(hipMemcpyAsync(w.mv, mv.data(), size_t(k) * 4, hipMemcpyHostToDevice, t->stream), "k-means movement upload");
+    hipLaunchKernelGGL(k_kmeans_shift_bounds, km_grid(n), dim3(kKmBlock), 0, t->stream, (const unsigned *)d_clusters, n, (const float *)w.mv, longest_idx, longest, second,
+                       d_bounds);
+    RS_HIP(hipGetLastError(), "k_kmeans_shift_bounds");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");   // mv (host vector) was the source of an async copy
+    centers = mass;                    // self.centers = new_centers
+    return RS_OK;
+}
+
+// sum of the upper bounds in data order (f32, sequential), as the reference prints it
+int upper_bound_sum(rs_table *t, const float *d_bounds, size_t n, float *out) {
+    std::vector<float> b(2 * n);
+    RS_HIP(hipMemcpyAsync(b.data(), d_bounds, b.size() * 4, hipMemcpyDeviceToHost, t->stream), "k-means bounds download");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum += b[2 * i + 1];
+    *out = sum;
+    return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Kmeans::init_s (kmeans.rs:267-285) for callers that drive the loop themselves: s (HOST, in/out, n_centers floats) is only ever lowered, then halved
+int rs_kmeans_init_s(rs_table *t, int dist, const float *centers, int n_centers, int n_bins, float *s) {
+    if (int rc = check_args("rs_kmeans_init_s", t, dist, centers, 0, centers, n_centers, n_bins)) return rc;
+    if (!s) return fail(RS_ERR_INVALID, "rs_kmeans_init_s: s is NULL");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    KmDevice w;
+    if (int rc = w.alloc(n_centers, n_bins)) return rc;
+    RS_HIP(hipMemcpy(w.s, s, size_t(n_centers) * 4, hipMemcpyHostToDevice), "s upload");
+    if (int rc = init_s_device(t, dist, centers, n_centers, n_bins, w)) return rc;
+    RS_HIP(hipMemcpyAsync(s, w.s, size_t(n_centers) * 4, hipMemcpyDeviceToHost, t->stream), "s download");
+    RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+    return RS_OK;
+}
+
+// Kmeans::reassign_clusters (kmeans.rs:287-334) = assignment_with_bounds (:213-265): d_clusters[n] and d_bounds[n][2] = (lower, upper) are DEVICE arrays updated
+// in place; d_order (DEVICE, may be NULL): datum i is dataset[d_order[i]]; centers and s on the HOST.  Synchronises.
+int rs_kmeans_reassign(rs_table *t, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, const float *centers, int n_centers, int n_bins, const float *s,
+                       uint32_t *d_clusters, float *d_bounds) {
+    if (int rc = check_args("rs_kmeans_reassign", t, dist, d_dataset, n, centers, n_centers, n_bins)) return rc;
+    if (!s || ((!d_clusters || !d_bounds) && n)) return fail(RS_ERR_INVALID, "rs_kmeans_reassign: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    const int nb = padded_bins(n_bins);
+    float *d_centers = nullptr;
+    unsigned char *d_zero = nullptr;
+    if (int rc = stage_for(t, dist, centers, n_centers, n_bins, nb, &d_centers, &d_zero)) return rc;
+    float *d_s = nullptr;
+    RS_HIP(hipMalloc((void **)&d_s, size_t(n_centers) * 4), "hipMalloc(s)");
+    hipError_t e = hipMemcpy(d_s, s, size_t(n_centers) * 4, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? reassign_device(t, dist, d_dataset, d_order, n, n_centers, n_bins, d_s, d_clusters, d_bounds) : hip_fail(e, "s upload");
+    if (rc == RS_OK && (e = hipStreamSynchronize(t->stream)) != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+    (void)hipFree(d_s);
+    return rc;
+}
+
+// Kmeans::fit_regular (kmeans.rs:497-600): `iterations` rounds (the reference: 10, :589) of init_s -> reassign_clusters -> means -> bound shifts.
+// centers: HOST in/out [n_centers][n_bins]; d_clusters: DEVICE out [n] (the returned Vec<usize>); d_bounds: DEVICE out [n][2], may be NULL;
+// inertia: HOST out, may be NULL (sum of the upper bounds / n as printed at :594).  Synchronises.
+int rs_kmeans_fit_regular(rs_table *t, int dist, const float *d_dataset, size_t n, float *centers, int n_centers, int n_bins, int iterations, uint32_t *d_clusters,
+                          float *d_bounds, float *inertia) {
+    if (int rc = fit_check("rs_kmeans_fit_regular", t, dist, d_dataset, n, centers, n_centers, n_bins)) return rc;
+    if (!d_clusters || iterations < 1) return fail(RS_ERR_INVALID, "rs_kmeans_fit_regular: d_clusters is NULL or iterations < 1");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    KmDevice w;
+    if (int rc = w.alloc(n_centers, n_bins)) return rc;
+    float *own_bounds = nullptr;
+    if (!d_bounds) {
+        RS_HIP(hipMalloc((void **)&own_bounds, n * 8), "hipMalloc(bounds)");
+        d_bounds = own_bounds;
+    }
+    std::vector<float> c(centers, centers + size_t(n_centers) * n_bins), mv, counts, sq;
+    std::vector<float> s0(size_t(n_centers), 3.40282347e+38f);           // vec![f32::MAX; k], created ONCE (kmeans.rs:518)
+    int rc = RS_OK;
+    hipError_t e = hipMemcpy(w.s, s0.data(), s0.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "s upload");
+    if (rc == RS_OK) {
+        hipLaunchKernelGGL(k_kmeans_init_state, km_grid(n), dim3(kKmBlock), 0, t->stream, n, (unsigned *)d_clusters, d_bounds);
+        if ((e = hipGetLastError()) != hipSuccess) rc = hip_fail(e, "k_kmeans_init_state");
+    }
+    for (int it = 0; rc == RS_OK && it < iterations; ++it) {
+        rc = init_s_device(t, dist, c.data(), n_centers, n_bins, w);
+        if (rc == RS_OK) rc = reassign_device(t, dist, d_dataset, nullptr, n, n_centers, n_bins, w.s, d_clusters, d_bounds);
+        if (rc == RS_OK) rc = update_step(t, dist, d_dataset, nullptr, n, c, n_centers, n_bins, false, d_clusters, d_bounds, w, mv, counts, sq);
+    }
+    if (rc == RS_OK && inertia) {
+        float sum = 0.0f;
+        rc = upper_bound_sum(t, d_bounds, n, &sum);
+        *inertia = sum / float(n);
+    }
+    if (rc == RS_OK) std::memcpy(centers, c.data(), c.size() * 4);
+    if (own_bounds) (void)hipFree(own_bounds);
+    return rc;
+}
+
+// Kmeans::fit_growbatch AS CODED (kmeans.rs:336-495: the loop body ends in an unconditional `break`, :492): one pass over the first `batch` items of the
+// shuffled data.  d_order: DEVICE [>= batch], shuffled_data[i] = dataset[d_order[i]] (the reference shuffles with its rng, :352: the permutation is an input);
+// centers: HOST in/out; d_clusters [batch] / d_bounds [batch][2]: DEVICE out; stats: HOST out {min_change p (:466-471), inertia as printed (:478)}, may be NULL.
+int rs_kmeans_fit_growbatch(rs_table *t, int dist, const float *d_dataset, size_t n, const uint32_t *d_order, size_t batch, float *centers, int n_centers, int n_bins,
+                            uint32_t *d_clusters, float *d_bounds, float *stats) {
+    if (int rc = fit_check("rs_kmeans_fit_growbatch", t, dist, d_dataset, n, centers, n_centers, n_bins)) return rc;
+    if (!d_order || !d_clusters || !d_bounds || batch == 0 || batch > n) return fail(RS_ERR_INVALID, "rs_kmeans_fit_growbatch: NULL argument or batch outside 1..n");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    KmDevice w;
+    if (int rc = w.alloc(n_centers, n_bins)) return rc;
+    std::vector<float> c(centers, centers + size_t(n_centers) * n_bins), mv, counts, sq;
+    std::vector<float> s0(size_t(n_centers), 3.40282347e+38f);
+    RS_HIP(hipMemcpy(w.s, s0.data(), s0.size() * 4, hipMemcpyHostToDevice), "s upload");
+    hipLaunchKernelGGL(k_kmeans_init_state, km_grid(batch), dim3(kKmBlock), 0, t->stream, batch, (unsigned *)d_clusters, d_bounds);
+    RS_HIP(hipGetLastError(), "k_kmeans_init_state");
+    if (int rc = init_s_device(t, dist, c.data(), n_centers, n_bins, w)) return rc;
+    if (int rc = reassign_device(t, dist, d_dataset, d_order, batch, n_centers, n_bins, w.s, d_clusters, d_bounds)) return rc;
+    if (int rc = update_step(t, dist, d_dataset, d_order, batch, c, n_centers, n_bins, true, d_clusters, d_bounds, w, mv, counts, sq)) return rc;
+    if (stats) {
+        float min_change = 0.0f;
+        for (int j = 0; j < n_centers; ++j) {   // kmeans.rs:454-471
+            const float cn = counts[size_t(j)];
+            const float sd = cn <= 1.0f ? INFINITY : std::sqrt(std::fabs(sq[size_t(j)] / (cn * (cn - 1.0f))));
+            const float ch = sd / (mv[size_t(j)] + 1e-9f);
+            if (j == 0 || ch < min_change) min_change = ch;
+        }
+        float sum = 0.0f;
+        if (int rc = upper_bound_sum(t, d_bounds, batch, &sum)) return rc;
+        stats[0] = min_change;
+        stats[1] = sum / float(std::min(n, 2 * batch));   // current_batch_idx has already doubled when the inertia is formed (:476-478)
+    }
+    std::memcpy(centers, c.data(), c.size() * 4);
     return RS_OK;
 }
 

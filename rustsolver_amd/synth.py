@@ -39,6 +39,19 @@ def table_node_values(table, node, seed, lo, hi, ssum=False):
     return fill_values(s, idx, lo, hi)
 
 
+def table_lane_values(table, node, seed, lo, hi, lanes, ssum=False):
+    """[A][len(lanes)] int64 values rs_table_fill_random wrote for the given lanes of `node`: table_node_values for a lane subset, for tables far too
+    big to mirror as a whole (config 3: 11.76 M lanes per river node)"""
+    d = table.node_desc(node)
+    off = table.cell_offset(node)
+    s = (seed ^ 0x5353554D) if ssum else seed
+    T = np.uint64(table.tile_lanes(node))
+    lane = np.asarray(lanes, dtype=np.uint64)[None, :]
+    a = np.arange(d.n_actions, dtype=np.uint64)[:, None]
+    idx = np.uint64(off) + ((lane // T) * np.uint64(d.n_actions) + a) * T + lane % T
+    return fill_values(s, idx, lo, hi)
+
+
 def uniform_f32(seed, n, lo, hi):
     """k_fill_uniform: lo + (hi-lo) * u, u = top 24 bits of the hash * 2^-24, f32 mul then add"""
     h = _hash(seed, np.arange(n, dtype=np.uint64))

@@ -150,3 +150,85 @@ def test_predict_rejects_bad_inputs(table):
         km.predict(np.zeros((0, 8), dtype=np.float32))           # no centers: Rust indexes centers[0]
     with pytest.raises(ValueError):
         km.predict(np.zeros((2, 9), dtype=np.float32))
+
+
+# ---- the training loops: init_s, reassign_clusters, fit_regular, fit_growbatch (kmeans.rs:213-601) -----------------------------------------------
+
+@pytest.mark.parametrize("dist,odist", [(ab.DIST_EMD, orc.DIST_EMD), (ab.DIST_L2, orc.DIST_L2)])
+@pytest.mark.parametrize("n_bins,kind", [(20, "counts"), (8, "sparse"), (30, "dense")])
+def test_init_s_and_reassign_equal_oracle(table, dist, odist, n_bins, kind):
+    rng = np.random.Generator(np.random.PCG64(500 + n_bins))
+    n, k = 5000, 23
+    data = histograms(rng, n, n_bins, kind)
+    data[::131] = 0
+    centers = data[rng.choice(n, size=k, replace=False)].copy()
+    centers[7] = centers[2]                              # duplicate centers: s = 0 there
+    km = ab.Kmeans(table, data)
+    s = np.full(k, np.finfo(np.float32).max, dtype=np.float32)
+    for round_ in range(2):                              # s is in/out: the second call starts from the halved values (kmeans.rs:518, :267-285)
+        got = km.init_s(centers, s, dist)
+        want = orc.kmeans_init_s(centers, s.copy(), odist)
+        assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+        s = got
+    clusters = rng.integers(0, k, size=n).astype(np.uint32)          # arbitrary state: some bounds hold, some force one distance, some a full scan
+    bounds = np.stack([rng.random(n) * 0.3, rng.random(n) * 3.0], axis=1).astype(np.float32)
+    bounds[::5, 1] = np.finfo(np.float32).max
+    oc, ob = clusters.copy(), bounds.copy()
+    orc.kmeans_reassign(data, centers, s, oc, ob, odist)
+    gc, gb = km.reassign(centers, s, clusters, bounds, dist)
+    assert (gc == oc).all() and (gb.view(np.uint32) == ob.view(np.uint32)).all()
+    skipped = int((ob[:, 1] == bounds[:, 1]).sum())
+    assert 0 < skipped < n, "the case must exercise both the skip and the scan"
+    order = rng.permutation(n)[:1500].astype(np.uint32)              # growbatch's shuffled view
+    c2, b2 = clusters[:1500].copy(), bounds[:1500].copy()
+    orc.kmeans_reassign(data, centers, s, c2, b2, odist, order=order)
+    g2, gb2 = km.reassign(centers, s, clusters[:1500], bounds[:1500], dist, order=order)
+    assert (g2 == c2).all() and (gb2.view(np.uint32) == b2.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("dist,odist", [(ab.DIST_EMD, orc.DIST_EMD), (ab.DIST_L2, orc.DIST_L2)])
+def test_fit_regular_equals_oracle(table, dist, odist):
+    """ten rounds as in the reference (kmeans.rs:589): clusters, centers, bounds and the printed inertia, bit for bit; and the assignment is the arg-min
+    against the centers the LAST reassign saw (Hamerly's bounds only skip work)"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n, k, n_bins = 20000, 40, 20
+    data = histograms(rng, n, n_bins, "counts")
+    centers = data[rng.choice(n, size=k, replace=False)].copy()
+    km = ab.Kmeans(table, data)
+    gc, gcent, gb, gin = km.fit_regular(centers, dist, 10)
+    oc, ocent, ob, oin = orc.kmeans_fit_regular(data, centers, odist, 10)
+    assert (gc == oc).all()
+    assert (gcent.view(np.uint32) == ocent.view(np.uint32)).all()
+    assert (gb.view(np.uint32) == ob.view(np.uint32)).all()
+    assert np.float32(gin).view(np.uint32) == np.float32(oin).view(np.uint32)
+    _, c9, _, _ = km.fit_regular(centers, dist, 9)
+    pc, _ = km.predict(c9, dist)
+    assert (pc == gc).mean() >= (1.0 if dist == ab.DIST_L2 else 0.8)     # emd_1d is no metric: the reference's bounds skip too much there (test_kmeans_cpu.py)
+    assert len(np.unique(gc)) > k // 2
+
+
+def test_fit_growbatch_equals_oracle(table):
+    """gen_emd's call (gen_abstraction/main.rs:352-361: init_random, fit_growbatch, predict) with a given shuffle: one pass over the first batch"""
+    rng = np.random.Generator(np.random.PCG64(78))
+    n, k, n_bins, batch = 30000, 50, 20, 4000
+    data = histograms(rng, n, n_bins, "counts")
+    centers = data[rng.choice(n, size=k, replace=False)].copy()
+    order = rng.permutation(n).astype(np.uint32)
+    km = ab.Kmeans(table, data)
+    for dist, odist in ((ab.DIST_EMD, orc.DIST_EMD), (ab.DIST_L2, orc.DIST_L2)):
+        gc, gcent, gb, gst = km.fit_growbatch(order, batch, centers, dist)
+        oc, ocent, ob, ost = orc.kmeans_fit_growbatch(data, order, batch, centers, odist)
+        assert (gc == oc).all() and (gcent.view(np.uint32) == ocent.view(np.uint32)).all() and (gb.view(np.uint32) == ob.view(np.uint32)).all()
+        assert gst.view(np.uint32).tolist() == ost.view(np.uint32).tolist()
+        cl, _ = km.predict(gcent, dist)                                   # ... and the bucket file gen_emd would write from these centers
+        ocl, _ = orc.kmeans_predict(data, ocent, odist, threads=8)
+        assert (cl == ocl).all()
+
+
+def test_fit_rejects_bad_arguments(table):
+    data = np.ones((10, 4), dtype=np.float32)
+    km = ab.Kmeans(table, data)
+    with pytest.raises(rs.RsError):
+        km.fit_regular(data[:1], ab.DIST_L2, 3)                           # one center: the reference indexes center_movement[1]
+    with pytest.raises(rs.RsError):
+        km.fit_growbatch(np.arange(10, dtype=np.uint32), 11, data[:3], ab.DIST_L2)   # batch > n

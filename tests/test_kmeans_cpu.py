@@ -95,3 +95,77 @@ def test_oracle_predict_takes_the_first_strict_minimum():
     assert cl.tolist() == [1, 3, 0] and md.tolist() == [0.0, 1.0, 0.0]
     cl2, _ = orc.kmeans_predict(data, centers, orc.DIST_L2, threads=3)
     assert cl2.tolist() == [1, 0, 0]      # [0,0,0,1] and the empty histogram are equidistant from every center: the first one wins
+
+
+# ---- the oracle's training loops (oracle/kmeans_fit.c): what they are pinned by, since the reference holds no test for them ---------------------
+
+def _hist(rng, n, n_bins):
+    centres = rng.random(n)[:, None] * n_bins
+    width = (0.5 + 6 * rng.random(n))[:, None]
+    x = np.exp(-0.5 * ((np.arange(n_bins)[None, :] - centres) / width) ** 2)
+    return (np.floor(x / x.sum(axis=1, keepdims=True) * 250) / 250.0).astype(np.float32)
+
+
+def test_oracle_hamerly_assignment_is_the_brute_force_assignment():
+    """reassign_clusters only SKIPS distance evaluations (kmeans.rs:287-334): after every round of fit_regular the clusters must be Kmeans::predict's arg-min against
+    the centers that round's reassign saw.  Exact for l2_dist (a metric).  emd_1d is a heuristic WITHOUT a triangle inequality, so with it the reference's own
+    bounds skip evaluations they should not (about one datum in ten changes cluster here): for EMD the check is only that most assignments agree -- the
+    disagreement is the reference's algorithm, reproduced, not an error of the restatement (the GPU path must match the oracle bit for bit either way)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    data = _hist(rng, 4000, 20)
+    centers = data[rng.choice(len(data), size=25, replace=False)].copy()
+    for kind, floor in ((orc.DIST_L2, 1.0), (orc.DIST_EMD, 0.8)):
+        prev = centers
+        for it in range(1, 6):
+            cl, cent, bounds, inertia = orc.kmeans_fit_regular(data, centers, kind, it)
+            want, _ = orc.kmeans_predict(data, prev, kind)
+            assert (cl == want).mean() >= floor, (kind, it, (cl == want).mean())
+            assert (bounds[:, 1] >= 0).all()
+            prev = cent
+
+
+def test_oracle_fit_regular_first_round_by_hand():
+    """one round from scratch is plain k-means: every bound starts at (0, f32::MAX), so every datum scans all centers; means are sums in data order / counts,
+    bins that sum to 0 stay 0 (kmeans.rs:537), and the centers come back as those means"""
+    rng = np.random.Generator(np.random.PCG64(6))
+    data = _hist(rng, 500, 8)
+    centers = data[:5].copy()
+    cl, cent, bounds, inertia = orc.kmeans_fit_regular(data, centers, orc.DIST_L2, 1)
+    want_cl, want_d = orc.kmeans_predict(data, centers, orc.DIST_L2)
+    assert (cl == want_cl).all()
+    for j in range(5):
+        acc = np.zeros(8, dtype=np.float32)
+        cnt = np.float32(0)
+        for i in np.nonzero(cl == j)[0]:                      # ascending data order, f32
+            acc = (acc + data[i]).astype(np.float32)
+            cnt = np.float32(cnt + np.float32(1))
+        mean = np.where(acc > 0, (acc / cnt).astype(np.float32), acc)
+        assert mean.view(np.uint32).tolist() == cent[j].view(np.uint32).tolist()
+    mv = np.array([orc.l2_dist(cent[j], centers[j]) for j in range(5)], dtype=np.float32)
+    assert (bounds[:, 1].view(np.uint32) == (want_d + mv[cl]).astype(np.float32).view(np.uint32)).all()   # upper = distance + own center's movement
+
+
+def test_oracle_init_s_is_in_out_as_coded():
+    """kmeans.rs:518 creates s once; init_s (:267-285) lowers and halves it, so a second call on unchanged centers halves it AGAIN"""
+    rng = np.random.Generator(np.random.PCG64(7))
+    centers = _hist(rng, 6, 10)
+    s = np.full(6, np.finfo(np.float32).max, dtype=np.float32)
+    orc.kmeans_init_s(centers, s, orc.DIST_L2)
+    want = np.array([min(orc.l2_dist(centers[i], centers[j]) for j in range(6) if j != i) / np.float32(2) for i in range(6)], dtype=np.float32)
+    assert s.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+    orc.kmeans_init_s(centers, s, orc.DIST_L2)
+    assert s.view(np.uint32).tolist() == (want / np.float32(2)).astype(np.float32).view(np.uint32).tolist()
+
+
+def test_oracle_growbatch_is_one_pass_over_the_batch():
+    rng = np.random.Generator(np.random.PCG64(8))
+    data = _hist(rng, 3000, 12)
+    centers = data[rng.choice(3000, size=9, replace=False)].copy()
+    order = rng.permutation(3000).astype(np.uint32)
+    cl, cent, bounds, stats = orc.kmeans_fit_growbatch(data, order, 700, centers, orc.DIST_EMD)
+    want, _ = orc.kmeans_predict(data[order[:700]], centers, orc.DIST_EMD)
+    assert (cl == want).all()                                  # first round: every datum scans every center
+    assert np.isfinite(stats).all() and stats[1] > 0
+    for j in range(9):
+        if (cl == j).sum() == 0:
+            assert (cent[j] == 0).all()                        # empty cluster: the mean of nothing is the zero histogram (`count > 0.0`, kmeans.rs:412)
