@@ -162,9 +162,9 @@ def test_oracle_growbatch_is_one_pass_over_the_batch():
     data = _hist(rng, 3000, 12)
     centers = data[rng.choice(3000, size=9, replace=False)].copy()
     order = rng.permutation(3000).astype(np.uint32)
-    cl, cent, bounds, stats = orc.kmeans_fit_growbatch(data, order, 700, centers, orc.DIST_EMD)
-    want, _ = orc.kmeans_predict(data[order[:700]], centers, orc.DIST_EMD)
-    assert (cl == want).all()                                  # first round: every datum scans every center
+    cl, cent, bounds, stats = orc.kmeans_fit_growbatch(data, order, 700, centers, orc.DIST_L2)
+    want, _ = orc.kmeans_predict(data[order[:700]], centers, orc.DIST_L2)
+    assert (cl == want).all()                                  # first round: a datum keeps cluster 0 only if it is within s[0] of it, else it scans every center
     assert np.isfinite(stats).all() and stats[1] > 0
     for j in range(9):
         if (cl == j).sum() == 0:
