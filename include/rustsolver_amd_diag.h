@@ -28,7 +28,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
 int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels);
 
 /* ---- table checksum ----------------------------------------------------------------------------------------------------------------
- * out[0] / out[1] = sum over the cells i of regrets / strategy_sum (pitch padding included: it stays zero) of splitmix64(i ^ bits(cell_i) * 0x9E3779B97F4A7C15)
+ * out[0] / out[1] = sum over the REAL cells i of regrets / strategy_sum (pitch-padding lanes excluded) of splitmix64(i ^ bits(cell_i) * 0x9E3779B97F4A7C15)
  * mod 2^64: order-independent, so two tables of the same shape and layout hold the same bits iff (with overwhelming probability) the sums agree.
  * Synchronises.  Used to compare whole 135 GB tables (fused against level plan) without moving them to the host. */
 int rs_table_checksum(rs_table *table, uint64_t *out /*[2]*/);

@@ -129,7 +129,7 @@ hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, fl
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
 hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_t n, uint32_t A, size_t tile, size_t es, void *d_out, hipStream_t stream);
-hipError_t launch_checksum(const void *x, size_t n, size_t es, unsigned long long *d_out, hipStream_t stream);
+hipError_t launch_checksum(const void *x /* one node block */, size_t n, size_t cell_off, uint32_t A, size_t tile, size_t lanes, size_t es, unsigned long long *d_out, hipStream_t stream);
 hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream);      // d = snap - x; x = snap; snap = d
 
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
@@ -151,11 +151,12 @@ struct JitSubtree {
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
     size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
+    size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -585,12 +585,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_lanes(const E *__restrict__ b
     }
 }
 
-// order-independent checksum of an array of n cells (rs_table_checksum): sum of splitmix64(i ^ bits * GOLD)
+// order-independent checksum of the REAL cells of one node block (rs_table_checksum): sum of splitmix64(cell index ^ bits * GOLD); pitch-padding lanes are skipped
+// (kernels that walk only real lanes leave them at whatever the fill put there)
 template <typename E>
-__global__ __launch_bounds__(kBlock) void k_checksum(const E *__restrict__ x, size_t n, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_checksum(const E *__restrict__ x, size_t n, size_t cell_off, uint32_t A, uint32_t T, size_t lanes, unsigned long long *__restrict__ out) {
     unsigned long long acc = 0;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-        acc += splitmix64((uint64_t)i ^ ((uint64_t)x[i] * 0x9E3779B97F4A7C15ull));
+    const size_t tile_cells = (size_t)A * T;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const size_t lane = (i / tile_cells) * T + i % T;
+        if (lane < lanes) acc += splitmix64((uint64_t)(cell_off + i) ^ ((uint64_t)x[i] * 0x9E3779B97F4A7C15ull));
+    }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
@@ -789,10 +793,10 @@ hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_
     else hipLaunchKernelGGL((k_gather_lanes<uint16_t>), grid, block_, 0, stream, (const uint16_t *)block, d_lanes, n, A, (uint32_t)tile, (uint16_t *)d_out);
     return hipGetLastError();
 }
-hipError_t launch_checksum(const void *x, size_t n, size_t es, unsigned long long *d_out, hipStream_t stream) {
+hipError_t launch_checksum(const void *x, size_t n, size_t cell_off, uint32_t A, size_t tile, size_t lanes, size_t es, unsigned long long *d_out, hipStream_t stream) {
     dim3 grid(grid_for(n)), block_(kBlock);
-    if (es == 4) hipLaunchKernelGGL((k_checksum<uint32_t>), grid, block_, 0, stream, (const uint32_t *)x, n, d_out);
-    else hipLaunchKernelGGL((k_checksum<uint16_t>), grid, block_, 0, stream, (const uint16_t *)x, n, d_out);
+    if (es == 4) hipLaunchKernelGGL((k_checksum<uint32_t>), grid, block_, 0, stream, (const uint32_t *)x, n, cell_off, A, (uint32_t)tile, lanes, d_out);
+    else hipLaunchKernelGGL((k_checksum<uint16_t>), grid, block_, 0, stream, (const uint16_t *)x, n, cell_off, A, (uint32_t)tile, lanes, d_out);
     return hipGetLastError();
 }
 hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream) {

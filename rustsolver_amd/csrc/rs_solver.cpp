@@ -211,6 +211,7 @@ struct Builder {
     const std::vector<rs_tree_node> &nodes;
     std::vector<int> depth, lane_round;
     std::vector<char> has_own, closed, fused_root, inside;
+    std::vector<char> fan_root;       // fused root directly below an ENUM chance node whose deals its kernel walks itself (no expand / reduce launch, no child-round rows)
     std::vector<ReachSrc> reach;      // reach source feeding each node
     std::vector<size_t> util_off;     // arena offset of a node's util buffer (+1; 0 = none)
     std::vector<size_t> reach_off;    // arena offset of a node's own reach buffer (+1; 0 = alias / const)
@@ -322,6 +323,17 @@ struct Builder {
         if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
             fused_root[id] = 1;
             mark_inside(id);
+            // Directly below an ENUM chance node (cfr.rs:502-522) the subtree's kernel can take over the chance node's work.  Needs whole vectors per board
+            // (n_clusters % 4 == 0) and the node's deals in one contiguous [boards][C] block (not the chance node entering a SHARDED round, whose deals live
+            // in other ranks' slots).  RS_JIT_FAN: 0 = never; 1 (default) = the kernel scales the chance node's own incoming reach itself (no expand launch,
+            // no per-deal reach rows); 2 = it also walks the node's deals itself and sums them in order (no reduce launch, no per-deal rows at all: 7 GB
+            // less workspace at config-3 size, but measured 11 % slower there, so only on request)
+            const int par = nd.parent;
+            if (par >= 0 && chance_enum(nodes[par]) && !boundary(par) && s->n_clusters % 4 == 0 && !s->deal_mode) {
+                const char *fm = getenv("RS_JIT_FAN");
+                const int mode = fm ? atoi(fm) : 1;
+                if (mode == 1 || mode == 2) fan_root[id] = char(mode);
+            }
             return;
         }
         for (int k = 0; k < nd.n_children; ++k) mark_fused(nd.children[k]);
@@ -372,7 +384,7 @@ struct Builder {
     void layout(int id) {
         const rs_tree_node &nd = nodes[id];
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
-        if ((nd.kind == RS_NODE_ACTION && nd.n_children > 0) || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);
+        if (((nd.kind == RS_NODE_ACTION && nd.n_children > 0) && fan_root[id] != 2) || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);   // a deal-walking root returns through its chance node's row
         if (fused_root[id]) return;   // everything below lives in registers / LDS of k_subtree
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
@@ -441,6 +453,7 @@ struct Builder {
         has_own.assign(n, 0);
         closed.assign(n, 0);
         fused_root.assign(n, 0);
+        fan_root.assign(n, 0);
         inside.assign(n, 0);
         reach.assign(n, ReachSrc{});
         util_override.assign(n, nullptr);
@@ -490,6 +503,7 @@ struct Builder {
                 if (nodes[c].kind == RS_NODE_TERMINAL || !has_own[c]) continue;
                 if (reach_off[c]) reach_is_buf[c] = 1;
                 else if (chance_enum(nd)) {
+                    if (fan_root[c]) continue;   // its kernel reads the chance node's own incoming reach and scales it in registers
                     if (reach_is_buf[id]) {
                         reach_off[c] = alloc(lane_round[c]);
                         reach_is_buf[c] = 1;
@@ -543,7 +557,10 @@ struct Builder {
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below, round_mode ? &fused_root : nullptr, js);
+                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below, round_mode ? &fused_root : nullptr, js,
+                         int(fan_root[id]));
+        const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
+        const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
         if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
         auto bi = by_fn.find(fn);
@@ -577,12 +594,20 @@ struct Builder {
             put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
         }
         put_ptr(js.off_reach, reach[id].ptr);
-        put_ptr(js.off_out, uptr(id));
+        put_ptr(js.off_out, fan ? uptr(fan_par) : uptr(id));
         put_ptr(js.off_seed, s->d_seed());
         put_f32(js.off_reach_const, reach[id].cst);
         put_f32(js.off_scale, s->params.scale);
-        const uint32_t n_vec = uint32_t(s->pitch[lane_round[id]] / size_t(js.lanes));
+        // fan: one thread per 4 clusters of a PARENT board (n_clusters % 4 == 0: exactly lanes / 4 vectors, no padding lanes)
+        const uint32_t n_vec = fan ? uint32_t(size_t(s->n_boards[lane_round[fan_par]]) * s->n_clusters / 4)
+                               : (xfan ? uint32_t(size_t(s->n_boards[lane_round[id]]) * s->n_clusters / 4) : uint32_t(s->pitch[lane_round[id]] / size_t(js.lanes)));
         put_u32(js.off_n_vec, n_vec);
+        if (!s->deal_mode) {
+            const uint32_t f = fan_par >= 0 ? fan_of(fan_par) : 1u;
+            put_u32(js.off_fan, f);
+            put_f32(js.off_inv, 1.0f / float(f));   // the same f32 quotient k_chance_expand multiplies by
+            put_u32(js.off_cvec, s->n_clusters / 4);
+        }
         put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
         {   // every node of a fused subtree lives on one round: same lanes, same tiling
             const int n0 = nodes[size_t(js.node_ids.empty() ? id : js.node_ids[0])].index;
@@ -659,7 +684,9 @@ struct Builder {
         }
         JL.n_jobs += 1;
         JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
-        JL.bytes += (bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0)) / parts.first;
+        if (fan) JL.bytes += bytes + lanes(id) * 4.0 * js.leaf_terms.size() + lanes(fan_par) * ((reach[id].ptr ? 4.0 : 0.0) + 4.0);
+        else if (xfan) JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + 4.0) + lanes(fan_par) * (reach[id].ptr ? 4.0 : 0.0);
+        else JL.bytes += (bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0)) / parts.first;
         }   // parts
         return RS_OK;
     }
@@ -705,7 +732,9 @@ struct Builder {
                 for (int k = 0; k < nd.n_children; ++k) {
                     const int c = nd.children[k];
                     if (nodes[c].kind == RS_NODE_TERMINAL || !has_own[c]) continue;
-                    if (reach_off[c]) {
+                    if (fan_root[c]) {
+                        reach[c] = reach[id];   // the subtree's kernel multiplies by 1 / len itself (cfr.rs:510), once per deal
+                    } else if (reach_off[c]) {
                         reach[c] = ReachSrc{aptr(reach_off[c]), 0.0f, true};
                         any_child_buf = true;
                     } else if (chance_enum(nd)) {
@@ -900,6 +929,7 @@ struct Builder {
                 if (nd.kind == RS_NODE_ACTION) (nd.player == p ? upd_groups : util_groups)[nd.n_children].push_back(id);
                 else if (chance_enum(nd)) {
                     const int c = nd.children[0];
+                    if (fan_root[c] == 2) continue;   // the child's kernel sums its deals in order and writes this node's row itself (cfr.rs:519)
                     const ChildSrc src = child_source(c);
                     if (src.kind != CH_BUF) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: chance node above a terminal");
                     ChanceJob cj{};
@@ -926,9 +956,11 @@ struct Builder {
                 std::map<hipFunction_t, int> by_fn;
                 for (int id : sub_roots)
                     if (int rc = add_jit_job(id, false, sparse_slot, by_fn)) return rc;
+                const int group = by_fn.size() > 1 ? ++next_group : 0;   // the subtrees of one depth touch disjoint nodes and buffers: their launches may overlap
                 for (auto &kv : by_fn) {
                     Launch L;
                     L.kind = L_TREE;
+                    L.group = group;
                     L.first_job = kv.second;
                     L.bytes = plan.jit[kv.second].bytes;
                     plan.launches.push_back(L);
@@ -1252,7 +1284,8 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    if (s->deal_mode && s->params.fuse_subtrees && !getenv("RS_JIT_NO_OVERLAP")) {   // streams for independent round subtrees
+    // streams for independent round subtrees (deal sweeps) and, on request (RS_LANE_OVERLAP=1), for the independent subtree launches of one tree depth in lane sweeps
+    if (((s->deal_mode && !getenv("RS_JIT_NO_OVERLAP")) || (!s->deal_mode && getenv("RS_LANE_OVERLAP") && atoi(getenv("RS_LANE_OVERLAP")) != 0)) && s->params.fuse_subtrees) {
         e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
         for (int k = 0; e == hipSuccess && k < rs_solver::kAux; ++k) {
             e = hipStreamCreateWithFlags(&s->aux[k], hipStreamNonBlocking);
@@ -1478,11 +1511,15 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             const rs_tree_node &nd = nodes[i];
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
-            JitSubtree js;
-            jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, false, 4, nullptr, js);
-            if (seen.count(js.source)) continue;
-            seen[js.source] = 1;
-            if (int rc = jit_compile_only(js.source)) return rc;
+            for (int fan = 0; fan < 3; ++fan) {   // below a public chance node also the forms that take over the node's expand (1) and its deal loop (2)
+                if (fan && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
+                JitSubtree js;
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, false, 4, nullptr, js,
+                                 fan);
+                if (seen.count(js.source)) continue;
+                seen[js.source] = 1;
+                if (int rc = jit_compile_only(js.source)) return rc;
+            }
         }
     }
     if (n_kernels) *n_kernels = int(seen.size());

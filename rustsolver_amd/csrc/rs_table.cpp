@@ -386,8 +386,13 @@ int rs_table_checksum(rs_table *t, uint64_t *out) {
     unsigned long long *d = nullptr;
     hipError_t e = hipMalloc((void **)&d, 16);
     if (e == hipSuccess) e = hipMemsetAsync(d, 0, 16, t->stream);
-    if (e == hipSuccess) e = launch_checksum(t->d_regrets, t->n_cells, elem_size(t->dtype), d, t->stream);
-    if (e == hipSuccess) e = launch_checksum(t->d_ssum, t->n_cells, elem_size(t->dtype), d + 1, t->stream);
+    for (int n = 0; n < int(t->nodes.size()) && e == hipSuccess; ++n) {
+        const rs_node_desc &nd = t->nodes[size_t(n)];
+        if (nd.n_actions == 0) continue;
+        const size_t cells = t->pitch[size_t(n)] * nd.n_actions, lanes = size_t(nd.n_boards) * nd.n_clusters;
+        e = launch_checksum(t->regrets_ptr(n), cells, t->cell_off[size_t(n)], nd.n_actions, t->tile[size_t(n)], lanes, elem_size(t->dtype), d, t->stream);
+        if (e == hipSuccess) e = launch_checksum(t->ssum_ptr(n), cells, t->cell_off[size_t(n)], nd.n_actions, t->tile[size_t(n)], lanes, elem_size(t->dtype), d + 1, t->stream);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     if (d) (void)hipFree(d);

@@ -21,6 +21,6 @@ tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))
 K = int(os.environ.get("BATCHES", "20"))
 tr.train(5); tr.infosets.sync()
 best = 1e9
-for _ in range(5):
+for _ in range(int(os.environ.get("REPS", "5"))):
     t0 = time.perf_counter(); tr.train(K); tr.infosets.sync(); best = min(best, (time.perf_counter() - t0) / K * 1e3)
 print(os.environ.get("TAG", ""), "best %.3f ms/batch" % best)

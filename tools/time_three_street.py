@@ -29,5 +29,6 @@ t0 = time.perf_counter()
 tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE)
 print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.infosets.nbytes / 1e6 if not callable(tr.infosets.nbytes) else tr.infosets.nbytes() / 1e6))
 tr.train(2); tr.status()
-t0 = time.perf_counter(); tr.train(5); tr.infosets.sync(); dt = (time.perf_counter() - t0) / 5
+KB = int(os.environ.get("BATCHES", "5"))
+t0 = time.perf_counter(); tr.train(KB); tr.infosets.sync(); dt = (time.perf_counter() - t0) / KB
 print("three-street, %d clusters, %d deals per batch: %.2f ms per batch = %.3g deal-iterations/s" % (K, n, dt * 1e3, n / dt))
