@@ -128,7 +128,7 @@ def test_full_size_config3_sampled_clusters_match_oracle():
 
 def test_full_size_config5_f16_tables_twice_the_boards():
     """configs[4] on one GPU: binary16 regret / strategy tables with f32 arithmetic, 2x the boards in the same 135 GB"""
-    run_case([1, 98, 4704], 5000, [7, 4321], rs.F16, orc.T_F16, ((-2000, 2000), (0, 2000)), 1.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64, False)
+    run_case([1, 98, 4704], 5000, [7, 4321], rs.F16, orc.T_F16, ((-2000, 2000), (0, 2000)), 2.0 ** -12, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64, False)
 
 
 @pytest.mark.parametrize("fuse", [1, 0])
