@@ -27,6 +27,10 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
  * over a live-deal list, with and without LDS tiles */
 int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_kernels);
 
+/* ---- self-test of the short exact division regret matching uses on i32 tables (rs_device.hpp div_exact_pos) against the compiler's f32 division, on the device:
+ * n hashed (regret, sum) pairs; *mismatches must be 0.  first_bad (may be NULL): [2] = the first differing pair. */
+int rs_selftest_division(rs_table *table, size_t n, uint64_t seed, uint64_t *mismatches, float *first_bad);
+
 /* ---- table checksum ----------------------------------------------------------------------------------------------------------------
  * out[0] / out[1] = sum over the REAL cells i of regrets / strategy_sum (pitch-padding lanes excluded) of splitmix64(i ^ bits(cell_i) * 0x9E3779B97F4A7C15)
  * mod 2^64: order-independent, so two tables of the same shape and layout hold the same bits iff (with overwhelming probability) the sums agree.

@@ -104,6 +104,7 @@ SYMBOLS = {
     "rs_table_download_node": (C.c_int, [_P, C.c_int, _P, _P]),
     "rs_get_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rs_get_infosets": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, _P]),
+    "rs_selftest_division": (C.c_int, [_P, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "rs_table_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rs_set_infoset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rs_get_strategy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -277,6 +277,26 @@ __device__ __forceinline__ void mask_tail_lanes(float (&reach)[kVecD], unsigned 
         if (v * kVecD + j >= n_lanes) reach[j] = __builtin_nanf("");
 }
 
+// a / b, correctly rounded, for POSITIVE NORMAL a and b whose quotient is far from the f32 range limits (2^-96 < a / b < 2^96): the compiler's own f32 division
+// (v_div_scale x2, v_rcp, five fma, a mul, v_div_fmas, v_div_fixup) minus the three instructions that only matter outside that domain -- the scaling of operands
+// with extreme exponents and the fix-up of zeros / infinities / NaNs.  Same reciprocal, same Newton steps in the same order, hence the same bits as `a / b`
+// (rs_selftest_division compares the two on the device).  Regret matching on i32 tables divides a positive regret by the sum of the positive regrets: both are
+// integers in [1, 2^34] as floats, the quotient lies in [2^-34, 1].  Explicit fma calls are not contractions: -ffp-contract=off does not touch them.
+__device__ __forceinline__ float div_exact_pos(float a, float b) {
+#ifdef RS_NO_FAST_DIV
+    return a / b;
+#else
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+#endif
+}
+
 // ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
 template <int A, typename V>
 __device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {
@@ -285,8 +305,13 @@ __device__ __forceinline__ void regret_match(const V (&r)[A], float (&sig)[A]) {
     for (int a = 0; a < A; a++)
         if (r[a] > (V)0) norm += (float)r[a];
     const float uni = 1.0f / (float)A;
+    if constexpr (sizeof(V) == sizeof(int) && (V)0.5 == (V)0) {   // i32 regrets: positive integers over their positive sum (float tables keep the general division)
 #pragma unroll
-    for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
+        for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? div_exact_pos((float)r[a], norm) : 0.0f) : uni;
+    } else {
+#pragma unroll
+        for (int a = 0; a < A; a++) sig[a] = (norm > 0.0f) ? ((r[a] > (V)0) ? (float)r[a] / norm : 0.0f) : uni;
+    }
 }
 
 // ---- the traverser visit for one lane --------------------------------------------------------------

@@ -130,6 +130,7 @@ hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipS
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
 hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_t n, uint32_t A, size_t tile, size_t es, void *d_out, hipStream_t stream);
 hipError_t launch_checksum(const void *x /* one node block */, size_t n, size_t cell_off, uint32_t A, size_t tile, size_t lanes, size_t es, unsigned long long *d_out, hipStream_t stream);
+hipError_t launch_selftest_division(size_t n, uint64_t seed, unsigned long long *d_mismatches, float *d_first_bad, hipStream_t stream);
 hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream);      // d = snap - x; x = snap; snap = d
 
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------

@@ -599,6 +599,24 @@ __global__ __launch_bounds__(kBlock) void k_checksum(const E *__restrict__ x, si
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+// rs_selftest_division: div_exact_pos against the compiler's division on pairs (positive integer regret, positive sum >= it) drawn from a hash plus the edges
+__global__ __launch_bounds__(kBlock) void k_selftest_division(size_t n, uint64_t seed, unsigned long long *__restrict__ mismatches, float *__restrict__ first_bad) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const uint64_t h = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull)), g = splitmix64(h);
+        // a: an i32 regret as f32 (all magnitudes: the shift spreads the exponents); b: a sum of up to 8 such values, >= a
+        const float a = (float)(int)(((uint32_t)h >> ((g >> 8) % 31)) | 1u) ;
+        float extra = (float)(uint32_t)(g >> 32) * (float)((g >> 3) & 7u);
+        if ((i & 15) == 0) extra = 0.0f;                               // b == a: quotient 1
+        const float b = a + extra, want = a / b, got = div_exact_pos(a, b);
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            if (atomicAdd(mismatches, 1ull) == 0) {
+                first_bad[0] = a;
+                first_bad[1] = b;
+            }
+        }
+    }
+}
+
 // d = snap - x;  x = snap;  snap = d: every rank restarts from the bit-identical snapshot (x + (snap - x) is NOT snap in f32, and its rounding error depends on the rank's own x)
 template <int DT>
 __global__ __launch_bounds__(kBlock) void k_delta_swap(void *__restrict__ x, void *__restrict__ snap, size_t n) {
@@ -797,6 +815,10 @@ hipError_t launch_checksum(const void *x, size_t n, size_t cell_off, uint32_t A,
     dim3 grid(grid_for(n)), block_(kBlock);
     if (es == 4) hipLaunchKernelGGL((k_checksum<uint32_t>), grid, block_, 0, stream, (const uint32_t *)x, n, cell_off, A, (uint32_t)tile, lanes, d_out);
     else hipLaunchKernelGGL((k_checksum<uint16_t>), grid, block_, 0, stream, (const uint16_t *)x, n, cell_off, A, (uint32_t)tile, lanes, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_selftest_division(size_t n, uint64_t seed, unsigned long long *d_mismatches, float *d_first_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selftest_division, dim3(grid_for(n)), dim3(kBlock), 0, stream, n, seed, d_mismatches, d_first_bad);
     return hipGetLastError();
 }
 hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream) {

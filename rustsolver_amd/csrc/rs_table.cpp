@@ -380,6 +380,25 @@ int rs_get_infosets(rs_table *t, int node, const uint32_t *lanes, size_t n, void
     return RS_OK;
 }
 
+// div_exact_pos (rs_device.hpp: the division of regret matching on i32 tables without the scale / fix-up instructions) against the compiler's `a / b` on n hashed
+// pairs from its domain: *mismatches must come back 0; first_bad (may be NULL) = the first differing (a, b)
+int rs_selftest_division(rs_table *t, size_t n, uint64_t seed, uint64_t *mismatches, float *first_bad) {
+    if (!t || !mismatches) return fail(RS_ERR_INVALID, "rs_selftest_division: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    char *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, 16, t->stream);
+    if (e == hipSuccess) e = launch_selftest_division(n, seed, (unsigned long long *)d, (float *)(d + 8), t->stream);
+    char host[16] = {0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, d, 16, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (d) (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "rs_selftest_division");
+    std::memcpy(mismatches, host, 8);
+    if (first_bad) std::memcpy(first_bad, host + 8, 8);
+    return RS_OK;
+}
+
 int rs_table_checksum(rs_table *t, uint64_t *out) {
     if (!t || !out) return fail(RS_ERR_INVALID, "rs_table_checksum: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");

@@ -238,3 +238,16 @@ def test_stale_jit_cache_is_recompiled(tmp_path):
     assert [ln for ln in first.stdout.splitlines() if ln.startswith("UTIL")] == [ln for ln in second.stdout.splitlines() if ln.startswith("UTIL")]
     for f in blobs:
         assert os.path.getsize(os.path.join(tmp_path, f)) > 1000, "the unusable blob must have been replaced by a fresh compile"
+
+
+def test_short_division_of_regret_matching_equals_the_compilers():
+    """regret matching on i32 tables divides with div_exact_pos (rs_device.hpp): the compiler's f32 division minus the operand scaling and the special-case fix-up,
+    valid for positive normal operands -- 2^28 hashed (regret, sum of positive regrets) pairs must give the same bits as `a / b` on the device"""
+    import ctypes as C
+    n, tree = rs.build_game_tree(rs.default_flop())
+    table = rs.create_infosets(n, tree, [4], [1])
+    bad, first = C.c_uint64(123), (C.c_float * 2)()
+    for seed in (1, 2):
+        L.check(L.load().rs_selftest_division(table._h, 1 << 28, seed, C.byref(bad), first))
+        assert bad.value == 0, "div_exact_pos differs from a / b, first at a = %r b = %r" % (first[0], first[1])
+    table.destroy()
