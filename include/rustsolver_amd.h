@@ -203,6 +203,16 @@ int rs_calc_br(rs_table *table, const rs_tree *tree, float *out /*[2]*/);
 enum { RS_BR_MAX = 0, RS_BR_AVERAGE = 1 };
 int rs_best_response(rs_table *table, const rs_tree *tree, const uint8_t *board, const uint8_t *hands_p0, size_t n_hands_p0, const uint32_t *cluster_p0,
                      const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *cluster_p1, int mode, double *out /*[2]*/);
+/* The same over MULTI-ROUND trees (flop or turn start).  A lane is (run-out b, hand h): generate_hand (cfr.rs:100-143) completes the board to five cards first --
+ * ordered sequences without replacement, uniform -- then draws the hands; every showdown compares seven-card hands on the full board and chance nodes pass through
+ * (cfr.rs:306-313).  cluster[r * 2 + p] (HOST) = dense cluster ids of player p in betting round r, [prefixes of round r][n_hands_p]: the prefix of a run-out is its
+ * first r new cards, prefixes and run-outs enumerated with the first new card most significant, cards ascending among those still in the deck (rs_br_runouts writes
+ * the run-outs, [NB][5], and returns NB = 1, 48 or 2 352); entries of (prefix, hand) pairs that share a card are ignored.  RS_BR_MAX: at each of p's nodes every cluster
+ * takes the action with the largest SUM of its lanes' counterfactual values over all run-outs and hands -- the best response inside the abstraction when it has perfect
+ * recall, otherwise the value of a valid pure strategy of the abstracted game (a lower bound).  f64, fixed-order sums; synchronises. */
+int rs_best_response_rounds(rs_table *table, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0,
+                            const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, int mode, double *out /*[2]*/);
+size_t rs_br_runouts(const uint8_t *board0, int n_board0, uint8_t *out_cards /* [NB][5], may be NULL */);
 
 /* One traverser visit of every lane of `node` (cfr.rs:370-466 / :571-623):
  *   sigma = get_strategy(); util = sum_a utils[a]*sigma[a]; regrets / strategy_sum updated with

@@ -232,3 +232,221 @@ int orc_best_response(const orc_tree *tree, const orc_table *tb, const uint8_t *
     for (p = 0; p < 2; p++) { free(c.mask[p]); free(c.score[p]); }
     return 0;
 }
+
+/* ---- best response over MULTI-ROUND trees (the reader train() would need at cfr.rs:244-246 for a flop- or turn-start game) -------------
+ * The same vector walk as orc_best_response with one change of index: a LANE is (run-out b, hand h) instead of a hand.  generate_hand (cfr.rs:100-143) completes the
+ * board to five cards BEFORE the hands are drawn -- K = 5 - n_board0 new cards, uniform over ORDERED sequences without replacement (the first one is the turn of a
+ * flop start), so P(B) = 1 / (D (D-1) ..) with D = 52 - n_board0 -- then player 0's combo uniformly among its range's combos that avoid the FULL board, then
+ * player 1's among those that avoid board and player 0:  P(B, h0, h1) = P(B) [h0, h1, B disjoint] / (N0(B) N1(B, h0)).  Every showdown -- also an all-in on the flop --
+ * compares the seven-card hands on the full board (cfr.rs:323-347: hand.get_hand uses all of hand.board), and chance nodes pass through (one run-out per deal,
+ * cfr.rs:306-313).  So every node carries vectors over ALL NB x n lanes; what changes from round to round is only the cluster id a lane is looked up under:
+ * cid[r][p][prefix_r(b) * n_p + h], prefix_r(b) = b / (completions left after r new cards) = the index of the first r new cards, run-outs enumerated with the first new
+ * card most significant, cards ascending among those still in the deck.
+ * mode 0: at each of p's nodes every cluster takes the action with the largest SUM of its lanes' counterfactual values (all run-outs, all hands: a best response inside
+ * the abstraction when the abstraction has perfect recall; in general the value of a valid pure strategy of the abstracted game, i.e. a lower bound on it);
+ * mode 1: p plays its own average strategy.  f64, every sum in ascending lane / action order.  PARITY UNPINNED (the reference has nothing of the kind). */
+typedef struct {
+    const orc_tree *tree;
+    const orc_table *tb;
+    int mode, p, n_rounds;
+    size_t n[2], NB;
+    size_t per_prefix[ORC_MAX_ROUNDS];          /* run-outs per distinct board prefix of round r */
+    const uint32_t *cid[ORC_MAX_ROUNDS][2];
+    const uint64_t *hmask[2];
+    const uint64_t *bmask;                      /* [NB] the new cards of a run-out */
+    uint32_t *score[2];                         /* [NB * n_p] */
+    double *pw[2];                              /* [NB * n_p] traverser weights */
+} brr_ctx;
+
+static size_t brr_cluster(const brr_ctx *c, int r, int pl, size_t b, size_t h) { return c->cid[r][pl][(b / c->per_prefix[r]) * c->n[pl] + h]; }
+
+static void brr_walk(const brr_ctx *c, int node_id, const double *q, double *v) {
+    const orc_node *n = &c->tree->nodes[node_id];
+    const int p = c->p, o = 1 - c->p;
+    const size_t np = c->n[p], no = c->n[o], NB = c->NB;
+    size_t b, h, g;
+    int a;
+    if (n->kind == ORC_TERMINAL) {
+        const double pot = (double)(float)n->value;
+        for (b = 0; b < NB; b++)
+            for (h = 0; h < np; h++) {
+                double acc = 0.0;
+                const uint64_t mine = c->hmask[p][h];
+                if (mine & c->bmask[b]) { v[b * np + h] = 0.0; continue; }      /* the hand uses a card of this run-out: no such deal */
+                for (g = 0; g < no; g++) {
+                    double u;
+                    const uint64_t theirs = c->hmask[o][g];
+                    if ((theirs & c->bmask[b]) || (theirs & mine)) continue;
+                    if (n->ttype == ORC_UNCONTESTED) u = (p == (int)n->last_to_act) ? -pot : pot;                                       /* cfr.rs:316-322 */
+                    else u = c->score[p][b * np + h] > c->score[o][b * no + g] ? pot : (c->score[p][b * np + h] < c->score[o][b * no + g] ? -pot : 0.0);
+                    acc += q[b * no + g] * u;
+                }
+                v[b * np + h] = c->pw[p][b * np + h] * acc;
+            }
+        return;
+    }
+    if (n->kind != ORC_ACTION) {
+        brr_walk(c, n->children[0], q, v);
+        return;
+    }
+    {
+        const int A = n->n_children, r = n->round_idx;
+        double *vch = (double *)malloc((size_t)A * NB * np * sizeof(double));
+        float sig[ORC_MAX_ACTIONS];
+        if ((int)n->player == p) {
+            for (a = 0; a < A; a++) brr_walk(c, n->children[a], q, vch + (size_t)a * NB * np);
+            if (c->mode == 0) {
+                const size_t n_clusters = c->tb->row_len[n->index];
+                double *s = (double *)calloc(n_clusters * (size_t)A, sizeof(double));
+                for (a = 0; a < A; a++)
+                    for (b = 0; b < NB; b++)
+                        for (h = 0; h < np; h++) s[brr_cluster(c, r, p, b, h) * A + a] += vch[(size_t)a * NB * np + b * np + h];
+                for (b = 0; b < NB; b++)
+                    for (h = 0; h < np; h++) {
+                        const size_t k = brr_cluster(c, r, p, b, h);
+                        int best = 0;
+                        for (a = 1; a < A; a++)
+                            if (s[k * A + best] < s[k * A + a]) best = a;
+                        v[b * np + h] = vch[(size_t)best * NB * np + b * np + h];
+                    }
+                free(s);
+            } else {
+                for (b = 0; b < NB; b++)
+                    for (h = 0; h < np; h++) {
+                        double acc = 0.0;
+                        final_strategy_of(c->tb, n->index, brr_cluster(c, r, p, b, h), sig);
+                        for (a = 0; a < A; a++) acc += (double)sig[a] * vch[(size_t)a * NB * np + b * np + h];
+                        v[b * np + h] = acc;
+                    }
+            }
+        } else {
+            double *qch = (double *)malloc((size_t)A * NB * no * sizeof(double));
+            for (b = 0; b < NB; b++)
+                for (g = 0; g < no; g++) {
+                    final_strategy_of(c->tb, n->index, brr_cluster(c, r, o, b, g), sig);
+                    for (a = 0; a < A; a++) qch[(size_t)a * NB * no + b * no + g] = q[b * no + g] * (double)sig[a];
+                }
+            for (a = 0; a < A; a++) brr_walk(c, n->children[a], qch + (size_t)a * NB * no, vch + (size_t)a * NB * np);
+            for (b = 0; b < NB; b++)
+                for (h = 0; h < np; h++) {
+                    double acc = 0.0;
+                    for (a = 0; a < A; a++) acc += vch[(size_t)a * NB * np + b * np + h];
+                    v[b * np + h] = acc;
+                }
+            free(qch);
+        }
+        free(vch);
+    }
+}
+
+/* the run-outs of a board with n_board0 cards: out_cards[NB][5] (the initial cards first, in the order given), returns NB */
+size_t orc_br_runouts(const uint8_t *board0, int n_board0, uint8_t *out_cards) {
+    uint8_t deck[52];
+    int D = 0, i, j, k, c;
+    const int K = 5 - n_board0;
+    size_t nb = 0;
+    for (c = 0; c < 52; c++) {
+        int used = 0;
+        for (i = 0; i < n_board0; i++) used |= board0[i] == c;
+        if (!used) deck[D++] = (uint8_t)c;
+    }
+    if (K == 0) {
+        if (out_cards) memcpy(out_cards, board0, 5);
+        return 1;
+    }
+    for (i = 0; i < D; i++) {
+        if (K == 1) {
+            if (out_cards) { memcpy(out_cards + nb * 5, board0, (size_t)n_board0); out_cards[nb * 5 + 4] = deck[i]; }
+            nb++;
+            continue;
+        }
+        for (j = 0; j < D; j++) {
+            if (j == i) continue;
+            if (out_cards) {
+                for (k = 0; k < n_board0; k++) out_cards[nb * 5 + k] = board0[k];
+                out_cards[nb * 5 + 3] = deck[i];
+                out_cards[nb * 5 + 4] = deck[j];
+            }
+            nb++;
+        }
+    }
+    return nb;
+}
+
+int orc_best_response_rounds(const orc_tree *tree, const orc_table *tb, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n0,
+                             const uint8_t *hands_p1, size_t n1, const uint32_t *const *cid /* [n_rounds * 2]: [r * 2 + p] -> [prefixes_r][n_p] */, int n_rounds,
+                             int mode, double *out) {
+    brr_ctx c;
+    const uint8_t *hands[2];
+    const int K = 5 - n_board0, D = 52 - n_board0;
+    uint8_t *cards;
+    uint64_t *bmask, *hm[2];
+    double *w0, *ones, *q0, *v;
+    size_t NB, b, h, g;
+    int p, r, i;
+    if (n_board0 < 3 || n_board0 > 5 || n_rounds < 1 || n_rounds > K + 1) return -1;
+    memset(&c, 0, sizeof c);
+    NB = orc_br_runouts(board0, n_board0, NULL);
+    cards = (uint8_t *)malloc(NB * 5);
+    orc_br_runouts(board0, n_board0, cards);
+    c.tree = tree; c.tb = tb; c.mode = mode; c.n_rounds = n_rounds; c.NB = NB;
+    c.n[0] = n0; c.n[1] = n1;
+    hands[0] = hands_p0; hands[1] = hands_p1;
+    for (r = 0; r < n_rounds; r++) {   /* completions left after r new cards: P(D - r, K - r) */
+        size_t left = 1;
+        for (i = r; i < K; i++) left *= (size_t)(D - i);
+        c.per_prefix[r] = left;
+        c.cid[r][0] = cid[r * 2];
+        c.cid[r][1] = cid[r * 2 + 1];
+    }
+    bmask = (uint64_t *)malloc(NB * sizeof(uint64_t));
+    for (b = 0; b < NB; b++) {
+        bmask[b] = 0;
+        for (i = n_board0; i < 5; i++) bmask[b] |= 1ull << cards[b * 5 + i];
+    }
+    c.bmask = bmask;
+    for (p = 0; p < 2; p++) {
+        hm[p] = (uint64_t *)malloc(c.n[p] * sizeof(uint64_t));
+        c.score[p] = (uint32_t *)malloc(NB * c.n[p] * sizeof(uint32_t));
+        for (h = 0; h < c.n[p]; h++) hm[p][h] = (1ull << hands[p][2 * h]) | (1ull << hands[p][2 * h + 1]);
+        for (b = 0; b < NB; b++)
+            for (h = 0; h < c.n[p]; h++) {
+                uint8_t c7[7];
+                c7[0] = hands[p][2 * h]; c7[1] = hands[p][2 * h + 1];
+                for (i = 0; i < 5; i++) c7[2 + i] = cards[b * 5 + i];
+                c.score[p][b * c.n[p] + h] = (hm[p][h] & bmask[b]) ? 0u : orc_evaluate7(c7);
+            }
+        c.hmask[p] = hm[p];
+    }
+    /* the deal distribution: weight of (b, h0), everything player 1 contributes is 1 */
+    w0 = (double *)malloc(NB * n0 * sizeof(double));
+    ones = (double *)malloc(NB * n1 * sizeof(double));
+    {
+        double pb = 1.0;
+        for (i = 0; i < K; i++) pb /= (double)(D - i);
+        for (b = 0; b < NB; b++) {
+            size_t cnt0 = 0;
+            for (h = 0; h < n0; h++) cnt0 += (hm[0][h] & bmask[b]) == 0;
+            for (h = 0; h < n0; h++) {
+                size_t cnt1 = 0;
+                if (hm[0][h] & bmask[b]) { w0[b * n0 + h] = 0.0; continue; }
+                for (g = 0; g < n1; g++) cnt1 += ((hm[1][g] & bmask[b]) == 0) && ((hm[1][g] & hm[0][h]) == 0);
+                w0[b * n0 + h] = cnt1 ? pb / ((double)cnt0 * (double)cnt1) : 0.0;
+            }
+            for (g = 0; g < n1; g++) ones[b * n1 + g] = 1.0;
+        }
+    }
+    c.pw[0] = w0; c.pw[1] = ones;
+    v = (double *)malloc(NB * (n0 > n1 ? n0 : n1) * sizeof(double));
+    for (p = 0; p < 2; p++) {
+        double total = 0.0;
+        c.p = p;
+        q0 = p == 0 ? ones : w0;
+        brr_walk(&c, 0, q0, v);
+        for (b = 0; b < NB * c.n[p]; b++) total += v[b];
+        out[p] = total;
+    }
+    free(v); free(w0); free(ones); free(bmask); free(cards);
+    for (p = 0; p < 2; p++) { free(hm[p]); free(c.score[p]); }
+    return 0;
+}

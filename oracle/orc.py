@@ -410,6 +410,21 @@ class OracleTable:
                                 c1.ctypes.data, mode, out.ctypes.data)
         return out
 
+    def best_response_rounds(self, board0, hands0, hands1, cids, mode=0):
+        """multi-round best response (best_response.c orc_best_response_rounds): cids[r][p] = uint32 [prefixes of round r][n_p] dense cluster ids"""
+        b0 = np.ascontiguousarray(board0, dtype=np.uint8)
+        h0, h1 = np.ascontiguousarray(hands0, dtype=np.uint8), np.ascontiguousarray(hands1, dtype=np.uint8)
+        keep = [np.ascontiguousarray(cids[r][p], dtype=np.uint32) for r in range(len(cids)) for p in (0, 1)]
+        arr = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        out = np.zeros(2, dtype=np.float64)
+        fn = lib().orc_best_response_rounds
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(Tree), C.POINTER(Table), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        rc = fn(C.byref(self.tree.t), C.byref(self.tb), b0.ctypes.data, len(b0), h0.ctypes.data, len(h0), h1.ctypes.data, len(h1), arr, len(cids), mode, out.ctypes.data)
+        if rc != 0:
+            raise ValueError("orc_best_response_rounds: bad arguments")
+        return out
+
     def __del__(self):
         try:
             lib().orc_table_free(C.byref(self.tb))
@@ -716,6 +731,18 @@ def update_min_dists(min_dists, dataset, new_center, kind=DIST_EMD):
     assert min_dists.dtype == np.float32 and min_dists.flags.c_contiguous
     lib().orc_update_min_dists(kind, _f32(min_dists), _f32(d), len(d), _f32(c), d.shape[1])
     return min_dists
+
+
+def br_runouts(board0):
+    """the run-outs of an initial board, in the enumeration order of the multi-round best response: uint8 [NB][5]"""
+    b0 = np.ascontiguousarray(board0, dtype=np.uint8)
+    fn = lib().orc_br_runouts
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    nb = fn(b0.ctypes.data, len(b0), None)
+    out = np.zeros((nb, 5), dtype=np.uint8)
+    fn(b0.ctypes.data, len(b0), out.ctypes.data)
+    return out
 
 
 # ---- k-means training loops (kmeans_fit.c) -----------------------------------------------------------------------------------------------

@@ -196,6 +196,8 @@ SYMBOLS = {
     "rs_kmeans_predict": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
     "rs_update_min_dists": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     "rs_showdown_sign": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "rs_best_response_rounds": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "rs_br_runouts": (C.c_size_t, [_P, C.c_int, _P]),
     "rs_kmeans_init_s": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P]),
     "rs_kmeans_reassign": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P, _P]),
     "rs_kmeans_fit_regular": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_float)]),

@@ -278,15 +278,94 @@ int rs_calc_br(rs_table *t, const rs_tree *tree, float *out) {
 }  // extern "C"
 
 // ---- best response proper -----------------------------------------------------------------------------------------------
+// Lanes are (run-out b, hand h), lane = b * n_hands + h: generate_hand (cfr.rs:100-143) completes the board to five cards before it draws the hands, every showdown
+// compares seven-card hands on the FULL board and chance nodes pass through (cfr.rs:306-313), so every node carries vectors over all NB * n lanes; the betting round
+// of a node only selects which cluster id a lane is looked up under.  A single-round game on a full board is NB = 1.
 namespace rs {
 
+// seven-card scores of every lane (0 where the hand uses a card of the run-out: no such deal)
+__global__ __launch_bounds__(kBrBlock) void k_lane_scores(const uint8_t *__restrict__ hands /*[n][2]*/, uint32_t n, const uint8_t *__restrict__ boards /*[NB][5]*/, uint32_t n_board0,
+                                                          uint32_t NB, uint32_t *__restrict__ score) {
+    const size_t lane = (size_t)blockIdx.x * kBrBlock + threadIdx.x;
+    if (lane >= (size_t)NB * n) return;
+    const uint32_t b = (uint32_t)(lane / n), h = (uint32_t)(lane - (size_t)b * n);
+    const uint32_t c0 = hands[2 * h], c1 = hands[2 * h + 1];
+    uint32_t m[4] = {0, 0, 0, 0};
+    bool blocked = false;
+    for (uint32_t i = 0; i < 5; i++) {
+        const uint32_t c = boards[b * 5 + i];
+        add_card(m, c);
+        if (i >= n_board0 && (c == c0 || c == c1)) blocked = true;
+    }
+    add_card(m, c0);
+    add_card(m, c1);
+    score[lane] = blocked ? 0u : evaluate_suits(m);
+}
+
+// the deal distribution: w0[b, h0] = P(B) / (N0(B) * N1(B, h0)) (0 for a blocked lane or when no h1 fits)
+__global__ __launch_bounds__(kBrBlock) void k_br_weights(const uint64_t *__restrict__ mask0, uint32_t n0, const uint64_t *__restrict__ mask1, uint32_t n1,
+                                                         const uint64_t *__restrict__ bmask, const uint32_t *__restrict__ cnt0, uint32_t NB, double pb,
+                                                         double *__restrict__ w0) {
+    const size_t lane = (size_t)blockIdx.x * kBrBlock + threadIdx.x;
+    if (lane >= (size_t)NB * n0) return;
+    const uint32_t b = (uint32_t)(lane / n0), h = (uint32_t)(lane - (size_t)b * n0);
+    const uint64_t mine = mask0[h], bm = bmask[b];
+    if (mine & bm) {
+        w0[lane] = 0.0;
+        return;
+    }
+    uint32_t cnt1 = 0;
+    for (uint32_t g = 0; g < n1; g++) cnt1 += ((mask1[g] & bm) == 0 && (mask1[g] & mine) == 0) ? 1u : 0u;
+    w0[lane] = cnt1 ? pb / ((double)cnt0[b] * (double)cnt1) : 0.0;
+}
+
+// terminal: v[b, hp] = pw[b, hp] * sum over the opponent's hands ho of the SAME run-out that share no card with hp or the run-out, ascending, of q[b, ho] * u;
+// u as the trainer's leaves (cfr.rs:314-348).  One workgroup = up to 256 hands of one run-out; the opponent's side of that run-out is staged in LDS.
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
+                                                                 uint32_t n_p, const uint64_t *__restrict__ mask_o, const uint32_t *__restrict__ score_o,
+                                                                 const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, int uncontested,
+                                                                 double value, double *__restrict__ v) {
+    extern __shared__ unsigned char br_lds[];
+    double *lq = (double *)br_lds;
+    uint64_t *lm = (uint64_t *)(lq + n_o);
+    uint32_t *ls = (uint32_t *)(lm + n_o);
+    const uint32_t b = blockIdx.y;
+    const uint64_t bm = bmask[b];
+    for (uint32_t g = threadIdx.x; g < n_o; g += kBrBlock) {
+        lq[g] = q[(size_t)b * n_o + g];
+        lm[g] = mask_o[g];
+        ls[g] = score_o[(size_t)b * n_o + g];
+    }
+    __syncthreads();
+    const uint32_t hp = blockIdx.x * kBrBlock + threadIdx.x;
+    if (hp >= n_p) return;
+    const size_t lane = (size_t)b * n_p + hp;
+    const uint64_t mp = mask_p[hp];
+    if (mp & bm) {
+        v[lane] = 0.0;
+        return;
+    }
+    const uint32_t sp = score_p[lane];
+    const uint64_t avoid = mp | bm;
+    double acc = 0.0;
+    for (uint32_t ho = 0; ho < n_o; ho++) {
+        if (lm[ho] & avoid) continue;
+        const uint32_t so = ls[ho];
+        const double u = uncontested ? value : (sp > so ? value : (sp < so ? -value : 0.0));
+        acc += lq[ho] * u;
+    }
+    v[lane] = pw[lane] * acc;
+}
+
 struct BrSide {
-    uint32_t n = 0, n_pad = 0, n_clusters = 0;
-    uint8_t *d_hands = nullptr;
-    uint64_t *d_mask = nullptr;
-    uint32_t *d_score = nullptr, *d_cid = nullptr, *d_start = nullptr, *d_order = nullptr;
-    double *d_init_q = nullptr;   // this side's hands as the OPPONENT's initial reach (its share of the deal probability)
-    double *d_pw = nullptr;       // this side's hands as the TRAVERSER's weight
+    uint32_t n_hands = 0;
+    uint32_t n = 0, n_pad = 0;     // lanes = NB * n_hands
+    uint32_t n_clusters[RS_MAX_ROUNDS] = {0, 0, 0};
+    uint64_t *d_mask = nullptr;    // [n_hands]
+    uint32_t *d_score = nullptr;   // [n]
+    uint32_t *d_cid[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_start[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_order[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
+    double *d_init_q = nullptr;    // this side's lanes as the OPPONENT's initial reach (its share of the deal probability)
+    double *d_pw = nullptr;        // this side's lanes as the TRAVERSER's weight
 };
 
 struct BrRun {
@@ -294,9 +373,11 @@ struct BrRun {
     const rs_tree *tree = nullptr;
     int mode = RS_BR_MAX;
     int p = 0;
+    uint32_t NB = 1;
+    uint64_t *d_bmask = nullptr;
     BrSide side[2];
     std::vector<void *> allocs;
-    std::vector<double *> q_level, v_level;   // per tree depth: [RS_MAX_ACTIONS][n_pad] children buffers
+    std::vector<double *> q_level, v_level;   // per tree depth: [max actions][n_pad] children buffers
     hipError_t err = hipSuccess;
 
     template <typename T> T *dalloc(size_t n) {
@@ -322,25 +403,27 @@ struct BrRun {
             const int unc = n.ttype == RS_TERM_UNCONTESTED;
             const double pot = double(float(n.value));   // tn.value as f32 (cfr.rs:316)
             const double value = unc ? (p == int(n.last_to_act) ? -pot : pot) : pot;
-            hipLaunchKernelGGL(k_br_terminal, dim3(grid1(me.n)), dim3(kBrBlock), 0, t->stream, me.d_mask, me.d_score, me.d_pw, me.n, op.d_mask, op.d_score, q, op.n,
-                               unc, value, v_out);
+            const size_t lds = size_t(op.n_hands) * (sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t));
+            hipLaunchKernelGGL(k_br_terminal_boards, dim3(grid1(me.n_hands), NB), dim3(kBrBlock), lds, t->stream, me.d_mask, me.d_score, me.d_pw, me.n_hands, op.d_mask,
+                               op.d_score, q, op.n_hands, d_bmask, unc, value, v_out);
             err = hipGetLastError();
             return;
         }
-        if (n.kind != RS_NODE_ACTION) return walk(n.children[0], q, v_out, level);   // the private-chance root
+        if (n.kind != RS_NODE_ACTION) return walk(n.children[0], q, v_out, level);   // chance nodes pass through (cfr.rs:306-313)
         const BrNodeRow row = row_of(t, n.index);
+        const int r = n.round_idx;
         double *vch = v_level[size_t(level)];
         if (int(n.player) == p) {
             for (int a = 0; a < n.n_children; ++a) walk(n.children[a], q, vch + size_t(a) * me.n_pad, level + 1);
             if (err != hipSuccess) return;
-#define RS_OWN(DT_)                                                                                                                                      \
-    hipLaunchKernelGGL((k_br_own<DT_>), dim3(grid1(me.n_clusters)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, me.d_start, me.d_order, me.n_clusters, \
+#define RS_OWN(DT_)                                                                                                                                            \
+    hipLaunchKernelGGL((k_br_own<DT_>), dim3(grid1(me.n_clusters[r])), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, me.d_start[r], me.d_order[r], me.n_clusters[r], \
                        me.n_pad, vch, mode, v_out)
             RS_BR_DT(t->dtype, RS_OWN);
 #undef RS_OWN
         } else {
             double *qch = q_level[size_t(level)];
-#define RS_OPP(DT_) hipLaunchKernelGGL((k_br_opp_reach<DT_>), dim3(grid1(op.n)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, op.d_cid, op.n, op.n_pad, q, qch)
+#define RS_OPP(DT_) hipLaunchKernelGGL((k_br_opp_reach<DT_>), dim3(grid1(op.n)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, op.d_cid[r], op.n, op.n_pad, q, qch)
             RS_BR_DT(t->dtype, RS_OPP);
 #undef RS_OPP
             err = hipGetLastError();
@@ -356,38 +439,79 @@ static int tree_depth(const std::vector<rs_tree_node> &nodes, int id) {
     const rs_tree_node &n = nodes[size_t(id)];
     int d = 0;
     for (int a = 0; a < n.n_children; ++a) d = std::max(d, tree_depth(nodes, n.children[a]));
-    return d + 1;
+    return d + (n.kind == RS_NODE_ACTION ? 1 : 0);   // only action nodes take a level of child buffers
+}
+
+// run-outs of an initial board in the enumeration order of the lanes: the first new card most significant, cards ascending among those still in the deck
+static size_t enumerate_runouts(const uint8_t *board0, int n_board0, std::vector<uint8_t> *out) {
+    uint8_t deck[52];
+    int D = 0;
+    for (int c = 0; c < 52; ++c) {
+        bool used = false;
+        for (int i = 0; i < n_board0; ++i) used = used || board0[i] == c;
+        if (!used) deck[D++] = uint8_t(c);
+    }
+    const int K = 5 - n_board0;
+    size_t nb = 0;
+    auto emit = [&](int c3, int c4) {
+        if (out) {
+            uint8_t row[5];
+            for (int k = 0; k < n_board0; ++k) row[k] = board0[k];
+            if (K == 2) row[3] = uint8_t(c3);
+            if (K >= 1) row[4] = uint8_t(c4);
+            out->insert(out->end(), row, row + 5);
+        }
+        ++nb;
+    };
+    if (K == 0) emit(0, 0);
+    else if (K == 1)
+        for (int i = 0; i < D; ++i) emit(0, deck[i]);
+    else
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j)
+                if (j != i) emit(deck[i], deck[j]);
+    return nb;
 }
 
 }  // namespace rs
 
 extern "C" {
 
-int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, const uint8_t *hands_p0, size_t n_hands_p0, const uint32_t *cluster_p0,
-                     const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *cluster_p1, int mode, double *out) {
-    if (!t || !tree || !board || !hands_p0 || !hands_p1 || !cluster_p0 || !cluster_p1 || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+size_t rs_br_runouts(const uint8_t *board0, int n_board0, uint8_t *out_cards) {
+    if (!board0 || n_board0 < 3 || n_board0 > 5) return 0;
+    std::vector<uint8_t> cards;
+    const size_t nb = enumerate_runouts(board0, n_board0, out_cards ? &cards : nullptr);
+    if (out_cards) std::memcpy(out_cards, cards.data(), cards.size());
+    return nb;
+}
+
+int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
+                            size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, int mode, double *out) {
+    if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
     if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE");
     if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_best_response: empty tree");
+    if (n_board0 < 3 || n_board0 > 5) return fail(RS_ERR_INVALID, "rs_best_response: the initial board has 3, 4 or 5 cards (state.rs:59-64)");
+    const int K = 5 - n_board0, D = 52 - n_board0;
+    if (n_rounds < 1 || n_rounds > K + 1 || n_rounds > RS_MAX_ROUNDS) return fail(RS_ERR_INVALID, "rs_best_response: 1 .. (6 - board cards) betting rounds");
     if (n_hands_p0 == 0 || n_hands_p1 == 0 || n_hands_p0 > 1326 || n_hands_p1 > 1326) return fail(RS_ERR_INVALID, "rs_best_response: 1..1326 hands per range");
     if (int rc = check_tree_against_table(t, tree, "rs_best_response")) return rc;
-    uint32_t n_clusters[2] = {0, 0};
+    uint32_t n_clusters[RS_MAX_ROUNDS][2] = {{0, 0}, {0, 0}, {0, 0}};
     for (const rs_tree_node &n : tree->nodes) {
-        if (n.kind == RS_NODE_PUBLIC_CHANCE)
-            return fail(RS_ERR_UNSUPPORTED, "rs_best_response: single-round trees only (a public chance node would need the run-outs enumerated)");
         if (n.kind != RS_NODE_ACTION) continue;
         const rs_node_desc &nd = t->nodes[size_t(n.index)];
-        if (n.round_idx != 0 || nd.n_boards != 1 || t->tiled(n.index)) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: one round, one board (the reference's table shape)");
+        if (n.round_idx >= n_rounds) return fail(RS_ERR_INVALID, "rs_best_response: the tree has more betting rounds than n_rounds");
+        if (nd.n_boards != 1 || t->tiled(n.index)) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: tables of the reference's shape [action node][cluster] (n_boards = 1)");
         if (n.player > 1) return fail(RS_ERR_INVALID, "rs_best_response: two players");
-        if (n_clusters[n.player] && n_clusters[n.player] != nd.n_clusters) return fail(RS_ERR_INVALID, "rs_best_response: a player's nodes differ in cluster count");
-        n_clusters[n.player] = nd.n_clusters;
+        uint32_t &nc = n_clusters[n.round_idx][n.player];
+        if (nc && nc != nd.n_clusters) return fail(RS_ERR_INVALID, "rs_best_response: a player's nodes of one round differ in cluster count");
+        nc = nd.n_clusters;
     }
     uint64_t board_mask = 0;
-    for (int i = 0; i < 5; ++i) {
-        if (board[i] >= 52 || (board_mask >> board[i] & 1)) return fail(RS_ERR_INVALID, "rs_best_response: the board is five distinct cards");
-        board_mask |= 1ull << board[i];
+    for (int i = 0; i < n_board0; ++i) {
+        if (board0[i] >= 52 || (board_mask >> board0[i] & 1)) return fail(RS_ERR_INVALID, "rs_best_response: the board is distinct cards below 52");
+        board_mask |= 1ull << board0[i];
     }
     const uint8_t *hands[2] = {hands_p0, hands_p1};
-    const uint32_t *cluster[2] = {cluster_p0, cluster_p1};
     const size_t n_hands[2] = {n_hands_p0, n_hands_p1};
     std::vector<uint64_t> mask[2];
     for (int p = 0; p < 2; ++p) {
@@ -397,57 +521,92 @@ int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, con
             if (a >= 52 || b >= 52 || a == b) return fail(RS_ERR_INVALID, "rs_best_response: bad hole cards in a range");
             mask[p][h] = 1ull << a | 1ull << b;
             if (mask[p][h] & board_mask) return fail(RS_ERR_INVALID, "rs_best_response: a range combo uses a board card");
-            if (n_clusters[p] && cluster[p][h] >= n_clusters[p])
-                return fail(RS_ERR_OOB, "rs_best_response: cluster id " + std::to_string(cluster[p][h]) + " of player " + std::to_string(p) + " is outside the table");
         }
     }
-    // the deal distribution of generate_hand on a full board (cfr.rs:124-137): player 0's combo uniform over its range, then player 1's
-    // uniform over the combos of ITS range that avoid it: P(h0, h1) = [disjoint] / (N0 * N1(h0))
-    std::vector<double> w0(n_hands[0]), ones(n_hands[1], 1.0);
-    for (size_t h0 = 0; h0 < n_hands[0]; ++h0) {
-        size_t n1 = 0;
-        for (size_t h1 = 0; h1 < n_hands[1]; ++h1) n1 += (mask[0][h0] & mask[1][h1]) == 0;
-        w0[h0] = n1 ? 1.0 / (double(n_hands[0]) * double(n1)) : 0.0;   // n1 == 0: the reference would spin forever at cfr.rs:127; such a hand gets no weight
+    std::vector<uint8_t> cards;
+    const size_t NB = enumerate_runouts(board0, n_board0, &cards);
+    if (NB * std::max(n_hands[0], n_hands[1]) >= (size_t(1) << 31)) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: too many lanes");
+    std::vector<uint64_t> bmask(NB, 0);
+    std::vector<uint32_t> cnt0(NB, 0);
+    for (size_t b = 0; b < NB; ++b) {
+        for (int i = n_board0; i < 5; ++i) bmask[b] |= 1ull << cards[b * 5 + size_t(i)];
+        for (size_t h = 0; h < n_hands[0]; ++h) cnt0[b] += (mask[0][h] & bmask[b]) == 0;
+    }
+    size_t per_prefix[RS_MAX_ROUNDS] = {1, 1, 1};
+    for (int r = 0; r < n_rounds; ++r) {   // completions left after r new cards
+        size_t left = 1;
+        for (int i = r; i < K; ++i) left *= size_t(D - i);
+        per_prefix[r] = left;
     }
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     BrRun run;
     run.t = t;
     run.tree = tree;
     run.mode = mode;
+    run.NB = uint32_t(NB);
+    run.d_bmask = run.upload(bmask);
+    uint8_t *d_boards = run.upload(cards);
+    uint32_t *d_cnt0 = run.upload(cnt0);
     for (int p = 0; p < 2; ++p) {
         BrSide &s = run.side[p];
-        s.n = uint32_t(n_hands[p]);
-        s.n_pad = uint32_t(round_up(n_hands[p], 64));
-        s.n_clusters = n_clusters[p];
+        s.n_hands = uint32_t(n_hands[p]);
+        s.n = uint32_t(NB * n_hands[p]);
+        s.n_pad = uint32_t(round_up(size_t(s.n), 64));
         std::vector<uint8_t> hv(hands[p], hands[p] + 2 * n_hands[p]);
-        std::vector<uint32_t> cv(cluster[p], cluster[p] + n_hands[p]);
-        // info set -> its hands, ascending (counting sort)
-        std::vector<uint32_t> start(size_t(s.n_clusters) + 1, 0), order(n_hands[p]);
-        for (size_t h = 0; h < n_hands[p]; ++h) start[size_t(cv[h]) + 1]++;
-        for (size_t c = 0; c < s.n_clusters; ++c) start[c + 1] += start[c];
-        {
-            std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-            for (size_t h = 0; h < n_hands[p]; ++h) order[fill[cv[h]]++] = uint32_t(h);
-        }
-        s.d_hands = run.upload(hv);
+        uint8_t *d_hands = run.upload(hv);
         s.d_mask = run.upload(mask[p]);
-        s.d_cid = run.upload(cv);
-        s.d_start = run.upload(start);
-        s.d_order = run.upload(order);
-        s.d_score = run.dalloc<uint32_t>(n_hands[p]);
-        s.d_init_q = run.upload(p == 0 ? w0 : ones);
-        s.d_pw = run.upload(p == 0 ? w0 : ones);
+        s.d_score = run.dalloc<uint32_t>(s.n);
         if (run.err == hipSuccess) {
-            hipLaunchKernelGGL(k_hand_scores, dim3(grid1(s.n)), dim3(kBrBlock), 0, t->stream, s.d_hands, s.n, uint32_t(board[0]), uint32_t(board[1]), uint32_t(board[2]),
-                               uint32_t(board[3]), uint32_t(board[4]), s.d_score);
+            hipLaunchKernelGGL(k_lane_scores, dim3(grid1(s.n)), dim3(kBrBlock), 0, t->stream, d_hands, s.n_hands, d_boards, uint32_t(n_board0), uint32_t(NB), s.d_score);
             run.err = hipGetLastError();
         }
+        for (int r = 0; r < n_rounds; ++r) {
+            const uint32_t *src = cluster[size_t(r) * 2 + size_t(p)];
+            s.n_clusters[r] = n_clusters[r][p];
+            if (!s.n_clusters[r]) continue;   // the player has no node in this round
+            if (!src) return fail(RS_ERR_INVALID, "rs_best_response: no cluster ids for round " + std::to_string(r) + " player " + std::to_string(p));
+            // lane-level ids (a blocked lane keeps whatever the caller put there, clamped: it carries no weight) and, per info set, its lanes in ascending order
+            std::vector<uint32_t> cv(s.n), start(size_t(s.n_clusters[r]) + 1, 0), order(s.n);
+            for (size_t b = 0; b < NB; ++b)
+                for (size_t h = 0; h < n_hands[p]; ++h) {
+                    uint32_t k = src[(b / per_prefix[r]) * n_hands[p] + h];
+                    if (mask[p][h] & bmask[b]) k = std::min(k, s.n_clusters[r] - 1);
+                    else if (k >= s.n_clusters[r])
+                        return fail(RS_ERR_OOB, "rs_best_response: cluster id " + std::to_string(k) + " of player " + std::to_string(p) + " is outside the table");
+                    cv[b * n_hands[p] + h] = k;
+                }
+            for (uint32_t k : cv) start[size_t(k) + 1]++;
+            for (size_t c = 0; c < s.n_clusters[r]; ++c) start[c + 1] += start[c];
+            {
+                std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+                for (size_t l = 0; l < cv.size(); ++l) order[fill[cv[l]]++] = uint32_t(l);
+            }
+            s.d_cid[r] = run.upload(cv);
+            s.d_start[r] = run.upload(start);
+            s.d_order[r] = run.upload(order);
+        }
     }
+    // the deal distribution of generate_hand (cfr.rs:100-143): the run-out uniform over ordered completions, player 0's combo uniform over the combos of its range
+    // that avoid the full board, player 1's over those that avoid board and player 0: P = P(B) [disjoint] / (N0(B) N1(B, h0)); the whole weight rides on player 0's lane
+    double pb = 1.0;
+    for (int i = 0; i < K; ++i) pb /= double(D - i);
+    double *d_w0 = run.dalloc<double>(run.side[0].n);
+    if (run.err == hipSuccess) {
+        hipLaunchKernelGGL(k_br_weights, dim3(grid1(run.side[0].n)), dim3(kBrBlock), 0, t->stream, run.side[0].d_mask, run.side[0].n_hands, run.side[1].d_mask,
+                           run.side[1].n_hands, run.d_bmask, d_cnt0, uint32_t(NB), pb, d_w0);
+        run.err = hipGetLastError();
+    }
+    std::vector<double> ones(run.side[1].n, 1.0);
+    double *d_ones = run.upload(ones);
+    run.side[0].d_init_q = run.side[0].d_pw = d_w0;
+    run.side[1].d_init_q = run.side[1].d_pw = d_ones;
+    int max_a = 1;
+    for (const rs_tree_node &n : tree->nodes) max_a = std::max(max_a, n.n_children);
     const int depth = tree_depth(tree->nodes, 0);
     const size_t n_pad_max = std::max(run.side[0].n_pad, run.side[1].n_pad);
     for (int l = 0; l < depth; ++l) {
-        run.q_level.push_back(run.dalloc<double>(size_t(RS_MAX_ACTIONS) * n_pad_max));
-        run.v_level.push_back(run.dalloc<double>(size_t(RS_MAX_ACTIONS) * n_pad_max));
+        run.q_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
+        run.v_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
     }
     double *d_root = run.dalloc<double>(n_pad_max);
     std::vector<double> root(n_pad_max);
@@ -457,7 +616,7 @@ int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, con
         if (run.err == hipSuccess) run.err = hipMemcpyAsync(root.data(), d_root, run.side[p].n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
         if (run.err == hipSuccess) run.err = hipStreamSynchronize(t->stream);
         double total = 0.0;
-        for (uint32_t h = 0; h < run.side[p].n; ++h) total += root[h];   // ascending, like the oracle
+        for (uint32_t l = 0; l < run.side[p].n; ++l) total += root[l];   // ascending, like the oracle
         out[p] = total;
     }
     // on error drain the stream before ~BrRun frees what queued kernels may still touch
@@ -466,6 +625,19 @@ int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, con
         return hip_fail(run.err, "rs_best_response");
     }
     return RS_OK;
+}
+
+// the single-round game on a full board (the configuration the reference ships): NB = 1
+int rs_best_response(rs_table *t, const rs_tree *tree, const uint8_t *board, const uint8_t *hands_p0, size_t n_hands_p0, const uint32_t *cluster_p0,
+                     const uint8_t *hands_p1, size_t n_hands_p1, const uint32_t *cluster_p1, int mode, double *out) {
+    if (!t || !tree || !board || !hands_p0 || !hands_p1 || !cluster_p0 || !cluster_p1 || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+    for (const rs_tree_node &n : tree->nodes)
+        if (n.kind == RS_NODE_PUBLIC_CHANCE) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: a single-round tree (multi-round games: rs_best_response_rounds)");
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < i; ++j)
+            if (board[i] >= 52 || board[i] == board[j]) return fail(RS_ERR_INVALID, "rs_best_response: the board is five distinct cards");
+    const uint32_t *cl[2] = {cluster_p0, cluster_p1};
+    return rs_best_response_rounds(t, tree, board, 5, hands_p0, n_hands_p0, hands_p1, n_hands_p1, cl, 1, mode, out);
 }
 
 }  // extern "C"

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_selftest_division(size_t n, uint64_t
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
         const uint64_t h = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull)), g = splitmix64(h);
         // a: an i32 regret as f32 (all magnitudes: the shift spreads the exponents); b: a sum of up to 8 such values, >= a
-        const float a = (float)(int)(((uint32_t)h >> ((g >> 8) % 31)) | 1u) ;
+        const float a = (float)((((uint32_t)h >> 1) >> ((g >> 8) % 31)) | 1u);   // 1 .. 2^31 - 1
         float extra = (float)(uint32_t)(g >> 32) * (float)((g >> 3) & 7u);
         if ((i & 15) == 0) extra = 0.0f;                               // b == a: quotient 1
         const float b = a + extra, want = a / b, got = div_exact_pos(a, b);

@@ -315,26 +315,50 @@ int rs_deal_trainer_calc_br(rs_deal_trainer *tr, float *out) {
 // (hole cards first, then the board: cfr.rs:357-365)
 int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
     if (!tr || !out) return fail(RS_ERR_INVALID, "rs_deal_trainer_best_response: NULL argument");
-    if (tr->n_rounds != 1 || __builtin_popcountll(tr->params.board_mask) != 5)
-        return fail(RS_ERR_UNSUPPORTED, "rs_deal_trainer_best_response: single-round trainers on a five-card board");
+    const int n_board0 = __builtin_popcountll(tr->params.board_mask);
+    if (n_board0 < 3 || n_board0 > 5 || tr->n_rounds > 6 - n_board0) return fail(RS_ERR_UNSUPPORTED, "rs_deal_trainer_best_response: a board of 3..5 cards and at most one betting round per street");
     uint8_t board[5];
     int nb = 0;
     for (int c = 0; c < 52; ++c)
         if (tr->params.board_mask >> c & 1) board[nb++] = uint8_t(c);
-    std::vector<uint32_t> cluster[2];
-    for (int p = 0; p < 2; ++p) {
-        const size_t n = tr->n_hands[p];
-        std::vector<uint8_t> cards(n * 7);
-        for (size_t h = 0; h < n; ++h) {
-            cards[7 * h] = tr->h_hands[p][2 * h];
-            cards[7 * h + 1] = tr->h_hands[p][2 * h + 1];
-            std::memcpy(&cards[7 * h + 2], board, 5);
+    // the run-outs in the lane order of rs_best_response_rounds; round r looks a lane up under the cluster of (hole cards, initial board + its first r new cards)
+    const size_t NB = rs_br_runouts(board, n_board0, nullptr);
+    std::vector<uint8_t> runouts(NB * 5);
+    rs_br_runouts(board, n_board0, runouts.data());
+    const int K = 5 - n_board0, D = 52 - n_board0;
+    std::vector<uint32_t> cluster[RS_MAX_ROUNDS][2];
+    const uint32_t *ptrs[RS_MAX_ROUNDS * 2] = {};
+    for (int r = 0; r < tr->n_rounds; ++r) {
+        size_t per_prefix = 1;
+        for (int i = r; i < K; ++i) per_prefix *= size_t(D - i);
+        const size_t n_prefix = NB / per_prefix, nc = size_t(2 + n_board0 + r);
+        for (int p = 0; p < 2; ++p) {
+            const size_t n = tr->n_hands[p];
+            cluster[r][p].assign(n_prefix * n, 0);
+            std::vector<uint8_t> cards;
+            std::vector<size_t> where;
+            for (size_t pf = 0; pf < n_prefix; ++pf) {
+                const uint8_t *bc = &runouts[pf * per_prefix * 5];   // the first run-out with this prefix
+                for (size_t h = 0; h < n; ++h) {
+                    const uint8_t c0 = tr->h_hands[p][2 * h], c1 = tr->h_hands[p][2 * h + 1];
+                    bool blocked = false;
+                    for (int i = n_board0; i < n_board0 + r; ++i) blocked = blocked || bc[i] == c0 || bc[i] == c1;
+                    if (blocked) continue;   // no such deal: the lane carries no weight
+                    cards.push_back(c0);
+                    cards.push_back(c1);
+                    cards.insert(cards.end(), bc, bc + n_board0 + r);
+                    where.push_back(pf * n + h);
+                }
+            }
+            std::vector<uint32_t> ids(where.size());
+            if (int rc = rs_card_abs_get_cluster(tr->abs[r], cards.data(), where.size(), p, ids.data())) return rc;
+            for (size_t i = 0; i < where.size(); ++i) cluster[r][p][where[i]] = ids[i];
+            (void)nc;
+            ptrs[r * 2 + p] = cluster[r][p].data();
         }
-        cluster[p].resize(n);
-        if (int rc = rs_card_abs_get_cluster(tr->abs[0], cards.data(), n, p, cluster[p].data())) return rc;
     }
-    return rs_best_response(tr->table, tr->tree, board, tr->h_hands[0].data(), tr->n_hands[0], cluster[0].data(), tr->h_hands[1].data(), tr->n_hands[1],
-                            cluster[1].data(), mode, out);
+    return rs_best_response_rounds(tr->table, tr->tree, board, n_board0, tr->h_hands[0].data(), tr->n_hands[0], tr->h_hands[1].data(), tr->n_hands[1], ptrs, tr->n_rounds,
+                                   mode, out);
 }
 
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {

@@ -377,6 +377,18 @@ class InfosetTable:
         L.check(L.load().rs_best_response(self._h, tree._h, _vp(b), _vp(h0), len(h0), _vp(c0), _vp(h1), len(h1), _vp(c1), mode, _vp(out)))
         return out
 
+    def best_response_rounds(self, tree, board0, hands0, hands1, clusters, mode=L.BR_MAX):
+        """multi-round best response (rs_best_response_rounds): clusters[r][p] = uint32 [prefixes of round r][n_hands_p] dense ids"""
+        b = np.ascontiguousarray(board0, dtype=np.uint8)
+        h0 = np.ascontiguousarray(hands0, dtype=np.uint8).reshape(-1, 2)
+        h1 = np.ascontiguousarray(hands1, dtype=np.uint8).reshape(-1, 2)
+        keep = [np.ascontiguousarray(clusters[r][p], dtype=np.uint32) for r in range(len(clusters)) for p in (0, 1)]
+        arr = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        out = np.zeros(2, dtype=np.float64)
+        L.check(L.load().rs_best_response_rounds(self._h, tree._h, _vp(b), len(b), _vp(h0), len(h0), _vp(h1), len(h1), arr, len(clusters), mode,
+                                                 out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def update_node(self, node, action_utils, reach=None, scale=100.0, mode=L.UPD_CLAMP_I64):
         """One traverser visit of every lane (cfr.rs:370-466 / :571-623).  Returns node util [lanes]."""
         a = self.node_desc(node).n_actions

@@ -132,3 +132,96 @@ def test_best_response_folding_everything_loses_the_pot():
         tb.set_node(d["index"], np.zeros((a, n)), S)
     br = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], 0)
     assert br[1] >= 35.0 - 1e-9
+
+
+# ---- multi-round best response (oracle/best_response.c orc_best_response_rounds) ------------------------------------------------------------
+
+def multi_round_game(rng, board0, n0, n1, bets, raises, n_clusters):
+    """a turn- or flop-start game: ranges avoiding the initial board, a tree with one betting round per street left, random cluster ids per (round, board prefix, hand)
+    -- imperfect recall on purpose -- and a random table"""
+    K = 5 - len(board0)
+    free = [c for c in range(52) if c not in board0]
+    combos = np.array([(a, b) for i, a in enumerate(free) for b in free[i + 1:]], dtype=np.uint8)
+    h = [combos[np.sort(rng.choice(len(combos), n, replace=False))] for n in (n0, n1)]
+    ot = orc.OracleTree(orc.make_options(n_board_cards=len(board0), bet_sizes=bets, raise_sizes=raises))
+    runouts = orc.br_runouts(board0)
+    D = 52 - len(board0)
+    prefixes = [1, D, D * (D - 1)][: K + 1]
+    cids = [[rng.integers(0, n_clusters[r], size=(prefixes[r], len(h[p]))).astype(np.uint32) for p in (0, 1)] for r in range(K + 1)]
+    tb = orc.OracleDealTable(ot, [(n_clusters[r], n_clusters[r]) for r in range(K + 1)])
+    fs = fill(tb, ot, rng, sparse=0.15)
+    return ot, tb, fs, h, cids, runouts
+
+
+def brute_force_average_value(ot, fs, board0, h, cids, runouts):
+    """EV of player 0 when both play their average strategies: an explicit sum over every deal generate_hand can draw (cfr.rs:100-143), one scalar tree walk
+    per deal -- written independently of the vector walk in best_response.c"""
+    nodes = ot.as_dicts()
+    K = 5 - len(board0)
+    D = 52 - len(board0)
+    per_prefix = [int(np.prod([D - i for i in range(r, K)])) for r in range(K + 1)]
+    pb = 1.0 / len(runouts)
+
+    def walk(i, b, hi, s0, s1):
+        d = nodes[i]
+        if d["kind"] == orc.TERMINAL:
+            pot = float(np.float32(d["value"]))
+            if d["ttype"] == orc.UNCONTESTED:
+                return -pot if d["last_to_act"] == 0 else pot
+            return pot if s0 > s1 else (-pot if s0 < s1 else 0.0)
+        if d["kind"] != orc.ACTION:
+            return walk(d["children"][0], b, hi, s0, s1)
+        r, p = d["round_idx"], d["player"]
+        k = cids[r][p][b // per_prefix[r], hi[p]]
+        sig = fs[d["index"]][:, k]
+        return sum(float(sig[a]) * walk(c, b, hi, s0, s1) for a, c in enumerate(d["children"]) if sig[a] != 0)
+
+    total = 0.0
+    for b, cards in enumerate(runouts):
+        new = set(int(c) for c in cards[len(board0):])
+        ok0 = [i for i, x in enumerate(h[0]) if not (set(map(int, x)) & new)]
+        for i0 in ok0:
+            used = new | set(map(int, h[0][i0]))
+            ok1 = [j for j, y in enumerate(h[1]) if not (set(map(int, y)) & used)]
+            if not ok1:
+                continue
+            w = pb / (len(ok0) * len(ok1))
+            s0 = orc.evaluate7(list(h[0][i0]) + list(cards))
+            for i1 in ok1:
+                s1 = orc.evaluate7(list(h[1][i1]) + list(cards))
+                total += w * walk(0, b, (i0, i1), s0, s1)
+    return total
+
+
+def test_multi_round_oracle_reduces_to_the_single_round_one():
+    rng = np.random.Generator(np.random.PCG64(31))
+    ot, tb, fs, h, cid = oracle_game(rng, 70, 50, 3)
+    for mode in (0, 1):
+        one = tb.best_response(BOARD, h[0], cid[0], h[1], cid[1], mode)
+        many = tb.best_response_rounds(BOARD, h[0], h[1], [[cid[0][None, :], cid[1][None, :]]], mode)
+        assert one.view(np.uint64).tolist() == many.view(np.uint64).tolist()
+
+
+def test_multi_round_average_value_equals_a_deal_by_deal_enumeration():
+    """turn start (48 run-outs), two betting rounds, imperfect-recall clusters: the vector walk's average-profile value = the explicit sum over all deals"""
+    rng = np.random.Generator(np.random.PCG64(32))
+    board0 = [4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3, 4 * 1 + 0]
+    ot, tb, fs, h, cids, runouts = multi_round_game(rng, board0, 9, 7, ((0.5,), (1.0,)), ((), ()), [5, 4])
+    assert len(runouts) == 48 and ot.n_action_nodes > 8
+    got = tb.best_response_rounds(board0, h[0], h[1], cids, 1)
+    want = brute_force_average_value(ot, fs, board0, h, cids, runouts)
+    assert abs(got[0] - want) < 1e-9 * max(1.0, abs(want)) and abs(got[0] + got[1]) < 1e-9
+
+
+@pytest.mark.parametrize("board0,n_clusters", [([4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3], [3, 4, 5]), ([4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3, 4 * 1 + 0], [6, 2])])
+def test_multi_round_best_response_properties(board0, n_clusters):
+    """flop start (2 352 ordered run-outs) and turn start: zero-sum average profile, best response >= average, and one cluster per lane (perfect information about
+    one's own lane) can only do better than coarse clusters"""
+    rng = np.random.Generator(np.random.PCG64(33 + len(board0)))
+    K = 5 - len(board0)
+    ot, tb, fs, h, cids, runouts = multi_round_game(rng, board0, 10, 8, ((0.5,),) * (K + 1), ((),) * (K + 1), n_clusters)
+    ev = tb.best_response_rounds(board0, h[0], h[1], cids, 1)
+    br = tb.best_response_rounds(board0, h[0], h[1], cids, 0)
+    assert abs(ev.sum()) < 1e-9
+    assert (br >= ev - 1e-9).all()
+    assert br.sum() / 2 > 0
