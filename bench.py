@@ -425,6 +425,45 @@ def solve_leg(rs, device):
     return out
 
 
+def solve_three_street_leg(rs, device):
+    """Does the batched trainer solve a MULTI-ROUND game?  Flop start 7h8hQc, the reference's three-street tree (706 action nodes), lossless (ISOMORPHIC) abstractions
+    on flop, turn and river, 200-combo ranges (a seeded subset of the random range: the best response is O(hands^2) per showdown leaf and run-out), 65 536 deals per
+    batch.  Exploitability = (BR value of player 0 + BR value of player 1) / 2 per deal against the average strategies, best response over all 2 352 run-outs
+    (rs_best_response_rounds), before training and along the way."""
+    import numpy as np
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd import abstraction as ab
+    mask = ab.card_mask("7h8hQc")
+    rng = np.random.Generator(np.random.PCG64(2))
+    hands = ab.random_range(mask)
+    hands = hands[np.sort(rng.choice(len(hands), 200, replace=False))]
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, None) for r in range(3)]
+    n = 1 << 16
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=1, device=device)
+    t0 = time.perf_counter()
+    e0 = tr.exploitability()
+    first_br_s = time.perf_counter() - t0
+    curve, done, train_s = [[0, e0]], 0, 0.0
+    for upto in (64, 256, 1024):
+        t0 = time.perf_counter()
+        tr.train(upto - done)
+        tr.status()
+        train_s += time.perf_counter() - t0
+        done = upto
+        t0 = time.perf_counter()
+        curve.append([done * n, tr.exploitability()])
+        br_s = time.perf_counter() - t0
+    ev = tr.best_response(L.BR_AVERAGE)
+    out = {"what": "flop-start three-street game (%d action nodes), ISOMORPHIC abstractions on all three streets (%s clusters per player), 200-combo ranges, %d deals per "
+                   "batch, discount and prune schedules as coded; exploitability per deal (pot 35) from a best response over all 2 352 run-outs"
+                   % (n_actions, "/".join(str(a_.get_size(0)) for a_ in card_abs), n),
+           "exploitability_curve": curve, "seconds_training": train_s, "seconds_first_best_response": first_br_s, "seconds_best_response_both_players": br_s,
+           "average_profile_values": [float(x) for x in ev], "table_bytes": int(tr.infosets.nbytes)}
+    tr.destroy()
+    return out
+
+
 def kmeans_leg(rs, device, with_cpu, cpu_seconds):
     """SURVEY N4 measured at the reference's own size: gen_emd(1, 500, 250, 20) (gen_abstraction/main.rs:384) = Kmeans::predict of the
     1 286 792 canonical flop histograms (20 bins, counts out of 250 samples) against 500 centers with emd_1d: the sweep whose output is
@@ -1002,6 +1041,11 @@ def main():
         out["solve"] = solve_leg(rs, device)
     except Exception as e:
         out["solve"] = {"error": str(e)}
+
+    try:
+        out["solve_three_street"] = solve_three_street_leg(rs, device)
+    except Exception as e:
+        out["solve_three_street"] = {"error": str(e)}
 
     try:
         out["kmeans_predict"] = kmeans_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))

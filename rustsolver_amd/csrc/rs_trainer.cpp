@@ -29,6 +29,7 @@ struct rs_deal_trainer {
     uint64_t threshold = 0;        // next discount tick (cfr.rs:203)
     uint64_t batches = 0;
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
+    std::vector<uint32_t> br_cluster[RS_MAX_ROUNDS][2];   // cluster ids of every (board prefix, hand) of every round: they never change, computed at the first best response
     // train()'s prune schedule (cfr.rs:213-221): with a finite prune_threshold the solver runs in RS_UPD_PRUNE mode from the start and every
     // traverser visit honours the deal's flag byte -- all zero (= unpruned, bit for bit) until a batch reaches beyond the threshold
     uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
@@ -326,9 +327,12 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
     std::vector<uint8_t> runouts(NB * 5);
     rs_br_runouts(board, n_board0, runouts.data());
     const int K = 5 - n_board0, D = 52 - n_board0;
-    std::vector<uint32_t> cluster[RS_MAX_ROUNDS][2];
+    std::vector<uint32_t> (&cluster)[RS_MAX_ROUNDS][2] = tr->br_cluster;
     const uint32_t *ptrs[RS_MAX_ROUNDS * 2] = {};
-    for (int r = 0; r < tr->n_rounds; ++r) {
+    const bool cached = !cluster[0][0].empty();
+    for (int r = 0; r < tr->n_rounds && cached; ++r)
+        for (int p = 0; p < 2; ++p) ptrs[r * 2 + p] = cluster[r][p].data();
+    for (int r = 0; r < tr->n_rounds && !cached; ++r) {
         size_t per_prefix = 1;
         for (int i = r; i < K; ++i) per_prefix *= size_t(D - i);
         const size_t n_prefix = NB / per_prefix, nc = size_t(2 + n_board0 + r);

@@ -219,12 +219,12 @@ def test_stale_jit_cache_is_recompiled(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = ("import sys; sys.path.insert(0, %r); import numpy as np; import rustsolver_amd as rs\\n"
-            "n, tree = rs.build_game_tree(rs.default_flop()); t = rs.create_infosets(n, tree, [8], [2])\\n"
-            "sv = np.ones(16, dtype=np.float32); b = t.lane_buffer(0, 1, sv)\\n"
-            "lv = {i: (rs.LEAF_SIGN, b) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}\\n"
-            "tr = rs.MCCFRTrainer(tree, t, lv, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=1)\\n"
-            "u = tr.iterate(0, want_root_util=True); print('UTIL', u[:16].view(np.uint32).tolist())\\n") % root
+    prog = ("import sys; sys.path.insert(0, %r); import numpy as np; import rustsolver_amd as rs\n"
+            "n, tree = rs.build_game_tree(rs.default_flop()); t = rs.create_infosets(n, tree, [8], [2])\n"
+            "sv = np.ones(16, dtype=np.float32); b = t.lane_buffer(0, 1, sv)\n"
+            "lv = {i: (rs.LEAF_SIGN, b) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}\n"
+            "tr = rs.MCCFRTrainer(tree, t, lv, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=rs.CHANCE_PASS, fuse_subtrees=1)\n"
+            "u = tr.iterate(0, want_root_util=True); print('UTIL', u[:16].view(np.uint32).tolist())\n") % root
     env = dict(os.environ, RS_JIT_CACHE=str(tmp_path))
     first = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
     assert first.returncode == 0, first.stderr[-2000:]
