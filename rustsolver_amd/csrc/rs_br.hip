@@ -135,9 +135,11 @@ __global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ 
 // own node: one thread per info set (cluster).  RS_BR_MAX: the action with the largest value summed over the cluster's hands
 // (ascending hand order; first maximum, strict < as cfr.rs:684-690) is played by every hand of the cluster; RS_BR_AVERAGE: sigma_bar.
 template <int DT>
-__global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 1]*/,
+__global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
                                                      const uint32_t *__restrict__ order, uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch,
                                                      int mode, double *__restrict__ v) {
+    // lanes that are no deal at all (the hand uses a card of the run-out) are listed after the last cluster: worth 0, summed nowhere (x + 0.0 == x)
+    for (uint32_t i = start[n_clusters] + blockIdx.x * kBrBlock + threadIdx.x; i < start[n_clusters + 1]; i += gridDim.x * kBrBlock) v[order[i]] = 0.0;
     const uint32_t c = blockIdx.x * kBrBlock + threadIdx.x;
     if (c >= n_clusters) return;
     const uint32_t lo = start[c], hi = start[c + 1];
@@ -145,8 +147,17 @@ __global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ss
     if (mode == RS_BR_MAX) {
         double s[RS_MAX_ACTIONS];
         for (uint32_t a = 0; a < row.n_actions; a++) {
+            const double *va = vch + (size_t)a * n_pad;
             double acc = 0.0;
-            for (uint32_t i = lo; i < hi; i++) acc += vch[(size_t)a * n_pad + order[i]];
+            uint32_t i = lo;
+            for (; i + 8 <= hi; i += 8) {   // eight gathers in flight, the additions still one after the other in list order
+                double t[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[k] = va[order[i + k]];
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc += t[k];
+            }
+            for (; i < hi; i++) acc += va[order[i]];
             s[a] = acc;
         }
         uint32_t best = 0;
@@ -565,21 +576,24 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
             s.n_clusters[r] = n_clusters[r][p];
             if (!s.n_clusters[r]) continue;   // the player has no node in this round
             if (!src) return fail(RS_ERR_INVALID, "rs_best_response: no cluster ids for round " + std::to_string(r) + " player " + std::to_string(p));
-            // lane-level ids (a blocked lane keeps whatever the caller put there, clamped: it carries no weight) and, per info set, its lanes in ascending order
-            std::vector<uint32_t> cv(s.n), start(size_t(s.n_clusters[r]) + 1, 0), order(s.n);
+            // lane-level ids and, per info set, its lanes in ascending order.  A blocked lane (its hand uses a card of the run-out: no such deal) belongs to no
+            // info set: it is listed in an extra segment after the last cluster (k_br_own writes its 0) and looks up cluster 0 where an id is needed but not used
+            const uint32_t NC = s.n_clusters[r];
+            std::vector<uint32_t> cv(s.n), seg(s.n), start(size_t(NC) + 2, 0), order(s.n);
             for (size_t b = 0; b < NB; ++b)
                 for (size_t h = 0; h < n_hands[p]; ++h) {
                     uint32_t k = src[(b / per_prefix[r]) * n_hands[p] + h];
-                    if (mask[p][h] & bmask[b]) k = std::min(k, s.n_clusters[r] - 1);
-                    else if (k >= s.n_clusters[r])
+                    const bool blocked = (mask[p][h] & bmask[b]) != 0;
+                    if (!blocked && k >= NC)
                         return fail(RS_ERR_OOB, "rs_best_response: cluster id " + std::to_string(k) + " of player " + std::to_string(p) + " is outside the table");
-                    cv[b * n_hands[p] + h] = k;
+                    cv[b * n_hands[p] + h] = blocked ? 0u : k;
+                    seg[b * n_hands[p] + h] = blocked ? NC : k;
                 }
-            for (uint32_t k : cv) start[size_t(k) + 1]++;
-            for (size_t c = 0; c < s.n_clusters[r]; ++c) start[c + 1] += start[c];
+            for (uint32_t k : seg) start[size_t(k) + 1]++;
+            for (size_t c = 0; c <= NC; ++c) start[c + 1] += start[c];
             {
                 std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-                for (size_t l = 0; l < cv.size(); ++l) order[fill[cv[l]]++] = uint32_t(l);
+                for (size_t l = 0; l < seg.size(); ++l) order[fill[seg[l]]++] = uint32_t(l);
             }
             s.d_cid[r] = run.upload(cv);
             s.d_start[r] = run.upload(start);
