@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (single board, deal batches, trainers, solve, k-means): "
                     "the rocprofv3 --pmc passes only need the headline kernels, and counter collection serialises every dispatch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--skip", default="", help="comma-separated auxiliary legs to leave out (e.g. solve_three_street under rocprofv3, whose 10^5 small dispatches the tracer does not survive)")
     ap.add_argument("--config3-steps", type=int, default=5, help="timed iterations of the config 3 / config 4 leg (0 = skip the leg)")
     return ap.parse_args()
 
@@ -1042,10 +1043,11 @@ def main():
     except Exception as e:
         out["solve"] = {"error": str(e)}
 
-    try:
-        out["solve_three_street"] = solve_three_street_leg(rs, device)
-    except Exception as e:
-        out["solve_three_street"] = {"error": str(e)}
+    if "solve_three_street" not in a.skip.split(","):
+        try:
+            out["solve_three_street"] = solve_three_street_leg(rs, device)
+        except Exception as e:
+            out["solve_three_street"] = {"error": str(e)}
 
     try:
         out["kmeans_predict"] = kmeans_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))

@@ -59,7 +59,11 @@ if trace:
     upd = [d for k, v in per_kernel.items() if "k_update" in k for d in v]
     if upd:
         lines += ["", "all `k_update` full-size dispatches: %d, average %.1f us" % (len(upd), sum(upd) / len(upd) / 1e3), ""]
-    tre = [d for k, v in per_kernel.items() if "rs_tree_p" in k and "_lanes" in k and "_sampled" not in k for d in v]
+    tre = [d for k, v in per_kernel.items() if k in ("rs_tree_p0_lanes", "rs_tree_p1_lanes") for d in v]
+    xr = [d for k, v in per_kernel.items() if k in ("rs_tree_p0_lanes_xr", "rs_tree_p1_lanes_xr") for d in v]
+    if xr:
+        lines += ["all `rs_tree_p*_lanes_xr` (config 3: river subtrees below ENUM chance nodes, 11.76 M lanes each) full-size dispatches: %d, average %.1f us"
+                  % (len(xr), sum(xr) / len(xr) / 1e3), ""]
     if tre:
         lines += ["all `rs_tree_p*_lanes` (river tree, lane model) full-size dispatches: %d, average %.1f us"
                   % (len(tre), sum(tre) / len(tre) / 1e3), ""]
@@ -86,7 +90,7 @@ if traffic:
         total = fa * 2 * 1024 + wa * 1024
         lines.append("| `%s` | %d | %.0f | %.4g | %.0f | %.4g | %.4g |" % (k, max(len(fv), len(wv)), fa, fa * 2048, wa, wa * 1024, total))
         for name in fam:
-            if ("k_" + name in k) or (name == "tree" and "rs_tree_p" in k and "_lanes" in k and "_sampled" not in k):
+            if ("k_" + name in k) or (name == "tree" and k in ("rs_tree_p0_lanes", "rs_tree_p1_lanes")):
                 fam[name][0] += total * max(len(fv), len(wv))
                 fam[name][1] += max(len(fv), len(wv))
     for name, (tot, n) in fam.items():

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 ( while sleep 60; do echo "profile_round: still running"; done ) &
 HEART=$!
 trap "kill $HEART 2>/dev/null" EXIT
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 50 --warmup 10 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 50 --warmup 10 --skip solve_three_street > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 echo "trace pass done" && tail -c 400 "$OUT/trace_bench.json" | head -c 200 && echo
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-extra > "$OUT/pmc_fetch_bench.json" 2> "$OUT/pmc_fetch.err"
 echo "fetch pass done"
