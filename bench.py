@@ -328,6 +328,48 @@ def deal_batch_leg(rs, device, n_deals, n_clusters, with_cpu, cpu_seconds):
     return out
 
 
+def roofline_deals(workload, ms_per_batch_now):
+    """The deal kernels are not HBM-streaming kernels: they gather a cache-resident table and spend their time issuing vector instructions and waiting on gathers.
+    Bound: VALU issue (a wave64 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz).  The instruction counts and the issue / stall / wait shares
+    of the waves' lifetime come from the committed rocprofv3 --pmc passes of the same workload (profiles/r*_deals.json: CANNED, counters cannot be read in-process);
+    the time is this run's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_deals.json")))
+    if not files:
+        return None
+    try:
+        prof = json.load(open(files[-1]))[workload]
+    except Exception:
+        return None
+    simd_issue_per_s = 256 * 4 * 2.4e9 / 4.0          # wave-instructions per second the chip can issue
+    tot_valu = tot_ms = 0.0
+    kernels = {}
+    batches = None
+    for k, v in prof["kernels"].items():
+        if not k.startswith("rs_tree_") or not v.get("valu_insts_per_wave") or not v.get("waves_per_dispatch"):
+            continue
+        if batches is None:
+            batches = v["dispatches"]                 # the first-round kernel of a traverser runs once per batch
+        batches = min(batches, v["dispatches"])
+    if not batches:
+        return None
+    for k, v in prof["kernels"].items():
+        if not k.startswith("rs_tree_") or not v.get("valu_insts_per_wave") or not v.get("waves_per_dispatch"):
+            continue
+        per_batch = v["dispatches"] / batches
+        valu = v["valu_insts_per_wave"] * v["waves_per_dispatch"] * per_batch
+        tot_valu += valu
+        tot_ms += v["avg_us"] * per_batch / 1e3
+        kernels[k] = {"dispatches_per_batch": per_batch, "avg_us": v["avg_us"], "valu_wave_insts_per_batch": valu, "issue_share": v["issue_share"],
+                      "issue_stall_share": v["issue_stall_share"], "wait_share": v["wait_share"], "hbm_bytes_per_dispatch": v["hbm_bytes_per_dispatch"]}
+    floor_ms = tot_valu / simd_issue_per_s * 1e3
+    return {"bound": "valu", "unit": "fraction of the VALU issue slots of 1 024 SIMDs at 2.4 GHz", "peak": 1.0,
+            "achieved": floor_ms / ms_per_batch_now if ms_per_batch_now else None, "frac": floor_ms / ms_per_batch_now if ms_per_batch_now else None,
+            "valu_issue_floor_ms_per_batch": floor_ms, "ms_per_batch_this_run": ms_per_batch_now, "tree_kernel_ms_per_batch_in_profile": tot_ms,
+            "canned": True, "source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc SQ_* passes of tools/time_deal_trainer.py / time_three_street.py, committed)",
+            "kernels": kernels}
+
+
 def deal_trainer_leg(rs, device, n_deals, with_cpu, cpu_seconds):
     """The reference's train() as coded, end to end on the device: options::default_flop() (board 4d5dAs3cKs, random ranges, ISOMORPHIC river
     abstraction = 1081 clusters per player, cfr.rs:159-184).  Per batch: generate_hand (cfr.rs:100-143) -> get_cluster for both players
@@ -359,6 +401,8 @@ def deal_trainer_leg(rs, device, n_deals, with_cpu, cpu_seconds):
                    % (card_abs.get_size(0), n_deals),
            "value": n_deals * k / dt, "unit": "deal-iterations/s", "ms_per_batch": dt / k * 1e3, "ms_dealing_only": dt_deal / k * 1e3,
            "n_deals": n_deals}
+    if n_deals == 1 << 22:
+        out["roofline_deals"] = roofline_deals("river_4m", out["ms_per_batch"])
     tr.destroy()
     if with_cpu:
         from oracle import orc
@@ -510,14 +554,14 @@ def kmeans_leg(rs, device, with_cpu, cpu_seconds):
 
 def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     """The reference's commented-out "real" configuration (options.rs:68-77): flop start, three betting rounds (706 action nodes), 5 000-bucket
-    files on every street (EMD / OCHS shape: index -> bucket file -> dense id), sampled mccfr over 1 M deals per batch, everything on the device.
+    files on every street (EMD / OCHS shape: index -> bucket file -> dense id), sampled mccfr over 4 M deals per batch, everything on the device.
     Round subtrees with reach-down / walk-up kernels, live-deal lists, cluster-partitioned LDS tiles."""
     import numpy as np
     from rustsolver_amd import abstraction as ab
     rng = np.random.Generator(np.random.PCG64(1))
     mask = ab.card_mask("7h8hQc")
     hands = ab.random_range(mask)
-    k, n = 5000, 1 << 20
+    k, n = 5000, 1 << 22
     files = [rng.integers(0, k, size=size, dtype=np.uint32) for size in (1286792, 13960050, 123156254)]   # hand_indexer sizes of [2,3] [2,4] [2,5]
     n_actions, tree = rs.build_game_tree(rs.three_street_options())
     card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
@@ -535,6 +579,7 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
                    "opponents: deal sampling, hand indexing through the bucket files, showdowns and the sweep on the device" % (n_actions, k, n),
            "value": n / dt, "unit": "deal-iterations/s", "ms_per_batch": dt * 1e3, "n_deals": n, "clusters": [a_.get_size(0) for a_ in card_abs],
            "table_bytes": int(tr.infosets.nbytes if not callable(tr.infosets.nbytes) else tr.infosets.nbytes()), "trainer_create_s": create_s}
+    out["roofline_deals"] = roofline_deals("three_street_4m", out["ms_per_batch"])
     sizes = [(a_.get_size(0), a_.get_size(1)) for a_ in card_abs]
     tr.destroy()
     if with_cpu:   # the same loop on the host cores: the oracle's train-from-cards (reference layout, per-visit allocations), 8 threads
