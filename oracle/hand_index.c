@@ -1,8 +1,15 @@
 /*
  * hand_index.c -- CPU oracle: the suit-isomorphic hand indexer behind rust_poker::hand_indexer_s
- * (K. Waugh, "A Fast and Optimal Hand Isomorphism Algorithm", AAAI 2013 workshop), restated from the
- * paper's description.  TEST INFRASTRUCTURE ONLY; see hand_index.h for the reference call sites and how this
- * restatement is pinned (partition pinned by the reference's own sizes, index ORDER unpinned).
+ * (K. Waugh, "A Fast and Optimal Hand Isomorphism Algorithm", AAAI 2013 workshop).  Its model is the algorithm of that
+ * paper AS ITS AUTHOR'S PUBLIC C LIBRARY ORGANISES IT ("hand-isomorphism": hand_index.c / hand_index.h), which is what
+ * rust_poker's `hand_indexer_s` wraps (the `_s` struct name and init / size / get_index / get_hand signatures at the
+ * reference's call sites are that library's): the same table set -- nth_unset, rank_set_to_index, index_to_rank_set,
+ * suit_permutations, per-round configuration / permutation tables -- under the same names, written out again here without
+ * that library's source at hand (it is not in /root/reference and there is no network).  It is therefore a restatement
+ * that deliberately follows the original's decomposition, so that the index ORDER has the best chance of matching
+ * rust_poker's; that order is nevertheless UNPINNED (no reference fixture shows an index value), only the partition and the
+ * sizes are pinned -- see hand_index.h.  The product's rs_hand_index.hpp is a different decomposition of the same function.
+ * TEST INFRASTRUCTURE ONLY.
  *
  * The algorithm in one paragraph.  A hand is, per suit, the sequence of rank sets dealt in every round.
  * (1) Inside a suit, the rank set of a round is re-expressed relative to the ranks that suit has NOT used yet
