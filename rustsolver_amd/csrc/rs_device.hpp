@@ -24,6 +24,7 @@ constexpr int kARITH_CLAMP = 0, kARITH_WRAP = 1;           // == RS_UPD_CLAMP_I6
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Every table / utility pointer reaches the kernels through a job descriptor in memory, so the compiler cannot
@@ -477,6 +478,19 @@ __device__ __forceinline__ void gather_u32_ids(const unsigned *base, const unsig
     const RS_GLOBAL unsigned *p = as_global<unsigned>(base);
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = real[j] ? p[ids[j]] : 0u;
+}
+// the packed per-deal inputs of a round (k_pack_attr): {cluster id of player 0, of player 1, leaf value bits, prune flag} in ONE 16-byte gather per live deal
+__device__ __forceinline__ void gather_attr(const void *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], unsigned (&c0)[kVecD], unsigned (&c1)[kVecD],
+                                            float (&leaf)[kVecD], unsigned (&flag)[kVecD]) {
+    const RS_GLOBAL u32x4 *p = as_global<u32x4>((const unsigned *)base);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        const u32x4 r = real[j] ? p[ids[j]] : u32x4{0u, 0u, 0u, 0u};
+        c0[j] = r.x;
+        c1[j] = r.y;
+        leaf[j] = __uint_as_float(r.z);
+        flag[j] = r.w;
+    }
 }
 __device__ __forceinline__ void scatter_f32_ids(float *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], const float (&in)[kVecD]) {
     RS_GLOBAL float *p = as_global<float>(base);

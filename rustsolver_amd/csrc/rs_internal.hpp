@@ -109,6 +109,16 @@ struct CompactJob {
     const uint32_t *key;  // nullptr when n_parts == 1
     uint32_t part_size, n_parts, list_stride, count_stride;
 };
+// deal sweeps: packed per-deal inputs of one round (rs_kernels.hip k_pack_attr)
+struct u32x4_host { uint32_t x, y, z, w; };
+struct PackJob {
+    const uint32_t *cid0, *cid1;   // [n] dense cluster ids of the two players on this round (either may be null: a player without nodes there)
+    const float *leaf;             // [n] the one leaf buffer every showdown / all-in terminal shares
+    const uint8_t *prune;          // [n] or null
+    u32x4_host *out;               // [pitch]
+    uint32_t n;
+};
+hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream);
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
 // d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
@@ -151,13 +161,14 @@ struct JitSubtree {
     size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
     size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
+    size_t off_attr = 0;                                                                  // sparse deal sweeps: packed per-deal inputs of the subtree's round, may be null
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

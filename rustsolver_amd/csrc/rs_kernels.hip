@@ -491,6 +491,20 @@ __global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__rest
     }
 }
 
+// ---- deal batches: the per-deal inputs of a round -- both players' cluster ids, the showdown sign (or utility), the prune flag -- packed into ONE 16-byte record per deal,
+// so that a sparse subtree kernel fetches them with one gather per live deal instead of four 4-byte gathers that move a 64-byte sector each (rs_device.hpp gather_attr)
+__global__ __launch_bounds__(kBlock) void k_pack_attr(const PackJob *__restrict__ jobs) {
+    const PackJob job = jobs[blockIdx.y];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < job.n; i += gridDim.x * kBlock) {
+        u32x4 rec;
+        rec.x = job.cid0 ? job.cid0[i] : 0u;
+        rec.y = job.cid1 ? job.cid1[i] : 0u;
+        rec.z = job.leaf ? __float_as_uint(job.leaf[i]) : 0u;
+        rec.w = job.prune ? (uint32_t)job.prune[i] : 1u;   // no flag vector = every deal is traversed with prune = true (cfr.rs:219)
+        ((u32x4 *)job.out)[i] = rec;
+    }
+}
+
 // ---- deal batches: table += delta (wrapping), delta = 0; 32 bytes per cell, whole table, end of every sweep ------
 __global__ __launch_bounds__(kBlock) void k_apply_delta(int32_t *__restrict__ regrets, int32_t *__restrict__ dregrets,
                                                         int32_t *__restrict__ ssum, int32_t *__restrict__ dssum, size_t n_vec) {
@@ -722,6 +736,12 @@ hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max
     if (n_jobs <= 0) return d_seed_state ? launch_next_seed(d_seed_state, stream) : hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
     hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs, d_seed_state);
+    return hipGetLastError();
+}
+hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid(grid_for(max_n), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_pack_attr, grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream) {

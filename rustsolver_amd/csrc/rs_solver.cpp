@@ -22,7 +22,7 @@ using namespace rs;
 namespace {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK };
 
 struct Launch {
     int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
@@ -111,6 +111,10 @@ struct rs_solver {
     ShadowJob *d_shadow_jobs = nullptr;
     int n_shadow_jobs = 0;
     uint32_t shadow_max_clusters = 0;
+    // sparse deal sweeps fetch the per-deal inputs of a round (both cluster ids, leaf value, prune flag) as ONE packed 16-byte record per live deal
+    void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
+    PackJob *d_pack_jobs = nullptr;
+    int n_pack_jobs = 0;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -558,7 +562,7 @@ struct Builder {
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                          (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below, round_mode ? &fused_root : nullptr, js,
-                         int(fan_root[id]));
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
@@ -654,6 +658,7 @@ struct Builder {
             put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
             put_u32(js.off_rp, rp);
             put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
+            put_ptr(js.off_attr, sparse ? s->d_attr[nodes[id].round_idx] : nullptr);
             if (use_lds) {
                 const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
@@ -705,6 +710,12 @@ struct Builder {
                     util_override[nodes[id].children[0]] =
                         s->d_exchange + (size_t(s->params.shard_rank) * plan.n_boundary + boundary_k[id]) * s->slot_lanes;
 
+        if (s->n_pack_jobs) {   // the batch's per-deal inputs, packed per round (the deals of a trainer change from batch to batch: every sweep)
+            Launch L;
+            L.kind = L_PACK;
+            L.bytes = double(s->deals.n_deals) * s->n_pack_jobs * 29.0;
+            plan.launches.push_back(L);
+        }
         if (s->d_shadow) {   // the table as of sweep start, transposed for the deal kernels' gathers; sampled sweeps: the same launch advances the seed
             Launch L;
             L.kind = L_SHADOW;
@@ -1053,6 +1064,10 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
     }
+    if (L.kind == L_PACK) {
+        RS_HIP(launch_pack_attr(s->d_pack_jobs, s->n_pack_jobs, s->deals.n_deals, t->stream), "k_pack_attr");
+        return RS_OK;
+    }
     if (L.kind == L_SHADOW) {
         prof_begin(t, RS_K_STRATEGY, L.bytes);
         hipError_t es = launch_build_shadow(s->d_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr);
@@ -1205,6 +1220,13 @@ void rs::solver_release_device(rs_solver *s) {
     s->ev_fork = nullptr;
     if (s->d_shadow) (void)hipFree(s->d_shadow);
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
+    for (int r = 0; r < RS_MAX_ROUNDS; ++r) {
+        if (s->d_attr[r]) (void)hipFree(s->d_attr[r]);
+        s->d_attr[r] = nullptr;
+    }
+    if (s->d_pack_jobs) (void)hipFree(s->d_pack_jobs);
+    s->d_pack_jobs = nullptr;
+    s->n_pack_jobs = 0;
     s->d_shadow = nullptr;
     s->d_shadow_jobs = nullptr;
     if (s->d_seed_state) (void)hipFree(s->d_seed_state);
@@ -1329,6 +1351,44 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             rc = hip_fail(e, "rs_solver_create: table shadow");
             rs_solver_destroy(s);
             return rc;
+        }
+    }
+    // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
+    // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
+    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !getenv("RS_JIT_NO_SPARSE") && !getenv("RS_JIT_NO_PACK")) {
+        const float *leaf = nullptr;
+        bool one = true;
+        for (size_t i = 0; i < n && one; ++i) {
+            const rs_tree_node &nd = tree->nodes[i];
+            if (nd.kind != RS_NODE_TERMINAL || nd.ttype == RS_TERM_UNCONTESTED) continue;
+            for (int p = 0; p < 2; ++p) {
+                if (!leaf) leaf = s->leaves[p][i].d_buf;
+                one = one && leaf == s->leaves[p][i].d_buf;
+            }
+        }
+        if (one) {
+            std::vector<PackJob> jobs;
+            const size_t pitch = round_up(s->deals.n_deals, kLanePad);
+            for (int r = 0; r < s->n_rounds && e == hipSuccess; ++r) {
+                e = hipMalloc(&s->d_attr[r], pitch * 16);
+                if (e == hipSuccess) e = hipMemsetAsync(s->d_attr[r], 0, pitch * 16, table->stream);
+                PackJob j{};
+                j.cid0 = s->deals.d_cluster[r][0];
+                j.cid1 = s->deals.d_cluster[r][1];
+                j.leaf = leaf;
+                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
+                j.n = s->deals.n_deals;
+                jobs.push_back(j);
+            }
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_pack_jobs, std::max<size_t>(jobs.size() * sizeof(PackJob), 256));
+            if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                rc = hip_fail(e, "rs_solver_create: packed deal inputs");
+                rs_solver_destroy(s);
+                return rc;
+            }
+            s->n_pack_jobs = int(jobs.size());
         }
     }
     Builder b0(s, 0), b1(s, 1);
@@ -1566,7 +1626,8 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js);
+                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, 0, sparse);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
+                                                                                               // fallback for solvers whose leaves do not share one buffer: compiled by the GPU tests)
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
