@@ -215,6 +215,12 @@ struct Builder {
     const std::vector<rs_tree_node> &nodes;
     std::vector<int> depth, lane_round;
     std::vector<char> has_own, closed, fused_root, inside;
+    // Lane sweeps with ENUM chance nodes: a round's action nodes that have chance nodes below them form a ROUND SUBTREE cut at those chance nodes: a reach-down kernel
+    // (rows for the chance nodes that need one) and a walk-up kernel that reads the chance nodes' utility rows -- instead of one level kernel per depth, kind and action count
+    std::vector<char> lr_root;        // root of such a round subtree
+    std::vector<char> next_root;      // action node directly below a chance node: where the generated kernels stop (`cut`)
+    std::vector<std::vector<int>> lr_bnd;   // per lr root: the ENUM chance nodes below it (inside its round)
+    bool lane_rounds = false;
     std::vector<char> fan_root;       // fused root directly below an ENUM chance node whose deals its kernel walks itself (no expand / reduce launch, no child-round rows)
     std::vector<ReachSrc> reach;      // reach source feeding each node
     std::vector<size_t> util_off;     // arena offset of a node's util buffer (+1; 0 = none)
@@ -321,8 +327,39 @@ struct Builder {
             mark_inside(nodes[id].children[k]);
         }
     }
+    void fan_mode(int id) {   // may the kernel of root `id` take over work of the ENUM chance node above it?
+        const int par = nodes[id].parent;
+        if (par >= 0 && chance_enum(nodes[par]) && !boundary(par) && s->n_clusters % 4 == 0 && !s->deal_mode) {
+            const char *fm = getenv("RS_JIT_FAN");
+            const int mode = fm ? atoi(fm) : 1;
+            if (mode == 1 || (mode == 2 && closed[id])) fan_root[id] = char(mode);
+            else if (mode == 2) fan_root[id] = 1;   // a round subtree with chance nodes below cannot walk its own deals (its rows are per deal of the round above): expand step only
+        }
+    }
+    void mark_lane_round_inside(int root, int id) {
+        for (int k = 0; k < nodes[id].n_children; ++k) {
+            const int c = nodes[id].children[k];
+            const rs_tree_node &cn = nodes[c];
+            if (cn.kind == RS_NODE_ACTION) {
+                inside[c] = 1;
+                mark_lane_round_inside(root, c);
+            } else if (chance_enum(cn)) {
+                lr_bnd[size_t(root)].push_back(c);
+                mark_fused(cn.children[0]);
+            } else if (cn.kind != RS_NODE_TERMINAL) {
+                mark_fused(c);   // cannot happen below the root (private chance only there), kept for safety
+            }
+        }
+    }
     void mark_fused(int id) {
         const rs_tree_node &nd = nodes[id];
+        if (lane_rounds && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && !closed[id]) {
+            fused_root[id] = 1;
+            lr_root[id] = 1;
+            fan_mode(id);
+            mark_lane_round_inside(id, id);
+            return;
+        }
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0 && !s->deal_mode;   // lane sweeps: prune keeps the level plan (NaN-reach bookkeeping); deal kernels have a pruned form
         if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
             fused_root[id] = 1;
@@ -332,12 +369,7 @@ struct Builder {
             // in other ranks' slots).  RS_JIT_FAN: 0 = never; 1 (default) = the kernel scales the chance node's own incoming reach itself (no expand launch,
             // no per-deal reach rows); 2 = it also walks the node's deals itself and sums them in order (no reduce launch, no per-deal rows at all: 7 GB
             // less workspace at config-3 size, but measured 11 % slower there, so only on request)
-            const int par = nd.parent;
-            if (par >= 0 && chance_enum(nodes[par]) && !boundary(par) && s->n_clusters % 4 == 0 && !s->deal_mode) {
-                const char *fm = getenv("RS_JIT_FAN");
-                const int mode = fm ? atoi(fm) : 1;
-                if (mode == 1 || mode == 2) fan_root[id] = char(mode);
-            }
+            fan_mode(id);
             return;
         }
         for (int k = 0; k < nd.n_children; ++k) mark_fused(nd.children[k]);
@@ -389,6 +421,14 @@ struct Builder {
         const rs_tree_node &nd = nodes[id];
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
         if (((nd.kind == RS_NODE_ACTION && nd.n_children > 0) && fan_root[id] != 2) || chance_enum(nd)) util_off[id] = alloc(lane_round[id]);   // a deal-walking root returns through its chance node's row
+        if (lr_root[id]) {   // a round subtree: rows only for its chance nodes (utility up, reach down where a traverser node lies below), then the next round
+            for (int ch : lr_bnd[size_t(id)]) {
+                util_off[ch] = alloc(lane_round[ch]);
+                if (has_own[ch]) reach_off[ch] = alloc(lane_round[ch]);
+                layout(nodes[ch].children[0]);
+            }
+            return;
+        }
         if (fused_root[id]) return;   // everything below lives in registers / LDS of k_subtree
         for (int k = 0; k < nd.n_children; ++k) {
             const int c = nd.children[k];
@@ -458,6 +498,9 @@ struct Builder {
         closed.assign(n, 0);
         fused_root.assign(n, 0);
         fan_root.assign(n, 0);
+        lr_root.assign(n, 0);
+        next_root.assign(n, 0);
+        lr_bnd.assign(n, {});
         inside.assign(n, 0);
         reach.assign(n, ReachSrc{});
         util_override.assign(n, nullptr);
@@ -493,12 +536,22 @@ struct Builder {
             mark_round(first_root);
             layout_round(first_root);
         } else {
+            // lane sweeps: round subtrees above the last round (full-width cfr() with ENUM chance nodes; prune keeps the level plan's NaN bookkeeping)
+            lane_rounds = !s->deal_mode && s->params.fuse_subtrees && s->params.chance_mode == RS_CHANCE_ENUM && s->params.opp_mode == RS_OPP_FULL &&
+                          (s->params.mode & RS_UPD_PRUNE) == 0 && !getenv("RS_JIT_NO_LANE_ROUNDS");
+            for (size_t id = 0; id < n; ++id)
+                if (nodes[id].kind == RS_NODE_PUBLIC_CHANCE) {
+                    const int c = nodes[id].children[0];
+                    if (nodes[c].kind == RS_NODE_ACTION && nodes[c].n_children > 0) next_root[size_t(c)] = 1;
+                }
             mark_fused(0);
             layout(0);
         }
         // ENUM chance children: need their own reach buffer when the chance node's reach is a buffer.
         // Resolve top-down in id order (parents have smaller ids than children).
         std::vector<char> reach_is_buf(n, 0);
+        for (size_t id = 0; id < n; ++id)
+            if (reach_off[id]) reach_is_buf[id] = 1;   // the chance nodes of lane round subtrees: their reach row is written by the subtree's reach-down kernel
         for (size_t id = 0; id < n; ++id) {
             const rs_tree_node &nd = nodes[id];
             if (fused_root[id] || inside[id]) continue;
@@ -561,7 +614,8 @@ struct Builder {
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below, round_mode ? &fused_root : nullptr, js,
+                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below,
+                         round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
                          int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
@@ -611,6 +665,12 @@ struct Builder {
             put_u32(js.off_fan, f);
             put_f32(js.off_inv, 1.0f / float(f));   // the same f32 quotient k_chance_expand multiplies by
             put_u32(js.off_cvec, s->n_clusters / 4);
+            for (size_t k = 0; k < js.boundary_roots.size(); ++k) {   // lane round subtrees: the rows of the ENUM chance node above every next-round root
+                const int ch = nodes[size_t(js.boundary_roots[k])].parent;
+                put_ptr(js.off_butil + 8 * k, uptr(ch));
+                put_ptr(js.off_breach + 8 * k, reach_off[size_t(ch)] ? aptr(reach_off[size_t(ch)]) : nullptr);
+                bytes += lanes(id) * 4.0;
+            }
         }
         put_u32(js.off_pitch, uint32_t(s->pitch[lane_round[id]]));
         {   // every node of a fused subtree lives on one round: same lanes, same tiling
@@ -728,14 +788,25 @@ struct Builder {
             plan.launches.push_back(L);
         }
         reach[0] = ReachSrc{nullptr, 1.0f, true};  // self.cfr(0, player, hand, 1f32, ..), cfr.rs:217
+        const std::vector<int> sparse_slot_none(n, -1);
         // ---- top-down ------------------------------------------------------------------------------
         for (int d = 0; d <= max_depth; ++d) {
             std::map<int, std::vector<int>> reach_groups, prune_groups;  // by n_actions
             Launch LE;   // every ENUM chance node of this depth that has to expand a reach buffer
             LE.kind = L_EXPAND;
             LE.first_job = int(plan.chance_jobs.size());
+            std::vector<int> down_roots;
             for (int id : by_depth[d]) {
                 const rs_tree_node &nd = nodes[id];
+                if (lr_root[id]) {   // lane round subtree: its reach-down kernel writes the reach row of every chance node below that has a traverser node under it
+                    bool any = false;
+                    for (int ch : lr_bnd[size_t(id)])
+                        if (reach_off[size_t(ch)]) {
+                            reach[size_t(ch)] = ReachSrc{aptr(reach_off[size_t(ch)]), 0.0f, true};
+                            any = true;
+                        }
+                    if (any) down_roots.push_back(id);
+                }
                 if (nd.kind == RS_NODE_TERMINAL || fused_root[id] || inside[id] || dead_end(id)) continue;
                 const bool opp = nd.kind == RS_NODE_ACTION && nd.player != p;
                 const bool own = nd.kind == RS_NODE_ACTION && nd.player == p;
@@ -777,6 +848,20 @@ struct Builder {
             }
             LE.n_jobs = int(plan.chance_jobs.size()) - LE.first_job;
             if (LE.n_jobs) plan.launches.push_back(LE);
+            if (!down_roots.empty()) {
+                std::map<hipFunction_t, int> by_fn;
+                for (int id : down_roots)
+                    if (int rc = add_jit_job(id, true, sparse_slot_none, by_fn)) return rc;
+                const int group = by_fn.size() > 1 ? ++next_group : 0;
+                for (auto &kv : by_fn) {
+                    Launch L;
+                    L.kind = L_TREE;
+                    L.group = group;
+                    L.first_job = kv.second;
+                    L.bytes = plan.jit[kv.second].bytes;
+                    plan.launches.push_back(L);
+                }
+            }
             for (int which = 0; which < 2; ++which) {
                 for (auto &g : (which == 0 ? reach_groups : prune_groups)) {
                     Launch L;
@@ -1565,6 +1650,25 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             if (nd.kind == RS_NODE_TERMINAL && nd.ttype != RS_TERM_UNCONTESTED) {
                 leaf_buf[i] = nd.round;
                 leaf_flags[i] = 1;
+            }
+        }
+        std::vector<char> next_root(n, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (nodes[i].kind == RS_NODE_PUBLIC_CHANCE && nodes[size_t(nodes[i].children[0])].kind == RS_NODE_ACTION && nodes[size_t(nodes[i].children[0])].n_children > 0)
+                next_root[size_t(nodes[i].children[0])] = 1;
+        for (size_t i = 0; i < n && opp_mode == RS_OPP_FULL; ++i) {   // lane round subtrees (ENUM sweeps): reach-down and walk-up kernel of every non-closed round root
+            const rs_tree_node &nd = nodes[i];
+            if (nd.kind != RS_NODE_ACTION || closed[i] || nd.n_children == 0) continue;
+            if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION) continue;   // inside a round subtree
+            for (int form = 0; form < 4; ++form) {   // walk-up / reach-down, each reading its own reach row or the chance node's above (expand step taken over)
+                const bool down = (form & 1) != 0, xr = (form & 2) != 0;
+                if (xr && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
+                JitSubtree js;
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, false, false, false, false, down, false, 4, &next_root, js, xr ? 1 : 0);
+                if (down && js.boundary_roots.empty()) continue;
+                if (seen.count(js.source)) continue;
+                seen[js.source] = 1;
+                if (int rc = jit_compile_only(js.source)) return rc;
             }
         }
         for (size_t i = 0; i < n; ++i) {
