@@ -762,6 +762,18 @@ struct Builder {
         const rs_table *t = s->table;
         const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
         const double es = double(elem_size(t->dtype));
+        // The plan walks the tree in dependency order: by tree depth for the level plan -- or, when every action node lives in a generated subtree (lane round
+        // subtrees), by ROUND: root (0), round-0 subtrees (1), the chance nodes below them (2), round-1 subtrees (3), ...  Subtrees of one round never depend on
+        // each other whatever their depth, so same-shape subtrees of ALL depths share one launch and a round's chance nodes one expand / reduce launch.
+        if (lane_rounds) {
+            max_depth = 2 * s->n_rounds;
+            for (size_t id = 0; id < n; ++id) {
+                const rs_tree_node &nd = nodes[id];
+                if (nd.kind == RS_NODE_PRIVATE_CHANCE) depth[id] = 0;
+                else if (nd.kind == RS_NODE_PUBLIC_CHANCE) depth[id] = 2 * lane_round[id] + 2;
+                else depth[id] = 2 * lane_round[id] + 1;   // action nodes and terminals of round r
+            }
+        }
         std::vector<std::vector<int>> by_depth(max_depth + 1);
         for (size_t id = 0; id < n; ++id) by_depth[depth[id]].push_back(int(id));
         if (s->sharded)
