@@ -548,6 +548,32 @@ def kmeans_leg(rs, device, with_cpu, cpu_seconds):
                                "sample": "%d x (%d histograms x %d centers), literal emd.rs:53-113, %d threads, %.1f s; identical to the GPU result: %s"
                                          % (reps, ns, k, threads, dtc, same)}
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    # ---- the training loop that produces those centers: Kmeans::fit_regular (kmeans.rs:497-600), ten Hamerly-bounded rounds, same data ----------------------
+    try:
+        t0 = time.perf_counter()
+        fc, fcent, fb, finertia = km.fit_regular(centers, ab.DIST_EMD, 10)
+        dtf = time.perf_counter() - t0
+        fit = {"what": "Kmeans::fit_regular, emd_1d, 10 rounds of init_s -> reassign_clusters (Hamerly bounds) -> means -> bound shifts over the same %d histograms and %d "
+                       "centers; time includes the downloads of clusters and bounds" % (n, k),
+               "seconds": dtf, "inertia": float(finertia), "clusters_used": int(len(np.unique(fc)))}
+        if with_cpu:
+            from oracle import orc
+            ns = 20000   # the literal port on a sample, and the device on the same sample: identical bits or the comparison is void
+            t0 = time.perf_counter()
+            oc, ocent, ob, oin = orc.kmeans_fit_regular(data[:ns], centers, orc.DIST_EMD, 10)
+            dtc = time.perf_counter() - t0
+            kms = ab.Kmeans(table, data[:ns])
+            gc, gcent, gb, gin = kms.fit_regular(centers, ab.DIST_EMD, 10)
+            same = bool((gc == oc).all() and (gcent.view(np.uint32) == ocent.view(np.uint32)).all() and (gb.view(np.uint32) == ob.view(np.uint32)).all())
+            fit["cpu_baseline"] = {"value": ns * 10 / dtc, "unit": "datum-rounds/s", "cores": 1, "kind": "port",
+                                   "sample": "10 rounds over %d histograms, literal kmeans.rs:497-600 (oracle/kmeans_fit.c), 1 thread, %.1f s; identical to the GPU result on the "
+                                             "same sample: %s" % (ns, dtc, same)}
+            fit["value"] = n * 10 / dtf
+            fit["unit"] = "datum-rounds/s"
+            fit["gpu_over_cpu"] = fit["value"] / fit["cpu_baseline"]["value"]
+        out["fit_regular"] = fit
+    except Exception as e:
+        out["fit_regular"] = {"error": str(e)}
     table.destroy()
     return out
 
