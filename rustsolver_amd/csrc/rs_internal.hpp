@@ -162,13 +162,15 @@ struct JitSubtree {
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
     size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
     size_t off_attr = 0;                                                                  // sparse deal sweeps: packed per-deal inputs of the subtree's round, may be null
+    size_t off_rlist = 0;                                                                 // append mode: the reach of every entry of the live list, may be null
+    size_t off_blist = 0, off_brlist = 0, off_bcount = 0, off_bkey = 0, off_bpsize = 0, off_bnparts = 0, off_blstride = 0;   // append mode: the next round's lists, per boundary root
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false, bool append = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

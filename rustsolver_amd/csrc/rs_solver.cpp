@@ -22,7 +22,7 @@ using namespace rs;
 namespace {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ZERO_COUNTS };
 
 struct Launch {
     int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
@@ -63,6 +63,8 @@ struct Plan {
     std::vector<Launch> launches;
     // sparse deal sweeps: per subtree root the list of live deals (reach not NaN), rebuilt by k_compact_live after the top-down pass
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
+    float *d_rlists = nullptr;          // append mode: the reach of every list entry, same shape as d_lists
+    size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
     uint32_t *d_counts = nullptr;       // [n_compact]
     CompactJob *d_compact_jobs = nullptr;
     std::vector<CompactJob> compact_jobs;
@@ -242,6 +244,7 @@ struct Builder {
     int next_group = 0;
     int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
     bool want_lists = false, want_parts = false;
+    bool append_mode = false;                // reach-down kernels append (deal, reach) to the next round's live lists themselves: no dense reach rows, no compaction scans
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
     // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
     // cluster and each (root, range) becomes its own kernel job whose tiles cover that range only -- all resident, zeroed and flushed once.
@@ -528,6 +531,7 @@ struct Builder {
             const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
             want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
             want_parts = round_mode && want_lists && !parts_off;
+            append_mode = round_mode && want_lists && !getenv("RS_JIT_NO_APPEND");
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
             if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
             if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
@@ -616,7 +620,7 @@ struct Builder {
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                          (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below,
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
-                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr);
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
@@ -698,12 +702,24 @@ struct Builder {
             for (size_t k = 0; k < js.boundary_roots.size(); ++k) {   // round subtrees: what the next round's roots return / are handed
                 const int b = js.boundary_roots[k];
                 put_ptr(js.off_butil + 8 * k, uptr(b));
-                put_ptr(js.off_breach + 8 * k, nan_ptr(b));
+                put_ptr(js.off_breach + 8 * k, append_mode ? nullptr : nan_ptr(b));
+                if (append_mode && down) {   // where the deals this kernel sends on join the next round's lists
+                    const CompactJob &bj = plan.compact_jobs[size_t(sparse_slot[size_t(b)])];
+                    put_ptr(js.off_blist + 8 * k, bj.list);
+                    put_ptr(js.off_brlist + 8 * k, plan.d_rlists + (bj.list - plan.d_lists));
+                    put_ptr(js.off_bcount + 8 * k, bj.count);
+                    put_ptr(js.off_bkey + 8 * k, bj.key);
+                    put_u32(js.off_bpsize + 4 * k, bj.part_size);
+                    put_u32(js.off_bnparts + 4 * k, bj.n_parts);
+                    put_u32(js.off_blstride + 4 * k, bj.list_stride);
+                }
             }
             if (sparse) {   // the subtree walks only its live deals
                 const CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
                 put_ptr(js.off_list, cj.list + size_t(part) * cj.list_stride);
                 put_ptr(js.off_count, cj.count + size_t(part) * cj.count_stride);
+                // append mode: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
+                put_ptr(js.off_rlist, (append_mode && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             }
             // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
             // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
@@ -919,6 +935,8 @@ struct Builder {
                 n_counts += pr.first;
             }
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
+            if (ea == hipSuccess && append_mode) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
+            plan.n_count_words = n_counts * kCountStride;
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
@@ -969,7 +987,7 @@ struct Builder {
                         if (roots_of_round.size() <= r + 1) roots_of_round.emplace_back();
                         roots_of_round[r + 1].push_back(b);
                     }
-            if (n_nan) {
+            if (n_nan && !append_mode) {
                 plan.reach_nan_bytes = size_t(n_nan) * s->pitch[0] * sizeof(float);
                 hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
                 if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
@@ -990,12 +1008,17 @@ struct Builder {
                     listed.insert(listed.end(), roots_of_round[r].begin(), roots_of_round[r].end());
                 }
             if (int rc = make_lists(listed, [&](int id) { return id == first_root ? (const float *)nullptr : (const float *)nan_ptr(id); })) return rc;
+            if (append_mode && plan.n_count_words) {   // the lists of this sweep start empty
+                Launch L;
+                L.kind = L_ZERO_COUNTS;
+                plan.launches.push_back(L);
+            }
             for (size_t r = 0; r < roots_of_round.size(); ++r) {
-                push_compact(slots_of_round[r].first, slots_of_round[r].second);
+                if (r == 0 || !append_mode) push_compact(slots_of_round[r].first, slots_of_round[r].second);   // append mode: only the first root's partition by cluster range
                 std::map<hipFunction_t, int> by_fn;
                 for (int root : roots_of_round[r]) {
                     if (bnd[size_t(root)].empty()) continue;
-                    for (int b : bnd[size_t(root)]) reach[b] = ReachSrc{nan_ptr(b), 0.0f, true};
+                    for (int b : bnd[size_t(root)]) reach[b] = append_mode ? ReachSrc{nullptr, 0.0f, true} : ReachSrc{nan_ptr(b), 0.0f, true};
                     if (int rc = add_jit_job(root, true, sparse_slot, by_fn)) return rc;
                 }
                 const int group = ++next_group;   // the DOWN kernels of one round write different reach buffers
@@ -1161,6 +1184,10 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
     }
+    if (L.kind == L_ZERO_COUNTS) {
+        RS_HIP(hipMemsetAsync(plan.d_counts, 0, plan.n_count_words * sizeof(uint32_t), t->stream), "live-list counters");
+        return RS_OK;
+    }
     if (L.kind == L_PACK) {
         RS_HIP(launch_pack_attr(s->d_pack_jobs, s->n_pack_jobs, s->deals.n_deals, t->stream), "k_pack_attr");
         return RS_OK;
@@ -1300,6 +1327,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_chance_jobs) (void)hipFree(pl.d_chance_jobs);
         if (pl.d_reach_nan) (void)hipFree(pl.d_reach_nan);
         if (pl.d_lists) (void)hipFree(pl.d_lists);
+        if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
         for (JitLaunch &JL : pl.jit)
@@ -1742,7 +1770,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, 0, sparse);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
+                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, 0, sparse, opp_mode == RS_OPP_SAMPLE);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
                                                                                                // fallback for solvers whose leaves do not share one buffer: compiled by the GPU tests)
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (seen.count(js.source)) continue;
