@@ -160,7 +160,9 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
     if dtype == "i32":
         scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
     else:
-        scale, m = 1.0, rs.UPD_CLAMP_I64
+        # float tables: the utility of an ENUM chance node is a SUM over its deals (cfr.rs:519), so a flop regret delta reaches millions on the three-street tree and
+        # overflows binary16 at scale 1 (and a NaN reach marks an inactive lane on the device: an overflowing run would measure kernels that skip their stores)
+        scale, m = (2.0 ** -12 if three else 1.0), rs.UPD_CLAMP_I64
     sampled = opp == "sample"
     chance = rs.CHANCE_PASS if (not three or sampled) else rs.CHANCE_ENUM
     trainer = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=m, chance_mode=chance, use_graph=bool(graph),
