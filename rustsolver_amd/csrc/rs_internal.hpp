@@ -108,6 +108,11 @@ struct CompactJob {
     // cluster-partitioned workgroups: a live deal goes to the list of part key[lane] / part_size (key = its traverser cluster id)
     const uint32_t *key;  // nullptr when n_parts == 1
     uint32_t part_size, n_parts, list_stride, count_stride;
+    // Only the deals the PARENT subtree walked can be live here: scan the parent's live lists (one per cluster range of the parent) instead of the whole batch.
+    // nullptr: the parent walks every deal (an unlisted first root): scan lanes 0 .. n_lanes.
+    const uint32_t *src_list;
+    const uint32_t *src_count;
+    uint32_t src_parts, src_list_stride, src_count_stride;
 };
 // deal sweeps: packed per-deal inputs of one round (rs_kernels.hip k_pack_attr)
 struct u32x4_host { uint32_t x, y, z, w; };

@@ -416,19 +416,24 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
     __shared__ uint32_t wave_count[kBlock / 64][kMaxParts];   // live lanes of every wave, per cluster range
     __shared__ uint32_t part_base[kMaxParts];                 // list slot reserved for this workgroup, per cluster range
     const CompactJob *job = jobs + blockIdx.y;
-    const uint32_t n = job->n_lanes, n_parts = job->n_parts, part_size = job->part_size;
+    const uint32_t n_parts = job->n_parts, part_size = job->part_size;
     const float *__restrict__ reach = job->reach;
     const uint32_t *__restrict__ key = job->key;
     const uint32_t lane_in_wave = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr uint32_t kTile = kBlock * kCompactPerThread;
+    const uint32_t src_parts = job->src_list ? job->src_parts : 1u;
+    for (uint32_t sq = 0; sq < src_parts; ++sq) {   // the parent's live lists, or once over the whole batch
+    const uint32_t n = job->src_list ? job->src_count[(size_t)sq * job->src_count_stride] : job->n_lanes;
+    const uint32_t *__restrict__ src = job->src_list ? job->src_list + (size_t)sq * job->src_list_stride : nullptr;
     for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {   // whole workgroups iterate together
         bool live[kCompactPerThread];
-        uint32_t part[kCompactPerThread], rank[kCompactPerThread];   // rank: among this wave's live lanes of the same part, over all sub-rounds
+        uint32_t deal[kCompactPerThread], part[kCompactPerThread], rank[kCompactPerThread];   // rank: among this wave's live lanes of the same part, over all sub-rounds
 #pragma unroll
-        for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers lanes base + i*256 .. +255: coalesced reads
-            const uint32_t l = base + i * kBlock + threadIdx.x;
-            live[i] = l < n && (!reach || reach[l] == reach[l]);
-            part[i] = (live[i] && key) ? min(key[l] / part_size, n_parts - 1u) : 0u;
+        for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers entries base + i*256 .. +255: coalesced reads
+            const uint32_t e = base + i * kBlock + threadIdx.x;
+            deal[i] = e < n ? (src ? src[e] : e) : 0u;
+            live[i] = e < n && (!reach || reach[deal[i]] == reach[deal[i]]);
+            part[i] = (live[i] && key) ? min(key[deal[i]] / part_size, n_parts - 1u) : 0u;
             rank[i] = 0;
         }
         for (uint32_t q = 0; q < n_parts; ++q) {   // ballots only: no barrier inside
@@ -454,9 +459,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
             if (live[i]) {
                 uint32_t slot = part_base[part[i]] + rank[i];
                 for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part[i]];
-                job->list[(size_t)part[i] * job->list_stride + slot] = base + i * kBlock + threadIdx.x;
+                job->list[(size_t)part[i] * job->list_stride + slot] = deal[i];
             }
         __syncthreads();   // wave_count / part_base are rewritten by the next iteration
+    }
     }
 }
 

@@ -244,6 +244,7 @@ struct Builder {
     int next_group = 0;
     int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
     bool want_lists = false, want_parts = false;
+    std::vector<int> parent_root_;           // round subtrees: the root of the round subtree above a root
     bool append_mode = false;                // reach-down kernels append (deal, reach) to the next round's live lists themselves: no dense reach rows, no compaction scans
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
     // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
@@ -966,6 +967,20 @@ struct Builder {
                 plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
             }
             plan.count_off[n_sparse] = cat;
+            // a deal can only be live in a round subtree if its PARENT subtree walked it: scan the parent's live lists rather than the whole batch (the parent's reach-down
+            // kernel writes every boundary row for every deal it walks -- reach or NaN -- so nothing stale is ever read and the rows need no NaN fill per sweep)
+            if (round_mode && !getenv("RS_JIT_SCAN_ALL"))
+                for (size_t k = 0; k < n_sparse; ++k) {
+                    const int par = parent_root_.empty() ? -1 : parent_root_[size_t(ids[k])];
+                    if (par < 0 || sparse_slot[size_t(par)] < 0) continue;
+                    const CompactJob &pj = plan.compact_jobs[size_t(sparse_slot[size_t(par)])];
+                    CompactJob &cj = plan.compact_jobs[k];
+                    cj.src_list = pj.list;
+                    cj.src_count = pj.count;
+                    cj.src_parts = pj.n_parts;
+                    cj.src_list_stride = pj.list_stride;
+                    cj.src_count_stride = pj.count_stride;
+                }
             ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
             return RS_OK;
@@ -989,14 +1004,23 @@ struct Builder {
                         if (roots_of_round.size() <= r + 1) roots_of_round.emplace_back();
                         roots_of_round[r + 1].push_back(b);
                     }
+            std::vector<int> &parent_root = parent_root_;
+            parent_root.assign(n, -1);
+            for (size_t r = 0; r < roots_of_round.size(); ++r)
+                for (int root : roots_of_round[r])
+                    for (int b : bnd[size_t(root)]) parent_root[size_t(b)] = root;
             if (n_nan && !append_mode) {
                 plan.reach_nan_bytes = size_t(n_nan) * s->pitch[0] * sizeof(float);
                 hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
                 if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
                 if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
-                Launch L;
-                L.kind = L_NANFILL;
-                plan.launches.push_back(L);
+                // dense sweeps read every lane of a root's row: lanes nobody handed a reach to must hold NaN.  List sweeps only ever read what the parent's reach-down
+                // kernel wrote in THIS sweep (the compaction scans the parent's lists), so they need no fill -- unless the old whole-batch scan is asked for
+                if (!want_lists || getenv("RS_JIT_SCAN_ALL")) {
+                    Launch L;
+                    L.kind = L_NANFILL;
+                    plan.launches.push_back(L);
+                }
             }
             std::vector<int> listed;
             std::vector<std::pair<int, int>> slots_of_round(roots_of_round.size(), {0, 0});   // (first compact job, count)
