@@ -245,6 +245,7 @@ struct Builder {
     int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
     bool want_lists = false, want_parts = false;
     std::vector<int> parent_root_;           // round subtrees: the root of the round subtree above a root
+    bool scan_parent = false;                // the compaction of a root's live deals scans its parent's lists, not the whole batch
     bool append_mode = false;                // reach-down kernels append (deal, reach) to the next round's live lists themselves: no dense reach rows, no compaction scans
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
     // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
@@ -535,6 +536,10 @@ struct Builder {
             // measured SLOWER than dense rows + compaction (three streets, 4 M deals per batch: 14.49 against 13.36 ms; 1 M: 6.99 against 5.98): the appends are one
             // atomic per wave, boundary and cluster range on a few dozen counters, where k_compact_live reserves once per workgroup and 1 024 lanes.  Off unless asked for.
             append_mode = round_mode && want_lists && getenv("RS_JIT_APPEND") && atoi(getenv("RS_JIT_APPEND")) != 0;
+            // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
+            // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
+            scan_parent = round_mode && want_lists && s->deals.n_deals > kSmallDealBatch;
+            if (const char *e = getenv("RS_JIT_SCAN_ALL")) scan_parent = round_mode && want_lists && atoi(e) == 0;
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
             if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
             if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
@@ -969,7 +974,7 @@ struct Builder {
             plan.count_off[n_sparse] = cat;
             // a deal can only be live in a round subtree if its PARENT subtree walked it: scan the parent's live lists rather than the whole batch (the parent's reach-down
             // kernel writes every boundary row for every deal it walks -- reach or NaN -- so nothing stale is ever read and the rows need no NaN fill per sweep)
-            if (round_mode && !getenv("RS_JIT_SCAN_ALL"))
+            if (scan_parent)
                 for (size_t k = 0; k < n_sparse; ++k) {
                     const int par = parent_root_.empty() ? -1 : parent_root_[size_t(ids[k])];
                     if (par < 0 || sparse_slot[size_t(par)] < 0) continue;
@@ -1016,7 +1021,7 @@ struct Builder {
                 if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
                 // dense sweeps read every lane of a root's row: lanes nobody handed a reach to must hold NaN.  List sweeps only ever read what the parent's reach-down
                 // kernel wrote in THIS sweep (the compaction scans the parent's lists), so they need no fill -- unless the old whole-batch scan is asked for
-                if (!want_lists || getenv("RS_JIT_SCAN_ALL")) {
+                if (!scan_parent) {
                     Launch L;
                     L.kind = L_NANFILL;
                     plan.launches.push_back(L);
