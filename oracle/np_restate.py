@@ -272,10 +272,21 @@ def splitmix64(x):
 
 
 def sample_bits(seed, node_index, lanes):
+    """the 32-bit counter hash of the opponent sampler (rs_device.hpp sample_bits): seed, node and lane words xor-ed, lowbias32 finisher"""
     lanes = np.asarray(lanes, dtype=np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    seed = np.uint64(seed)
     with np.errstate(over="ignore"):
-        k = np.uint64(seed) ^ (np.uint64(node_index + 1) * np.uint64(0xD1B54A32D192ED03)) ^ (lanes * np.uint64(0x9E3779B97F4A7C15))
-    return (splitmix64(k) >> np.uint64(32)).astype(np.uint32)
+        s_mix = (seed & M) ^ (((seed >> np.uint64(32)) * np.uint64(0x85EBCA6B)) & M)
+        n_mix = (np.uint64(node_index + 1) * np.uint64(0xC2B2AE35)) & M
+        l_mix = (((lanes & M) * np.uint64(0x9E3779B9)) & M) ^ (((lanes >> np.uint64(32)) * np.uint64(0x27D4EB2F)) & M)
+        x = (s_mix ^ n_mix ^ l_mix) & M
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7FEB352D)) & M
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & M
+        x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
 
 
 def sweep_seed(base_seed, call_index):

@@ -628,8 +628,17 @@ uint64_t orc_splitmix64(uint64_t x) {
 }
 
 uint32_t orc_sample_bits(uint64_t seed, uint32_t node_index, uint64_t lane) {
-    uint64_t h = orc_splitmix64(seed ^ ((uint64_t)(node_index + 1u) * 0xD1B54A32D192ED03ull) ^ (lane * 0x9E3779B97F4A7C15ull));
-    return (uint32_t)(h >> 32);
+    /* the 32-bit counter hash of rs_device.hpp sample_bits (lowbias32 finisher over seed, node and lane words) */
+    uint32_t s_mix = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    uint32_t n_mix = (node_index + 1u) * 0xC2B2AE35u;
+    uint32_t l_mix = ((uint32_t)lane * 0x9E3779B9u) ^ ((uint32_t)(lane >> 32) * 0x27D4EB2Fu);
+    uint32_t x = s_mix ^ n_mix ^ l_mix;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 
 uint64_t orc_sweep_seed(uint64_t base_seed, uint64_t call_index) {

@@ -417,9 +417,19 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 __device__ __forceinline__ unsigned sample_bits(unsigned long long seed, unsigned node_index, unsigned long long lane) {
-    const unsigned long long h =
-        splitmix64(seed ^ ((unsigned long long)(node_index + 1u) * 0xD1B54A32D192ED03ull) ^ (lane * 0x9E3779B97F4A7C15ull));
-    return (unsigned)(h >> 32);
+    // A 32-bit counter hash (round 2; round 1 ran splitmix64 here: two 64-bit multiplies, about 40 vector instructions per opponent node and lane, a fifth of a deal
+    // kernel's VALU work).  The sweep seed and the node fold into wave-uniform words (scalar ALU), the lane into one 32-bit multiply that the compiler shares between
+    // all opponent nodes of a kernel; the finisher is the two-multiply "lowbias32" mixer.  23 of the 32 bits reach the sampler (u01 = (bits >> 9) * 2^-23).
+    const unsigned s_mix = (unsigned)seed ^ ((unsigned)(seed >> 32) * 0x85EBCA6Bu);
+    const unsigned n_mix = (node_index + 1u) * 0xC2B2AE35u;
+    const unsigned l_mix = ((unsigned)lane * 0x9E3779B9u) ^ ((unsigned)(lane >> 32) * 0x27D4EB2Fu);
+    unsigned x = s_mix ^ n_mix ^ l_mix;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 __device__ __forceinline__ unsigned long long sweep_seed(unsigned long long base_seed, unsigned long long call_index) {
     return splitmix64(base_seed + call_index * 0x632BE59BD9B4E019ull);
