@@ -487,7 +487,7 @@ def solve_three_street_leg(rs, device):
     n_actions, tree = rs.build_game_tree(rs.three_street_options())
     card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, None) for r in range(3)]
     n = 1 << 16
-    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=1, device=device)
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=1, use_graph=True, device=device)
     t0 = time.perf_counter()
     e0 = tr.exploitability()
     first_br_s = time.perf_counter() - t0
@@ -594,7 +594,7 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     n_actions, tree = rs.build_game_tree(rs.three_street_options())
     card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
     t0 = time.perf_counter()
-    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, device=device)
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, use_graph=True, device=device)   # graph replay: 10-17 % on this tree (A/B: DESIGN.md 8a)
     create_s = time.perf_counter() - t0
     tr.train(2)
     tr.status()

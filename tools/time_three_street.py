@@ -26,7 +26,7 @@ card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in 
 print("abstractions: %.1f s, sizes" % (time.perf_counter() - t0), [a.get_size(0) for a in card_abs], "action nodes", n_actions)
 n = int(os.environ.get("N", str(1 << 20)))
 t0 = time.perf_counter()
-tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE)
+tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE, use_graph=bool(int(os.environ.get("GRAPH", "0"))))
 print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.infosets.nbytes / 1e6 if not callable(tr.infosets.nbytes) else tr.infosets.nbytes() / 1e6))
 tr.train(2); tr.status()
 KB = int(os.environ.get("BATCHES", "5"))
