@@ -477,6 +477,10 @@ int rs_update_min_dists(rs_table *table, int dist, float *d_min_dists, const flo
  *   rs_kmeans_fit_growbatch Kmeans::fit_growbatch AS CODED (:336-495: one pass over the first `batch` shuffled items, then `break`); the shuffle (:352) is the
  *                           caller's: d_order; stats (may be NULL) = {min_change, inertia as printed} */
 int rs_kmeans_init_s(rs_table *table, int dist, const float *centers, int n_centers, int n_bins, float *s);
+/* Kmeans::init_random's choice among restarts (kmeans.rs:104-165): the caller draws the candidate center sets with its rng (`choose_multiple`, :120), this scores them
+ * as coded (mean pairwise distance, f32 sums in index order, :133-148) and returns the most spread one (*best; the last of equal maxima, :151-156).
+ * centers: HOST [n_restarts][n_centers][n_bins]; cluster_dists: HOST out [n_restarts], may be NULL.  (init_pp's heavy step is rs_update_min_dists.) */
+int rs_kmeans_pick_restart(rs_table *table, int dist, const float *centers, int n_restarts, int n_centers, int n_bins, float *cluster_dists, int *best);
 int rs_kmeans_reassign(rs_table *table, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, const float *centers, int n_centers, int n_bins,
                        const float *s, uint32_t *d_clusters, float *d_bounds);
 int rs_kmeans_fit_regular(rs_table *table, int dist, const float *d_dataset, size_t n, float *centers, int n_centers, int n_bins, int iterations, uint32_t *d_clusters,

@@ -1,5 +1,6 @@
 /*
  * kmeans_fit.c -- CPU restatement of the abstraction generator's k-means TRAINING loops:
+ *   Kmeans::init_random (scoring)   gen_abstraction/kmeans.rs:124-156
  *   Kmeans::init_s                  gen_abstraction/kmeans.rs:267-285
  *   Kmeans::reassign_clusters       gen_abstraction/kmeans.rs:287-334   (= assignment_with_bounds :213-265, same body)
  *   Kmeans::fit_regular             gen_abstraction/kmeans.rs:497-600
@@ -42,6 +43,30 @@ void orc_kmeans_init_s(int kind, const float *centers, int k, int len, float *s)
         }
         s[i] /= 2.0f;
     }
+}
+
+/* Kmeans::init_random's scoring of the candidate center sets (kmeans.rs:124-156): cluster_dists[r] = (sum_i sum_{j != i} dist(c_i, c_j)) / count, the index of the
+ * maximum is returned (Iterator::max_by keeps the LAST of equal maxima; partial_cmp(..).unwrap_or(Equal) makes a NaN "equal") */
+int orc_kmeans_pick_restart(int kind, const float *centers, int n_restarts, int k, int len, float *cluster_dists) {
+    int r, i, j, arg = 0;
+    for (r = 0; r < n_restarts; r++) {
+        const float *c = centers + (size_t)r * k * len;
+        float sum = 0.0f;
+        size_t count = 0;
+        for (i = 0; i < k; i++) {
+            float di = 0.0f;                       /* distances[i], kmeans.rs:137 */
+            for (j = 0; j < k; j++) {
+                if (j == i) continue;
+                di += dist(kind, c + (size_t)i * len, c + (size_t)j * len, len);
+                count += 1;
+            }
+            sum += di;
+        }
+        cluster_dists[r] = sum / (float)count;
+    }
+    for (r = 1; r < n_restarts; r++)
+        if (!(cluster_dists[r] < cluster_dists[arg])) arg = r;
+    return arg;
 }
 
 /* kmeans.rs:287-334 (and :213-265).  order != NULL: datum i is dataset[order[i]] (fit_growbatch's shuffled_data).  bounds = (lower, upper) pairs. */

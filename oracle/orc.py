@@ -758,6 +758,16 @@ def kmeans_init_s(centers, s, kind=DIST_EMD):
     return s
 
 
+def kmeans_pick_restart(candidates, kind=DIST_EMD):
+    """Kmeans::init_random's scoring (kmeans.rs:124-156): candidates [n_restarts][k][n_bins] -> (best index, cluster_dists)"""
+    c = np.ascontiguousarray(candidates, dtype=np.float32)
+    cd = np.zeros(c.shape[0], dtype=np.float32)
+    fn = lib().orc_kmeans_pick_restart
+    fn.restype = C.c_int
+    best = fn(kind, _f32(c), c.shape[0], c.shape[1], c.shape[2], _f32(cd))
+    return int(best), cd
+
+
 def kmeans_reassign(dataset, centers, s, clusters, bounds, kind=DIST_EMD, order=None):
     """Kmeans::reassign_clusters (kmeans.rs:287-334); clusters (uint32 [n]) and bounds (float32 [n][2] = lower, upper) in place"""
     d, c = np.ascontiguousarray(dataset, dtype=np.float32), np.ascontiguousarray(centers, dtype=np.float32)

@@ -199,6 +199,7 @@ SYMBOLS = {
     "rs_best_response_rounds": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rs_br_runouts": (C.c_size_t, [_P, C.c_int, _P]),
     "rs_kmeans_init_s": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "rs_kmeans_pick_restart": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
     "rs_kmeans_reassign": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P, _P]),
     "rs_kmeans_fit_regular": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_float)]),
     "rs_kmeans_fit_growbatch": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P, _P]),

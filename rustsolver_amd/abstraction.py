@@ -303,6 +303,15 @@ class Kmeans:
         L.check(L.load().rs_kmeans_init_s(self.table._h, dist, c.ctypes.data, len(c), self.n_bins, out.ctypes.data))
         return out
 
+    def pick_restart(self, candidates, dist=DIST_EMD):
+        """Kmeans::init_random's scoring (kmeans.rs:124-156): candidates [n_restarts][k][n_bins] -> (index of the most spread set, mean pairwise distances)"""
+        import ctypes as C
+        c = np.ascontiguousarray(candidates, dtype=np.float32)
+        cd = np.zeros(c.shape[0], dtype=np.float32)
+        best = C.c_int()
+        L.check(L.load().rs_kmeans_pick_restart(self.table._h, dist, c.ctypes.data, c.shape[0], c.shape[1], c.shape[2], cd.ctypes.data, C.byref(best)))
+        return best.value, cd
+
     def reassign(self, centers, s, clusters, bounds, dist=DIST_EMD, order=None):
         """Kmeans::reassign_clusters (kmeans.rs:287-334) -> (clusters uint32 [m], bounds float32 [m][2]); m = len(clusters) items, item i = dataset[order[i]]"""
         c = np.ascontiguousarray(centers, dtype=np.float32)

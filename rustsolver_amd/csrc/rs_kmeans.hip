@@ -175,6 +175,24 @@ __global__ __launch_bounds__(kKmBlock) void k_kmeans_init_s(const float *__restr
     s[i] = si / 2.0f;
 }
 
+// Kmeans::init_random's scoring loop (kmeans.rs:133-147): distances[i] = sum over j != i, ascending, of dist(c_i, c_j) -- one thread per center of one restart
+template <int NB, int DIST>
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_row_sums(const float *__restrict__ raw, int n_bins, const float *__restrict__ centers,
+                                                              const unsigned char *__restrict__ center_zero, int k, float *__restrict__ out) {
+    extern __shared__ float lds[];
+    float *r_col = lds + threadIdx.x;
+    const int i = blockIdx.x * kKmBlock + threadIdx.x;
+    if (i >= k) return;
+    float p[NB];
+    const bool live = load_datum<NB, DIST>(raw, (size_t)i, n_bins, p);
+    float acc = 0.0f;
+    for (int j = 0; j < k; ++j) {
+        if (j == i) continue;
+        acc += datum_dist<NB, DIST>(live, p, centers, center_zero, j, n_bins, r_col);
+    }
+    out[i] = acc;
+}
+
 // Kmeans::reassign_clusters / assignment_with_bounds (kmeans.rs:287-334, :213-265): one thread per datum; order != nullptr: datum i is dataset[order[i]]
 // (fit_growbatch's shuffled_data).  bounds[i] = (lower, upper).
 template <int NB, int DIST>
@@ -605,6 +623,41 @@ int upper_bound_sum(rs_table *t, const float *d_bounds, size_t n, float *out) {
 }  // namespace
 
 extern "C" {
+
+// Kmeans::init_random's choice among restarts (kmeans.rs:104-165): the caller draws `n_restarts` candidate center sets with its rng (`choose_multiple`, :120); this
+// scores them exactly as coded -- per restart, distances[i] = sum over j != i of dist(c_i, c_j), sum over i, divided by the k (k - 1) pairs (:133-147) -- and returns
+// the index of the maximum (the LAST of equal maxima: Iterator::max_by, :151-156).  centers: HOST [n_restarts][k][n_bins]; cluster_dists: HOST out [n_restarts], may be NULL.
+int rs_kmeans_pick_restart(rs_table *t, int dist, const float *centers, int n_restarts, int n_centers, int n_bins, float *cluster_dists, int *best) {
+    if (!best || n_restarts < 1) return fail(RS_ERR_INVALID, "rs_kmeans_pick_restart: bad argument");
+    if (int rc = check_args("rs_kmeans_pick_restart", t, dist, centers, 0, centers, n_centers, n_bins)) return rc;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    KmDevice w;
+    if (int rc = w.alloc(n_centers, n_bins)) return rc;
+    const int nb = padded_bins(n_bins);
+    std::vector<float> row(static_cast<size_t>(n_centers), 0.0f), cd(static_cast<size_t>(n_restarts), 0.0f);
+    for (int r = 0; r < n_restarts; ++r) {
+        const float *cr = centers + size_t(r) * n_centers * n_bins;
+        float *d_centers = nullptr;
+        unsigned char *d_zero = nullptr;
+        if (int rc = stage_for(t, dist, cr, n_centers, n_bins, nb, &d_centers, &d_zero)) return rc;
+        RS_HIP(hipMemcpy(w.raw, cr, size_t(n_centers) * n_bins * 4, hipMemcpyHostToDevice), "k-means centers upload");
+        const dim3 grid((unsigned)((n_centers + kKmBlock - 1) / kKmBlock)), block(kKmBlock);
+        const int k = n_centers;
+        RS_KM_DISPATCH(k_kmeans_row_sums, grid, block, (const float *)w.raw, n_bins, (const float *)d_centers, (const unsigned char *)d_zero, k, w.s);
+        RS_HIP(hipGetLastError(), "k_kmeans_row_sums");
+        RS_HIP(hipMemcpyAsync(row.data(), w.s, size_t(n_centers) * 4, hipMemcpyDeviceToHost, t->stream), "row sums download");
+        RS_HIP(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+        float sum = 0.0f;
+        for (int i = 0; i < n_centers; ++i) sum += row[size_t(i)];                  // sum += distances[i], kmeans.rs:146
+        cd[size_t(r)] = sum / float(size_t(n_centers) * size_t(n_centers - 1));   // count = k (k - 1) pairs, :148
+    }
+    int arg = 0;
+    for (int r = 1; r < n_restarts; ++r)   // max_by(partial_cmp): the last of equal maxima; NaN compares Equal (unwrap_or) and so replaces too
+        if (!(cd[size_t(r)] < cd[size_t(arg)])) arg = r;
+    if (cluster_dists) std::memcpy(cluster_dists, cd.data(), cd.size() * 4);
+    *best = arg;
+    return RS_OK;
+}
 
 // Kmeans::init_s (kmeans.rs:267-285) for callers that drive the loop themselves: s (HOST, in/out, n_centers floats) is only ever lowered, then halved
 int rs_kmeans_init_s(rs_table *t, int dist, const float *centers, int n_centers, int n_bins, float *s) {

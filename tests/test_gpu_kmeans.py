@@ -232,3 +232,17 @@ def test_fit_rejects_bad_arguments(table):
         km.fit_regular(data[:1], ab.DIST_L2, 3)                           # one center: the reference indexes center_movement[1]
     with pytest.raises(rs.RsError):
         km.fit_growbatch(np.arange(10, dtype=np.uint32), 11, data[:3], ab.DIST_L2)   # batch > n
+
+
+def test_pick_restart_equals_oracle(table):
+    """Kmeans::init_random's choice among restarts (kmeans.rs:124-156): mean pairwise center distance per candidate set, f32 sums in index order, arg-max"""
+    rng = np.random.Generator(np.random.PCG64(79))
+    data = histograms(rng, 4000, 20, "counts")
+    km = ab.Kmeans(table, data[:8])
+    cands = np.stack([data[rng.choice(len(data), size=37, replace=False)] for _ in range(6)])
+    cands[4] = cands[1]                                   # equal scores: max_by keeps the LAST
+    for dist, odist in ((ab.DIST_EMD, orc.DIST_EMD), (ab.DIST_L2, orc.DIST_L2)):
+        best, cd = km.pick_restart(cands, dist)
+        obest, ocd = orc.kmeans_pick_restart(cands, odist)
+        assert cd.view(np.uint32).tolist() == ocd.view(np.uint32).tolist() and best == obest
+        assert cd[4] == cd[1] and best != 1

@@ -169,3 +169,12 @@ def test_oracle_growbatch_is_one_pass_over_the_batch():
     for j in range(9):
         if (cl == j).sum() == 0:
             assert (cent[j] == 0).all()                        # empty cluster: the mean of nothing is the zero histogram (`count > 0.0`, kmeans.rs:412)
+
+
+def test_oracle_pick_restart_by_hand():
+    """three candidate sets of three centers on a line (l2_dist): the mean pairwise distance by hand, the arg-max, and the last-of-equal-maxima rule of max_by"""
+    def line(xs):
+        return np.array([[x, 0.0] for x in xs], dtype=np.float32)
+    cands = np.stack([line([0, 1, 2]), line([0, 3, 6]), line([1, 4, 7])])     # mean pairwise distances 4/3, 4, 4
+    best, cd = orc.kmeans_pick_restart(cands, orc.DIST_L2)
+    assert np.allclose(cd, [8.0 / 6.0, 4.0, 4.0]) and best == 2
