@@ -158,7 +158,9 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
                 L.check(L.load().rs_fill_uniform_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 17 + r, -1.0, 1.0))
             leaves[i] = (rs.LEAF_SIGN, signs[r])
     if dtype == "i32":
-        scale, m = (100.0, rs.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, rs.UPD_WRAP_I32)
+        scale, m = (100.0, rs.UPD_CLAMP_I64) if mode.startswith("clamp") else (10000.0, rs.UPD_WRAP_I32)
+        if mode.endswith("+prune"):   # cfr() with prune = true (cfr.rs:379-386); the synthetic regrets stay above the threshold, so this prices the pruned kernels, not skipped work
+            m |= rs.UPD_PRUNE
     else:
         # float tables: the utility of an ENUM chance node is a SUM over its deals (cfr.rs:519), so a flop regret delta reaches millions on the three-street tree and
         # overflows binary16 at scale 1 (and a NaN reach marks an inactive lane on the device: an overflowing run would measure kernels that skip their stores)

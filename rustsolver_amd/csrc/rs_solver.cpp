@@ -365,8 +365,8 @@ struct Builder {
             mark_lane_round_inside(id, id);
             return;
         }
-        const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0 && !s->deal_mode;   // lane sweeps: prune keeps the level plan (NaN-reach bookkeeping); deal kernels have a pruned form
-        if (s->params.fuse_subtrees && !prune && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
+        // (pruned lane sweeps kept the level plan in round 1; since round 2 the generated lane kernels have the pruned forms the deal kernels always had)
+        if (s->params.fuse_subtrees && nd.kind == RS_NODE_ACTION && nd.n_children > 0 && closed[id]) {
             fused_root[id] = 1;
             mark_inside(id);
             // Directly below an ENUM chance node (cfr.rs:502-522) the subtree's kernel can take over the chance node's work.  Needs whole vectors per board
@@ -550,7 +550,7 @@ struct Builder {
         } else {
             // lane sweeps: round subtrees above the last round (full-width cfr() with ENUM chance nodes; prune keeps the level plan's NaN bookkeeping)
             lane_rounds = !s->deal_mode && s->params.fuse_subtrees && s->params.chance_mode == RS_CHANCE_ENUM && s->params.opp_mode == RS_OPP_FULL &&
-                          (s->params.mode & RS_UPD_PRUNE) == 0 && !getenv("RS_JIT_NO_LANE_ROUNDS");
+                          !getenv("RS_JIT_NO_LANE_ROUNDS");
             for (size_t id = 0; id < n; ++id)
                 if (nodes[id].kind == RS_NODE_PUBLIC_CHANCE) {
                     const int c = nodes[id].children[0];
@@ -1735,7 +1735,8 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
                 const bool down = (form & 1) != 0, xr = (form & 2) != 0;
                 if (xr && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
                 JitSubtree js;
-                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, false, false, false, false, down, false, 4, &next_root, js, xr ? 1 : 0);
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, false, false, false, false, down, (mode & RS_UPD_PRUNE) != 0, 4, &next_root, js,
+                                 xr ? 1 : 0);
                 if (down && js.boundary_roots.empty()) continue;
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
@@ -1749,8 +1750,8 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             for (int fan = 0; fan < 3; ++fan) {   // below a public chance node also the forms that take over the node's expand (1) and its deal loop (2)
                 if (fan && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
                 JitSubtree js;
-                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false, false, 4, nullptr, js,
-                                 fan);
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false,
+                                 (mode & RS_UPD_PRUNE) != 0, 4, nullptr, js, fan);
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
                 if (int rc = jit_compile_only(js.source)) return rc;

@@ -154,6 +154,9 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 2     # mccfr(): sampled opponent
     _, tree3 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5,), (1.0,)), raise_sizes=((3.0,), (3.0,))))
     assert rs.jit_check_tree(tree3, rs.I32, rs.UPD_WRAP_I32) >= 2
+    # pruned lane sweeps (RS_UPD_PRUNE): the generated kernels' pruned forms, river tree and round subtrees
+    assert rs.jit_check_tree(tree, rs.I32, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE) == 2
+    assert rs.jit_check_tree(tree3, rs.I32, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE) >= 2
     # deal batches: round subtrees (reach-down half, walk; dense / live-deal list; LDS tiles / direct atomics), sampled and full width
     assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 16         # river tree: no reach-down half; 4 walks per traverser, each with 4 and 1 deals per thread
     assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) > 8

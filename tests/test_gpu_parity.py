@@ -339,8 +339,8 @@ def test_iterate_river_tree_vs_oracle(C, B, mode, graph, fuse):
     scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if mode == "wrap" else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), chance_mode=rs.CHANCE_PASS,
                          use_graph=graph, fuse_subtrees=fuse)
-    # fused: the whole river tree is ONE tree-specialised launch per traverser (prune falls back to the level plan)
-    assert tr.n_launches(0) == (1 if fuse and not prune else (10 if prune else 8))
+    # fused: the whole river tree is ONE tree-specialised launch per traverser, pruned or not
+    assert tr.n_launches(0) == (1 if fuse else (10 if prune else 8))
     osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, prune=prune, chance_mode=orc.CHANCE_PASS)
     for it in range(3):
         for player in (0, 1):
@@ -360,6 +360,28 @@ def test_iterate_three_street_tree_vs_oracle(boards, chance, fuse, C):
     tr = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=cm_g, fuse_subtrees=fuse)
     osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=cm_o)
     for it in range(2):
+        for player in (0, 1):
+            got = tr.iterate(player, want_root_util=True)
+            want = osol.iterate(player, threads=4)
+            assert_bits(got, want, "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+
+
+@pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([1, 3, 3], "enum"), ([2, 2, 2], "pass")])
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_iterate_three_street_tree_pruned_vs_oracle(boards, chance, fuse):
+    """cfr() with prune = true over lanes (cfr.rs:379-386): since round 2 the generated kernels (river subtrees, round subtrees and their
+    reach-down halves) have pruned forms, so a pruned sweep takes the same launch plan as an unpruned one.  Every 11th lane of action 0
+    sits below the threshold."""
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), boards, 12, 43)
+    cm_g, cm_o = (rs.CHANCE_ENUM, orc.CHANCE_ENUM) if chance == "enum" else (rs.CHANCE_PASS, orc.CHANCE_PASS)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, chance_mode=cm_g, fuse_subtrees=fuse)
+    if fuse and chance == "enum":
+        ref = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, chance_mode=cm_g, fuse_subtrees=fuse)
+        assert tr.n_launches(0) == ref.n_launches(0) and tr.n_launches(1) == ref.n_launches(1)
+        del ref
+    osol = orc.OracleSolver(otree, otab, lo, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=True, chance_mode=cm_o)
+    for it in range(3):
         for player in (0, 1):
             got = tr.iterate(player, want_root_util=True)
             want = osol.iterate(player, threads=4)
