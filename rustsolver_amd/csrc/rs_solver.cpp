@@ -525,6 +525,9 @@ struct Builder {
             // thread puts four times as many waves on the chip, each walking a quarter of the code (RS_JIT_LANES = 1 / 4 overrides)
             // Only the first round's subtree sees the whole batch; the subtrees behind chance nodes walk the live-deal lists of their roots, a small
             // share of it each (three streets, 1 M deals per batch: 6.46 -> 5.87 ms with one deal per thread everywhere; 128 K deals: 3.81 -> 2.45)
+            // Round 2: kernels with LDS delta tiles take one deal per thread at every batch size -- their tiles hold the CU to ONE workgroup, which is 1 024 threads for
+            // the one-deal forms and 512 for the four-deal forms (registers), and 16 lean waves per CU beat 8 fat ones (river game, 4 M deals per batch: 0.858 -> 0.768 ms,
+            // 1 M: 0.295 -> 0.274, 256 K: 0.143 -> 0.123; gpurun_out/r02z/ab_l1.log).  The rule below is left for the kernels without tiles.
             jit_lanes = (s->deal_mode && s->deals.n_deals <= kSmallDealBatch) ? 1 : 4;
             jit_lanes_below = s->deal_mode ? 1 : 4;
             if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = jit_lanes_below = atoi(e) == 1 ? 1 : 4;
@@ -626,7 +629,7 @@ struct Builder {
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                         (id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below,
+                         (use_lds && !getenv("RS_JIT_LANES")) ? 1 : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
                          int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
