@@ -113,6 +113,10 @@ struct CompactJob {
     const uint32_t *src_list;
     const uint32_t *src_count;
     uint32_t src_parts, src_list_stride, src_count_stride;
+    // Position-indexed rows: the parent's reach-down kernel wrote `reach` at the parent's LIST POSITION (part * src_list_stride + entry), so this scan reads it coalesced;
+    // the reach of every live deal is then stored beside its new list entry (rlist, same layout as list), where the subtree's kernels read it coalesced too.
+    uint32_t pos_rows, pad_;
+    float *rlist;         // [n_parts][list_stride] or nullptr
 };
 // deal sweeps: packed per-deal inputs of one round (rs_kernels.hip k_pack_attr)
 struct u32x4_host { uint32_t x, y, z, w; };
@@ -175,7 +179,8 @@ struct JitSubtree {
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false, bool append = false);
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false, bool append = false,
+                      bool posrows = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

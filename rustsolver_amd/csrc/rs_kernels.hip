@@ -427,12 +427,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
     const uint32_t *__restrict__ src = job->src_list ? job->src_list + (size_t)sq * job->src_list_stride : nullptr;
     for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {   // whole workgroups iterate together
         bool live[kCompactPerThread];
+        float rv[kCompactPerThread];
         uint32_t deal[kCompactPerThread], part[kCompactPerThread], rank[kCompactPerThread];   // rank: among this wave's live lanes of the same part, over all sub-rounds
 #pragma unroll
         for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers entries base + i*256 .. +255: coalesced reads
             const uint32_t e = base + i * kBlock + threadIdx.x;
             deal[i] = e < n ? (src ? src[e] : e) : 0u;
-            live[i] = e < n && (!reach || reach[deal[i]] == reach[deal[i]]);
+            rv[i] = (e < n && reach) ? reach[(src && job->pos_rows) ? (size_t)sq * job->src_list_stride + e : (size_t)deal[i]] : 0.0f;
+            live[i] = e < n && rv[i] == rv[i];
             part[i] = (live[i] && key) ? min(key[deal[i]] / part_size, n_parts - 1u) : 0u;
             rank[i] = 0;
         }
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
                 uint32_t slot = part_base[part[i]] + rank[i];
                 for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part[i]];
                 job->list[(size_t)part[i] * job->list_stride + slot] = deal[i];
+                if (job->rlist) job->rlist[(size_t)part[i] * job->list_stride + slot] = rv[i];
             }
         __syncthreads();   // wave_count / part_base are rewritten by the next iteration
     }

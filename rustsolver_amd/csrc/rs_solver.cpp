@@ -246,6 +246,9 @@ struct Builder {
     bool want_lists = false, want_parts = false;
     std::vector<int> parent_root_;           // round subtrees: the root of the round subtree above a root
     bool scan_parent = false;                // the compaction of a root's live deals scans its parent's lists, not the whole batch
+    bool pos_rows = false;                   // scan_parent only: the reach rows between a listed root's reach-down kernel and its children's compaction are indexed by the root's
+                                             // LIST POSITION (written and read coalesced) and the compaction stores every live deal's reach beside its list entry
+    std::vector<size_t> nan_off;             // per reach row of the round subtrees: float offset in plan.d_reach_nan (rows of listed parents hold one segment per cluster range)
     bool append_mode = false;                // reach-down kernels append (deal, reach) to the next round's live lists themselves: no dense reach rows, no compaction scans
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
     // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
@@ -295,7 +298,9 @@ struct Builder {
     std::vector<float *> util_override;   // sharded: the utility rows of boundary children live in the exchange buffer
     std::vector<int> boundary_k;          // chance node id -> index among the boundary nodes, -1 otherwise
     float *uptr(int id) const { return util_override[id] ? util_override[id] : aptr(util_off[id]); }
-    float *nan_ptr(int id) const { return plan.d_reach_nan + size_t(nan_slot[size_t(id)]) * s->pitch[0]; }   // round mode: a root's reach buffer
+    float *nan_ptr(int id) const { return plan.d_reach_nan + nan_off[size_t(nan_slot[size_t(id)])]; }   // round mode: a root's reach buffer
+    // will `root` walk a live-deal list?  (every round root but the first does once lists are wanted; the first only when its tiles had to be partitioned)
+    bool listed_root(int root) { return want_lists && (root != first_root || parts_of(first_root).first > 1); }
     // deals below a chance node: global count when its child round is the sharded one
     uint32_t fan_of(int chance_id) const {
         const int c = nodes[chance_id].children[0];
@@ -543,6 +548,7 @@ struct Builder {
             // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
             scan_parent = round_mode && want_lists && s->deals.n_deals > kSmallDealBatch;
             if (const char *e = getenv("RS_JIT_SCAN_ALL")) scan_parent = round_mode && want_lists && atoi(e) == 0;
+            pos_rows = scan_parent && !append_mode && !getenv("RS_JIT_NO_POSROWS");
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
             if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
             if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
@@ -631,7 +637,7 @@ struct Builder {
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                          (use_lds && !getenv("RS_JIT_LANES")) ? 1 : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
-                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode);
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode, pos_rows);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
@@ -713,7 +719,8 @@ struct Builder {
             for (size_t k = 0; k < js.boundary_roots.size(); ++k) {   // round subtrees: what the next round's roots return / are handed
                 const int b = js.boundary_roots[k];
                 put_ptr(js.off_butil + 8 * k, uptr(b));
-                put_ptr(js.off_breach + 8 * k, append_mode ? nullptr : nan_ptr(b));
+                // position-indexed rows: this job's segment of the row starts where its list does
+                put_ptr(js.off_breach + 8 * k, append_mode ? nullptr : nan_ptr(b) + ((pos_rows && sparse && down) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
                 if (append_mode && down) {   // where the deals this kernel sends on join the next round's lists
                     const CompactJob &bj = plan.compact_jobs[size_t(sparse_slot[size_t(b)])];
                     put_ptr(js.off_blist + 8 * k, bj.list);
@@ -730,7 +737,7 @@ struct Builder {
                 put_ptr(js.off_list, cj.list + size_t(part) * cj.list_stride);
                 put_ptr(js.off_count, cj.count + size_t(part) * cj.count_stride);
                 // append mode: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
-                put_ptr(js.off_rlist, (append_mode && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
+                put_ptr(js.off_rlist, ((append_mode || pos_rows) && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             }
             // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
             // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
@@ -946,7 +953,7 @@ struct Builder {
                 n_counts += pr.first;
             }
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
-            if (ea == hipSuccess && append_mode) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
+            if (ea == hipSuccess && (append_mode || pos_rows)) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
             plan.n_count_words = n_counts * kCountStride;
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
@@ -988,7 +995,11 @@ struct Builder {
                     cj.src_parts = pj.n_parts;
                     cj.src_list_stride = pj.list_stride;
                     cj.src_count_stride = pj.count_stride;
+                    cj.pos_rows = pos_rows ? 1u : 0u;
                 }
+            if (pos_rows)   // every list but the first root's carries the reach of its entries (the first root's deals are all live, with the constant root reach)
+                for (size_t k = 0; k < n_sparse; ++k)
+                    if (ids[k] != first_root) plan.compact_jobs[k].rlist = plan.d_rlists + (plan.compact_jobs[k].list - plan.d_lists);
             ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
             return RS_OK;
@@ -1017,8 +1028,15 @@ struct Builder {
             for (size_t r = 0; r < roots_of_round.size(); ++r)
                 for (int root : roots_of_round[r])
                     for (int b : bnd[size_t(root)]) parent_root[size_t(b)] = root;
+            nan_off.assign(size_t(n_nan) + 1, 0);
+            for (size_t b = 0; b < n; ++b)
+                if (nan_slot[b] >= 0) {   // rows of a listed parent hold one list-position segment per cluster range of the parent
+                    const int par = parent_root[b];
+                    nan_off[size_t(nan_slot[b]) + 1] = s->pitch[0] * ((pos_rows && par >= 0 && listed_root(par)) ? size_t(parts_of(par).first) : size_t(1));
+                }
+            for (size_t k = 0; k < size_t(n_nan); ++k) nan_off[k + 1] += nan_off[k];
             if (n_nan && !append_mode) {
-                plan.reach_nan_bytes = size_t(n_nan) * s->pitch[0] * sizeof(float);
+                plan.reach_nan_bytes = nan_off[size_t(n_nan)] * sizeof(float);
                 hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
                 if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
                 if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
@@ -1808,9 +1826,19 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                  (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, 0, sparse, opp_mode == RS_OPP_SAMPLE);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
                                                                                                // fallback for solvers whose leaves do not share one buffer: compiled by the GPU tests)
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
-                if (seen.count(js.source)) continue;
-                seen[js.source] = 1;
-                if (int rc = jit_compile_only(js.source)) return rc;
+                if (!seen.count(js.source)) {
+                    seen[js.source] = 1;
+                    if (int rc = jit_compile_only(js.source)) return rc;
+                }
+                if (down && sparse) {   // the form that writes the next round's reach rows at its list position (large batches)
+                    JitSubtree jp;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jp, 0, sparse, false, true);
+                    if (!seen.count(jp.source)) {
+                        seen[jp.source] = 1;
+                        if (int rc = jit_compile_only(jp.source)) return rc;
+                    }
+                }
             }
         }
     }

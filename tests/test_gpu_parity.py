@@ -567,6 +567,30 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("rows", ["list-position", "deal-id", "whole-batch-scan"])
+def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
+    """What batches beyond 256 K deals get, forced onto a small one: LDS capped so that EVERY round subtree (the first included) is cut into cluster ranges,
+    the compaction of a root's live deals scans its parent's per-range lists, and -- "list-position" -- the parent's reach-down kernel writes the reach rows
+    at its list position, the compaction stores every live deal's reach beside its list entry.  "deal-id" keeps rows indexed by deal (RS_JIT_NO_POSROWS),
+    "whole-batch-scan" the small-batch compaction.  Same bits, equal to the oracle."""
+    monkeypatch.setenv("RS_JIT_LDS_MAX", "16384")
+    if rows != "whole-batch-scan":
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    if rows == "deal-id":
+        monkeypatch.setenv("RS_JIT_NO_POSROWS", "1")
+    n_deals = 30011
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(300, 280), (500, 450), (700, 650)], n_deals, 92)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=13)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=True, opp_mode=orc.OPP_SAMPLE, base_seed=13)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_deal_batches_reject_bad_inputs():
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(5, 6)], 10, 3)
     with pytest.raises(rs.RsError):
