@@ -117,6 +117,7 @@ struct CompactJob {
     // the reach of every live deal is then stored beside its new list entry (rlist, same layout as list), where the subtree's kernels read it coalesced too.
     uint32_t pos_rows, pad_;
     float *rlist;         // [n_parts][list_stride] or nullptr
+    uint32_t *plist;      // [n_parts][list_stride] or nullptr: where the parent subtree will read this deal's utility (its list position; the deal id below an unlisted parent)
 };
 // deal sweeps: packed per-deal inputs of one round (rs_kernels.hip k_pack_attr)
 struct u32x4_host { uint32_t x, y, z, w; };
@@ -171,7 +172,8 @@ struct JitSubtree {
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
     size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
     size_t off_attr = 0;                                                                  // sparse deal sweeps: packed per-deal inputs of the subtree's round, may be null
-    size_t off_rlist = 0;                                                                 // append mode: the reach of every entry of the live list, may be null
+    size_t off_rlist = 0;                                                                 // the reach of every entry of the live list (position-indexed rows, append mode), may be null
+    size_t off_plist = 0;                                                                 // the parent-subtree position of every entry of the live list, may be null
     size_t off_blist = 0, off_brlist = 0, off_bcount = 0, off_bkey = 0, off_bpsize = 0, off_bnparts = 0, off_blstride = 0;   // append mode: the next round's lists, per boundary root
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself

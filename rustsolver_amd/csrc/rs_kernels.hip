@@ -463,6 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
                 for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part[i]];
                 job->list[(size_t)part[i] * job->list_stride + slot] = deal[i];
                 if (job->rlist) job->rlist[(size_t)part[i] * job->list_stride + slot] = rv[i];
+                if (job->plist) job->plist[(size_t)part[i] * job->list_stride + slot] = (src && job->pos_rows) ? sq * job->src_list_stride + (base + i * kBlock + threadIdx.x) : deal[i];
             }
         __syncthreads();   // wave_count / part_base are rewritten by the next iteration
     }

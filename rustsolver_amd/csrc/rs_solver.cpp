@@ -63,7 +63,8 @@ struct Plan {
     std::vector<Launch> launches;
     // sparse deal sweeps: per subtree root the list of live deals (reach not NaN), rebuilt by k_compact_live after the top-down pass
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
-    float *d_rlists = nullptr;          // append mode: the reach of every list entry, same shape as d_lists
+    float *d_rlists = nullptr;          // position-indexed rows / append mode: the reach of every list entry, same shape as d_lists
+    uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
     size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
     uint32_t *d_counts = nullptr;       // [n_compact]
     CompactJob *d_compact_jobs = nullptr;
@@ -289,9 +290,9 @@ struct Builder {
 
     Builder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
 
-    size_t alloc(int round) {
+    size_t alloc(int round, size_t segments = 1) {
         const size_t off = arena;
-        arena += round_up(s->pitch[round] * sizeof(float), 256);
+        arena += round_up(s->pitch[round] * segments * sizeof(float), 256);
         return off + 1;
     }
     float *aptr(size_t off1) const { return reinterpret_cast<float *>(s->d_arena + (off1 - 1)); }
@@ -411,11 +412,13 @@ struct Builder {
         fused_root[root] = 1;
         mark_round_inside(root, root);
     }
-    void layout_round(int root) {
-        util_off[root] = alloc(lane_round[root]);
+    // `segments`: the utility row of a root below a LISTED parent is addressed by the parent's list position, one segment per cluster range of the parent (pos_rows)
+    void layout_round(int root, size_t segments = 1) {
+        util_off[root] = alloc(lane_round[root], segments);
+        const size_t below = (pos_rows && listed_root(root)) ? size_t(parts_of(root).first) : size_t(1);
         for (int b : bnd[size_t(root)]) {
             nan_slot[size_t(b)] = n_nan++;
-            layout_round(b);
+            layout_round(b, below);
         }
     }
 
@@ -718,7 +721,7 @@ struct Builder {
             put_u32(js.off_n_lanes + 4, s->params.deal_offset);   // JArgs.lane_base
             for (size_t k = 0; k < js.boundary_roots.size(); ++k) {   // round subtrees: what the next round's roots return / are handed
                 const int b = js.boundary_roots[k];
-                put_ptr(js.off_butil + 8 * k, uptr(b));
+                put_ptr(js.off_butil + 8 * k, uptr(b) + ((pos_rows && sparse) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
                 // position-indexed rows: this job's segment of the row starts where its list does
                 put_ptr(js.off_breach + 8 * k, append_mode ? nullptr : nan_ptr(b) + ((pos_rows && sparse && down) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
                 if (append_mode && down) {   // where the deals this kernel sends on join the next round's lists
@@ -738,6 +741,7 @@ struct Builder {
                 put_ptr(js.off_count, cj.count + size_t(part) * cj.count_stride);
                 // append mode: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
                 put_ptr(js.off_rlist, ((append_mode || pos_rows) && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
+                put_ptr(js.off_plist, (pos_rows && id != first_root) ? plan.d_plists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             }
             // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
             // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
@@ -954,6 +958,7 @@ struct Builder {
             }
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
             if (ea == hipSuccess && (append_mode || pos_rows)) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
+            if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_plists, list_elems * sizeof(uint32_t));
             plan.n_count_words = n_counts * kCountStride;
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
@@ -999,7 +1004,10 @@ struct Builder {
                 }
             if (pos_rows)   // every list but the first root's carries the reach of its entries (the first root's deals are all live, with the constant root reach)
                 for (size_t k = 0; k < n_sparse; ++k)
-                    if (ids[k] != first_root) plan.compact_jobs[k].rlist = plan.d_rlists + (plan.compact_jobs[k].list - plan.d_lists);
+                    if (ids[k] != first_root) {
+                        plan.compact_jobs[k].rlist = plan.d_rlists + (plan.compact_jobs[k].list - plan.d_lists);
+                        plan.compact_jobs[k].plist = plan.d_plists + (plan.compact_jobs[k].list - plan.d_lists);
+                    }
             ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
             return RS_OK;
@@ -1380,6 +1388,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_reach_nan) (void)hipFree(pl.d_reach_nan);
         if (pl.d_lists) (void)hipFree(pl.d_lists);
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
+        if (pl.d_plists) (void)hipFree(pl.d_plists);
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
         for (JitLaunch &JL : pl.jit)
@@ -1830,7 +1839,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                     seen[js.source] = 1;
                     if (int rc = jit_compile_only(js.source)) return rc;
                 }
-                if (down && sparse) {   // the form that writes the next round's reach rows at its list position (large batches)
+                if (sparse && !js.boundary_roots.empty()) {   // the forms that address the rows shared with the next round by list position (large batches)
                     JitSubtree jp;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
                                      (mode & RS_UPD_PRUNE) != 0, lanes, &root, jp, 0, sparse, false, true);
