@@ -65,6 +65,7 @@ struct Plan {
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
     float *d_rlists = nullptr;          // position-indexed rows / append mode: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
+    size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees
     size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
     uint32_t *d_counts = nullptr;       // [n_compact]
     CompactJob *d_compact_jobs = nullptr;
@@ -959,6 +960,7 @@ struct Builder {
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
             if (ea == hipSuccess && (append_mode || pos_rows)) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
             if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_plists, list_elems * sizeof(uint32_t));
+            plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + ((append_mode || pos_rows) ? 1 : 0) + (pos_rows ? 1 : 0));
             plan.n_count_words = n_counts * kCountStride;
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
@@ -1045,6 +1047,7 @@ struct Builder {
             for (size_t k = 0; k < size_t(n_nan); ++k) nan_off[k + 1] += nan_off[k];
             if (n_nan && !append_mode) {
                 plan.reach_nan_bytes = nan_off[size_t(n_nan)] * sizeof(float);
+                plan.aux_bytes += plan.reach_nan_bytes;
                 hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
                 if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
                 if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
@@ -1724,7 +1727,7 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
     return RS_OK;
 }
 
-size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes : 0; }
+size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes : 0; }
 
 int rs_jit_available(void) { return jit_available() ? 1 : 0; }
 
