@@ -536,10 +536,12 @@ struct Builder {
             // share of it each (three streets, 1 M deals per batch: 6.46 -> 5.87 ms with one deal per thread everywhere; 128 K deals: 3.81 -> 2.45)
             // Round 2: kernels with LDS delta tiles take one deal per thread at every batch size -- their tiles hold the CU to ONE workgroup, which is 1 024 threads for
             // the one-deal forms and 512 for the four-deal forms (registers), and 16 lean waves per CU beat 8 fat ones (river game, 4 M deals per batch: 0.858 -> 0.768 ms,
-            // 1 M: 0.295 -> 0.274, 256 K: 0.143 -> 0.123; gpurun_out/r02z/ab_l1.log).  The rule below is left for the kernels without tiles.
+            // 1 M: 0.295 -> 0.274, 256 K: 0.143 -> 0.123; gpurun_out/r02z/ab_l1.log).  Beyond 256 K deals per batch the kernel that walks the WHOLE batch (the first round's) takes TWO deals per thread
+            // (still 1 024 threads, twice the gathers in flight per wave): river game 4 M deals 0.770 -> 0.738 ms, 1 M 0.269 -> 0.259; at 64 K it loses (0.078 -> 0.102), and so
+            // do the list-walking kernels of later rounds at 1 M deals (three streets 3.70 -> 4.01 ms), which stay at one (gpurun_out/r03o/ab_l2.log, r03p/times.log).  The rule below is left for the kernels without tiles.
             jit_lanes = (s->deal_mode && s->deals.n_deals <= kSmallDealBatch) ? 1 : 4;
             jit_lanes_below = s->deal_mode ? 1 : 4;
-            if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = jit_lanes_below = atoi(e) == 1 ? 1 : 4;
+            if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = jit_lanes_below = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 4;
             round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
             const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
@@ -639,7 +641,7 @@ struct Builder {
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                         (use_lds && !getenv("RS_JIT_LANES")) ? 1 : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
+                         (use_lds && !getenv("RS_JIT_LANES")) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
                          int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode, pos_rows);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;

@@ -17,9 +17,9 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# The generated deal kernels exist in two forms -- four deals per thread, and one for batches of up to 256 K deals (rs_solver.cpp,
-# kSmallDealBatch) -- and every test batch is small: the deal-sweep tests below therefore run once with the library's own choice (one) and
-# once with RS_JIT_LANES=4, the form the big batches of bench.py use.
+# The generated deal kernels exist in three forms -- one, two or four deals per thread (rs_solver.cpp: kernels with LDS tiles take one, the first round's two beyond
+# 256 K deals per batch; kernels without tiles one and four) -- and every test batch is small: the deal-sweep tests below
+# therefore run once with the library's own choice (one), once with RS_JIT_LANES=2 and once with RS_JIT_LANES=4, the forms big batches get.
 DEALS_PER_THREAD_TESTS = {
     "test_deal_batches_vs_oracle", "test_deal_batches_large_cluster_counts", "test_deal_batches_many_trips_per_workgroup",
     "test_sparse_subtree_sweeps_three_streets_many_deals", "test_wide_nodes_in_deal_batches", "test_deal_trainer_reference_as_coded",
@@ -62,7 +62,7 @@ def pytest_generate_tests(metafunc):
     if metafunc.function.__name__ in DEALS_PER_THREAD_TESTS:
         if "deals_per_thread" not in metafunc.fixturenames:
             metafunc.fixturenames.append("deals_per_thread")
-        metafunc.parametrize("deals_per_thread", ["auto", "4"], indirect=True)
+        metafunc.parametrize("deals_per_thread", ["auto", "2", "4"], indirect=True)
 
 
 @pytest.fixture
