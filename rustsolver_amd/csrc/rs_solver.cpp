@@ -119,6 +119,7 @@ struct rs_solver {
     void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
     PackJob *d_pack_jobs = nullptr;
     int n_pack_jobs = 0;
+    unsigned attr_used = 0;             // bit r: some generated kernel reads the packed records of round r (only the list-walking forms do)
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -760,6 +761,7 @@ struct Builder {
             put_u32(js.off_rp, rp);
             put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
             put_ptr(js.off_attr, sparse ? s->d_attr[nodes[id].round_idx] : nullptr);
+            if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
             if (use_lds) {
                 const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
@@ -1586,6 +1588,52 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     if ((rc = b0.build()) != RS_OK || (rc = b1.build()) != RS_OK) {
         rs_solver_destroy(s);
         return rc;
+    }
+    // Only the list-walking kernels read the packed records: a round whose subtrees all walk the whole batch (the first round; every round of a one-round game) needs none
+    if (s->n_pack_jobs) {
+        std::vector<PackJob> keep;
+        for (int r = 0; r < s->n_rounds; ++r) {
+            if (!s->d_attr[r]) continue;
+            if (s->attr_used & (1u << r)) {
+                PackJob j{};
+                j.cid0 = s->deals.d_cluster[r][0];
+                j.cid1 = s->deals.d_cluster[r][1];
+                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
+                j.n = s->deals.n_deals;
+                keep.push_back(j);
+            } else {
+                (void)hipFree(s->d_attr[r]);
+                s->d_attr[r] = nullptr;
+            }
+        }
+        if (int(keep.size()) != s->n_pack_jobs) {
+            std::vector<PackJob> all(size_t(s->n_pack_jobs));
+            e = hipMemcpy(all.data(), s->d_pack_jobs, all.size() * sizeof(PackJob), hipMemcpyDeviceToHost);
+            for (PackJob &j : keep) j.leaf = all[0].leaf;   // one leaf buffer for every round (the condition under which records are packed at all)
+            if (e == hipSuccess && !keep.empty()) e = hipMemcpy(s->d_pack_jobs, keep.data(), keep.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                rc = hip_fail(e, "rs_solver_create: packed deal inputs");
+                rs_solver_destroy(s);
+                return rc;
+            }
+            s->n_pack_jobs = int(keep.size());
+            if (keep.empty())
+                for (int p = 0; p < 2; ++p) {   // the pack launch goes too (plan.split counts launches: keep it pointing at the same one)
+                    Plan &pl = s->plan[p];
+                    std::vector<Launch> kept;
+                    size_t split = pl.split;
+                    for (size_t i = 0; i < pl.launches.size(); ++i) {
+                        if (pl.launches[i].kind == L_PACK) {
+                            if (i < pl.split) --split;
+                            continue;
+                        }
+                        kept.push_back(pl.launches[i]);
+                    }
+                    pl.launches.swap(kept);
+                    pl.split = split;
+                }
+        }
     }
     s->arena_bytes = std::max(s->plan[0].arena_bytes, s->plan[1].arena_bytes);
     if ((e = hipMalloc((void **)&s->d_arena, std::max<size_t>(s->arena_bytes, 256))) != hipSuccess) {
