@@ -26,6 +26,11 @@ DEALS_PER_THREAD_TESTS = {
     "test_deal_trainer_prune_schedule", "test_deal_trainer_three_streets_from_a_flop_with_bucket_files", "test_deal_trainer_ragged_batches",
     "test_data_parallel_ranks_equal_one_gpu_with_the_union_batch",
 }
+# the two-deal forms are one more value of the same template parameter: the cheaper half of the list runs them too
+TWO_DEALS_PER_THREAD_TESTS = {
+    "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup", "test_sparse_subtree_sweeps_three_streets_many_deals",
+    "test_wide_nodes_in_deal_batches", "test_deal_trainer_reference_as_coded", "test_deal_trainer_ragged_batches",
+}
 
 
 # Lane tables of at least 2^20 lanes keep the rows of a node interleaved in 16 384-lane tiles (rs_table.cpp); the lane-model tests below run once
@@ -62,7 +67,7 @@ def pytest_generate_tests(metafunc):
     if metafunc.function.__name__ in DEALS_PER_THREAD_TESTS:
         if "deals_per_thread" not in metafunc.fixturenames:
             metafunc.fixturenames.append("deals_per_thread")
-        metafunc.parametrize("deals_per_thread", ["auto", "2", "4"], indirect=True)
+        metafunc.parametrize("deals_per_thread", ["auto", "2", "4"] if metafunc.function.__name__ in TWO_DEALS_PER_THREAD_TESTS else ["auto", "4"], indirect=True)
 
 
 @pytest.fixture
