@@ -669,6 +669,25 @@ def _max_over_ranks(dist, x):
     return float(t.item())
 
 
+def _agree(dist, make, what):
+    """Runs `make()` (a rank-local setup step that may fail: allocation, kernel compilation) and lets every rank learn whether it worked EVERYWHERE before
+    anybody enters a collective: one failed rank would otherwise leave the others waiting in RCCL until the launcher's timeout."""
+    err, result = None, None
+    try:
+        result = make()
+    except Exception as e:   # reported on every rank below
+        err = e
+    if dist is not None:
+        import torch
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and err is None:
+            err = RuntimeError("%s failed on another rank" % what)
+    if err is not None:
+        raise RuntimeError("%s: %s" % (what, err))
+    return result
+
+
 def dp_deals_leg(rs, dist, rank, n_gpus, device, steps, warmup, n=1 << 22):
     """MCCFRTrainer::train as coded (see deal_trainer_leg), data-parallel: every rank deals and sweeps n deals of each global batch against
     its replica of the table; per traverser sweep the two i32 delta arrays are all-reduced over RCCL (xGMI) and every rank applies the union.
@@ -680,8 +699,12 @@ def dp_deals_leg(rs, dist, rank, n_gpus, device, steps, warmup, n=1 << 22):
     hands = ab.random_range(mask)
     n_actions, tree = rs.build_game_tree(rs.default_flop())
     card_abs = ab.CardAbstraction.init([hands, hands], mask, ab.RIVER)
-    tr = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=7, discount_interval=0, device=device, world=n_gpus, rank=rank)
-    tr.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))   # same seed on every rank: the replicas start identical
+    def make():
+        t = rs.DealTrainer(tree, [card_abs], [hands, hands], mask, n, seed=7, discount_interval=0, device=device, world=n_gpus, rank=rank)
+        t.infosets.fill_random(4321, (-10**6, 10**6), (0, 10**6))   # same seed on every rank: the replicas start identical
+        t.infosets.sync()
+        return t
+    tr = _agree(dist, make, "dp_deals trainer")
     comm = make_comm(tr.infosets, dist, rank, n_gpus)
     tr.attach_comm(comm)
 
@@ -729,7 +752,8 @@ def three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, steps):
         shard = (n_gpus, rank, 1, G[1])
         boards3 = [G[0], thi - tlo, (thi - tlo) * (G[2] // G[1])]
     t0 = time.perf_counter()
-    tr = make_trainer(rs, boards3, C_, a.mode, 0, device, 1234 + 2 + rank, a.fuse, "three-street", "i32", "full", shard)
+    tr = _agree(dist if n_gpus > 1 else None, lambda: make_trainer(rs, boards3, C_, a.mode, 0, device, 1234 + 2 + rank, a.fuse, "three-street", "i32", "full", shard),
+                "config%d tables and launch plan" % (3 if n_gpus == 1 else 4))
     create_s = time.perf_counter() - t0
     table = tr.infosets
     comm = None

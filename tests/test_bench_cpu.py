@@ -79,3 +79,17 @@ def test_the_launching_parent_never_touches_the_gpu():
     for node in top:
         mods = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""]
         assert not any(m.split(".")[0] in ("torch", "rustsolver_amd", "oracle") for m in mods)
+
+
+def test_rank_local_setup_failures_are_reported_not_hung_on():
+    """bench._agree: a setup step that fails raises on the spot with the leg's name in the message (with a process group every rank first learns
+    whether it worked everywhere, so nobody enters an RCCL collective alone); a step that works hands its result through"""
+    import pytest
+    b = load_bench()
+    assert b._agree(None, lambda: 41 + 1, "setup") == 42
+
+    def boom():
+        raise MemoryError("no room")
+    with pytest.raises(RuntimeError) as e:
+        b._agree(None, boom, "config4 tables and launch plan")
+    assert "config4 tables and launch plan" in str(e.value) and "no room" in str(e.value)
