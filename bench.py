@@ -669,6 +669,10 @@ def _max_over_ranks(dist, x):
     return float(t.item())
 
 
+class SetupFailed(RuntimeError):
+    """raised by _agree on EVERY rank alike: the leg can be skipped without leaving anybody in a collective"""
+
+
 def _agree(dist, make, what):
     """Runs `make()` (a rank-local setup step that may fail: allocation, kernel compilation) and lets every rank learn whether it worked EVERYWHERE before
     anybody enters a collective: one failed rank would otherwise leave the others waiting in RCCL until the launcher's timeout."""
@@ -684,7 +688,7 @@ def _agree(dist, make, what):
         if int(ok.item()) == 0 and err is None:
             err = RuntimeError("%s failed on another rank" % what)
     if err is not None:
-        raise RuntimeError("%s: %s" % (what, err))
+        raise SetupFailed("%s: %s" % (what, err))
     return result
 
 
@@ -1085,15 +1089,23 @@ def main():
         if a.config3_steps > 0:
             try:
                 out["config4" if n_gpus > 1 else "config3"] = three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, a.config3_steps)
+            except SetupFailed as e:     # every rank saw it before the leg's first collective: skip the leg, keep the rest
+                out["config4" if n_gpus > 1 else "config3"] = {"error": str(e)}
             except Exception as e:
                 out["config4" if n_gpus > 1 else "config3"] = {"error": str(e)}
-                if n_gpus > 1:
-                    raise        # a rank that drops out of a collective leaves the others hanging: fail the whole job loudly
+                if n_gpus > 1:   # a rank that drops out of a collective leaves the others hanging: report what was measured, then fail the whole job loudly
+                    if rank == 0:
+                        emit(out)
+                    raise
         try:
             out["dp_deals"] = dp_deals_leg(rs, dist, rank, n_gpus, device, 10, 3)
+        except SetupFailed as e:
+            out["dp_deals"] = {"error": str(e)}
         except Exception as e:
             out["dp_deals"] = {"error": str(e)}
             if n_gpus > 1:
+                if rank == 0:
+                    emit(out)
                 raise
         if rank == 0:
             emit(out)
