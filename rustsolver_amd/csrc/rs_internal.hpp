@@ -130,6 +130,9 @@ struct PackJob {
 };
 hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream);
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
+// the work list of one launch of list-walking kernels: wl[0] = ticket counter (zeroed), wl[1] = n_jobs, wl[2 + j] = trips of jobs 0 .. j-1, wl[2 + n_jobs] = all trips.
+// The count of job j is read through the pointer at blob + j * stride + off_count; a trip covers deals_per_trip list entries.
+hipError_t launch_worklist(const unsigned char *d_blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip, uint32_t *d_wl, hipStream_t stream);
 // d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
@@ -158,6 +161,7 @@ struct JitSubtree {
     std::string source;
     std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals|deals_lds}[_sampled]
     int threads = 256;             // workgroup size the kernel was generated for
+    bool worklist = false;         // the kernel takes a third argument (the work list of its launch, rs_kernels.hip k_worklist) and a 1-D grid
     int lanes = 4;                 // lanes (deals) per thread the kernel was generated for: n_vec = pitch / lanes
     std::vector<int> node_ids;     // tree node id of every action node, in the order the kernel indexes reg[] / ssm[]
     std::vector<int> leaf_terms;   // one terminal id per distinct leaf buffer, in the order of leaf[]
@@ -182,7 +186,7 @@ struct JitSubtree {
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false, bool append = false,
-                      bool posrows = false);
+                      bool posrows = false, bool worklist = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
 int jit_compile_only(const std::string &source);

@@ -742,6 +742,43 @@ hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t ma
     hipLaunchKernelGGL(k_compact_live, grid, block, 0, stream, d_jobs);
     return hipGetLastError();
 }
+// one workgroup: trips per job from the live-list counts, exclusive prefix (jobs in chunks of kBlock with a running carry)
+__global__ __launch_bounds__(kBlock) void k_worklist(const unsigned char *__restrict__ blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip,
+                                                     uint32_t *__restrict__ wl) {
+    __shared__ uint32_t scan[kBlock];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_jobs; base += kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        uint32_t need = 0;
+        if (j < n_jobs) {
+            const uint32_t *cp = *reinterpret_cast<const uint32_t *const *>(blob + (size_t)j * stride + off_count);
+            need = (*cp + deals_per_trip - 1) / deals_per_trip;
+        }
+        scan[threadIdx.x] = need;
+        __syncthreads();
+        for (uint32_t d = 1; d < kBlock; d <<= 1) {   // inclusive scan
+            const uint32_t x = threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
+            __syncthreads();
+            scan[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (j < n_jobs) wl[2 + j] = carry + scan[threadIdx.x] - need;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry += scan[kBlock - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        wl[2 + n_jobs] = carry;
+        wl[1] = n_jobs;
+        wl[0] = 0;
+    }
+}
+hipError_t launch_worklist(const unsigned char *d_blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip, uint32_t *d_wl, hipStream_t stream) {
+    hipLaunchKernelGGL(k_worklist, dim3(1), dim3(kBlock), 0, stream, d_blob, stride, off_count, n_jobs, deals_per_trip, d_wl);
+    return hipGetLastError();
+}
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state) {
     if (n_jobs <= 0) return d_seed_state ? launch_next_seed(d_seed_state, stream) : hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);

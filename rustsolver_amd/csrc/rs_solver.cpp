@@ -22,6 +22,7 @@ using namespace rs;
 namespace {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
+constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ZERO_COUNTS };
 
 struct Launch {
@@ -52,6 +53,9 @@ struct JitLaunch {
     int threads = 256;
     size_t lds_bytes = 0;
     bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
+    bool worklist = false;              // list-walking kernels with LDS tiles: a 1-D grid of resident workgroups pulls (job, trip) items; k_worklist runs right before
+    uint32_t *d_wl = nullptr;           // [2 + n_jobs + 1]
+    uint32_t off_count = 0, deals_per_trip = 0;
 };
 
 struct Plan {
@@ -558,6 +562,7 @@ struct Builder {
             pos_rows = scan_parent && !append_mode && !getenv("RS_JIT_NO_POSROWS");
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
             if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+            lds_limit -= int(kWorklistLdsBytes);   // the work-list kernels keep their ticket in front of the tiles
             if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
         }
         if (round_mode) {
@@ -644,7 +649,7 @@ struct Builder {
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                          (use_lds && !getenv("RS_JIT_LANES")) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
-                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode, pos_rows);
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode, pos_rows, !getenv("RS_JIT_NO_WORKLIST"));
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
@@ -656,6 +661,9 @@ struct Builder {
             plan.jit.back().fn = fn;
             plan.jit.back().stride = js.args_size;
             plan.jit.back().threads = js.threads;
+            plan.jit.back().worklist = js.worklist;
+            plan.jit.back().off_count = uint32_t(js.off_count);
+            plan.jit.back().deals_per_trip = uint32_t(js.threads * js.lanes);
         }
         JitLaunch &JL = plan.jit[bi->second];
         for (uint32_t part = 0; part < parts.first; ++part) {   // one job per cluster range (one in all unless the tiles had to be partitioned)
@@ -1290,6 +1298,16 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
             blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(atoi(cap))));
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
+        if (JL.worklist) {   // trips per job from the live-list counts, then resident workgroups that pull them
+            e = launch_worklist(JL.d_blob, uint32_t(JL.stride), JL.off_count, uint32_t(JL.n_jobs), JL.deals_per_trip, JL.d_wl, tree_stream);
+            if (e != hipSuccess) break;
+            size_t grid = size_t(s->n_cus) * ((JL.lds_bytes + kWorklistLdsBytes) * 2 <= size_t(160) * 1024 ? 2 : 1);
+            if (const char *cap = getenv("RS_JIT_MAX_BLOCKS")) grid = std::max<size_t>(1, std::min<size_t>(grid, size_t(atoi(cap))));
+            uint32_t *d_wl = JL.d_wl;
+            void *wparams[] = {&d_blob, &flags, &d_wl};
+            e = hipModuleLaunchKernel(JL.fn, (unsigned)grid, 1, 1, (unsigned)JL.threads, 1, 1, (unsigned)(JL.lds_bytes + kWorklistLdsBytes), tree_stream, wparams, nullptr);
+            break;
+        }
         void *params[] = {&d_blob, &flags};
         e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, tree_stream, params, nullptr);
         break;
@@ -1398,8 +1416,10 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_plists) (void)hipFree(pl.d_plists);
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
-        for (JitLaunch &JL : pl.jit)
+        for (JitLaunch &JL : pl.jit) {
             if (JL.d_blob) (void)hipFree(JL.d_blob);
+            if (JL.d_wl) (void)hipFree(JL.d_wl);
+        }
         pl = Plan{};
     }
     if (s->d_arena) (void)hipFree(s->d_arena);
@@ -1673,6 +1693,11 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
         for (JitLaunch &JL : pl.jit) {
+            if (JL.worklist && (e = hipMalloc((void **)&JL.d_wl, (size_t(JL.n_jobs) + 3) * sizeof(uint32_t))) != hipSuccess) {
+                rc = hip_fail(e, "rs_solver_create: work list");
+                rs_solver_destroy(s);
+                return rc;
+            }
             if ((e = hipMalloc((void **)&JL.d_blob, JL.blob.size())) != hipSuccess ||
                 (e = hipMemcpyAsync(JL.d_blob, JL.blob.data(), JL.blob.size(), hipMemcpyHostToDevice, table->stream)) != hipSuccess) {
                 rc = hip_fail(e, "rs_solver_create: tree-kernel argument upload");
@@ -1891,6 +1916,15 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (!seen.count(js.source)) {
                     seen[js.source] = 1;
                     if (int rc = jit_compile_only(js.source)) return rc;
+                }
+                if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
+                    JitSubtree jw;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jw, 0, sparse, false, true, true);
+                    if (!seen.count(jw.source)) {
+                        seen[jw.source] = 1;
+                        if (int rc = jit_compile_only(jw.source)) return rc;
+                    }
                 }
                 if (sparse && !js.boundary_roots.empty()) {   // the forms that address the rows shared with the next round by list position (large batches)
                     JitSubtree jp;
