@@ -217,6 +217,28 @@ __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (
         gather_rec_half<A>(p + (size_t)idx[j] * (2 * H) + H, s, j);
     }
 }
+// A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
+// from the table's own [A][pitch] rows, one 4-byte gather per (action, array).  `shadow` is a kernel argument: the branch is uniform.
+template <int A>
+__device__ __forceinline__ void gather_node(const void *shadow, const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {
+    if (shadow) gather_rec<A>(shadow, idx, r);
+    else {
+#pragma unroll
+        for (int a = 0; a < A; a++) gather_i32(reg, a * tpitch, idx, r[a]);
+    }
+}
+template <int A>
+__device__ __forceinline__ void gather_node2(const void *shadow, const void *reg, const void *ssm, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD],
+                                             int (&s)[A][kVecD]) {
+    if (shadow) gather_rec2<A>(shadow, idx, r, s);
+    else {
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            gather_i32(reg, a * tpitch, idx, r[a]);
+            gather_i32(ssm, a * tpitch, idx, s[a]);
+        }
+    }
+}
 __device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, const unsigned (&idx)[kVecD], const int (&now)[kVecD],
                                                 const int (&before)[kVecD]) {
     RS_GLOBAL int *p = as_global<int>((int *)base + row_off);

@@ -136,6 +136,12 @@ hipError_t launch_worklist(const unsigned char *d_blob, uint32_t stride, uint32_
 // d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
+// the same over the cell ranges of some nodes only (a traverser's sweep writes deltas at ITS nodes; the other half of the delta arrays is zero and need not be read)
+struct ApplyJob {
+    size_t first_vec;   // in vectors of 4 cells from the start of the table
+    size_t n_vec;
+};
+hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, void *dssum, const ApplyJob *d_jobs, int n_jobs, size_t max_vec, hipStream_t stream);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
 hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned blocks, hipStream_t stream);   // rs_stream_probe

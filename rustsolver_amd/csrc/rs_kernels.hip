@@ -538,6 +538,30 @@ __global__ __launch_bounds__(kBlock) void k_apply_delta(int32_t *__restrict__ re
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_apply_delta_jobs(int32_t *__restrict__ regrets, int32_t *__restrict__ dregrets, int32_t *__restrict__ ssum,
+                                                             int32_t *__restrict__ dssum, const ApplyJob *__restrict__ jobs) {
+    const ApplyJob job = jobs[blockIdx.y];
+    const i32x4 zero = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < job.n_vec; i += (size_t)gridDim.x * kBlock) {
+        const size_t v = job.first_vec + i;
+        const i32x4 dr = ((const i32x4 *)dregrets)[v], ds = ((const i32x4 *)dssum)[v];
+        if (dr.x | dr.y | dr.z | dr.w) {
+            const i32x4 r = ((i32x4 *)regrets)[v];
+            const i32x4 n = {(int)((unsigned)r.x + (unsigned)dr.x), (int)((unsigned)r.y + (unsigned)dr.y),
+                             (int)((unsigned)r.z + (unsigned)dr.z), (int)((unsigned)r.w + (unsigned)dr.w)};
+            ((i32x4 *)regrets)[v] = n;
+            ((i32x4 *)dregrets)[v] = zero;
+        }
+        if (ds.x | ds.y | ds.z | ds.w) {
+            const i32x4 q = ((i32x4 *)ssum)[v];
+            const i32x4 n = {(int)((unsigned)q.x + (unsigned)ds.x), (int)((unsigned)q.y + (unsigned)ds.y),
+                             (int)((unsigned)q.z + (unsigned)ds.z), (int)((unsigned)q.w + (unsigned)ds.w)};
+            ((i32x4 *)ssum)[v] = n;
+            ((i32x4 *)dssum)[v] = zero;
+        }
+    }
+}
+
 // ---- showdown evaluation on the device (cfr.rs:38-46, :324-333): the evaluator itself is rs_eval.hpp ------------
 // cards[9][pitch] u8: rows 0-4 board, 5-6 player 0 hole cards, 7-8 player 1 hole cards; sign[lane] = sign(score0 - score1)
 __global__ __launch_bounds__(kBlock) void k_showdown_sign(const uint8_t *__restrict__ cards, float *__restrict__ sign, uint32_t n,
@@ -796,6 +820,12 @@ hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *d
     dim3 grid(grid_for(n_vec)), block(kBlock);
     hipLaunchKernelGGL(k_apply_delta, grid, block, 0, stream, (int32_t *)regrets, (int32_t *)dregrets, (int32_t *)ssum,
                        (int32_t *)dssum, n_vec);
+    return hipGetLastError();
+}
+hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, void *dssum, const ApplyJob *d_jobs, int n_jobs, size_t max_vec, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((max_vec + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_apply_delta_jobs, grid, block, 0, stream, (int32_t *)regrets, (int32_t *)dregrets, (int32_t *)ssum, (int32_t *)dssum, d_jobs);
     return hipGetLastError();
 }
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream) {

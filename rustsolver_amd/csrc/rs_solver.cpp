@@ -69,6 +69,9 @@ struct Plan {
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
     float *d_rlists = nullptr;          // position-indexed rows / append mode: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
+    ApplyJob *d_apply_jobs = nullptr;   // deal sweeps: the cell ranges of the traverser's own nodes (where its deltas are)
+    int n_apply_jobs = 0;
+    size_t apply_max_vec = 0;
     size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees
     size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
     uint32_t *d_counts = nullptr;       // [n_compact]
@@ -722,7 +725,7 @@ struct Builder {
                 const rs_tree_node &an = nodes[js.node_ids[k]];
                 put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
                 put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
-                put_ptr(js.off_shd + 8 * k, s->d_shadow + s->shadow_off[an.index]);
+                put_ptr(js.off_shd + 8 * k, s->shadow_off[an.index] == SIZE_MAX ? nullptr : s->d_shadow + s->shadow_off[an.index]);
                 tp[an.player] = uint32_t(t->pitch[an.index]);
             }
             for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
@@ -1216,10 +1219,27 @@ struct Builder {
                 }
             }
         if (!s->sharded) plan.split = plan.launches.size();   // deal batches: phase 0 = the sweep, phase 1 = the apply below
-        if (s->deal_mode) {   // table += delta, delta = 0
+        if (s->deal_mode) {   // table += delta, delta = 0: over the traverser's own nodes (nobody else's deltas were written: the other half of the delta arrays stays unread)
+            std::vector<ApplyJob> aj;
+            double cells = 0.0;
+            for (size_t i = 0; i < t->nodes.size(); ++i) {
+                const rs_node_desc &d = t->nodes[i];
+                if (d.n_actions == 0 || d.player != p) continue;
+                const size_t nc = size_t(d.n_actions) * t->pitch[i];
+                if ((t->cell_off[i] % kVec) || (nc % kVec)) { aj.clear(); break; }   // never with 64-lane padded pitches; the whole-table form is the fallback
+                aj.push_back(ApplyJob{t->cell_off[i] / kVec, nc / kVec});
+                plan.apply_max_vec = std::max(plan.apply_max_vec, nc / kVec);
+                cells += double(nc);
+            }
+            if (!aj.empty() && !getenv("RS_APPLY_WHOLE_TABLE")) {
+                hipError_t ea = hipMalloc((void **)&plan.d_apply_jobs, aj.size() * sizeof(ApplyJob));
+                if (ea == hipSuccess) ea = hipMemcpy(plan.d_apply_jobs, aj.data(), aj.size() * sizeof(ApplyJob), hipMemcpyHostToDevice);
+                if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");
+                plan.n_apply_jobs = int(aj.size());
+            }
             Launch L;
             L.kind = L_APPLY;
-            L.bytes = double(t->n_cells) * 32.0;
+            L.bytes = (plan.n_apply_jobs ? cells : double(t->n_cells)) * 32.0;
             plan.launches.push_back(L);
         }
         // value returned at node 0
@@ -1237,7 +1257,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
     if (L.kind == L_APPLY) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
-        hipError_t ea = launch_apply_delta(t->d_regrets, t->d_dregrets, t->d_ssum, t->d_dssum, t->n_cells, t->stream);
+        hipError_t ea = plan.n_apply_jobs ? launch_apply_delta_jobs(t->d_regrets, t->d_dregrets, t->d_ssum, t->d_dssum, plan.d_apply_jobs, plan.n_apply_jobs, plan.apply_max_vec, t->stream)
+                                          : launch_apply_delta(t->d_regrets, t->d_dregrets, t->d_ssum, t->d_dssum, t->n_cells, t->stream);
         prof_end(t);
         RS_HIP(ea, "k_apply_delta");
         return RS_OK;
@@ -1414,6 +1435,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_lists) (void)hipFree(pl.d_lists);
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
+        if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
         for (JitLaunch &JL : pl.jit) {
@@ -1536,9 +1558,28 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         std::vector<ShadowJob> jobs;
         size_t ints = 0;
         s->shadow_off.assign(table->nodes.size(), 0);
+        // A record is worth transposing when the sweep reads it: sampled sweeps reach a node of a later round with probability ~ 1 / (round subtrees of that round), so a
+        // node gets a shadow only while n_deals / roots * 8 >= its cells -- 64 K deals against 180 234 river clusters (lossless abstraction, 2 GB table) spent 0.9 ms per
+        // sweep transposing records nobody read.  Without one the kernels gather the table's own rows (rs_device.hpp gather_node).  RS_JIT_SHADOW_ALL keeps every shadow.
+        std::vector<size_t> round_roots(size_t(s->n_rounds) + 1, 0);
+        {
+            const int first = [&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }();
+            if (tree->nodes[size_t(first)].kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(tree->nodes[size_t(first)].round_idx, s->n_rounds))] += 1;
+            for (size_t i = 1; i < n; ++i)
+                if (tree->nodes[i].kind == RS_NODE_PUBLIC_CHANCE && tree->nodes[i].n_children > 0) {
+                    const rs_tree_node &c = tree->nodes[size_t(tree->nodes[i].children[0])];
+                    if (c.kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(c.round_idx, s->n_rounds))] += 1;
+                }
+        }
+        const bool shadow_all = getenv("RS_JIT_SHADOW_ALL") != nullptr || s->params.opp_mode != RS_OPP_SAMPLE;
         for (size_t i = 0; i < table->nodes.size(); ++i) {
             const rs_node_desc &d = table->nodes[i];
             if (d.n_actions == 0) continue;
+            const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
+            if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) {
+                s->shadow_off[i] = SIZE_MAX;   // no shadow: J.shd = nullptr
+                continue;
+            }
             const uint32_t half = d.n_actions <= 4 ? 4 : 8;
             s->shadow_off[i] = ints;
             ShadowJob j{};
@@ -1556,7 +1597,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
         size_t k = 0;
         for (size_t i = 0; i < table->nodes.size(); ++i)
-            if (table->nodes[i].n_actions) jobs[k++].dst = s->d_shadow + s->shadow_off[i];
+            if (table->nodes[i].n_actions && s->shadow_off[i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off[i];
         s->n_shadow_jobs = int(jobs.size());
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
         if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
