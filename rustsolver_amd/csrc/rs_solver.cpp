@@ -22,6 +22,7 @@ using namespace rs;
 namespace {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
+constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ZERO_COUNTS };
 
@@ -560,7 +561,8 @@ struct Builder {
             append_mode = round_mode && want_lists && getenv("RS_JIT_APPEND") && atoi(getenv("RS_JIT_APPEND")) != 0;
             // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
             // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
-            scan_parent = round_mode && want_lists && s->deals.n_deals > kSmallDealBatch;
+            scan_parent = round_mode && want_lists && s->deals.n_deals > kScanParentMin;   // with list-position rows it pays from 128 K deals per batch on (1.21 -> 1.07 ms; 64 K: 1.00 -> 1.02,
+                                                                                           // lossless abstractions at 64 K 2.5 -> 2.9: gpurun_out/r04d/ab_scan_small.log)
             if (const char *e = getenv("RS_JIT_SCAN_ALL")) scan_parent = round_mode && want_lists && atoi(e) == 0;
             pos_rows = scan_parent && !append_mode && !getenv("RS_JIT_NO_POSROWS");
             if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
