@@ -567,13 +567,15 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("rows", ["list-position", "deal-id", "whole-batch-scan"])
+@pytest.mark.parametrize("rows", ["list-position", "deal-id", "whole-batch-scan", "many-ranges"])
 def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
     """What batches beyond 256 K deals get, forced onto a small one: LDS capped so that EVERY round subtree (the first included) is cut into cluster ranges,
     the compaction of a root's live deals scans its parent's per-range lists, and -- "list-position" -- the parent's reach-down kernel writes the reach rows
     at its list position, the compaction stores every live deal's reach beside its list entry.  "deal-id" keeps rows indexed by deal (RS_JIT_NO_POSROWS),
     "whole-batch-scan" the small-batch compaction.  Same bits, equal to the oracle."""
-    monkeypatch.setenv("RS_JIT_LDS_MAX", "16384")
+    # "many-ranges": half of the LDS again (64-cluster ranges on the river), so that the launches of the river round carry several hundred (subtree, range) jobs each -- more than one
+    # chunk of k_worklist's prefix scan -- most of them with a handful of deals or none
+    monkeypatch.setenv("RS_JIT_LDS_MAX", "8256" if rows == "many-ranges" else "16384")
     if rows != "whole-batch-scan":
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
     if rows == "deal-id":
