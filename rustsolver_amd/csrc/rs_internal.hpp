@@ -132,7 +132,16 @@ hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, h
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
 // the work list of one launch of list-walking kernels: wl[0] = ticket counter (zeroed), wl[1] = n_jobs, wl[2 + j] = trips of jobs 0 .. j-1, wl[2 + n_jobs] = all trips.
 // The count of job j is read through the pointer at blob + j * stride + off_count; a trip covers deals_per_trip list entries.
-hipError_t launch_worklist(const unsigned char *d_blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip, uint32_t *d_wl, hipStream_t stream);
+struct WorklistDesc {
+    const unsigned char *blob;
+    uint32_t *wl;
+    uint32_t stride, off_count, n_jobs, deals_per_trip;
+};
+constexpr int kWorklistBatch = 16;   // work lists one launch of k_worklist builds (one workgroup each): the launches of one group of independent round subtrees
+struct WorklistBatch {
+    WorklistDesc d[kWorklistBatch];
+};
+hipError_t launch_worklist(const WorklistBatch &batch, int n, hipStream_t stream);
 // d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);

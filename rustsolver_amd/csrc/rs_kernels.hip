@@ -767,8 +767,11 @@ hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t ma
     return hipGetLastError();
 }
 // one workgroup: trips per job from the live-list counts, exclusive prefix (jobs in chunks of kBlock with a running carry)
-__global__ __launch_bounds__(kBlock) void k_worklist(const unsigned char *__restrict__ blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip,
-                                                     uint32_t *__restrict__ wl) {
+__global__ __launch_bounds__(kBlock) void k_worklist(const WorklistBatch batch) {   // by value: the descriptors sit in the kernarg segment (scalar loads)
+    const WorklistDesc &D = batch.d[blockIdx.x];
+    const unsigned char *__restrict__ blob = D.blob;
+    const uint32_t stride = D.stride, off_count = D.off_count, n_jobs = D.n_jobs, deals_per_trip = D.deals_per_trip;
+    uint32_t *__restrict__ wl = D.wl;
     __shared__ uint32_t scan[kBlock];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -799,8 +802,9 @@ __global__ __launch_bounds__(kBlock) void k_worklist(const unsigned char *__rest
         wl[0] = 0;
     }
 }
-hipError_t launch_worklist(const unsigned char *d_blob, uint32_t stride, uint32_t off_count, uint32_t n_jobs, uint32_t deals_per_trip, uint32_t *d_wl, hipStream_t stream) {
-    hipLaunchKernelGGL(k_worklist, dim3(1), dim3(kBlock), 0, stream, d_blob, stride, off_count, n_jobs, deals_per_trip, d_wl);
+hipError_t launch_worklist(const WorklistBatch &batch, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_worklist, dim3((unsigned)n), dim3(kBlock), 0, stream, batch);
     return hipGetLastError();
 }
 hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state) {

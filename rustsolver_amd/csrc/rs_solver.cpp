@@ -1253,7 +1253,10 @@ struct Builder {
     }
 };
 
-int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree_stream = nullptr) {
+WorklistDesc worklist_desc(const JitLaunch &JL) { return WorklistDesc{JL.d_blob, JL.d_wl, uint32_t(JL.stride), JL.off_count, uint32_t(JL.n_jobs), JL.deals_per_trip}; }
+
+// wl_done: the work list of this launch was built by its group's shared k_worklist launch (run_range)
+int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree_stream = nullptr, bool wl_done = false) {
     rs_table *t = s->table;
     if (!tree_stream) tree_stream = t->stream;
     static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
@@ -1322,8 +1325,12 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         if (JL.worklist) {   // trips per job from the live-list counts, then resident workgroups that pull them
-            e = launch_worklist(JL.d_blob, uint32_t(JL.stride), JL.off_count, uint32_t(JL.n_jobs), JL.deals_per_trip, JL.d_wl, tree_stream);
-            if (e != hipSuccess) break;
+            if (!wl_done) {
+                WorklistBatch one{};
+                one.d[0] = worklist_desc(JL);
+                e = launch_worklist(one, 1, tree_stream);
+                if (e != hipSuccess) break;
+            }
             size_t grid = size_t(s->n_cus) * ((JL.lds_bytes + kWorklistLdsBytes) * 2 <= size_t(160) * 1024 ? 2 : 1);
             if (const char *cap = getenv("RS_JIT_MAX_BLOCKS")) grid = std::max<size_t>(1, std::min<size_t>(grid, size_t(atoi(cap))));
             uint32_t *d_wl = JL.d_wl;
@@ -1355,11 +1362,24 @@ int run_range(rs_solver *s, Plan &plan, size_t lo, size_t hi) {
                 if (int rc = run_launch(s, plan, plan.launches[i])) return rc;
             continue;
         }
+        {   // the work lists of the group's launches: one k_worklist launch (a workgroup per list) on the main stream, before the fork
+            WorklistBatch batch{};
+            int nb = 0;
+            for (size_t k = i; k < j; ++k) {
+                if (plan.launches[k].kind != L_TREE || !plan.jit[size_t(plan.launches[k].first_job)].worklist) continue;
+                batch.d[nb++] = worklist_desc(plan.jit[size_t(plan.launches[k].first_job)]);
+                if (nb == kWorklistBatch) {
+                    RS_HIP(launch_worklist(batch, nb, t->stream), "k_worklist");
+                    nb = 0;
+                }
+            }
+            RS_HIP(launch_worklist(batch, nb, t->stream), "k_worklist");
+        }
         RS_HIP(hipEventRecord(s->ev_fork, t->stream), "fork");
         const int used = int(std::min<size_t>(rs_solver::kAux, j - i));
         for (int k = 0; k < used; ++k) RS_HIP(hipStreamWaitEvent(s->aux[k], s->ev_fork, 0), "fork wait");
         for (size_t k = i; k < j; ++k)
-            if (int rc = run_launch(s, plan, plan.launches[k], s->aux[(k - i) % rs_solver::kAux])) return rc;
+            if (int rc = run_launch(s, plan, plan.launches[k], s->aux[(k - i) % rs_solver::kAux], true)) return rc;
         for (int k = 0; k < used; ++k) {
             RS_HIP(hipEventRecord(s->ev_join[k], s->aux[k]), "join");
             RS_HIP(hipStreamWaitEvent(t->stream, s->ev_join[k], 0), "join wait");
