@@ -200,12 +200,13 @@ __device__ __forceinline__ void gather_rec_half(const RS_GLOBAL int *rec, int (&
         if (A > 7) out[7 < A ? 7 : 0][j] = hi.w;
     }
 }
+// `stride` (ints between two clusters' records): 2H where the record holds regrets and strategy_sum (the sweep's traverser nodes), H where it holds regrets only (the
+// opponent's nodes: the shadow is rebuilt per sweep, so it holds what THIS traverser's sweep reads -- half the bytes and twice the records per cache line there)
 template <int A>
-__device__ __forceinline__ void gather_rec(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {   // regrets only
-    constexpr int H = A <= 4 ? 4 : 8;
+__device__ __forceinline__ void gather_rec(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {   // regrets only
     const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
 #pragma unroll
-    for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
+    for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)idx[j] * stride, r, j);
 }
 template <int A>
 __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
@@ -220,8 +221,8 @@ __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (
 // A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
 // from the table's own [A][pitch] rows, one 4-byte gather per (action, array).  `shadow` is a kernel argument: the branch is uniform.
 template <int A>
-__device__ __forceinline__ void gather_node(const void *shadow, const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {
-    if (shadow) gather_rec<A>(shadow, idx, r);
+__device__ __forceinline__ void gather_node(const void *shadow, unsigned stride, const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {
+    if (shadow) gather_rec<A>(shadow, stride, idx, r);
     else {
 #pragma unroll
         for (int a = 0; a < A; a++) gather_i32(reg, a * tpitch, idx, r[a]);

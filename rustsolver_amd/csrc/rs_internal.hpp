@@ -96,8 +96,9 @@ hipError_t launch_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_vec, i
 struct ShadowJob {
     const int32_t *regrets;   // [A][pitch]
     const int32_t *ssum;
-    int32_t *dst;             // [n_clusters][2 * half]
+    int32_t *dst;             // [n_clusters][stride]: regrets (half ints), then strategy_sum (half ints) when stride == 2 * half
     uint32_t pitch, n_clusters, n_actions, half;   // half = 4 (A <= 4) or 8
+    uint32_t stride, pad_;    // half: regrets only (a node of the sweep's opponent); 2 * half: both arrays (a traverser node)
 };
 // sparse deal sweeps: live deals (reach not NaN) of one subtree root, compacted (order irrelevant: every use commutes)
 struct CompactJob {
@@ -185,7 +186,7 @@ struct JitSubtree {
     size_t off_reg = 0, off_ssm = 0, off_leaf = 0, off_reach = 0, off_out = 0, off_seed = 0, off_cval = 0, off_nidx = 0,
            off_reach_const = 0, off_scale = 0, off_n_vec = 0, off_pitch = 0, off_row_stride = 0, off_tile_shift = 0, args_size = 0;
     size_t off_dreg = 0, off_dssm = 0, off_cidx = 0, off_tpitch = 0, off_n_lanes = 0;   // deal batches only
-    size_t off_loff = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
+    size_t off_loff = 0, off_sstride = 0, off_resident = 0, off_trans = 0;                               // deal batches: LDS tile placement
     size_t off_shd = 0;                                                                   // deal batches: AoS shadow of every node
     size_t off_list = 0, off_count = 0;                                                   // sparse deal sweeps: list of live deals and its length
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots

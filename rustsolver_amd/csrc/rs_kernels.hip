@@ -481,22 +481,25 @@ __global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__rest
     const uint32_t n = job->n_clusters, pitch = job->pitch, A = job->n_actions, half = job->half;
     const int32_t *__restrict__ reg = job->regrets, *__restrict__ ssm = job->ssum;
     int32_t *__restrict__ dst = job->dst;
+    const bool both = job->stride == 2 * half;
     for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < n; c += gridDim.x * kBlock) {
         int32_t rec[16];
 #pragma unroll
         for (uint32_t a = 0; a < 8; ++a) {
             rec[a] = a < A ? reg[(size_t)a * pitch + c] : 0;
-            rec[8 + a] = a < A ? ssm[(size_t)a * pitch + c] : 0;
+            rec[8 + a] = (both && a < A) ? ssm[(size_t)a * pitch + c] : 0;
         }
-        i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * 2 * half);
+        i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * job->stride);
         if (half == 4) {
             out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
-            out[1] = i32x4{rec[8], rec[9], rec[10], rec[11]};
+            if (both) out[1] = i32x4{rec[8], rec[9], rec[10], rec[11]};
         } else {
             out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
             out[1] = i32x4{rec[4], rec[5], rec[6], rec[7]};
-            out[2] = i32x4{rec[8], rec[9], rec[10], rec[11]};
-            out[3] = i32x4{rec[12], rec[13], rec[14], rec[15]};
+            if (both) {
+                out[2] = i32x4{rec[8], rec[9], rec[10], rec[11]};
+                out[3] = i32x4{rec[12], rec[13], rec[14], rec[15]};
+            }
         }
     }
 }

@@ -119,9 +119,10 @@ struct rs_solver {
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
     // deal sweeps through tree-specialised kernels read the table from an AoS shadow rebuilt at the start of every sweep
     int32_t *d_shadow = nullptr;
-    std::vector<size_t> shadow_off;     // per table node, in ints
-    ShadowJob *d_shadow_jobs = nullptr;
-    int n_shadow_jobs = 0;
+    ShadowJob *d_shadow_jobs = nullptr;   // the jobs of traverser 0's sweep, then those of traverser 1's (the same nodes, different record widths)
+    int n_shadow_jobs = 0;                // per traverser
+    std::vector<size_t> shadow_off_p[2];  // per traverser and table node, in ints (SIZE_MAX: no shadow)
+    std::vector<uint32_t> shadow_stride_p[2];
     uint32_t shadow_max_clusters = 0;
     // sparse deal sweeps fetch the per-deal inputs of a round (both cluster ids, leaf value, prune flag) as ONE packed 16-byte record per live deal
     void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
@@ -727,7 +728,8 @@ struct Builder {
                 const rs_tree_node &an = nodes[js.node_ids[k]];
                 put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
                 put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
-                put_ptr(js.off_shd + 8 * k, s->shadow_off[an.index] == SIZE_MAX ? nullptr : s->d_shadow + s->shadow_off[an.index]);
+                put_ptr(js.off_shd + 8 * k, s->shadow_off_p[p][an.index] == SIZE_MAX ? nullptr : s->d_shadow + s->shadow_off_p[p][an.index]);
+                put_u32(js.off_sstride + 4 * k, s->shadow_stride_p[p][an.index]);
                 tp[an.player] = uint32_t(t->pitch[an.index]);
             }
             for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
@@ -1295,7 +1297,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     }
     if (L.kind == L_SHADOW) {
         prof_begin(t, RS_K_STRATEGY, L.bytes);
-        hipError_t es = launch_build_shadow(s->d_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr);
+        const int which = &plan == &s->plan[1] ? 1 : 0;   // the shadow holds what THIS traverser's sweep reads: regrets everywhere, strategy sums at its own nodes
+        hipError_t es = launch_build_shadow(s->d_shadow_jobs + size_t(which) * s->n_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr);
         prof_end(t);
         RS_HIP(es, "k_build_shadow");
         return RS_OK;
@@ -1579,7 +1582,6 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     if (s->deal_mode && s->params.fuse_subtrees) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
         std::vector<ShadowJob> jobs;
         size_t ints = 0;
-        s->shadow_off.assign(table->nodes.size(), 0);
         // A record is worth transposing when the sweep reads it: sampled sweeps reach a node of a later round with probability ~ 1 / (round subtrees of that round), so a
         // node gets a shadow only while n_deals / roots * 8 >= its cells -- 64 K deals against 180 234 river clusters (lossless abstraction, 2 GB table) spent 0.9 ms per
         // sweep transposing records nobody read.  Without one the kernels gather the table's own rows (rs_device.hpp gather_node).  RS_JIT_SHADOW_ALL keeps every shadow.
@@ -1594,33 +1596,40 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 }
         }
         const bool shadow_all = getenv("RS_JIT_SHADOW_ALL") != nullptr || s->params.opp_mode != RS_OPP_SAMPLE;
-        for (size_t i = 0; i < table->nodes.size(); ++i) {
-            const rs_node_desc &d = table->nodes[i];
-            if (d.n_actions == 0) continue;
-            const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
-            if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) {
-                s->shadow_off[i] = SIZE_MAX;   // no shadow: J.shd = nullptr
-                continue;
+        for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
+            s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
+            s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
+            for (size_t i = 0; i < table->nodes.size(); ++i) {
+                const rs_node_desc &d = table->nodes[i];
+                if (d.n_actions == 0) continue;
+                const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
+                if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
+                const uint32_t half = d.n_actions <= 4 ? 4 : 8;
+                const uint32_t stride = (d.player == tp || getenv("RS_JIT_SHADOW_WIDE")) ? 2 * half : half;
+                s->shadow_off_p[tp][i] = ints;
+                s->shadow_stride_p[tp][i] = stride;
+                ShadowJob j{};
+                j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+                j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+                j.pitch = uint32_t(table->pitch[i]);
+                j.n_clusters = d.n_clusters;
+                j.n_actions = d.n_actions;
+                j.half = half;
+                j.stride = stride;
+                jobs.push_back(j);
+                ints += round_up(size_t(d.n_clusters) * stride, 64);
+                s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
             }
-            const uint32_t half = d.n_actions <= 4 ? 4 : 8;
-            s->shadow_off[i] = ints;
-            ShadowJob j{};
-            j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
-            j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
-            j.pitch = uint32_t(table->pitch[i]);
-            j.n_clusters = d.n_clusters;
-            j.n_actions = d.n_actions;
-            j.half = half;
-            jobs.push_back(j);
-            ints += round_up(size_t(d.n_clusters) * 2 * half, 64);
-            s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
         }
         e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
         if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
-        size_t k = 0;
-        for (size_t i = 0; i < table->nodes.size(); ++i)
-            if (table->nodes[i].n_actions && s->shadow_off[i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off[i];
-        s->n_shadow_jobs = int(jobs.size());
+        {
+            size_t k = 0;
+            for (int tp = 0; tp < 2; ++tp)
+                for (size_t i = 0; i < table->nodes.size(); ++i)
+                    if (s->shadow_off_p[tp][i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off_p[tp][i];
+        }
+        s->n_shadow_jobs = int(jobs.size() / 2);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
         if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
