@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 3   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h */
+#define RS_ABI_VERSION 4   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h;
+                              4: rs_kernel_forms inside rs_solver_params, rs_table_params + rs_table_create_with, rs_deal_trainer_params.prefetch, f32 deal batches */
 #define RS_MAX_ACTIONS 8
 #define RS_MAX_ROUNDS 3
 #define RS_MAX_SIZES 4
@@ -123,6 +124,13 @@ typedef struct rs_node_desc {           /* one row of InfosetTable = Vec<Vec<Inf
 
 /* order of `nodes` = ActionNode.index.  Zero-initialised like Infoset::init (infoset.rs:76-81). */
 int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int device, rs_table **out);
+/* the same with an explicit block layout: lanes per tile of a tiled node block (a power of two >= 64; 0 = the default, 16 384; UINT32_MAX = never tile) and the
+ * narrowest node that is tiled (0 = the default, 2^20 lanes).  rs_table_create / rs_create_infosets use the defaults. */
+typedef struct rs_table_params {
+    uint32_t tile_lanes;
+    uint32_t tile_min_lanes;
+} rs_table_params;
+int rs_table_create_with(const rs_node_desc *nodes, int n_nodes, int dtype, int device, const rs_table_params *params, rs_table **out);
 /* create_infosets(n_actions, tree, card_abs) (infoset.rs:8-49): sizes from the tree, the per-round
  * cluster counts n_clusters[round_idx][player] and board counts n_boards[round_idx]. */
 int rs_create_infosets(const rs_tree *tree, const uint32_t n_clusters[RS_MAX_ROUNDS][RS_MAX_PLAYERS],
@@ -250,6 +258,29 @@ typedef struct rs_leaf_desc {
     const float *d_buf;
 } rs_leaf_desc;
 
+/* Kernel-form choices a caller may legitimately make.  EVERY field: 0 = the engine's own choice (what a zeroed struct gets), so a caller that never looks at
+ * this struct loses nothing.  Results are bit-identical whatever is chosen here (the GPU tests run the forms against each other and against the oracle); only
+ * time and workspace change.  The remaining A/B switches of the kernel generator are test-only and come from the environment, read in one place
+ * (csrc/rs_knobs.cpp). */
+enum { RS_FORM_DEFAULT = 0, RS_FORM_ON = 1, RS_FORM_OFF = 2 };
+enum { RS_FAN_DEFAULT = 0,   /* = RS_FAN_EXPAND */
+       RS_FAN_NONE = 1,      /* lane sweeps, subtree directly below an ENUM chance node (cfr.rs:502-522): separate expand / reduce launches */
+       RS_FAN_EXPAND = 2,    /* the subtree's kernel scales the chance node's own reach row by 1/len itself: no expand launch, no per-deal reach rows */
+       RS_FAN_LOOP = 3 };    /* it also walks the node's deals and sums them in order: no reduce launch, 25x less workspace, 6-10 % slower at config-3 size */
+enum { RS_SHADOW_DEFAULT = 0,   /* = RS_SHADOW_RULE */
+       RS_SHADOW_RULE = 1,      /* deal sweeps: a node keeps an AoS shadow only while the batch is likely to read it (n_deals * 8 >= its cells * round subtrees) */
+       RS_SHADOW_ALL = 2,       /* a shadow for every node */
+       RS_SHADOW_WIDE = 3 };    /* every node, 32-byte records (regrets + strategy sums) at the opponent's nodes too */
+typedef struct rs_kernel_forms {
+    int32_t lane_fan;           /* RS_FAN_* */
+    int32_t deals_per_thread;   /* deal sweeps: 1, 2 or 4 deals per thread of the generated kernels */
+    int32_t worklist;           /* RS_FORM_*: list-walking deal kernels with LDS tiles pull (job, trip) items from a device-built work list */
+    int32_t shadow;             /* RS_SHADOW_* */
+    int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
+                                   sum their deltas by wave segments instead of LDS tiles (default: on from 64 deals per last-round cluster) */
+    int32_t reserved[3];        /* zero */
+} rs_kernel_forms;
+
 typedef struct rs_solver_params {
     float scale;            /* 100.0 (cfr.rs:424) or 10000.0 (cfr.rs:617) */
     int32_t mode;           /* RS_UPD_* */
@@ -277,6 +308,7 @@ typedef struct rs_solver_params {
      * rank owns it.  With a communicator attached rs_iterate sweeps, all-reduces the i32 deltas (ncclInt32 sum) and applies the
      * union: N ranks x n deals equal ONE GPU with N*n deals per batch, bit for bit. */
     uint32_t deal_offset;
+    rs_kernel_forms forms;  /* zeroed = the engine's choices */
 } rs_solver_params;
 
 /* leaves_p0 / leaves_p1: one entry per TREE node id (only terminals are read) for traverser 0 / 1;
@@ -421,6 +453,8 @@ typedef struct rs_deal_trainer_params {
     uint64_t prune_threshold;      /* cfr.rs:190 PRUNE_THRESHOLD (10 000 000): deals numbered beyond it are traversed with prune = true when their
                                       q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  With a finite threshold the solver runs
                                       in RS_UPD_PRUNE mode with per-deal flags that stay zero (= unpruned, bit for bit) before it */
+    int32_t prefetch;              /* RS_FORM_*: deal the next batch on a second stream while the current one is swept (default: on beyond 262 144 deals per batch) */
+    int32_t reserved;              /* zero */
 } rs_deal_trainer_params;
 /* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
  * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */

@@ -54,17 +54,26 @@ class DealBatch(C.Structure):
     _fields_ = [("n_deals", C.c_uint32), ("d_cluster", (C.c_void_p * MAX_PLAYERS) * MAX_ROUNDS), ("d_prune", C.c_void_p)]
 
 
+class KernelForms(C.Structure):   # rs_kernel_forms: every field 0 = the engine's own choice
+    _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("worklist", C.c_int32), ("shadow", C.c_int32),
+                ("deal_order", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class TableParams(C.Structure):
+    _fields_ = [("tile_lanes", C.c_uint32), ("tile_min_lanes", C.c_uint32)]
+
+
 class SolverParams(C.Structure):
     _fields_ = [("scale", C.c_float), ("mode", C.c_int32), ("chance_mode", C.c_int32), ("use_graph", C.c_int32),
                 ("fuse_subtrees", C.c_int32), ("opp_mode", C.c_int32), ("sample_seed", C.c_uint64),
                 ("shard_world", C.c_int32), ("shard_rank", C.c_int32), ("shard_round", C.c_int32), ("shard_global_boards", C.c_uint32),
-                ("deal_offset", C.c_uint32)]
+                ("deal_offset", C.c_uint32), ("forms", KernelForms)]
 
 
 class DealTrainerParams(C.Structure):
     _fields_ = [("board_mask", C.c_uint64), ("deals_per_batch", C.c_uint32), ("seed", C.c_uint64), ("discount_interval", C.c_uint64),
                 ("discount_cap", C.c_uint64), ("solver", SolverParams), ("world", C.c_uint32), ("rank", C.c_uint32),
-                ("prune_threshold", C.c_uint64)]
+                ("prune_threshold", C.c_uint64), ("prefetch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -86,6 +95,7 @@ SYMBOLS = {
     "rs_tree_n_action_nodes": (C.c_int, [_P]),
     "rs_tree_get_node": (C.c_int, [_P, C.c_int, C.POINTER(TreeNode)]),
     "rs_table_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int, C.c_int, C.c_int, _PP]),
+    "rs_table_create_with": (C.c_int, [C.POINTER(NodeDesc), C.c_int, C.c_int, C.c_int, C.POINTER(TableParams), _PP]),
     "rs_create_infosets": (C.c_int, [_P, C.POINTER((C.c_uint32 * MAX_PLAYERS) * MAX_ROUNDS), C.POINTER(C.c_uint32 * MAX_ROUNDS),
                                      C.c_int, C.c_int, _PP]),
     "rs_table_destroy": (None, [_P]),

@@ -39,15 +39,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define RS_LOADG(p) __builtin_nontemporal_load(p)
 #define RS_STOREG(v, p) __builtin_nontemporal_store(v, p)
 #endif
-#ifdef RS_AB_FLAT
-template <typename T> __device__ __forceinline__ const T *as_global(const void *p) { return (const T *)p; }
-template <typename T> __device__ __forceinline__ T *as_global(void *p) { return (T *)p; }
-#else
 template <typename T> __device__ __forceinline__ const RS_GLOBAL T *as_global(const void *p) {
     return (const RS_GLOBAL T *)(unsigned long long)p;
 }
 template <typename T> __device__ __forceinline__ RS_GLOBAL T *as_global(void *p) { return (RS_GLOBAL T *)(unsigned long long)p; }
-#endif
 
 // ---- Rust casts ---------------------------------------------------------------------------------
 // `f32 as i64` then `+ i64::from(r)` then clamp to i32 (cfr.rs:445-451).  2^32 <= |x| < 2^63 saturates the sum whatever r is, so x is first
@@ -512,43 +507,6 @@ __device__ __forceinline__ void gather_u32_ids(const unsigned *base, const unsig
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = real[j] ? p[ids[j]] : 0u;
 }
-// Reach-down kernels in APPEND mode: the deals whose reach into a next-round root is a number join that root's live list directly -- (deal id, reach) pairs, one
-// wave-aggregated atomic per wave and cluster range -- instead of being written into a dense per-root row of the whole batch that a compaction pass then scans
-// (84 roots x n_deals floats per sweep for the 706-node tree).  key != nullptr: the list is partitioned by the traverser's cluster range on the NEXT round
-// (cluster-partitioned workgroups), part = key[deal] / part_size.  Counters sit 256 B apart (kCountStrideDev ints).  List order is arbitrary: every consumer commutes.
-constexpr unsigned kCountStrideDev = 64;
-__device__ __forceinline__ void append_live(unsigned *list, float *rlist, unsigned *count, const unsigned *key, unsigned part_size, unsigned n_parts, unsigned list_stride,
-                                            const unsigned (&ids)[kVecD], const float (&reach)[kVecD]) {
-    RS_GLOBAL unsigned *gl = as_global<unsigned>(list);
-    RS_GLOBAL float *gr = as_global<float>(rlist);
-    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#pragma unroll
-    for (int j = 0; j < kVecD; j++) {
-        const bool live = reach[j] == reach[j];
-        unsigned part = 0;
-        if (live && key) {
-            part = as_global<unsigned>(key)[ids[j]] / part_size;
-            part = part < n_parts ? part : n_parts - 1u;
-        }
-        unsigned long long todo = __ballot(live);
-        while (todo) {   // one round per distinct cluster range among the wave's live lanes (one round without partitioning)
-            const int leader = __builtin_ctzll(todo);
-            const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)part, leader);
-            const bool mine = live && part == q;
-            const unsigned long long same = __ballot(mine);
-            unsigned base = 0;
-            if ((int)lane == leader) base = __hip_atomic_fetch_add(count + (size_t)q * kCountStrideDev, (unsigned)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-            if (mine) {
-                const size_t slot = (size_t)q * list_stride + base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-                gl[slot] = ids[j];
-                gr[slot] = reach[j];
-            }
-            todo &= ~same;
-        }
-    }
-}
-
 // the packed per-deal inputs of a round (k_pack_attr): {cluster id of player 0, of player 1, leaf value bits, prune flag} in ONE 16-byte gather per live deal
 __device__ __forceinline__ void gather_attr(const void *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], unsigned (&c0)[kVecD], unsigned (&c1)[kVecD],
                                             float (&leaf)[kVecD], unsigned (&flag)[kVecD]) {

@@ -172,6 +172,48 @@ hipError_t launch_checksum(const void *x /* one node block */, size_t n, size_t 
 hipError_t launch_selftest_division(size_t n, uint64_t seed, unsigned long long *d_mismatches, float *d_first_bad, hipStream_t stream);
 hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream_t stream);      // d = snap - x; x = snap; snap = d
 
+// ---- kernel-form switches (rs_knobs.cpp) -------------------------------------------------------------
+// What a solver / table / trainer was asked to do differently from the engine's own choices: rs_kernel_forms / rs_table_params / rs_deal_trainer_params.prefetch
+// (the caller's API), then the environment (tests and the A/B tools only), resolved ONCE per object in knobs_resolve -- the only place of the library that reads
+// a knob from the environment.  kUnset = nobody said anything: the code's own rule decides.
+constexpr int kUnset = -2147483647 - 1;
+struct Knobs {
+    // API-backed (rs_kernel_forms); the environment overrides them for tests
+    int fan = kUnset;               // RS_JIT_FAN: 0 / 1 / 2
+    int lanes = kUnset;             // RS_JIT_LANES: deals per thread 1 / 2 / 4
+    int no_worklist = 0;            // RS_JIT_NO_WORKLIST
+    int shadow_all = 0;             // RS_JIT_SHADOW_ALL
+    int shadow_wide = 0;            // RS_JIT_SHADOW_WIDE
+    int ordered = kUnset;           // RS_JIT_ORDERED: 1 on / 0 off
+    // generator switches (test-only)
+    int distance = kUnset;          // RS_JIT_DISTANCE
+    int threads = kUnset;           // RS_JIT_THREADS
+    int waves = 0;                  // RS_JIT_WAVES
+    int plain = 0;                  // RS_JIT_PLAIN
+    int no_fast_clamp = 0;          // RS_JIT_NO_FAST_CLAMP
+    int no_fast_div = 0;            // RS_JIT_NO_FAST_DIV
+    int dump = 0;                   // RS_JIT_DUMP
+    int no_rounds = 0;              // RS_JIT_NO_ROUNDS
+    int no_sparse = 0;              // RS_JIT_NO_SPARSE
+    int no_parts = 0;               // RS_JIT_NO_PARTS
+    int scan_all = kUnset;          // RS_JIT_SCAN_ALL
+    int no_posrows = 0;             // RS_JIT_NO_POSROWS
+    int lds_max = kUnset;           // RS_JIT_LDS_MAX
+    int no_lane_rounds = 0;         // RS_JIT_NO_LANE_ROUNDS
+    int no_lds = 0;                 // RS_JIT_NO_LDS
+    int no_resident = 0;            // RS_JIT_NO_RESIDENT
+    int apply_whole_table = 0;      // RS_APPLY_WHOLE_TABLE
+    int max_blocks = kUnset;        // RS_JIT_MAX_BLOCKS
+    int no_overlap = 0;             // RS_JIT_NO_OVERLAP
+    int lane_overlap = 0;           // RS_LANE_OVERLAP
+    int no_pack = 0;                // RS_JIT_NO_PACK
+    long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES
+    long tile_min_lanes = kUnset;   // RS_TABLE_TILE_MIN_LANES
+    int no_prefetch = 0;            // RS_TRAINER_NO_PREFETCH
+};
+Knobs knobs_resolve(const rs_kernel_forms *forms);
+std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), else ~/.cache/rustsolver_amd
+
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------
 struct JitSubtree {
     std::string source;
@@ -192,20 +234,19 @@ struct JitSubtree {
     size_t off_butil = 0, off_breach = 0;                                                 // round subtrees: utility / reach buffers of the next round's roots
     size_t off_prune = 0;                                                                 // deal batches: per-deal prune flags (u8), may be null
     size_t off_attr = 0;                                                                  // sparse deal sweeps: packed per-deal inputs of the subtree's round, may be null
-    size_t off_rlist = 0;                                                                 // the reach of every entry of the live list (position-indexed rows, append mode), may be null
+    size_t off_rlist = 0;                                                                 // the reach of every entry of the live list (position-indexed rows), may be null
     size_t off_plist = 0;                                                                 // the parent-subtree position of every entry of the live list, may be null
-    size_t off_blist = 0, off_brlist = 0, off_bcount = 0, off_bkey = 0, off_bpsize = 0, off_bnparts = 0, off_blstride = 0;   // append mode: the next round's lists, per boundary root
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
-                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, int fan = 0, bool packed = false, bool append = false,
+                      bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
                       bool posrows = false, bool worklist = false);
 bool jit_available();
-int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn);
-int jit_compile_only(const std::string &source);
+int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
+int jit_compile_only(const std::string &source, bool dump = false);
 const char *jit_device_source();
 
 // ---- host-side objects ----------------------------------------------------------------------------

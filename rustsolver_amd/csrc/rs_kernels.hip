@@ -21,28 +21,16 @@ namespace rs {
 static_assert(kVec == kVecD && kPruneThreshold == kPruneThresholdD, "device constants");
 static_assert(RS_I32 == kDT_I32 && RS_F32 == kDT_F32 && RS_F16 == kDT_F16 && RS_UPD_CLAMP_I64 == kARITH_CLAMP && RS_UPD_WRAP_I32 == kARITH_WRAP, "enum values");
 
-#ifdef RS_AB_REFJOB
-#define RS_JOB_DECL(T) const T &job = jobs[blockIdx.y];
-#else
 #define RS_JOB_DECL(T) const T job = jobs[blockIdx.y];   // by value, before any store: one-time scalar loads into SGPRs
-#endif
 
 // utility of one action for 4 lanes (cfr.rs:314-348 for terminals, child buffers otherwise), in two phases so
 // that the loads of all children are in flight together: issue_child only issues the row load (no use of the
 // data, hence no s_waitcnt in its branch); finish_child turns the raw row into the utility.
 __device__ __forceinline__ void issue_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
-#ifdef RS_AB_LOADCHILD
-    (void)c; (void)v; (void)out;
-#else
     if ((c.kind & 0xff) != CH_CONST) load_f32_row(c.buf, v, out);   // wave-uniform branch
-#endif
 }
 __device__ __forceinline__ void finish_child(const ChildSrc &c, uint32_t v, float (&out)[kVec]) {
-#ifdef RS_AB_LOADCHILD
-    if ((c.kind & 0xff) != CH_CONST) load_f32_row(c.buf, v, out);
-#else
     (void)v;
-#endif
     const int kind = c.kind & 0xff;
     if (kind == CH_CONST) {
 #pragma unroll

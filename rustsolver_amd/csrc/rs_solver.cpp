@@ -24,7 +24,7 @@ namespace {
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
 constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ZERO_COUNTS };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK };
 
 struct Launch {
     int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
@@ -68,7 +68,7 @@ struct Plan {
     std::vector<Launch> launches;
     // sparse deal sweeps: per subtree root the list of live deals (reach not NaN), rebuilt by k_compact_live after the top-down pass
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
-    float *d_rlists = nullptr;          // position-indexed rows / append mode: the reach of every list entry, same shape as d_lists
+    float *d_rlists = nullptr;          // position-indexed rows: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
     ApplyJob *d_apply_jobs = nullptr;   // deal sweeps: the cell ranges of the traverser's own nodes (where its deltas are)
     int n_apply_jobs = 0;
@@ -97,6 +97,8 @@ struct rs_solver {
     rs_table *table = nullptr;
     rs_tree tree;
     rs_solver_params params{};
+    Knobs knobs;                        // kernel-form switches, resolved once at creation (rs_knobs.cpp)
+    int lds_limit = 64 * 1024;          // LDS bytes the device gives ONE workgroup (MI355X: 160 KiB), queried at creation
     std::vector<rs_leaf_desc> leaves[2];
     Plan plan[2];
     char *d_arena = nullptr;
@@ -261,7 +263,6 @@ struct Builder {
     bool pos_rows = false;                   // scan_parent only: the reach rows between a listed root's reach-down kernel and its children's compaction are indexed by the root's
                                              // LIST POSITION (written and read coalesced) and the compaction stores every live deal's reach beside its list entry
     std::vector<size_t> nan_off;             // per reach row of the round subtrees: float offset in plan.d_reach_nan (rows of listed parents hold one segment per cluster range)
-    bool append_mode = false;                // reach-down kernels append (deal, reach) to the next round's live lists themselves: no dense reach rows, no compaction scans
     // Cluster-partitioned workgroups: when the LDS tiles of ALL traverser nodes of a round subtree do not fit together, the cluster axis is cut
     // into n_parts ranges of part_size clusters such that inside one range they do; every live deal is listed under the range of its traverser
     // cluster and each (root, range) becomes its own kernel job whose tiles cover that range only -- all resident, zeroed and flushed once.
@@ -352,8 +353,7 @@ struct Builder {
     void fan_mode(int id) {   // may the kernel of root `id` take over work of the ENUM chance node above it?
         const int par = nodes[id].parent;
         if (par >= 0 && chance_enum(nodes[par]) && !boundary(par) && s->n_clusters % 4 == 0 && !s->deal_mode) {
-            const char *fm = getenv("RS_JIT_FAN");
-            const int mode = fm ? atoi(fm) : 1;
+            const int mode = s->knobs.fan != kUnset ? s->knobs.fan : 1;
             if (mode == 1 || (mode == 2 && closed[id])) fan_root[id] = char(mode);
             else if (mode == 2) fan_root[id] = 1;   // a round subtree with chance nodes below cannot walk its own deals (its rows are per deal of the round above): expand step only
         }
@@ -538,7 +538,8 @@ struct Builder {
         bnd.assign(n, {});
         nan_slot.assign(n, -1);
         {
-            const bool round_off = getenv("RS_JIT_NO_ROUNDS") != nullptr;
+            const Knobs &kn = s->knobs;
+            const bool round_off = kn.no_rounds != 0;
             first_root = resolve(0);
             // Small deal batches leave most SIMDs without a wave, and a generated kernel is a long dependent instruction stream: one deal per
             // thread puts four times as many waves on the chip, each walking a quarter of the code (RS_JIT_LANES = 1 / 4 overrides)
@@ -551,25 +552,21 @@ struct Builder {
             // do the list-walking kernels of later rounds at 1 M deals (three streets 3.70 -> 4.01 ms), which stay at one (gpurun_out/r03o/ab_l2.log, r03p/times.log).  The rule below is left for the kernels without tiles.
             jit_lanes = (s->deal_mode && s->deals.n_deals <= kSmallDealBatch) ? 1 : 4;
             jit_lanes_below = s->deal_mode ? 1 : 4;
-            if (const char *e = getenv("RS_JIT_LANES")) jit_lanes = jit_lanes_below = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 4;
+            if (kn.lanes != kUnset) jit_lanes = jit_lanes_below = (kn.lanes == 1 || kn.lanes == 2) ? kn.lanes : 4;
             round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                          nodes[first_root].n_children > 0;
-            const bool sparse_off = getenv("RS_JIT_NO_SPARSE") != nullptr, parts_off = getenv("RS_JIT_NO_PARTS") != nullptr;
+            const bool sparse_off = kn.no_sparse != 0, parts_off = kn.no_parts != 0;
             want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
             want_parts = round_mode && want_lists && !parts_off;
-            // measured SLOWER than dense rows + compaction (three streets, 4 M deals per batch: 14.49 against 13.36 ms; 1 M: 6.99 against 5.98): the appends are one
-            // atomic per wave, boundary and cluster range on a few dozen counters, where k_compact_live reserves once per workgroup and 1 024 lanes.  Off unless asked for.
-            append_mode = round_mode && want_lists && getenv("RS_JIT_APPEND") && atoi(getenv("RS_JIT_APPEND")) != 0;
             // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
             // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
             scan_parent = round_mode && want_lists && s->deals.n_deals > kScanParentMin;   // with list-position rows it pays from 128 K deals per batch on (1.21 -> 1.07 ms; 64 K: 1.00 -> 1.02,
                                                                                            // lossless abstractions at 64 K 2.5 -> 2.9: gpurun_out/r04d/ab_scan_small.log)
-            if (const char *e = getenv("RS_JIT_SCAN_ALL")) scan_parent = round_mode && want_lists && atoi(e) == 0;
-            pos_rows = scan_parent && !append_mode && !getenv("RS_JIT_NO_POSROWS");
-            if (hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, s->table->device) != hipSuccess) lds_limit = 64 * 1024;
-            if (const char *e = getenv("RS_JIT_LDS_MAX")) lds_limit = std::min(lds_limit, atoi(e));
+            if (kn.scan_all != kUnset) scan_parent = round_mode && want_lists && kn.scan_all == 0;
+            pos_rows = scan_parent && !kn.no_posrows;
+            lds_limit = s->lds_limit;
+            if (kn.lds_max != kUnset) lds_limit = std::min(lds_limit, kn.lds_max);
             lds_limit -= int(kWorklistLdsBytes);   // the work-list kernels keep their ticket in front of the tiles
-            if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
         }
         if (round_mode) {
             mark_round(first_root);
@@ -577,7 +574,7 @@ struct Builder {
         } else {
             // lane sweeps: round subtrees above the last round (full-width cfr() with ENUM chance nodes; prune keeps the level plan's NaN bookkeeping)
             lane_rounds = !s->deal_mode && s->params.fuse_subtrees && s->params.chance_mode == RS_CHANCE_ENUM && s->params.opp_mode == RS_OPP_FULL &&
-                          !getenv("RS_JIT_NO_LANE_ROUNDS");
+                          !s->knobs.no_lane_rounds;
             for (size_t id = 0; id < n; ++id)
                 if (nodes[id].kind == RS_NODE_PUBLIC_CHANCE) {
                     const int c = nodes[id].children[0];
@@ -645,7 +642,7 @@ struct Builder {
                 }
             }
         }
-        const bool lds_off = getenv("RS_JIT_NO_LDS") != nullptr;
+        const bool lds_off = s->knobs.no_lds != 0;
         const bool sparse = sparse_slot[id] >= 0;
         const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
         if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
@@ -653,13 +650,13 @@ struct Builder {
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                         (use_lds && !getenv("RS_JIT_LANES")) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
-                         round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js,
-                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, append_mode, pos_rows, !getenv("RS_JIT_NO_WORKLIST"));
+                         (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
+                         round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
-        if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn)) return rc;
+        if (int rc = jit_get_kernel(js.source, js.entry, t->device, &fn, s->knobs.dump != 0)) return rc;
         auto bi = by_fn.find(fn);
         if (bi == by_fn.end()) {
             bi = by_fn.emplace(fn, int(plan.jit.size())).first;
@@ -742,24 +739,14 @@ struct Builder {
                 const int b = js.boundary_roots[k];
                 put_ptr(js.off_butil + 8 * k, uptr(b) + ((pos_rows && sparse) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
                 // position-indexed rows: this job's segment of the row starts where its list does
-                put_ptr(js.off_breach + 8 * k, append_mode ? nullptr : nan_ptr(b) + ((pos_rows && sparse && down) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
-                if (append_mode && down) {   // where the deals this kernel sends on join the next round's lists
-                    const CompactJob &bj = plan.compact_jobs[size_t(sparse_slot[size_t(b)])];
-                    put_ptr(js.off_blist + 8 * k, bj.list);
-                    put_ptr(js.off_brlist + 8 * k, plan.d_rlists + (bj.list - plan.d_lists));
-                    put_ptr(js.off_bcount + 8 * k, bj.count);
-                    put_ptr(js.off_bkey + 8 * k, bj.key);
-                    put_u32(js.off_bpsize + 4 * k, bj.part_size);
-                    put_u32(js.off_bnparts + 4 * k, bj.n_parts);
-                    put_u32(js.off_blstride + 4 * k, bj.list_stride);
-                }
+                put_ptr(js.off_breach + 8 * k, nan_ptr(b) + ((pos_rows && sparse && down) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
             }
             if (sparse) {   // the subtree walks only its live deals
                 const CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
                 put_ptr(js.off_list, cj.list + size_t(part) * cj.list_stride);
                 put_ptr(js.off_count, cj.count + size_t(part) * cj.count_stride);
-                // append mode: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
-                put_ptr(js.off_rlist, ((append_mode || pos_rows) && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
+                // position-indexed rows: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
+                put_ptr(js.off_rlist, (pos_rows && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
                 put_ptr(js.off_plist, (pos_rows && id != first_root) ? plan.d_plists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             }
             // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
@@ -778,7 +765,7 @@ struct Builder {
             put_ptr(js.off_attr, sparse ? s->d_attr[nodes[id].round_idx] : nullptr);
             if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
             if (use_lds) {
-                const bool resident_off = getenv("RS_JIT_NO_RESIDENT") != nullptr;
+                const bool resident_off = s->knobs.no_resident != 0;
                 std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
                 for (size_t k = 0; k < js.node_ids.size(); ++k) {
                     const rs_tree_node &an = nodes[js.node_ids[k]];
@@ -977,9 +964,9 @@ struct Builder {
                 n_counts += pr.first;
             }
             hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
-            if (ea == hipSuccess && (append_mode || pos_rows)) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
+            if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
             if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_plists, list_elems * sizeof(uint32_t));
-            plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + ((append_mode || pos_rows) ? 1 : 0) + (pos_rows ? 1 : 0));
+            plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + (pos_rows ? 2 : 0));
             plan.n_count_words = n_counts * kCountStride;
             if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
             if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
@@ -1064,7 +1051,7 @@ struct Builder {
                     nan_off[size_t(nan_slot[b]) + 1] = s->pitch[0] * ((pos_rows && par >= 0 && listed_root(par)) ? size_t(parts_of(par).first) : size_t(1));
                 }
             for (size_t k = 0; k < size_t(n_nan); ++k) nan_off[k + 1] += nan_off[k];
-            if (n_nan && !append_mode) {
+            if (n_nan) {
                 plan.reach_nan_bytes = nan_off[size_t(n_nan)] * sizeof(float);
                 plan.aux_bytes += plan.reach_nan_bytes;
                 hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
@@ -1090,17 +1077,12 @@ struct Builder {
                     listed.insert(listed.end(), roots_of_round[r].begin(), roots_of_round[r].end());
                 }
             if (int rc = make_lists(listed, [&](int id) { return id == first_root ? (const float *)nullptr : (const float *)nan_ptr(id); })) return rc;
-            if (append_mode && plan.n_count_words) {   // the lists of this sweep start empty
-                Launch L;
-                L.kind = L_ZERO_COUNTS;
-                plan.launches.push_back(L);
-            }
             for (size_t r = 0; r < roots_of_round.size(); ++r) {
-                if (r == 0 || !append_mode) push_compact(slots_of_round[r].first, slots_of_round[r].second);   // append mode: only the first root's partition by cluster range
+                push_compact(slots_of_round[r].first, slots_of_round[r].second);
                 std::map<hipFunction_t, int> by_fn;
                 for (int root : roots_of_round[r]) {
                     if (bnd[size_t(root)].empty()) continue;
-                    for (int b : bnd[size_t(root)]) reach[b] = append_mode ? ReachSrc{nullptr, 0.0f, true} : ReachSrc{nan_ptr(b), 0.0f, true};
+                    for (int b : bnd[size_t(root)]) reach[b] = ReachSrc{nan_ptr(b), 0.0f, true};
                     if (int rc = add_jit_job(root, true, sparse_slot, by_fn)) return rc;
                 }
                 const int group = ++next_group;   // the DOWN kernels of one round write different reach buffers
@@ -1235,7 +1217,7 @@ struct Builder {
                 plan.apply_max_vec = std::max(plan.apply_max_vec, nc / kVec);
                 cells += double(nc);
             }
-            if (!aj.empty() && !getenv("RS_APPLY_WHOLE_TABLE")) {
+            if (!aj.empty() && !s->knobs.apply_whole_table) {
                 hipError_t ea = hipMalloc((void **)&plan.d_apply_jobs, aj.size() * sizeof(ApplyJob));
                 if (ea == hipSuccess) ea = hipMemcpy(plan.d_apply_jobs, aj.data(), aj.size() * sizeof(ApplyJob), hipMemcpyHostToDevice);
                 if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");
@@ -1287,10 +1269,6 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
     }
-    if (L.kind == L_ZERO_COUNTS) {
-        RS_HIP(hipMemsetAsync(plan.d_counts, 0, plan.n_count_words * sizeof(uint32_t), t->stream), "live-list counters");
-        return RS_OK;
-    }
     if (L.kind == L_PACK) {
         RS_HIP(launch_pack_attr(s->d_pack_jobs, s->n_pack_jobs, s->deals.n_deals, t->stream), "k_pack_attr");
         return RS_OK;
@@ -1323,8 +1301,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
         blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
         if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
-        if (const char *cap = getenv("RS_JIT_MAX_BLOCKS"))   // tests: force several trips per workgroup
-            blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(atoi(cap))));
+        if (s->knobs.max_blocks != kUnset)   // tests: force several trips per workgroup
+            blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(std::max(1, s->knobs.max_blocks))));
         const void *d_blob = JL.d_blob;
         int flags = s->params.mode & ~RS_UPD_ARITH_MASK;
         if (JL.worklist) {   // trips per job from the live-list counts, then resident workgroups that pull them
@@ -1334,8 +1312,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
                 e = launch_worklist(one, 1, tree_stream);
                 if (e != hipSuccess) break;
             }
-            size_t grid = size_t(s->n_cus) * ((JL.lds_bytes + kWorklistLdsBytes) * 2 <= size_t(160) * 1024 ? 2 : 1);
-            if (const char *cap = getenv("RS_JIT_MAX_BLOCKS")) grid = std::max<size_t>(1, std::min<size_t>(grid, size_t(atoi(cap))));
+            size_t grid = size_t(s->n_cus) * ((JL.lds_bytes + kWorklistLdsBytes) * 2 <= size_t(s->lds_limit) ? 2 : 1);
+            if (s->knobs.max_blocks != kUnset) grid = std::max<size_t>(1, std::min<size_t>(grid, size_t(std::max(1, s->knobs.max_blocks))));
             uint32_t *d_wl = JL.d_wl;
             void *wparams[] = {&d_blob, &flags, &d_wl};
             e = hipModuleLaunchKernel(JL.fn, (unsigned)grid, 1, 1, (unsigned)JL.threads, 1, 1, (unsigned)(JL.lds_bytes + kWorklistLdsBytes), tree_stream, wparams, nullptr);
@@ -1530,6 +1508,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     table->solvers.push_back(s);
     s->tree = *tree;
     s->params = *params;
+    s->knobs = knobs_resolve(&params->forms);
     if (deals) {
         s->deal_mode = true;
         s->deals = *deals;
@@ -1567,7 +1546,9 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         }
     }
     // streams for independent round subtrees (deal sweeps) and, on request (RS_LANE_OVERLAP=1), for the independent subtree launches of one tree depth in lane sweeps
-    if (((s->deal_mode && !getenv("RS_JIT_NO_OVERLAP")) || (!s->deal_mode && getenv("RS_LANE_OVERLAP") && atoi(getenv("RS_LANE_OVERLAP")) != 0)) && s->params.fuse_subtrees) {
+    if (hipDeviceGetAttribute(&s->lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, table->device) != hipSuccess || s->lds_limit < 1024) s->lds_limit = 64 * 1024;
+    if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
+    if (((s->deal_mode && !s->knobs.no_overlap) || (!s->deal_mode && s->knobs.lane_overlap)) && s->params.fuse_subtrees) {
         e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
         for (int k = 0; e == hipSuccess && k < rs_solver::kAux; ++k) {
             e = hipStreamCreateWithFlags(&s->aux[k], hipStreamNonBlocking);
@@ -1595,7 +1576,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                     if (c.kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(c.round_idx, s->n_rounds))] += 1;
                 }
         }
-        const bool shadow_all = getenv("RS_JIT_SHADOW_ALL") != nullptr || s->params.opp_mode != RS_OPP_SAMPLE;
+        const bool shadow_all = s->knobs.shadow_all != 0 || s->params.opp_mode != RS_OPP_SAMPLE;
         for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
             s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
             s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
@@ -1605,7 +1586,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
                 if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
                 const uint32_t half = d.n_actions <= 4 ? 4 : 8;
-                const uint32_t stride = (d.player == tp || getenv("RS_JIT_SHADOW_WIDE")) ? 2 * half : half;
+                const uint32_t stride = (d.player == tp || s->knobs.shadow_wide) ? 2 * half : half;
                 s->shadow_off_p[tp][i] = ints;
                 s->shadow_stride_p[tp][i] = stride;
                 ShadowJob j{};
@@ -1640,7 +1621,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     }
     // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
     // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
-    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !getenv("RS_JIT_NO_SPARSE") && !getenv("RS_JIT_NO_PACK")) {
+    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack) {
         const float *leaf = nullptr;
         bool one = true;
         for (size_t i = 0; i < n && one; ++i) {
@@ -1885,6 +1866,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
     const std::vector<rs_tree_node> &nodes = tree->nodes;
     const size_t n = nodes.size();
     std::map<std::string, int> seen;
+    const Knobs knobs = knobs_resolve(nullptr);
     for (int p = 0; p < 2; ++p) {
         std::vector<char> has_own(n, 0), closed(n, 0);
         std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
@@ -1915,12 +1897,12 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
                 const bool down = (form & 1) != 0, xr = (form & 2) != 0;
                 if (xr && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
                 JitSubtree js;
-                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, false, false, false, false, down, (mode & RS_UPD_PRUNE) != 0, 4, &next_root, js,
+                jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, false, false, false, false, down, (mode & RS_UPD_PRUNE) != 0, 4, &next_root, js, knobs,
                                  xr ? 1 : 0);
                 if (down && js.boundary_roots.empty()) continue;
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
-                if (int rc = jit_compile_only(js.source)) return rc;
+                if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
             }
         }
         for (size_t i = 0; i < n; ++i) {
@@ -1931,10 +1913,10 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
                 if (fan && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false,
-                                 (mode & RS_UPD_PRUNE) != 0, 4, nullptr, js, fan);
+                                 (mode & RS_UPD_PRUNE) != 0, 4, nullptr, js, knobs, fan);
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
-                if (int rc = jit_compile_only(js.source)) return rc;
+                if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
             }
         }
     }
@@ -1960,6 +1942,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
             if (nodes[size_t(c)].kind == RS_NODE_ACTION && nodes[size_t(c)].n_children > 0) root[size_t(c)] = 1;
         }
     std::map<std::string, int> seen;
+    const Knobs knobs = knobs_resolve(nullptr);
     for (int p = 0; p < 2; ++p) {
         std::vector<char> has_own(n, 0);
         std::vector<int> leaf_buf(n, -1), leaf_flags(n, 0);
@@ -1982,29 +1965,29 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, 0, sparse, opp_mode == RS_OPP_SAMPLE);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
+                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, knobs, 0, sparse);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
                                                                                                // fallback for solvers whose leaves do not share one buffer: compiled by the GPU tests)
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (!seen.count(js.source)) {
                     seen[js.source] = 1;
-                    if (int rc = jit_compile_only(js.source)) return rc;
+                    if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
                 }
                 if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
                     JitSubtree jw;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jw, 0, sparse, false, true, true);
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jw, knobs, 0, sparse, true, true);
                     if (!seen.count(jw.source)) {
                         seen[jw.source] = 1;
-                        if (int rc = jit_compile_only(jw.source)) return rc;
+                        if (int rc = jit_compile_only(jw.source, knobs.dump != 0)) return rc;
                     }
                 }
                 if (sparse && !js.boundary_roots.empty()) {   // the forms that address the rows shared with the next round by list position (large batches)
                     JitSubtree jp;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jp, 0, sparse, false, true);
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jp, knobs, 0, sparse, true);
                     if (!seen.count(jp.source)) {
                         seen[jp.source] = 1;
-                        if (int rc = jit_compile_only(jp.source)) return rc;
+                        if (int rc = jit_compile_only(jp.source, knobs.dump != 0)) return rc;
                     }
                 }
             }

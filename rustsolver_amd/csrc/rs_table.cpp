@@ -163,6 +163,10 @@ int rs_device_count(int *out) {
 
 // ---- create / destroy --------------------------------------------------------------------------------
 int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int device, rs_table **out) {
+    return rs_table_create_with(nodes, n_nodes, dtype, device, nullptr, out);
+}
+
+int rs_table_create_with(const rs_node_desc *nodes, int n_nodes, int dtype, int device, const rs_table_params *params, rs_table **out) {
     if (!nodes || !out || n_nodes <= 0) return fail(RS_ERR_INVALID, "rs_table_create: bad argument");
     if (dtype != RS_I32 && dtype != RS_F32 && dtype != RS_F16) return fail(RS_ERR_INVALID, "rs_table_create: bad dtype");
     for (int i = 0; i < n_nodes; ++i) {
@@ -191,11 +195,14 @@ int rs_table_create(const rs_node_desc *nodes, int n_nodes, int dtype, int devic
     t->pitch.resize(n_nodes);
     t->cell_off.resize(n_nodes);
     size_t tile_lanes = kTileLanes, tile_min = kTileMinLanes;
-    if (const char *e = getenv("RS_TABLE_TILE_LANES")) {
-        const long v = atol(e);
+    if (params && params->tile_lanes) tile_lanes = (params->tile_lanes >= uint32_t(kLanePad) && (params->tile_lanes & (params->tile_lanes - 1)) == 0) ? size_t(params->tile_lanes) : 0;
+    if (params && params->tile_min_lanes) tile_min = params->tile_min_lanes;
+    const Knobs knobs = knobs_resolve(nullptr);   // tests force small tiles on small tables
+    if (knobs.tile_lanes != kUnset) {
+        const long v = knobs.tile_lanes;
         tile_lanes = (v >= long(kLanePad) && (v & (v - 1)) == 0) ? size_t(v) : 0;   // anything else: never tile
     }
-    if (const char *e = getenv("RS_TABLE_TILE_MIN_LANES")) tile_min = size_t(std::max(0L, atol(e)));
+    if (knobs.tile_min_lanes != kUnset) tile_min = size_t(std::max(0L, knobs.tile_min_lanes));
     t->tile.resize(size_t(n_nodes));
     size_t off = 0;
     for (int i = 0; i < n_nodes; ++i) {

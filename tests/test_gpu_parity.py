@@ -537,7 +537,7 @@ def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
 
 
 @pytest.mark.parametrize("blocks", [None, "2"])
-@pytest.mark.parametrize("sparse", [True, "unpacked", "append", "scan-parent", False, "no-rounds", "no-rounds-no-sparse"])
+@pytest.mark.parametrize("sparse", [True, "unpacked", "ordered", "scan-parent", False, "no-rounds", "no-rounds-no-sparse"])
 def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypatch):
     """sampled three-street sweeps over 40 000 deals: every river subtree walks only the compacted list of its live deals (several trips per
     workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked; with RS_JIT_NO_ROUNDS the flop and
@@ -550,8 +550,8 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         monkeypatch.setenv("RS_JIT_NO_PACK", "1")
     elif sparse == "scan-parent":   # the compaction of a root's live deals walks its parent's lists (what batches beyond 256 K deals get) instead of the whole batch
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
-    elif sparse == "append":      # the reach-down kernels append (deal, reach) to the next round's lists themselves instead of writing dense rows for k_compact_live (RS_JIT_APPEND)
-        monkeypatch.setenv("RS_JIT_APPEND", "1")
+    elif sparse == "ordered":     # the batch walked in the order of the traverser's river cluster, river deltas summed by wave segments (what big batches get: rs_kernel_forms.deal_order)
+        monkeypatch.setenv("RS_JIT_ORDERED", "1")
     elif isinstance(sparse, str):   # the level plan for flop / turn and chance-free river subtrees, as before the round subtrees
         monkeypatch.setenv("RS_JIT_NO_ROUNDS", "1")
     n_deals = 40000
