@@ -277,7 +277,7 @@ typedef struct rs_kernel_forms {
     int32_t worklist;           /* RS_FORM_*: list-walking deal kernels with LDS tiles pull (job, trip) items from a device-built work list */
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
-                                   sum their deltas by wave segments instead of LDS tiles (default: on from 64 deals per last-round cluster) */
+                                   sum their deltas by wave segments instead of LDS tiles (default: off -- measured slower at every batch size tried) */
     int32_t reserved[3];        /* zero */
 } rs_kernel_forms;
 
@@ -357,6 +357,8 @@ int rs_table_deltas(rs_table *table, int32_t **d_dregrets, int32_t **d_dstrategy
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
+/* which kernel forms the solver chose (rs_kernel_forms): bit 0 = deal sweeps walk the batch in last-round-cluster order (deal_order); negative = bad solver */
+int rs_solver_forms(const rs_solver *solver);
 
 /* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------
  * These entry points take canonical hand indices as INPUT (e.g. from the Rust side's own hand_indexer_s); the index itself is

@@ -155,6 +155,7 @@ SYMBOLS = {
     "rs_deal_trainer_finish_batch": (C.c_int, [_P]),
     "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
+    "rs_solver_forms": (C.c_int, [_P]),
     "rs_jit_available": (C.c_int, []),
     "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rs_jit_check_tree_deals": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),

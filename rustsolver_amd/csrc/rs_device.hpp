@@ -520,6 +520,104 @@ __device__ __forceinline__ void gather_attr(const void *base, const unsigned (&i
         flag[j] = r.w;
     }
 }
+// ---- ordered deal sweeps (rs_kernel_forms.deal_order) ---------------------------------------------------------------------------------------
+// The sweep of traverser p walks the batch in the order of p's cluster id on the LAST betting round (k_order_* in rs_kernels.hip sort the deals once per sweep),
+// and a "deal" inside the sweep is its RANK in that order.  The per-deal inputs of all rounds travel as ONE 32-byte record per rank,
+//   word 0..3 = cluster ids of rounds 0 and 1 ([2 * round + player]),  word 4, 5 = cluster ids of round 2,  word 6 = leaf value bits,
+//   word 7 = (original deal id << 1) | prune flag
+// so the last round's kernels -- most of a sweep's walks -- fetch the upper 16 bytes only.  The original id is what the opponent-sampling hash sees: the draw of a
+// deal does not depend on where the sort put it (and the oracle never sorts).
+template <int ROUND>
+__device__ __forceinline__ void load_arec(const void *base, const unsigned (&idx)[kVecD], const bool (&ok)[kVecD], unsigned (&c0)[kVecD], unsigned (&c1)[kVecD],
+                                          float (&leaf)[kVecD], unsigned (&flag)[kVecD], unsigned (&oid)[kVecD]) {
+    const RS_GLOBAL u32x4 *p = as_global<u32x4>((const unsigned *)base);
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        const u32x4 hi = ok[j] ? p[2 * (size_t)idx[j] + 1] : u32x4{0u, 0u, 0u, 0u};
+        if (ROUND == 2) {
+            c0[j] = hi.x;
+            c1[j] = hi.y;
+        } else {
+            const u32x4 lo = ok[j] ? p[2 * (size_t)idx[j]] : u32x4{0u, 0u, 0u, 0u};
+            c0[j] = ROUND == 0 ? lo.x : lo.z;
+            c1[j] = ROUND == 0 ? lo.y : lo.w;
+        }
+        leaf[j] = __uint_as_float(hi.z);
+        flag[j] = hi.w & 1u;
+        oid[j] = hi.w >> 1;
+    }
+}
+
+// Sum of x over the 64 lanes of the wave (every lane active), in a scalar register.  Inclusive prefix inside each row of 16 (row_shr with zero fill), then the rows
+// are folded with the two row broadcasts: lane 63 ends up with the total.
+__device__ __forceinline__ int wave_sum_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// In an ordered sweep the deals a wave walks in the last round come in runs of equal traverser cluster: all of them add into the SAME table cells.  Instead of
+// an LDS tile per traverser node (160 KB per workgroup, one workgroup per CU, zeroed and flushed around every 1 024 deals) the wave sums every delta over each
+// run of equal keys (wave_sum_i32) and issues ONE global atomic per run, node, action and array -- 2A lanes of one instruction.  bmask bit i = lane i starts a
+// new run (never lane 0).  Integer adds commute, so the result equals the tile form's, and the oracle's, bit for bit.
+constexpr int kSegMax = 6;   // more runs than this in one wave (small batches, list tails): every lane adds for itself
+struct Seg {
+    unsigned long long bmask;
+    unsigned lane;
+};
+__device__ __forceinline__ Seg seg_make(unsigned key) {
+    Seg sg;
+    sg.lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned prev = (unsigned)__builtin_amdgcn_ds_bpermute((int)((sg.lane - 1u) << 2), (int)key);   // lane 0 reads lane 63: masked below
+    sg.bmask = __builtin_amdgcn_ballot_w64(prev != key && sg.lane != 0u);
+    return sg;
+}
+template <int A>
+__device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch, const Seg &sg, unsigned key, const int (&r)[A][kVecD], const int (&q)[A][kVecD],
+                                        const int (&s)[A][kVecD], const int (&t)[A][kVecD]) {
+    static_assert(kVecD == 1, "segmented sums take one deal per lane");
+    int d[2 * A];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        d[a] = (int)((unsigned)r[a][0] - (unsigned)q[a][0]);
+        d[A + a] = (int)((unsigned)s[a][0] - (unsigned)t[a][0]);
+        any = any || d[a] != 0 || d[A + a] != 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;   // nobody in this wave visited the node
+    RS_GLOBAL int *pr = as_global<int>(dreg), *ps = as_global<int>(dssm);
+    if (__builtin_popcountll(sg.bmask) >= kSegMax) {
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            if (d[a] != 0) __hip_atomic_fetch_add(pr + (size_t)a * tpitch + key, d[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d[A + a] != 0) __hip_atomic_fetch_add(ps + (size_t)a * tpitch + key, d[A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    RS_GLOBAL int *mine_p = sg.lane < (unsigned)A ? pr + (size_t)sg.lane * tpitch : ps + (size_t)(sg.lane - (unsigned)A) * tpitch;   // lane i < 2A carries value i of a run
+    unsigned long long rest = sg.bmask;
+    unsigned lo = 0;
+    for (;;) {   // one trip per run: wave-uniform
+        const unsigned hi = rest ? (unsigned)__builtin_ctzll(rest) : 64u;
+        const bool in = sg.lane >= lo && sg.lane < hi;
+        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)lo);
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * A; i++) {
+            const int tot = wave_sum_i32(in ? d[i] : 0);
+            mine = sg.lane == (unsigned)i ? tot : mine;
+        }
+        if (sg.lane < 2u * (unsigned)A && mine != 0) __hip_atomic_fetch_add(mine_p + ckey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!rest) break;
+        rest &= rest - 1ull;
+        lo = hi;
+    }
+}
+
 __device__ __forceinline__ void scatter_f32_ids(float *base, const unsigned (&ids)[kVecD], const bool (&real)[kVecD], const float (&in)[kVecD]) {
     RS_GLOBAL float *p = as_global<float>(base);
 #pragma unroll

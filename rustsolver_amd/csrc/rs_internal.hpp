@@ -116,7 +116,7 @@ struct CompactJob {
     uint32_t src_parts, src_list_stride, src_count_stride;
     // Position-indexed rows: the parent's reach-down kernel wrote `reach` at the parent's LIST POSITION (part * src_list_stride + entry), so this scan reads it coalesced;
     // the reach of every live deal is then stored beside its new list entry (rlist, same layout as list), where the subtree's kernels read it coalesced too.
-    uint32_t pos_rows, pad_;
+    uint32_t pos_rows, key_stride;   // key_stride: words between two deals' keys (1: a plain id vector; 8: the 32-byte records of an ordered sweep)
     float *rlist;         // [n_parts][list_stride] or nullptr
     uint32_t *plist;      // [n_parts][list_stride] or nullptr: where the parent subtree will read this deal's utility (its list position; the deal id below an unlisted parent)
 };
@@ -130,6 +130,20 @@ struct PackJob {
     uint32_t n;
 };
 hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream);
+// ordered deal sweeps (rs_kernels.hip k_order_*): counting sort of the batch by `key` and the 32-byte per-deal records in that order
+constexpr uint32_t kOrderMaxBins = 16384;   // LDS counters of one workgroup
+struct OrderJob {
+    const uint32_t *key;       // [n] the traverser's cluster id on the last round
+    const uint32_t *cid[6];    // [n] cluster ids [2 * round + player], null = a player without nodes there
+    const float *leaf;         // [n]
+    const uint8_t *prune;      // [n] or null
+    uint32_t *hist;            // [n_chunks][n_bins] scratch
+    uint32_t *tot;             // [n_bins] scratch
+    void *arec;                // [pitch] x 32 bytes, out
+    uint32_t n, n_bins, n_chunks, chunk;
+};
+hipError_t launch_order(const OrderJob &job, hipStream_t stream);
+hipError_t launch_unpermute_f32(const float *in, const void *arec, float *out, uint32_t n, hipStream_t stream);
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream);
 // the work list of one launch of list-walking kernels: wl[0] = ticket counter (zeroed), wl[1] = n_jobs, wl[2 + j] = trips of jobs 0 .. j-1, wl[2 + n_jobs] = all trips.
 // The count of job j is read through the pointer at blob + j * stride + off_count; a trip covers deals_per_trip list entries.
@@ -243,7 +257,7 @@ struct JitSubtree {
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
-                      bool posrows = false, bool worklist = false);
+                      bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
 int jit_compile_only(const std::string &source, bool dump = false);

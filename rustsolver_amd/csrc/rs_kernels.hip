@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
             deal[i] = e < n ? (src ? src[e] : e) : 0u;
             rv[i] = (e < n && reach) ? reach[(src && job->pos_rows) ? (size_t)sq * job->src_list_stride + e : (size_t)deal[i]] : 0.0f;
             live[i] = e < n && rv[i] == rv[i];
-            part[i] = (live[i] && key) ? min(key[deal[i]] / part_size, n_parts - 1u) : 0u;
+            part[i] = (live[i] && key) ? min(key[(size_t)deal[i] * job->key_stride] / part_size, n_parts - 1u) : 0u;
             rank[i] = 0;
         }
         for (uint32_t q = 0; q < n_parts; ++q) {   // ballots only: no barrier inside
@@ -504,6 +504,93 @@ __global__ __launch_bounds__(kBlock) void k_pack_attr(const PackJob *__restrict_
         rec.w = job.prune ? (uint32_t)job.prune[i] : 1u;   // no flag vector = every deal is traversed with prune = true (cfr.rs:219)
         ((u32x4 *)job.out)[i] = rec;
     }
+}
+
+static inline uint32_t grid_for(size_t n_threads_needed);
+// ---- ordered deal sweeps: the batch in the order of the traverser's last-round cluster (rs_device.hpp load_arec, seg_add) ----------------------------------------
+// A counting sort over the cluster id (at most kOrderMaxBins bins) in three launches: every workgroup counts the keys of its chunk of the batch in LDS (k_order_hist), the
+// counts are turned into per-(chunk, bin) starts (k_order_colscan: one thread per bin walks the chunks), and every workgroup deals its chunk's records out to their
+// slots (k_order_scatter: LDS cursors, ds_add_rtn), writing the 32-byte record of each deal as it goes -- the per-deal input arrays are read coalesced, once.  The
+// order inside a bin is whatever the LDS atomics make it: every consumer commutes (i32 deltas), and nothing the oracle sees depends on it.
+__global__ __launch_bounds__(1024) void k_order_hist(const OrderJob job) {
+    extern __shared__ uint32_t lds_bins[];
+    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) lds_bins[b] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * job.chunk, hi = min(job.n, lo + job.chunk);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lds_bins[min(job.key[i], job.n_bins - 1u)], 1u);
+    __syncthreads();
+    uint32_t *__restrict__ out = job.hist + (size_t)blockIdx.x * job.n_bins;
+    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) out[b] = lds_bins[b];
+}
+__global__ __launch_bounds__(kBlock) void k_order_colscan(const OrderJob job) {   // hist[g][b] -> entries of bin b in chunks before g; tot[b]
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= job.n_bins) return;
+    uint32_t run = 0;
+    uint32_t *__restrict__ h = job.hist + b;
+#pragma unroll 8
+    for (uint32_t g = 0; g < job.n_chunks; ++g) {
+        const uint32_t x = h[(size_t)g * job.n_bins];
+        h[(size_t)g * job.n_bins] = run;
+        run += x;
+    }
+    job.tot[b] = run;
+}
+__global__ __launch_bounds__(1024) void k_order_scatter(const OrderJob job) {
+    extern __shared__ uint32_t lds_bins[];   // [n_bins] start of every bin for THIS chunk, then cursors
+    __shared__ uint32_t part[1024];
+    // exclusive scan of tot[] over the bins: thread t owns bins [t * per, (t + 1) * per)
+    const uint32_t per = (job.n_bins + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0 = threadIdx.x * per, b1 = min(job.n_bins, b0 + per);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += job.tot[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {   // inclusive scan of the per-thread sums
+        const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    const uint32_t *__restrict__ mine = job.hist + (size_t)blockIdx.x * job.n_bins;
+    for (uint32_t b = b0; b < b1; ++b) {
+        lds_bins[b] = run + mine[b];
+        run += job.tot[b];
+    }
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * job.chunk, hi = min(job.n, lo + job.chunk);
+    u32x4 *__restrict__ out = (u32x4 *)job.arec;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t slot = atomicAdd(&lds_bins[min(job.key[i], job.n_bins - 1u)], 1u);
+        u32x4 a, b;
+        a.x = job.cid[0] ? job.cid[0][i] : 0u;
+        a.y = job.cid[1] ? job.cid[1][i] : 0u;
+        a.z = job.cid[2] ? job.cid[2][i] : 0u;
+        a.w = job.cid[3] ? job.cid[3][i] : 0u;
+        b.x = job.cid[4] ? job.cid[4][i] : 0u;
+        b.y = job.cid[5] ? job.cid[5][i] : 0u;
+        b.z = job.leaf ? __float_as_uint(job.leaf[i]) : 0u;
+        b.w = (i << 1) | (job.prune ? (uint32_t)(job.prune[i] != 0) : 1u);   // no flag vector = every deal is traversed with prune = true (cfr.rs:219)
+        out[2 * (size_t)slot] = a;
+        out[2 * (size_t)slot + 1] = b;
+    }
+}
+hipError_t launch_order(const OrderJob &job, hipStream_t stream) {
+    if (job.n == 0) return hipSuccess;
+    const size_t lds = size_t(job.n_bins) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_order_hist, dim3(job.n_chunks), dim3(1024), lds, stream, job);
+    hipLaunchKernelGGL(k_order_colscan, dim3((job.n_bins + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, job);
+    hipLaunchKernelGGL(k_order_scatter, dim3(job.n_chunks), dim3(1024), lds, stream, job);
+    return hipGetLastError();
+}
+// the root utilities of an ordered sweep are by rank: hand them out by deal id
+__global__ __launch_bounds__(kBlock) void k_unpermute_f32(const float *__restrict__ in, const uint32_t *__restrict__ arec, float *__restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[arec[8 * (size_t)i + 7] >> 1] = in[i];
+}
+hipError_t launch_unpermute_f32(const float *in, const void *arec, float *out, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unpermute_f32, dim3(grid_for(n)), dim3(kBlock), 0, stream, in, (const uint32_t *)arec, out, n);
+    return hipGetLastError();
 }
 
 // ---- deal batches: table += delta (wrapping), delta = 0; 32 bytes per cell, whole table, end of every sweep ------

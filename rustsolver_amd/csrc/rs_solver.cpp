@@ -24,7 +24,7 @@ namespace {
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
 constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER };
 
 struct Launch {
     int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
@@ -54,6 +54,7 @@ struct JitLaunch {
     int threads = 256;
     size_t lds_bytes = 0;
     bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
+    bool seg = false;                   // ordered sweeps, last round: no LDS, 256-thread workgroups, many per CU
     bool worklist = false;              // list-walking kernels with LDS tiles: a 1-D grid of resident workgroups pulls (job, trip) items; k_worklist runs right before
     uint32_t *d_wl = nullptr;           // [2 + n_jobs + 1]
     uint32_t off_count = 0, deals_per_trip = 0;
@@ -131,6 +132,13 @@ struct rs_solver {
     PackJob *d_pack_jobs = nullptr;
     int n_pack_jobs = 0;
     unsigned attr_used = 0;             // bit r: some generated kernel reads the packed records of round r (only the list-walking forms do)
+    // ordered sweeps (rs_kernel_forms.deal_order): traverser p's sweep walks the batch sorted by p's cluster id on the last round; d_arec holds the 32-byte per-deal
+    // records in that order (rebuilt at the start of every sweep by k_order_*), d_attr[r] all point at it
+    bool ordered = false;
+    int order_round = 0;                // the last betting round of the tree
+    void *d_arec = nullptr;
+    uint32_t *d_order_hist = nullptr, *d_order_tot = nullptr;
+    OrderJob order_job[2];              // per traverser
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -270,6 +278,7 @@ struct Builder {
         uint32_t first, second;   // number of cluster ranges, clusters per range
         uint32_t n_clusters, pitch;   // of the TRAVERSER's nodes in this round subtree (the root may be the opponent's)
     };
+    bool seg_root(int root) const { return s->ordered && nodes[size_t(root)].round_idx == s->order_round; }   // its deltas are summed by wave segments: no LDS tiles
     Parts parts_of(int root) const {
         const rs_table *t = s->table;
         size_t sum_a = 0;
@@ -290,7 +299,7 @@ struct Builder {
             }
         }
         const size_t limit = size_t(lds_limit) / 4;
-        if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit) return Parts{1u, pitch, n_cl, pitch};
+        if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit || seg_root(root)) return Parts{1u, pitch, n_cl, pitch};
         // Partitioning costs list indirection (gathers instead of row loads, a bucketing pass).  When most tiles would be resident anyway --
         // 1 081 clusters miss the budget by 1 % and keep 5 of 7 -- it loses (measured 1.33 against 0.84 ms per batch): only partition when
         // fewer than half of the tile bytes fit.
@@ -646,13 +655,14 @@ struct Builder {
         const bool sparse = sparse_slot[id] >= 0;
         const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
         if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
-        const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down;
+        const bool seg = seg_root(id) && !down && t->dtype == RS_I32;
+        const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg;
         JitSubtree js;
         jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                          s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                          (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                          round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist);
+                         int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg);
         const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
         const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
         hipFunction_t fn = nullptr;
@@ -665,6 +675,7 @@ struct Builder {
             plan.jit.back().stride = js.args_size;
             plan.jit.back().threads = js.threads;
             plan.jit.back().worklist = js.worklist;
+            plan.jit.back().seg = seg;
             plan.jit.back().off_count = uint32_t(js.off_count);
             plan.jit.back().deals_per_trip = uint32_t(js.threads * js.lanes);
         }
@@ -762,7 +773,7 @@ struct Builder {
             put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
             put_u32(js.off_rp, rp);
             put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
-            put_ptr(js.off_attr, sparse ? s->d_attr[nodes[id].round_idx] : nullptr);
+            put_ptr(js.off_attr, (sparse || s->ordered) ? s->d_attr[nodes[id].round_idx] : nullptr);
             if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
             if (use_lds) {
                 const bool resident_off = s->knobs.no_resident != 0;
@@ -827,7 +838,12 @@ struct Builder {
                     util_override[nodes[id].children[0]] =
                         s->d_exchange + (size_t(s->params.shard_rank) * plan.n_boundary + boundary_k[id]) * s->slot_lanes;
 
-        if (s->n_pack_jobs) {   // the batch's per-deal inputs, packed per round (the deals of a trainer change from batch to batch: every sweep)
+        if (s->ordered) {   // the batch sorted by this traverser's last-round cluster, per-deal inputs of all rounds as 32-byte records in that order (every sweep)
+            Launch L;
+            L.kind = L_ORDER;
+            L.bytes = double(s->deals.n_deals) * (4.0 + 29.0 + 32.0);
+            plan.launches.push_back(L);
+        } else if (s->n_pack_jobs) {   // the batch's per-deal inputs, packed per round (the deals of a trainer change from batch to batch: every sweep)
             Launch L;
             L.kind = L_PACK;
             L.bytes = double(s->deals.n_deals) * s->n_pack_jobs * 29.0;
@@ -989,6 +1005,11 @@ struct Builder {
                 cj.list_stride = uint32_t(s->pitch[lane_round[id]]);
                 cj.count_stride = uint32_t(kCountStride);
                 cj.key = n_parts[k] > 1 ? s->deals.d_cluster[nodes[id].round_idx][p] : nullptr;   // the traverser's cluster on this round
+                cj.key_stride = 1;
+                if (cj.key && s->ordered) {   // list entries are ranks: the key sits in the rank's record
+                    cj.key = static_cast<const uint32_t *>(s->d_arec) + 2 * nodes[id].round_idx + p;
+                    cj.key_stride = 8;
+                }
                 plan.count_off[k] = cat;
                 at += size_t(n_parts[k]) * s->pitch[lane_round[id]];
                 cat += n_parts[k];
@@ -1269,6 +1290,13 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
     }
+    if (L.kind == L_ORDER) {
+        prof_begin(t, RS_K_REACH, L.bytes);
+        hipError_t eo = launch_order(s->order_job[&plan == &s->plan[1] ? 1 : 0], t->stream);
+        prof_end(t);
+        RS_HIP(eo, "k_order");
+        return RS_OK;
+    }
     if (L.kind == L_PACK) {
         RS_HIP(launch_pack_attr(s->d_pack_jobs, s->n_pack_jobs, s->deals.n_deals, t->stream), "k_pack_attr");
         return RS_OK;
@@ -1301,6 +1329,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
         blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
         if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
+        if (JL.seg && JL.n_jobs > 1) blocks = std::min<size_t>(blocks, std::max<size_t>(64, size_t(s->n_cus) * 32 / size_t(JL.n_jobs) * 4));   // list walkers: a list holds a share of the batch
         if (s->knobs.max_blocks != kUnset)   // tests: force several trips per workgroup
             blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(std::max(1, s->knobs.max_blocks))));
         const void *d_blob = JL.d_blob;
@@ -1459,9 +1488,14 @@ void rs::solver_release_device(rs_solver *s) {
     if (s->d_shadow) (void)hipFree(s->d_shadow);
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
     for (int r = 0; r < RS_MAX_ROUNDS; ++r) {
-        if (s->d_attr[r]) (void)hipFree(s->d_attr[r]);
+        if (s->d_attr[r] && s->d_attr[r] != s->d_arec) (void)hipFree(s->d_attr[r]);
         s->d_attr[r] = nullptr;
     }
+    if (s->d_arec) (void)hipFree(s->d_arec);
+    if (s->d_order_hist) (void)hipFree(s->d_order_hist);
+    if (s->d_order_tot) (void)hipFree(s->d_order_tot);
+    s->d_arec = nullptr;
+    s->d_order_hist = s->d_order_tot = nullptr;
     if (s->d_pack_jobs) (void)hipFree(s->d_pack_jobs);
     s->d_pack_jobs = nullptr;
     s->n_pack_jobs = 0;
@@ -1632,7 +1666,55 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 one = one && leaf == s->leaves[p][i].d_buf;
             }
         }
-        if (one) {
+        // Ordered sweeps: worth it when a wave of 64 consecutive deals of the sorted batch mostly shares its last-round cluster, i.e. from about 64 deals per cluster
+        // (three streets, 5 000-bucket files, 4 M deals per batch: 838 per cluster) -- small batches against big abstractions keep the unordered forms.
+        if (one && leaf) {
+            const rs_tree_node &fr = tree->nodes[size_t([&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }())];
+            const bool round_mode = fr.kind == RS_NODE_ACTION && fr.n_children > 0 && !s->knobs.no_rounds;
+            s->order_round = s->n_rounds - 1;
+            uint32_t bins[2] = {0, 0};
+            for (size_t i = 0; i < table->nodes.size(); ++i)
+                if (table->nodes[i].round_idx == s->order_round && table->nodes[i].n_actions > 0) bins[table->nodes[i].player] = std::max(bins[table->nodes[i].player], table->nodes[i].n_clusters);
+            const bool fits = bins[0] >= 1 && bins[1] >= 1 && bins[0] <= kOrderMaxBins && bins[1] <= kOrderMaxBins && s->deals.d_cluster[s->order_round][0] &&
+                              s->deals.d_cluster[s->order_round][1] && s->deals.n_deals < (1u << 31) && table->dtype == RS_I32;
+            // Measured (round 3, three streets, 5 000-bucket files, 4 M deals per batch): 10.05 ms per batch ordered against 8.69 ms with the LDS tiles -- the sort and the records
+            // cost 0.3 ms per batch and the segment-summing river kernels are no faster than the tile kernels (NOTES.md): the form is opt-in
+            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
+            if (s->ordered) {
+                const size_t pitch = round_up(s->deals.n_deals, kLanePad);
+                const uint32_t n = s->deals.n_deals;
+                const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus), (size_t(n) + 1023) / 1024));
+                const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, 1024));
+                const uint32_t max_bins = std::max(bins[0], bins[1]);
+                e = hipMalloc(&s->d_arec, pitch * 32);
+                if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_hist, size_t(n_chunks) * max_bins * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(max_bins) * sizeof(uint32_t));
+                if (e != hipSuccess) {
+                    rc = hip_fail(e, "rs_solver_create: ordered deal records");
+                    rs_solver_destroy(s);
+                    return rc;
+                }
+                for (int tp = 0; tp < 2; ++tp) {
+                    OrderJob &oj = s->order_job[tp];
+                    oj = OrderJob{};
+                    oj.key = s->deals.d_cluster[s->order_round][tp];
+                    for (int r = 0; r < s->n_rounds; ++r)
+                        for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = s->deals.d_cluster[r][pl];
+                    oj.leaf = leaf;
+                    oj.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                    oj.hist = s->d_order_hist;
+                    oj.tot = s->d_order_tot;
+                    oj.arec = s->d_arec;
+                    oj.n = n;
+                    oj.n_bins = bins[tp];
+                    oj.n_chunks = n_chunks;
+                    oj.chunk = chunk;
+                }
+                for (int r = 0; r < s->n_rounds; ++r) s->d_attr[r] = s->d_arec;   // what the generated kernels are handed as J.attr on every round
+            }
+        }
+        if (one && !s->ordered) {
             std::vector<PackJob> jobs;
             const size_t pitch = round_up(s->deals.n_deals, kLanePad);
             for (int r = 0; r < s->n_rounds && e == hipSuccess; ++r) {
@@ -1783,6 +1865,10 @@ void rs_solver_destroy(rs_solver *s) {
 }
 
 static int copy_root(rs_solver *s, int traverser, float *d_root_util) {
+    if (d_root_util && s->ordered) {   // the sweep's lanes are ranks of its order: hand the utilities out by deal id
+        RS_HIP(launch_unpermute_f32(s->plan[traverser].root_util, s->d_arec, d_root_util, s->deals.n_deals, s->table->stream), "rs_iterate: root util by deal id");
+        return RS_OK;
+    }
     if (d_root_util)
         RS_HIP(hipMemcpyAsync(d_root_util, s->plan[traverser].root_util, s->plan[traverser].root_lanes * sizeof(float),
                               hipMemcpyDeviceToDevice, s->table->stream),
@@ -1972,6 +2058,19 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                     seen[js.source] = 1;
                     if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
                 }
+                if (opp_mode == RS_OPP_SAMPLE && (f6 == 0 || f6 == 1 || f6 == 2 || f6 == 3) && (mode & RS_UPD_ARITH_MASK) == RS_UPD_CLAMP_I64) {
+                    // ordered sweeps (rs_kernel_forms.deal_order): 32-byte records by rank; the last round's walk sums its deltas by wave segments instead of LDS tiles
+                    int last_round = 0;
+                    for (const rs_tree_node &q : nodes)
+                        if (q.kind == RS_NODE_ACTION) last_round = std::max(last_round, int(q.round_idx));
+                    JitSubtree jo;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, true, true, lds, sparse, down, (mode & RS_UPD_PRUNE) != 0, lanes, &root, jo, knobs,
+                                     0, true, sparse, sparse && lds && !down, true, nodes[i].round_idx == last_round);
+                    if (!(down && jo.boundary_roots.empty()) && !seen.count(jo.source)) {
+                        seen[jo.source] = 1;
+                        if (int rc = jit_compile_only(jo.source, knobs.dump != 0)) return rc;
+                    }
+                }
                 if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
                     JitSubtree jw;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
@@ -1996,6 +2095,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }
+int rs_solver_forms(const rs_solver *s) { return s ? (s->ordered ? 1 : 0) : RS_ERR_INVALID; }
 int rs_solver_n_launches(const rs_solver *s, int traverser) {
     if (!s || traverser < 0 || traverser > 1) return RS_ERR_INVALID;
     return int(s->plan[traverser].launches.size());

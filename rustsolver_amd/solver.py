@@ -574,6 +574,11 @@ class MCCFRTrainer:
     def n_launches(self, player):
         return L.load().rs_solver_n_launches(self._h, player)
 
+    @property
+    def ordered(self):
+        """deal sweeps walk the batch in the order of the traverser's last-round cluster (rs_kernel_forms.deal_order)"""
+        return bool(L.load().rs_solver_forms(self._h) & 1)
+
     def iterate(self, player, want_root_util=False):
         """`self.cfr(0, player, hand, 1f32, ..)` for every lane (cfr.rs:217)"""
         root = self.game_tree.nodes[self.game_tree.nodes[0].children[0]]

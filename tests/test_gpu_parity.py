@@ -1034,3 +1034,33 @@ def test_allreduce_replicated_single_rank_is_identity():
     osol.iterate(0), osol.iterate(1)
     compare_tables(tree, table, otab)
     lib.rs_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("variant", ["river", "river+graph", "river+prune-per-deal", "three-street", "three-street+prune-per-deal", "three-street-wrap"])
+@pytest.mark.parametrize("sizes", ["few-clusters", "many-clusters"])
+def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
+    """rs_kernel_forms.deal_order (forced here through its test override): the sweep of traverser p walks the batch sorted by p's cluster on the last round, the per-deal
+    inputs travel as 32-byte records by rank, the sampler hashes the ORIGINAL deal id, and the last round's subtrees sum their deltas over the wave's runs of equal cluster
+    (seg_add) instead of LDS tiles.  "few-clusters": thousands of deals per cluster, every wave is one run; "many-clusters": a handful per cluster, most waves hold more
+    runs than kSegMax and fall back to per-lane atomics, the rest mix both.  Root utilities come back by deal id.  Same bits as the oracle, which never sorts."""
+    monkeypatch.setenv("RS_JIT_ORDERED", "1")
+    three, prune = variant.startswith("three"), "prune" in variant
+    n_deals = 20011 if three else 30005
+    last = (13, 17) if sizes == "few-clusters" else (3001, 2500)
+    flags = (np.random.Generator(np.random.PCG64(6)).integers(0, 3, n_deals) == 0).astype(np.uint8) if prune else None
+    if three:
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (211, 190), last], n_deals, 41)
+    else:
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [last], n_deals, 42)
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if "wrap" in variant else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=99,
+                         use_graph="graph" in variant, prune_deal=flags)
+    assert tr.ordered
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune, prune_deal=flags, opp_mode=orc.OPP_SAMPLE, base_seed=99)
+    for it in range(3):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
