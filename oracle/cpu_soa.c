@@ -249,3 +249,235 @@ size_t soa_table_bytes(const soa_ctx *c) {
         if (c->tree->nodes[n].kind == ORC_ACTION) cells += (size_t)c->tree->nodes[n].n_children * c->pitch;
     return cells * 8;
 }
+
+/* ====================================================================================================================================
+ * The same for the enumerating cfr() over a MULTI-ROUND tree (BASELINE configs[2]: 706 action nodes, boards 1 / t / r per round, ENUM chance nodes,
+ * src/solver/cfr.rs:502-522): `soae_*`.  The sweep decomposes by cluster -- cfr() enumerates boards, never clusters -- so the unit of work is a block of
+ * SOAE_BL consecutive clusters walked through the WHOLE tree, boards enumerated in deal order at the public chance nodes exactly as orc_traverse does
+ * (reach * (1.0 / len) down, util = util + u up).  Layout: per action node [cluster block][A][boards of the node's round][SOAE_BL] -- everything a unit
+ * touches is contiguous, first-touched by the thread that owns the unit.  Blocks are narrow (one 64-byte vector of f32) so that a 5 000-cluster table
+ * yields 313 units for the host's threads; units are dealt out round-robin and stay with their thread for every iteration.
+ * bench.py asserts identity with the per-lane restatement (orc_traverse, ORC_CHANCE_ENUM) on a small table before timing.
+ * ==================================================================================================================================== */
+#define SOAE_BL 16
+
+typedef struct {
+    const orc_tree *tree;
+    int n_rounds;
+    uint32_t boards[ORC_MAX_ROUNDS];
+    size_t n_clusters, n_blocks;
+    int32_t **reg, **ssm;          /* [action node index] -> [block][A][boards][SOAE_BL] */
+    float *sign[ORC_MAX_ROUNDS];   /* [block][boards][SOAE_BL] */
+    float scale;
+    int mode;
+} soae_ctx;
+
+static void ewalk(const soae_ctx *c, int node, int p, int r, size_t b, size_t blk, const float *restrict reach, float *restrict util) {
+    const orc_node *nd = &c->tree->nodes[node];
+    if (nd->kind == ORC_PRIVATE_CHANCE) {
+        ewalk(c, nd->children[0], p, r, b, blk, reach, util);
+        return;
+    }
+    if (nd->kind == ORC_PUBLIC_CHANCE) {   /* cfr.rs:502-522 */
+        const uint32_t fan = c->boards[r + 1] / c->boards[r];
+        const float inv = 1.0f / (float)fan;
+        float child_reach[SOAE_BL], u[SOAE_BL];
+        for (int i = 0; i < SOAE_BL; i++) child_reach[i] = (reach ? reach[i] : 1.0f) * inv;
+        for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
+        for (uint32_t d = 0; d < fan; d++) {
+            ewalk(c, nd->children[0], p, r + 1, b * fan + d, blk, child_reach, u);
+            for (int i = 0; i < SOAE_BL; i++) util[i] = util[i] + u[i];
+        }
+        return;
+    }
+    if (nd->kind == ORC_TERMINAL) {
+        const float pot = (float)nd->value;
+        if (nd->ttype == ORC_UNCONTESTED) {
+            const float v = (p == nd->last_to_act) ? -1.0f * pot : 1.0f * pot;
+            for (int i = 0; i < SOAE_BL; i++) util[i] = v;
+        } else {
+            const float *s = c->sign[r] + (blk * c->boards[r] + b) * SOAE_BL;
+            const float win0 = (p == 0) ? pot : -pot;
+            for (int i = 0; i < SOAE_BL; i++) util[i] = s[i] == 0.0f ? 0.0f : (s[i] > 0.0f ? win0 : -win0);
+        }
+        return;
+    }
+    const int A = nd->n_children;
+    const size_t B = c->boards[r], P = B * SOAE_BL;   /* P: elements between two actions' rows of this block */
+    float sigma[ORC_MAX_ACTIONS][SOAE_BL], u[ORC_MAX_ACTIONS][SOAE_BL], norm[SOAE_BL];
+    int32_t *restrict R = c->reg[nd->index] + (blk * (size_t)A * B + b) * SOAE_BL, *restrict S = c->ssm[nd->index] + (blk * (size_t)A * B + b) * SOAE_BL;
+    for (int i = 0; i < SOAE_BL; i++) norm[i] = 0.0f;
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < SOAE_BL; i++) {
+            const int32_t x = R[a * P + i];
+            norm[i] += x > 0 ? (float)x : 0.0f;
+        }
+    const float uni = 1.0f / (float)A;
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < SOAE_BL; i++) {
+            const int32_t x = R[a * P + i];
+            sigma[a][i] = norm[i] > 0.0f ? (x > 0 ? (float)x / norm[i] : 0.0f) : uni;
+        }
+    if (nd->player == p) {
+        for (int a = 0; a < A; a++) ewalk(c, nd->children[a], p, r, b, blk, reach, u[a]);
+        for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
+        for (int a = 0; a < A; a++)
+            for (int i = 0; i < SOAE_BL; i++) util[i] += u[a][i] * sigma[a][i];
+        const float scale = c->scale;
+        if (c->mode == ORC_UPD_CLAMP_I64) {
+            for (int a = 0; a < A; a++)
+                for (int i = 0; i < SOAE_BL; i++) {
+                    const float sr = scale * (reach ? reach[i] : 1.0f);
+                    R[a * P + i] = add_clamp(R[a * P + i], sr * (u[a][i] - util[i]));
+                    S[a * P + i] = add_clamp(S[a * P + i], sr * sigma[a][i]);
+                }
+        } else {
+            for (int a = 0; a < A; a++)
+                for (int i = 0; i < SOAE_BL; i++) {
+                    const float sr = scale * (reach ? reach[i] : 1.0f);
+                    R[a * P + i] = add_wrap(R[a * P + i], sr * (u[a][i] - util[i]));
+                    S[a * P + i] = add_wrap(S[a * P + i], sr * sigma[a][i]);
+                }
+        }
+    } else {
+        float child_reach[SOAE_BL];
+        for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
+        for (int a = 0; a < A; a++) {
+            for (int i = 0; i < SOAE_BL; i++) child_reach[i] = sigma[a][i] * (reach ? reach[i] : 1.0f);
+            ewalk(c, nd->children[a], p, r, b, blk, child_reach, u[a]);
+            for (int i = 0; i < SOAE_BL; i++) util[i] += u[a][i] * sigma[a][i];
+        }
+    }
+}
+
+typedef struct {
+    soae_ctx *c;
+    int tid, n_threads;
+    size_t iterations;
+    uint64_t seed;
+    int op;   /* 0 = fill (first touch), 1 = iterate */
+    int64_t rlo, rhi, slo, shi;
+} soae_job;
+
+static void *soae_worker(void *arg) {
+    soae_job *j = (soae_job *)arg;
+    soae_ctx *c = j->c;
+    if (j->op == 0) {
+        const uint64_t rspan = (uint64_t)(j->rhi - j->rlo) + 1, sspan = (uint64_t)(j->shi - j->slo) + 1;
+        for (size_t blk = (size_t)j->tid; blk < c->n_blocks; blk += (size_t)j->n_threads)
+            for (int n = 0; n < c->tree->n_nodes; n++) {
+                const orc_node *nd = &c->tree->nodes[n];
+                if (nd->kind != ORC_ACTION) continue;
+                const size_t B = c->boards[nd->round_idx];
+                for (int a = 0; a < nd->n_children; a++)
+                    for (size_t b = 0; b < B; b++)
+                        for (int i = 0; i < SOAE_BL; i++) {
+                            const size_t cl = blk * SOAE_BL + (size_t)i, lane = b * c->n_clusters + cl;
+                            const uint64_t key = ((uint64_t)nd->index << 40) ^ ((uint64_t)a << 36) ^ (uint64_t)lane;
+                            const int live = cl < c->n_clusters;
+                            const size_t at = ((blk * (size_t)nd->n_children + (size_t)a) * B + b) * SOAE_BL + (size_t)i;
+                            c->reg[nd->index][at] = live ? (int32_t)(j->rlo + (int64_t)(splitmix64(j->seed ^ key * 0x9E3779B97F4A7C15ull) % rspan)) : 0;
+                            c->ssm[nd->index][at] = live ? (int32_t)(j->slo + (int64_t)(splitmix64((j->seed ^ 0x5353554Dull) ^ key * 0x9E3779B97F4A7C15ull) % sspan)) : 0;
+                        }
+            }
+        return NULL;
+    }
+    float util[SOAE_BL];
+    for (size_t it = 0; it < j->iterations; it++)
+        for (int p = 0; p < 2; p++)
+            for (size_t blk = (size_t)j->tid; blk < c->n_blocks; blk += (size_t)j->n_threads) ewalk(c, 0, p, 0, 0, blk, NULL, util);
+    return NULL;
+}
+
+static int soae_run_threads(soae_ctx *c, soae_job proto, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > c->n_blocks) n_threads = (int)c->n_blocks;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    soae_job *jobs = (soae_job *)malloc((size_t)n_threads * sizeof(soae_job));
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i] = proto;
+        jobs[i].c = c;
+        jobs[i].tid = i;
+        jobs[i].n_threads = n_threads;
+        pthread_create(&th[i], NULL, soae_worker, &jobs[i]);
+    }
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    free(jobs);
+    return n_threads;
+}
+
+/* sign[r]: [boards[r]][n_clusters] per round (the per-lane oracle's lane order), may be NULL for a round without showdown terminals */
+soae_ctx *soae_create(const orc_tree *tree, int n_rounds, const uint32_t *boards, size_t n_clusters, const float *const *sign, float scale, int mode) {
+    soae_ctx *c = (soae_ctx *)calloc(1, sizeof(soae_ctx));
+    if (!c || n_rounds < 1 || n_rounds > ORC_MAX_ROUNDS) return NULL;
+    c->tree = tree;
+    c->n_rounds = n_rounds;
+    c->n_clusters = n_clusters;
+    c->n_blocks = (n_clusters + SOAE_BL - 1) / SOAE_BL;
+    c->scale = scale;
+    c->mode = mode;
+    for (int r = 0; r < n_rounds; r++) {
+        c->boards[r] = boards[r];
+        if (r > 0 && (boards[r] % boards[r - 1]) != 0) return NULL;
+        if (posix_memalign((void **)&c->sign[r], 64, c->n_blocks * boards[r] * SOAE_BL * sizeof(float))) return NULL;
+        memset(c->sign[r], 0, c->n_blocks * boards[r] * SOAE_BL * sizeof(float));
+        if (sign && sign[r])
+            for (size_t b = 0; b < boards[r]; b++)
+                for (size_t cl = 0; cl < n_clusters; cl++)
+                    c->sign[r][((cl / SOAE_BL) * boards[r] + b) * SOAE_BL + cl % SOAE_BL] = sign[r][b * n_clusters + cl];
+    }
+    c->reg = (int32_t **)calloc((size_t)tree->n_action_nodes, sizeof(int32_t *));
+    c->ssm = (int32_t **)calloc((size_t)tree->n_action_nodes, sizeof(int32_t *));
+    for (int n = 0; n < tree->n_nodes; n++) {
+        const orc_node *nd = &tree->nodes[n];
+        if (nd->kind != ORC_ACTION) continue;
+        if (nd->round_idx >= n_rounds) return NULL;
+        const size_t bytes = c->n_blocks * (size_t)nd->n_children * boards[nd->round_idx] * SOAE_BL * 4;
+        if (posix_memalign((void **)&c->reg[nd->index], 64, bytes ? bytes : 64) || posix_memalign((void **)&c->ssm[nd->index], 64, bytes ? bytes : 64)) return NULL;
+    }
+    return c;
+}
+void soae_destroy(soae_ctx *c) {
+    if (!c) return;
+    for (int i = 0; i < c->tree->n_action_nodes; i++) {
+        free(c->reg[i]);
+        free(c->ssm[i]);
+    }
+    for (int r = 0; r < c->n_rounds; r++) free(c->sign[r]);
+    free(c->reg);
+    free(c->ssm);
+    free(c);
+}
+int soae_fill(soae_ctx *c, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, int n_threads) {
+    soae_job j;
+    memset(&j, 0, sizeof(j));
+    j.op = 0;
+    j.seed = seed;
+    j.rlo = rlo; j.rhi = rhi; j.slo = slo; j.shi = shi;
+    return soae_run_threads(c, j, n_threads);
+}
+/* [A][boards * n_clusters] in the per-lane oracle's lane order (lane = board * n_clusters + cluster) */
+void soae_get_node(const soae_ctx *c, int index, int n_actions, int round, int32_t *regrets, int32_t *ssum) {
+    const size_t B = c->boards[round], L = B * c->n_clusters;
+    for (int a = 0; a < n_actions; a++)
+        for (size_t b = 0; b < B; b++)
+            for (size_t cl = 0; cl < c->n_clusters; cl++) {
+                const size_t at = (((cl / SOAE_BL) * (size_t)n_actions + (size_t)a) * B + b) * SOAE_BL + cl % SOAE_BL;
+                regrets[(size_t)a * L + b * c->n_clusters + cl] = c->reg[index][at];
+                ssum[(size_t)a * L + b * c->n_clusters + cl] = c->ssm[index][at];
+            }
+}
+int soae_run(soae_ctx *c, size_t iterations, int n_threads) {   /* returns the threads actually used (at most one per cluster block) */
+    soae_job j;
+    memset(&j, 0, sizeof(j));
+    j.op = 1;
+    j.iterations = iterations;
+    return soae_run_threads(c, j, n_threads);
+}
+size_t soae_table_bytes(const soae_ctx *c) {
+    size_t cells = 0;
+    for (int n = 0; n < c->tree->n_nodes; n++)
+        if (c->tree->nodes[n].kind == ORC_ACTION) cells += (size_t)c->tree->nodes[n].n_children * c->boards[c->tree->nodes[n].round_idx] * c->n_blocks * SOAE_BL;
+    return cells * 8;
+}

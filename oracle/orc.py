@@ -836,6 +836,15 @@ def soa_lib():
     L.soa_run.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.soa_table_bytes.argtypes = [C.c_void_p]
     L.soa_table_bytes.restype = C.c_size_t
+    L.soae_create.argtypes = [C.POINTER(Tree), C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.POINTER(C.c_float)), C.c_float, C.c_int]
+    L.soae_create.restype = C.c_void_p
+    L.soae_destroy.argtypes = [C.c_void_p]
+    L.soae_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]
+    L.soae_get_node.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.soae_run.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.soae_run.restype = C.c_int
+    L.soae_table_bytes.argtypes = [C.c_void_p]
+    L.soae_table_bytes.restype = C.c_size_t
     _soa_lib = L
     return L
 
@@ -871,6 +880,49 @@ class SoaSolver:
     def destroy(self):
         if self._h:
             soa_lib().soa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class SoaEnumSolver:
+    """The enumerating cfr() sweep over a multi-round tree (ENUM chance nodes, cfr.rs:502-522) on a block-major SoA layout: units of 16 clusters walked
+    through the whole tree, boards enumerated in deal order (oracle/cpu_soa.c soae_*).  Bench baseline only (config 3's CPU denominator)."""
+
+    def __init__(self, tree, boards, n_clusters, signs, scale=10000.0, mode=UPD_WRAP_I32):
+        self.tree, self.boards, self.n_clusters = tree, [int(b) for b in boards], int(n_clusters)
+        self._signs = [np.ascontiguousarray(x, dtype=np.float32) if x is not None else None for x in signs]
+        for r, x in enumerate(self._signs):
+            assert x is None or x.size == self.boards[r] * self.n_clusters
+        arr = (C.POINTER(C.c_float) * len(self.boards))(*[_f32(x) if x is not None else C.POINTER(C.c_float)() for x in self._signs])
+        self._h = soa_lib().soae_create(C.byref(tree.t), len(self.boards), (C.c_uint32 * len(self.boards))(*self.boards), self.n_clusters, arr, scale, mode)
+        if not self._h:
+            raise MemoryError("soae_create")
+
+    def fill(self, seed, regret_range=(-10**6, 10**6), ssum_range=(0, 10**6), threads=1):
+        return soa_lib().soae_fill(self._h, seed, regret_range[0], regret_range[1], ssum_range[0], ssum_range[1], threads)
+
+    def get_node(self, index, n_actions, round_idx):
+        n = self.boards[round_idx] * self.n_clusters
+        r = np.zeros((n_actions, n), dtype=np.int32)
+        s = np.zeros((n_actions, n), dtype=np.int32)
+        soa_lib().soae_get_node(self._h, index, n_actions, round_idx, _i32(r), _i32(s))
+        return r, s
+
+    def run(self, iterations, threads):
+        return soa_lib().soae_run(self._h, iterations, threads)
+
+    @property
+    def table_bytes(self):
+        return int(soa_lib().soae_table_bytes(self._h))
+
+    def destroy(self):
+        if self._h:
+            soa_lib().soae_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -560,20 +560,26 @@ __device__ __forceinline__ int wave_sum_i32(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-// In an ordered sweep the deals a wave walks in the last round come in runs of equal traverser cluster: all of them add into the SAME table cells.  Instead of
-// an LDS tile per traverser node (160 KB per workgroup, one workgroup per CU, zeroed and flushed around every 1 024 deals) the wave sums every delta over each
-// run of equal keys (wave_sum_i32) and issues ONE global atomic per run, node, action and array -- 2A lanes of one instruction.  bmask bit i = lane i starts a
-// new run (never lane 0).  Integer adds commute, so the result equals the tile form's, and the oracle's, bit for bit.
-constexpr int kSegMax = 6;   // more runs than this in one wave (small batches, list tails): every lane adds for itself
+// In an ordered sweep the deals a wave walks in the last round share a handful of traverser clusters (mostly one): all of them add into the SAME table cells.
+// Instead of an LDS tile per traverser node (160 KB per workgroup, one workgroup per CU, zeroed and flushed around every 1 024 deals) the wave sums every delta
+// over the lanes of each DISTINCT cluster (wave_sum_i32) and issues ONE global atomic per cluster, node, action and array -- 2A lanes of one instruction.  The
+// lanes of a cluster need not be neighbours (the compaction interleaves 64-entry granules).  Integer adds commute, so the result equals the tile form's, and the
+// oracle's, bit for bit.
+constexpr int kSegMax = 6;   // more distinct clusters than this in one wave (small batches, list tails): every lane adds for itself
 struct Seg {
-    unsigned long long bmask;
+    unsigned n_keys;   // distinct clusters among the wave's lanes, counted up to kSegMax + 1
     unsigned lane;
 };
 __device__ __forceinline__ Seg seg_make(unsigned key) {
     Seg sg;
     sg.lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const unsigned prev = (unsigned)__builtin_amdgcn_ds_bpermute((int)((sg.lane - 1u) << 2), (int)key);   // lane 0 reads lane 63: masked below
-    sg.bmask = __builtin_amdgcn_ballot_w64(prev != key && sg.lane != 0u);
+    sg.n_keys = 0;
+    unsigned long long todo = ~0ull;
+    while (todo && sg.n_keys <= (unsigned)kSegMax) {
+        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
+        todo &= ~__builtin_amdgcn_ballot_w64(key == ckey);
+        ++sg.n_keys;
+    }
     return sg;
 }
 template <int A>
@@ -588,9 +594,10 @@ __device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch,
         d[A + a] = (int)((unsigned)s[a][0] - (unsigned)t[a][0]);
         any = any || d[a] != 0 || d[A + a] != 0;
     }
-    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;   // nobody in this wave visited the node
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(any);   // lanes whose deal visited the node
+    if (todo == 0ull) return;
     RS_GLOBAL int *pr = as_global<int>(dreg), *ps = as_global<int>(dssm);
-    if (__builtin_popcountll(sg.bmask) >= kSegMax) {
+    if (sg.n_keys > (unsigned)kSegMax) {
 #pragma unroll
         for (int a = 0; a < A; a++) {
             if (d[a] != 0) __hip_atomic_fetch_add(pr + (size_t)a * tpitch + key, d[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -598,13 +605,11 @@ __device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch,
         }
         return;
     }
-    RS_GLOBAL int *mine_p = sg.lane < (unsigned)A ? pr + (size_t)sg.lane * tpitch : ps + (size_t)(sg.lane - (unsigned)A) * tpitch;   // lane i < 2A carries value i of a run
-    unsigned long long rest = sg.bmask;
-    unsigned lo = 0;
-    for (;;) {   // one trip per run: wave-uniform
-        const unsigned hi = rest ? (unsigned)__builtin_ctzll(rest) : 64u;
-        const bool in = sg.lane >= lo && sg.lane < hi;
-        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)lo);
+    RS_GLOBAL int *mine_p = sg.lane < (unsigned)A ? pr + (size_t)sg.lane * tpitch : ps + (size_t)(sg.lane - (unsigned)A) * tpitch;   // lane i < 2A carries value i of a cluster
+    while (todo) {   // one trip per distinct cluster that somebody visited the node with: wave-uniform
+        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
+        const bool in = key == ckey;
+        todo &= ~__builtin_amdgcn_ballot_w64(in);
         int mine = 0;
 #pragma unroll
         for (int i = 0; i < 2 * A; i++) {
@@ -612,9 +617,6 @@ __device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch,
             mine = sg.lane == (unsigned)i ? tot : mine;
         }
         if (sg.lane < 2u * (unsigned)A && mine != 0) __hip_atomic_fetch_add(mine_p + ckey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!rest) break;
-        rest &= rest - 1ull;
-        lo = hi;
     }
 }
 

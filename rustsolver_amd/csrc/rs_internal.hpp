@@ -131,14 +131,15 @@ struct PackJob {
 };
 hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream);
 // ordered deal sweeps (rs_kernels.hip k_order_*): counting sort of the batch by `key` and the 32-byte per-deal records in that order
-constexpr uint32_t kOrderMaxBins = 16384;   // LDS counters of one workgroup
+constexpr uint32_t kOrderMaxBins = 16384;   // LDS counters of one workgroup (twice: starts and counts)
+constexpr int kOrderThreads = 512;
 struct OrderJob {
     const uint32_t *key;       // [n] the traverser's cluster id on the last round
     const uint32_t *cid[6];    // [n] cluster ids [2 * round + player], null = a player without nodes there
     const float *leaf;         // [n]
     const uint8_t *prune;      // [n] or null
-    uint32_t *hist;            // [n_chunks][n_bins] scratch
-    uint32_t *tot;             // [n_bins] scratch
+    uint32_t *tot;             // [n_bins] scratch: deals per bin ...
+    uint32_t *cursor;          // [n_bins] ... and how many of them the workgroups have reserved so far (tot + n_bins: one memset clears both)
     void *arec;                // [pitch] x 32 bytes, out
     uint32_t n, n_bins, n_chunks, chunk;
 };

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
 constexpr uint32_t kMaxParts = 64;
 constexpr uint32_t kCompactPerThread = 4;   // lanes per thread and iteration: one slot reservation per workgroup covers 1 024 lanes
 __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__restrict__ jobs) {
-    __shared__ uint32_t wave_count[kBlock / 64][kMaxParts];   // live lanes of every wave, per cluster range
+    __shared__ uint32_t wave_count[kCompactPerThread][kBlock / 64][kMaxParts];   // live lanes of every (sub-round, wave) = 64 consecutive source entries, per cluster range
     __shared__ uint32_t part_base[kMaxParts];                 // list slot reserved for this workgroup, per cluster range
     const CompactJob *job = jobs + blockIdx.y;
     const uint32_t n_parts = job->n_parts, part_size = job->part_size;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
     for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {   // whole workgroups iterate together
         bool live[kCompactPerThread];
         float rv[kCompactPerThread];
-        uint32_t deal[kCompactPerThread], part[kCompactPerThread], rank[kCompactPerThread];   // rank: among this wave's live lanes of the same part, over all sub-rounds
+        uint32_t deal[kCompactPerThread], part[kCompactPerThread], rank[kCompactPerThread];   // rank: among the live lanes of the same part in this wave and sub-round
 #pragma unroll
         for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers entries base + i*256 .. +255: coalesced reads
             const uint32_t e = base + i * kBlock + threadIdx.x;
@@ -427,28 +427,28 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
             rank[i] = 0;
         }
         for (uint32_t q = 0; q < n_parts; ++q) {   // ballots only: no barrier inside
-            uint32_t seen = 0;
 #pragma unroll
             for (uint32_t i = 0; i < kCompactPerThread; ++i) {
                 const bool mine = live[i] && part[i] == q;
                 const unsigned long long ballot = __ballot(mine);
-                if (mine) rank[i] = seen + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
-                seen += (uint32_t)__popcll(ballot);
+                if (mine) rank[i] = (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
+                if (lane_in_wave == 0) wave_count[i][wave][q] = (uint32_t)__popcll(ballot);
             }
-            if (lane_in_wave == 0) wave_count[wave][q] = seen;
         }
         __syncthreads();
         if (threadIdx.x < n_parts) {   // ONE reservation per workgroup and part, issued by different threads
             uint32_t total = 0;
-            for (int w = 0; w < kBlock / 64; ++w) total += wave_count[w][threadIdx.x];
+            for (uint32_t i = 0; i < kCompactPerThread; ++i)
+                for (int w = 0; w < kBlock / 64; ++w) total += wave_count[i][w][threadIdx.x];
             part_base[threadIdx.x] = total ? atomicAdd(job->count + (size_t)threadIdx.x * job->count_stride, total) : 0u;
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t i = 0; i < kCompactPerThread; ++i)
-            if (live[i]) {
+            if (live[i]) {   // slots follow the SOURCE order inside the tile (sub-round, wave, lane): an ordered sweep's lists stay in runs of equal last-round cluster
                 uint32_t slot = part_base[part[i]] + rank[i];
-                for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w][part[i]];
+                for (uint32_t i2 = 0; i2 <= i; ++i2)
+                    for (uint32_t w = 0; w < (i2 < i ? (uint32_t)(kBlock / 64) : wave); ++w) slot += wave_count[i2][w][part[i]];
                 job->list[(size_t)part[i] * job->list_stride + slot] = deal[i];
                 if (job->rlist) job->rlist[(size_t)part[i] * job->list_stride + slot] = rv[i];
                 if (job->plist) job->plist[(size_t)part[i] * job->list_stride + slot] = (src && job->pos_rows) ? sq * job->src_list_stride + (base + i * kBlock + threadIdx.x) : deal[i];
@@ -508,39 +508,31 @@ __global__ __launch_bounds__(kBlock) void k_pack_attr(const PackJob *__restrict_
 
 static inline uint32_t grid_for(size_t n_threads_needed);
 // ---- ordered deal sweeps: the batch in the order of the traverser's last-round cluster (rs_device.hpp load_arec, seg_add) ----------------------------------------
-// A counting sort over the cluster id (at most kOrderMaxBins bins) in three launches: every workgroup counts the keys of its chunk of the batch in LDS (k_order_hist), the
-// counts are turned into per-(chunk, bin) starts (k_order_colscan: one thread per bin walks the chunks), and every workgroup deals its chunk's records out to their
-// slots (k_order_scatter: LDS cursors, ds_add_rtn), writing the 32-byte record of each deal as it goes -- the per-deal input arrays are read coalesced, once.  The
-// order inside a bin is whatever the LDS atomics make it: every consumer commutes (i32 deltas), and nothing the oracle sees depends on it.
-__global__ __launch_bounds__(1024) void k_order_hist(const OrderJob job) {
+// A counting sort over the cluster id (at most kOrderMaxBins bins) in two launches.  k_order_hist: every workgroup counts the keys of its chunk of the batch in LDS and
+// adds its counts to the global totals (coalesced atomics).  k_order_scatter: every workgroup scans the totals into bin starts (LDS), counts its chunk again, reserves its
+// share of every bin it holds with one returning atomic on that bin's cursor, and deals its chunk's records out to their slots (LDS cursors), writing the 32-byte record
+// of each deal as it goes -- the per-deal input arrays are read coalesced, once.  The order inside a bin is whatever the atomics make it: every consumer commutes
+// (i32 deltas), and nothing the oracle sees depends on it.  tot[] and cursor[] (2 x n_bins words, contiguous) are zeroed by a memset in front of the pair.
+__global__ __launch_bounds__(kOrderThreads) void k_order_hist(const OrderJob job) {
     extern __shared__ uint32_t lds_bins[];
     for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) lds_bins[b] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * job.chunk, hi = min(job.n, lo + job.chunk);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lds_bins[min(job.key[i], job.n_bins - 1u)], 1u);
     __syncthreads();
-    uint32_t *__restrict__ out = job.hist + (size_t)blockIdx.x * job.n_bins;
-    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) out[b] = lds_bins[b];
-}
-__global__ __launch_bounds__(kBlock) void k_order_colscan(const OrderJob job) {   // hist[g][b] -> entries of bin b in chunks before g; tot[b]
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= job.n_bins) return;
-    uint32_t run = 0;
-    uint32_t *__restrict__ h = job.hist + b;
-#pragma unroll 8
-    for (uint32_t g = 0; g < job.n_chunks; ++g) {
-        const uint32_t x = h[(size_t)g * job.n_bins];
-        h[(size_t)g * job.n_bins] = run;
-        run += x;
+    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) {
+        const uint32_t c = lds_bins[b];
+        if (c) atomicAdd(job.tot + b, c);
     }
-    job.tot[b] = run;
 }
-__global__ __launch_bounds__(1024) void k_order_scatter(const OrderJob job) {
-    extern __shared__ uint32_t lds_bins[];   // [n_bins] start of every bin for THIS chunk, then cursors
-    __shared__ uint32_t part[1024];
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(const OrderJob job) {
+    extern __shared__ uint32_t lds_bins[];   // [n_bins] start of every bin, then this workgroup's cursors; [n_bins] its counts
+    __shared__ uint32_t part[kOrderThreads];
+    uint32_t *cnt = lds_bins + job.n_bins;
+    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) cnt[b] = 0;
     // exclusive scan of tot[] over the bins: thread t owns bins [t * per, (t + 1) * per)
     const uint32_t per = (job.n_bins + blockDim.x - 1) / blockDim.x;
-    const uint32_t b0 = threadIdx.x * per, b1 = min(job.n_bins, b0 + per);
+    const uint32_t b0 = min(job.n_bins, threadIdx.x * per), b1 = min(job.n_bins, b0 + per);
     uint32_t sum = 0;
     for (uint32_t b = b0; b < b1; ++b) sum += job.tot[b];
     part[threadIdx.x] = sum;
@@ -552,13 +544,18 @@ __global__ __launch_bounds__(1024) void k_order_scatter(const OrderJob job) {
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    const uint32_t *__restrict__ mine = job.hist + (size_t)blockIdx.x * job.n_bins;
     for (uint32_t b = b0; b < b1; ++b) {
-        lds_bins[b] = run + mine[b];
+        lds_bins[b] = run;
         run += job.tot[b];
     }
-    __syncthreads();
     const uint32_t lo = blockIdx.x * job.chunk, hi = min(job.n, lo + job.chunk);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&cnt[min(job.key[i], job.n_bins - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < job.n_bins; b += blockDim.x) {   // this workgroup's share of every bin it holds: consecutive threads, consecutive cursors
+        const uint32_t c = cnt[b];
+        if (c) lds_bins[b] += atomicAdd(job.cursor + b, c);
+    }
+    __syncthreads();
     u32x4 *__restrict__ out = (u32x4 *)job.arec;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t slot = atomicAdd(&lds_bins[min(job.key[i], job.n_bins - 1u)], 1u);
@@ -577,10 +574,10 @@ __global__ __launch_bounds__(1024) void k_order_scatter(const OrderJob job) {
 }
 hipError_t launch_order(const OrderJob &job, hipStream_t stream) {
     if (job.n == 0) return hipSuccess;
-    const size_t lds = size_t(job.n_bins) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_order_hist, dim3(job.n_chunks), dim3(1024), lds, stream, job);
-    hipLaunchKernelGGL(k_order_colscan, dim3((job.n_bins + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, job);
-    hipLaunchKernelGGL(k_order_scatter, dim3(job.n_chunks), dim3(1024), lds, stream, job);
+    hipError_t e = hipMemsetAsync(job.tot, 0, size_t(2) * job.n_bins * sizeof(uint32_t), stream);   // tot[] and cursor[]
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_order_hist, dim3(job.n_chunks), dim3(kOrderThreads), size_t(job.n_bins) * sizeof(uint32_t), stream, job);
+    hipLaunchKernelGGL(k_order_scatter, dim3(job.n_chunks), dim3(kOrderThreads), size_t(2) * job.n_bins * sizeof(uint32_t), stream, job);
     return hipGetLastError();
 }
 // the root utilities of an ordered sweep are by rank: hand them out by deal id

@@ -137,7 +137,7 @@ struct rs_solver {
     bool ordered = false;
     int order_round = 0;                // the last betting round of the tree
     void *d_arec = nullptr;
-    uint32_t *d_order_hist = nullptr, *d_order_tot = nullptr;
+    uint32_t *d_order_tot = nullptr;    // [2][n_bins]: counts and cursors of the counting sort
     OrderJob order_job[2];              // per traverser
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
@@ -1492,10 +1492,9 @@ void rs::solver_release_device(rs_solver *s) {
         s->d_attr[r] = nullptr;
     }
     if (s->d_arec) (void)hipFree(s->d_arec);
-    if (s->d_order_hist) (void)hipFree(s->d_order_hist);
     if (s->d_order_tot) (void)hipFree(s->d_order_tot);
     s->d_arec = nullptr;
-    s->d_order_hist = s->d_order_tot = nullptr;
+    s->d_order_tot = nullptr;
     if (s->d_pack_jobs) (void)hipFree(s->d_pack_jobs);
     s->d_pack_jobs = nullptr;
     s->n_pack_jobs = 0;
@@ -1677,19 +1676,19 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 if (table->nodes[i].round_idx == s->order_round && table->nodes[i].n_actions > 0) bins[table->nodes[i].player] = std::max(bins[table->nodes[i].player], table->nodes[i].n_clusters);
             const bool fits = bins[0] >= 1 && bins[1] >= 1 && bins[0] <= kOrderMaxBins && bins[1] <= kOrderMaxBins && s->deals.d_cluster[s->order_round][0] &&
                               s->deals.d_cluster[s->order_round][1] && s->deals.n_deals < (1u << 31) && table->dtype == RS_I32;
-            // Measured (round 3, three streets, 5 000-bucket files, 4 M deals per batch): 10.05 ms per batch ordered against 8.69 ms with the LDS tiles -- the sort and the records
-            // cost 0.3 ms per batch and the segment-summing river kernels are no faster than the tile kernels (NOTES.md): the form is opt-in
+            // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
+            // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
+            // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
             s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
             if (s->ordered) {
                 const size_t pitch = round_up(s->deals.n_deals, kLanePad);
                 const uint32_t n = s->deals.n_deals;
-                const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus), (size_t(n) + 1023) / 1024));
-                const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, 1024));
+                const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus) * 2, (size_t(n) + kOrderThreads - 1) / kOrderThreads));
+                const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, kOrderThreads));
                 const uint32_t max_bins = std::max(bins[0], bins[1]);
                 e = hipMalloc(&s->d_arec, pitch * 32);
                 if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
-                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_hist, size_t(n_chunks) * max_bins * sizeof(uint32_t));
-                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(max_bins) * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(2) * max_bins * sizeof(uint32_t));
                 if (e != hipSuccess) {
                     rc = hip_fail(e, "rs_solver_create: ordered deal records");
                     rs_solver_destroy(s);
@@ -1703,8 +1702,8 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                         for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = s->deals.d_cluster[r][pl];
                     oj.leaf = leaf;
                     oj.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
-                    oj.hist = s->d_order_hist;
                     oj.tot = s->d_order_tot;
+                    oj.cursor = s->d_order_tot + bins[tp];
                     oj.arec = s->d_arec;
                     oj.n = n;
                     oj.n_bins = bins[tp];
