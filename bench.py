@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--skip", default="", help="comma-separated auxiliary legs to leave out (e.g. solve_three_street under rocprofv3, whose 10^5 small dispatches the tracer does not survive)")
     ap.add_argument("--config3-steps", type=int, default=5, help="timed iterations of the config 3 / config 4 leg (0 = skip the leg)")
+    ap.add_argument("--saturating", type=int, default=100, help="i32 tables: one regret cell in N gets |regret| > 2.1e9 (SURVEY.md 8(d): at least 1 %% of the lanes exercise the "
+                    "saturating adds); 0 = the plain +-10^6 fill of rounds 1 and 2")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full result (every leg, every per-kernel table, the descriptive strings) is "
+                    "written; stdout carries the compact line")
     return ap.parse_args()
 
 
@@ -134,8 +138,10 @@ def probe_main(kind):
     dist.destroy_process_group()
 
 
-def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full", shard=None):
-    """n_boards: int (river tree) or [flop, turn, river] (three-street tree)"""
+def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tree_kind="river", dtype="i32", opp="full", shard=None, saturating=0, outlier_leaves=0):
+    """n_boards: int (river tree) or [flop, turn, river] (three-street tree).  saturating: one regret cell in N beyond +-2.1e9 (i32 tables).  outlier_leaves: the
+    showdown leaves become RS_LEAF_UTIL rows ~ U(-pot, pot) in which one lane in N holds +-1e9, so that (scale * reach) * (u - util) passes 2^31 there and the wave takes
+    the exact i64 branch of the clamp update"""
     from rustsolver_amd import _lib as L
     three = tree_kind == "three-street"
     options = rs.three_street_options() if three else rs.default_flop()
@@ -148,6 +154,8 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
         table.fill_random(seed, (-2000, 2000), (0, 2000))       # binary16 holds integers exactly up to 2048
     else:
         table.fill_random(seed, (-10**6, 10**6), (0, 10**6))
+        if saturating and dtype == "i32":
+            L.check(L.load().rs_table_plant_saturating(table._h, seed, saturating))
     signs, leaves = {}, {}
     for i, nd in enumerate(tree.nodes):
         if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
@@ -155,8 +163,12 @@ def make_trainer(rs, n_boards, n_clusters, mode, graph, device, seed, fuse=1, tr
             r = parent.round_idx
             if r not in signs:
                 signs[r] = table.lane_buffer(parent.index, 1)
-                L.check(L.load().rs_fill_uniform_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 17 + r, -1.0, 1.0))
-            leaves[i] = (rs.LEAF_SIGN, signs[r])
+                if outlier_leaves:
+                    L.check(L.load().rs_fill_uniform_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 17 + r, -1035.0, 1035.0))
+                    L.check(L.load().rs_plant_outliers_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 29 + r, outlier_leaves, 1.0e9))
+                else:
+                    L.check(L.load().rs_fill_uniform_f32(table._h, signs[r].ptr, table.pitch(parent.index), seed + 17 + r, -1.0, 1.0))
+            leaves[i] = (rs.LEAF_UTIL if outlier_leaves else rs.LEAF_SIGN, signs[r])
     if dtype == "i32":
         scale, m = (100.0, rs.UPD_CLAMP_I64) if mode.startswith("clamp") else (10000.0, rs.UPD_WRAP_I32)
         if mode.endswith("+prune"):   # cfr() with prune = true (cfr.rs:379-386); the synthetic regrets stay above the threshold, so this prices the pruned kernels, not skipped work
@@ -182,14 +194,25 @@ def run_steps(trainer, k):
         L.check(lib.rs_iterate(h, 1, None))
 
 
+def _timed_iterations(run, seconds):
+    """run(iterations) -> None; one probing iteration, then as many as fit `seconds`; returns (iterations, seconds taken)"""
+    t0 = time.perf_counter()
+    run(1)
+    t1 = time.perf_counter() - t0
+    iters = max(1, int(seconds / max(t1, 1e-6)))
+    t0 = time.perf_counter()
+    run(iters)
+    return iters, time.perf_counter() - t0
+
+
 def cpu_baseline(n_clusters, mode, seconds):
     """The C restatement in REFERENCE LAYOUT (boxed AoS, scalar recursion per lane, per-visit allocations,
-    infoset.rs:85 / cfr.rs:372-373), 8 threads like the reference's N_THREADS (cfr.rs:195) or all cores
-    if fewer, on a bounded sample of the same workload."""
+    infoset.rs:85 / cfr.rs:372-373) on a bounded sample of the same workload: with 8 threads like the reference's
+    N_THREADS (cfr.rs:195) -- `value` -- and with every host core -- `all_cores` (BASELINE.md section 2 asks for both)."""
     import numpy as np
     from oracle import orc
     threads = min(8, os.cpu_count() or 1)
-    boards = 64
+    boards = max(64, 2 * (os.cpu_count() or 1))
     rng = np.random.Generator(np.random.PCG64(1235))
     tree = orc.OracleTree(orc.options_default_river())
     tb = orc.OracleTable(tree, [boards], n_clusters)
@@ -203,19 +226,97 @@ def cpu_baseline(n_clusters, mode, seconds):
               if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
     scale, m = (100.0, orc.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, orc.UPD_WRAP_I32)
     sol = orc.OracleSolver(tree, tb, leaves, scale=scale, mode=m, chance_mode=orc.CHANCE_PASS, ref_alloc=True)
-    t0 = time.perf_counter()
-    sol.run_iterations(1, threads)
-    t1 = time.perf_counter() - t0
-    iters = max(1, int(seconds / max(t1, 1e-6)))
-    t0 = time.perf_counter()
-    sol.run_iterations(iters, threads)
-    dt = time.perf_counter() - t0
-    return {
+    iters, dt = _timed_iterations(lambda k: sol.run_iterations(k, threads), seconds * 0.5)
+    out = {
         "value": boards * iters / dt, "unit": "board-iterations/s", "cores": threads, "kind": "port",
         "host_cores": os.cpu_count(),
         "sample": "%d iterations x %d boards x %d clusters of the same river tree, reference layout "
                   "(boxed AoS, per-visit allocs), %d threads, %.1f s" % (iters, boards, n_clusters, threads, dt),
     }
+    allc = os.cpu_count() or 1
+    if allc > threads:
+        iters2, dt2 = _timed_iterations(lambda k: sol.run_iterations(k, allc), seconds * 0.5)
+        out["all_cores"] = {"value": boards * iters2 / dt2, "unit": "board-iterations/s", "cores": allc,
+                            "sample": "%d iterations of the same sample on %d threads, %.1f s" % (iters2, allc, dt2)}
+    return out
+
+
+def cpu_config3(mode, seconds):
+    """The CPU side of config 3 (>= 6x node-vs-host on the 706-node, 5 000-bucket tree): the enumerating cfr() (cfr.rs:481-627, boards
+    enumerated at the public chance nodes, :502-522) on the three-street tree with 5 000 clusters per round and a board SUBSET that still leaves the caches,
+    (a) the literal per-lane restatement in reference layout with 8 threads (cfr.rs:195) and with every core, (b) `cpu_soa`: block-major SoA, 16 clusters per
+    unit, vectorised (oracle/cpu_soa.c soae_*), compared bit for bit with (a)'s code on a small table before it is timed.  Rates are river-board-iterations/s:
+    the unit the GPU leg reports, and per river board the work is the same whatever the fan."""
+    import numpy as np
+    from oracle import orc
+    C_ = 5000
+    scale, m = (100.0, orc.UPD_CLAMP_I64) if mode == "clamp" else (10000.0, orc.UPD_WRAP_I32)
+    tree = orc.OracleTree(orc.options_three_street())
+    dd = tree.as_dicts()
+    acts = [(d["index"], len(d["children"]), d["round_idx"]) for d in dd if d["kind"] == orc.ACTION]
+    showdowns = [(d["id"], dd[d["parent"]]["round_idx"]) for d in dd if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED]
+    rng = np.random.Generator(np.random.PCG64(1237))
+    allc = os.cpu_count() or 1
+    out = {}
+    # ---- identical outputs first: soae against the per-lane oracle, boards 1 / 2 / 6, 37 clusters, saturating ranges, 2 iterations ----------------------
+    vb, vc = [1, 2, 6], 37
+    vs = [np.sign(rng.uniform(-1, 1, size=b * vc)).astype(np.float32) for b in vb]
+    for x in vs:
+        x[::7] = 0.0
+    chk = orc.SoaEnumSolver(tree, vb, vc, vs, scale, m)
+    chk.fill(11, (-2**31, 2**31 - 1), (0, 2**31 - 1), threads=3)
+    tb = orc.OracleTable(tree, vb, vc)
+    for idx, na, r in acts:
+        r_, s_ = chk.get_node(idx, na, r)
+        tb.set_node(idx, r_, s_)
+    osol = orc.OracleSolver(tree, tb, {i: (orc.LEAF_SIGN, vs[r]) for i, r in showdowns}, scale=scale, mode=m, chance_mode=orc.CHANCE_ENUM)
+    osol.run_iterations(2, min(allc, 4))
+    chk.run(2, 3)
+    same = True
+    for idx, na, r in acts:
+        r_, s_ = chk.get_node(idx, na, r)
+        ro, so = tb.get_node(idx)
+        same = same and bool((r_ == ro).all() and (s_ == so).all())
+    chk.destroy()
+    del tb, osol
+    if not same:
+        raise RuntimeError("cpu_soa (enumerating) and the per-lane oracle disagree: refusing to time it")
+    # ---- (a) reference layout: boards 1 / 2 / 8 = 23 M boxed info sets, about 2 GB of heap ---------------------------------------------------------------
+    rb = [1, 2, 8]
+    t0 = time.perf_counter()
+    tb = orc.OracleTable(tree, rb, C_)
+    for idx, na, r in acts:
+        a_, n_ = tb.node_shape(idx)
+        tb.set_node(idx, rng.integers(-10**6, 10**6, size=(a_, n_)).astype(np.int32), rng.integers(0, 10**6, size=(a_, n_)).astype(np.int32))
+    rs_ = [np.sign(rng.uniform(-1, 1, size=b * C_)).astype(np.float32) for b in rb]
+    sol = orc.OracleSolver(tree, tb, {i: (orc.LEAF_SIGN, rs_[r]) for i, r in showdowns}, scale=scale, mode=m, chance_mode=orc.CHANCE_ENUM, ref_alloc=True)
+    build_s = time.perf_counter() - t0
+    t8 = min(8, allc)
+    iters, dt = _timed_iterations(lambda k: sol.run_iterations(k, t8), seconds * 0.3)
+    out["cpu_baseline"] = {"value": rb[2] * iters / dt, "unit": "river-board-iterations/s", "cores": t8, "host_cores": allc, "kind": "port",
+                           "sample": "%d iterations of the 706-node tree, %d clusters per round, boards %s, ENUM chance, reference layout (boxed AoS, per-visit allocs), "
+                                     "%d threads, %.1f s (+ %.1f s building the boxed table)" % (iters, C_, "/".join(map(str, rb)), t8, dt, build_s)}
+    if allc > t8:
+        iters2, dt2 = _timed_iterations(lambda k: sol.run_iterations(k, allc), seconds * 0.3)
+        out["cpu_baseline"]["all_cores"] = {"value": rb[2] * iters2 / dt2, "unit": "river-board-iterations/s", "cores": allc,
+                                            "sample": "%d iterations of the same sample on %d threads, %.1f s" % (iters2, allc, dt2)}
+    del sol, tb
+    # ---- (b) cpu_soa: boards 1 / 7 / 336 (19 GB) where the host has the memory and the threads to fill it, else 1 / 4 / 48 (2.8 GB) -------------------------
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    sb = [1, 7, 336] if (allc >= 64 and avail > 48 * 2**30) else [1, 4, 48]
+    ss = [np.sign(rng.uniform(-1, 1, size=b * C_)).astype(np.float32) for b in sb]
+    soa = orc.SoaEnumSolver(tree, sb, C_, ss, scale, m)
+    used = soa.fill(7, (-10**6, 10**6), (0, 10**6), threads=allc)
+    iters3, dt3 = _timed_iterations(lambda k: soa.run(k, allc), seconds * 0.4)
+    out["cpu_soa"] = {"value": sb[2] * iters3 / dt3, "unit": "river-board-iterations/s", "cores": used, "host_cores": allc, "kind": "port",
+                      "table_bytes": soa.table_bytes, "identical_to_per_lane_oracle": same,
+                      "sample": "%d iterations of the 706-node tree, %d clusters per round, boards %s, ENUM chance, block-major SoA, units of 16 clusters walked through the whole "
+                                "tree, gcc -O3 -march=native, %d threads (one per unit at most: 313 units), %.1f s" % (iters3, C_, "/".join(map(str, sb)), used, dt3)}
+    soa.destroy()
+    return out
 
 
 def cpu_soa(n_clusters, mode, seconds, boards=None, threads=None):
@@ -845,6 +946,87 @@ def pmc_traffic(a, kernel):
         return None, None
 
 
+def compact_line(out):
+    """The one line stdout carries: the contract keys, `roofline` and `cpu_baseline` as the task prescribes them, and ONE flat number per auxiliary leg."""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def r3(x):
+        return float("%.4g" % x) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+
+    if "metric" not in out or "roofline" not in out:   # the dp-deals line and the probes are short already
+        return out
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "n_boards_per_gpu", "n_clusters", "regret_fill", "table_bytes_per_gpu", "launches_per_step", "parallelism",
+                                          "process_group_ranks") if k in cfg}
+    rf = out["roofline"]
+    line["roofline"] = {k: r3(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_canned", "launches", "avg_launch_ms",
+                                               "algo_bytes_per_launch", "frac_of_copy_on_this_card") if k in rf}
+    line["roofline"]["kernel"] = "rs_tree_p{0,1}_lanes" if "rs_tree" in rf.get("kernel", "") else "rs::k_update"
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        line["cpu_baseline"] = {"value": r3(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:160]}
+        if "all_cores" in cb:
+            line["cpu_baseline"]["all_cores"] = {"value": r3(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}
+    flat = {
+        "step_ms_median": g(out, "step_ms_hip_events", "median"),
+        "exact_i64_value": g(out, "exact_i64_pass", "value"),
+        "gpu_over_cpu": out.get("gpu_over_cpu"), "gpu_over_cpu_all_cores": out.get("gpu_over_cpu_all_cores"),
+        "cpu_soa_value": g(out, "cpu_soa", "value"), "cpu_soa_cores": g(out, "cpu_soa", "cores"), "cpu_soa_GBps": g(out, "cpu_soa", "algo_GBps"),
+        "gpu_over_cpu_soa": out.get("gpu_over_cpu_soa"),
+        "update_node_frac": g(out, "roofline_update_node", "frac"), "discount_frac": g(out, "roofline_discount", "frac"),
+        "stream_copy_GBps": g(out, "stream_probe", "copy_GBps"),
+        "single_board_us": g(out, "single_board", "us_per_iteration"),
+        "deal_batch_Mps": (g(out, "deal_batch", "value") or 0) / 1e6 or None, "deal_batch_ms": g(out, "deal_batch", "ms_per_batch"),
+        "deal_trainer_Mps": (g(out, "deal_trainer", "value") or 0) / 1e6 or None, "deal_trainer_ms": g(out, "deal_trainer", "ms_per_batch"),
+        "deal_trainer_valu_frac": g(out, "deal_trainer", "roofline_deals", "frac"),
+        "deal_trainer_3s_Mps": (g(out, "deal_trainer_three_street", "value") or 0) / 1e6 or None, "deal_trainer_3s_ms": g(out, "deal_trainer_three_street", "ms_per_batch"),
+        "deal_trainer_3s_valu_frac": g(out, "deal_trainer_three_street", "roofline_deals", "frac"),
+        "solve_expl": [g(out, "solve", "exploitability_before"), g(out, "solve", "exploitability_after")], "solve_s": g(out, "solve", "seconds_training"),
+        "solve_3s_expl": [x[1] for x in (g(out, "solve_three_street", "exploitability_curve") or [])] or None, "solve_3s_s": g(out, "solve_three_street", "seconds_training"),
+        "solve_3s_br_s": g(out, "solve_three_street", "seconds_best_response_both_players"),
+        "kmeans_predict_ms": (g(out, "kmeans_predict", "seconds_per_sweep") or 0) * 1e3 or None, "kmeans_fit_regular_s": g(out, "kmeans_predict", "fit_regular", "seconds"),
+        "dp_deals_Mps": (g(out, "dp_deals", "value") or 0) / 1e6 or None,
+    }
+    for key in ("config3", "config4"):
+        c = out.get(key)
+        if not isinstance(c, dict):
+            continue
+        if "error" in c and "value" not in c:
+            flat[key + "_error"] = str(c["error"])[:120]
+            continue
+        flat[key + "_ms"] = c.get("ms_per_iteration")
+        flat[key + "_value"] = c.get("value")
+        flat[key + "_launches"] = c.get("launches_per_iteration")
+        flat[key + "_frac"] = (c["algo_GBps_all_kernels"] / HBM_PEAK_GBS) if c.get("algo_GBps_all_kernels") else None
+        flat[key + "_tree_kernel_frac"] = g(c, "kernels", "tree", "frac_of_8TBps")
+        flat[key + "_chance_kernel_frac"] = g(c, "kernels", "chance", "frac_of_8TBps")
+        flat[key + "_cpu8"] = g(c, "cpu_baseline", "value")
+        flat[key + "_cpu_all"] = g(c, "cpu_baseline", "all_cores", "value")
+        flat[key + "_cpu_all_cores"] = g(c, "cpu_baseline", "all_cores", "cores")
+        flat[key + "_cpu_soa"] = g(c, "cpu_soa", "value")
+        flat[key + "_cpu_soa_cores"] = g(c, "cpu_soa", "cores")
+        flat[key + "_gpu_over_cpu8"] = c.get("gpu_over_cpu")
+        flat[key + "_gpu_over_cpu_all"] = c.get("gpu_over_cpu_all_cores")
+        flat[key + "_gpu_over_cpu_soa"] = c.get("gpu_over_cpu_soa")
+        flat[key + "_allgather_ms"] = g(c, "phases_ms_per_iteration_rank0", "allgather")
+        if isinstance(c.get("cpu_baseline"), dict) and "error" in c["cpu_baseline"]:
+            flat[key + "_cpu_error"] = str(c["cpu_baseline"]["error"])[:120]
+    for k, v in flat.items():
+        if v is None or v == [None, None]:
+            continue
+        line[k] = [r3(x) for x in v] if isinstance(v, list) else r3(v)
+    for leg in ("single_board", "deal_batch", "deal_trainer", "deal_trainer_three_street", "solve", "solve_three_street", "kmeans_predict", "dp_deals", "exact_i64_pass"):
+        if isinstance(out.get(leg), dict) and "error" in out[leg]:
+            line[leg + "_error"] = str(out[leg]["error"])[:120]
+    return line
+
+
 def main():
     a = parse()
     if os.environ.get("RS_BENCH_PROBE") and "RANK" in os.environ:
@@ -880,9 +1062,18 @@ def main():
     device = local_rank % max(1, rs.device_count())
 
     def emit(obj):
+        """stdout: ONE compact JSON line (every contract key, `roofline`, `cpu_baseline`, one flat number per leg -- below 4 KB, so that a driver that keeps only a
+        tail of the output still holds all of it); the full result with every per-kernel table and descriptive string goes to --detail (bench_detail.json)"""
+        line = compact_line(obj)
+        try:
+            with open(a.detail, "w") as f:
+                json.dump(obj, f, indent=1)
+            line["detail"] = os.path.relpath(a.detail, ROOT)
+        except OSError as e:
+            line["detail"] = "not written: %s" % e
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(obj))
+        print(json.dumps(line, separators=(",", ":")))
         sys.stdout.flush()
         os.dup2(2, 1)
 
@@ -918,7 +1109,7 @@ def main():
         global_river = boards3[2]
         boards3 = [boards3[0], thi - tlo, (thi - tlo) * fan]
     trainer = make_trainer(rs, boards3 if three else a.boards, a.clusters, a.mode, a.graph, device, 1234 + 1 + rank, a.fuse,
-                           a.tree, a.dtype, a.opp, shard)
+                           a.tree, a.dtype, a.opp, shard, saturating=a.saturating)
     comm = None
     if shard is not None:
         comm = make_comm(trainer.infosets, dist, rank, n_gpus)
@@ -1069,6 +1260,28 @@ def main():
         except Exception as e:
             out["stream_probe"] = {"error": str(e)}
 
+    out["config"]["regret_fill"] = ("U{-10^6..10^6}, one cell in %d beyond +-2.1e9 (SURVEY 8(d) saturation note)" % a.saturating) if (a.saturating and a.dtype == "i32") \
+        else "U{-10^6..10^6}"
+    # ---- the same sweep with utilities that force |delta| >= 2^31 on one lane in 100 (RS_LEAF_UTIL rows with +-1e9 outliers): about half of the waves then take the exact
+    # i64 branch of the clamp update (the test is made per wave, rs_device.hpp visit_i32) -- the slow path priced once, beside the headline that stays on the fast one
+    if rank == 0 and n_gpus == 1 and not three and a.dtype == "i32" and a.mode == "clamp" and not a.no_extra:
+        try:
+            t2 = make_trainer(rs, a.boards, a.clusters, a.mode, a.graph, device, 1234 + 77, a.fuse, a.tree, a.dtype, a.opp, None, saturating=a.saturating, outlier_leaves=100)
+            run_steps(t2, 3)
+            t2.infosets.sync()
+            k2 = min(a.steps, 20)
+            t0 = time.perf_counter()
+            run_steps(t2, k2)
+            t2.infosets.sync()
+            dt2 = time.perf_counter() - t0
+            out["exact_i64_pass"] = {"value": a.boards * k2 / dt2, "unit": "board-iterations/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2,
+                                     "what": "the headline sweep with RS_LEAF_UTIL rows ~ U(-1035, 1035) in which one lane in 100 holds +-1e9: (100 * reach) * (u - util) passes 2^31 "
+                                             "there and the lane's whole wave takes the exact i64 add-and-clamp (cfr.rs:445-461) instead of the saturating-add fast path"}
+            t2.destroy()
+            t2.infosets.destroy()
+        except Exception as e:
+            out["exact_i64_pass"] = {"error": str(e)}
+
     # the headline's table is no longer needed: the legs below want the memory (config 3 / 4 is 135 GB on one GPU)
     if comm is not None:
         from rustsolver_amd import _lib as L4
@@ -1118,6 +1331,17 @@ def main():
             out["config3"] = three_street_sweep_leg(rs, None, 0, 1, device, a, a.config3_steps)
         except Exception as e:
             out["config3"] = {"error": str(e)}
+        if not a.no_cpu and "value" in out["config3"]:   # the denominator of BASELINE.md section 3's ">= 6x node-vs-host" on this tree
+            try:
+                c3 = cpu_config3(a.mode, max(10.0, a.cpu_seconds * 1.5))
+                out["config3"].update(c3)
+                g = out["config3"]["value"]
+                out["config3"]["gpu_over_cpu"] = g / c3["cpu_baseline"]["value"]
+                if "all_cores" in c3["cpu_baseline"]:
+                    out["config3"]["gpu_over_cpu_all_cores"] = g / c3["cpu_baseline"]["all_cores"]["value"]
+                out["config3"]["gpu_over_cpu_soa"] = g / c3["cpu_soa"]["value"]
+            except Exception as e:
+                out["config3"]["cpu_baseline"] = {"error": str(e)}
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:
@@ -1168,6 +1392,8 @@ def main():
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.clusters, a.mode, a.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if "all_cores" in out["cpu_baseline"]:
+            out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
         try:
             out["cpu_soa"] = cpu_soa(a.clusters, a.mode, min(a.cpu_seconds, 10.0))
             out["gpu_over_cpu_soa"] = out["value"] / out["cpu_soa"]["value"]

@@ -19,6 +19,12 @@ int rs_table_fill_random(rs_table *table, uint64_t seed, int64_t regret_lo, int6
                          int64_t ssum_hi);
 /* dst[i] = lo + (hi - lo) * u(seed, i), u in [0,1) from the same hash; i < n */
 int rs_fill_uniform_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi);
+/* SURVEY.md 8(d) "value-range note": one regret cell in `one_in` (hashed) is overwritten with a value of magnitude 2 100 000 000 .. 2 147 000 000 (either sign), so that the
+ * saturating adds of the clamp update (cfr.rs:445-461) are exercised; i32 tables */
+int rs_table_plant_saturating(rs_table *table, uint64_t seed, uint32_t one_in);
+/* one value in `one_in` of a per-lane f32 row becomes +-magnitude: as an RS_LEAF_UTIL row this drives (scale * reach) * (u - util) beyond 2^31, i.e. onto the exact i64 branch
+ * of the clamp update (rs_device.hpp visit_i32) */
+int rs_plant_outliers_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude);
 
 /* ---- checks of the generated (hipRTC) kernels without a GPU ---------------------------------------------------------------------- */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */

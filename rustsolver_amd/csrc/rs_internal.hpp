@@ -180,6 +180,8 @@ hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, i
 hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
                               hipStream_t stream);
 hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream);
+hipError_t launch_plant_saturating(void *regrets, size_t n_cells, uint64_t seed, uint32_t one_in, hipStream_t stream);
+hipError_t launch_plant_outliers(float *dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude, hipStream_t stream);
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap
 hipError_t launch_delta_add(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x += snap
 hipError_t launch_gather_lanes(const void *block, const uint32_t *d_lanes, size_t n, uint32_t A, size_t tile, size_t es, void *d_out, hipStream_t stream);

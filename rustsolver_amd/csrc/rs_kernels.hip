@@ -684,6 +684,31 @@ __global__ __launch_bounds__(kBlock) void k_fill_uniform(float *__restrict__ dst
     }
 }
 
+// bench inputs as SURVEY.md 8(d) prescribes: one cell in `one_in` gets |regret| > 2.1e9, so that the saturating adds of the clamp update are part of what is timed
+__global__ __launch_bounds__(kBlock) void k_plant_saturating(int32_t *__restrict__ regrets, size_t n, uint64_t seed, uint32_t one_in) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const uint64_t h = splitmix64((seed ^ 0x5341545552415445ull) ^ (i * 0x9E3779B97F4A7C15ull));
+        if (h % one_in != 0) continue;
+        const int32_t mag = 2100000000 + (int32_t)((h >> 20) % 47000000u);
+        regrets[i] = (h >> 63) ? -mag : mag;
+    }
+}
+// ... and one value in `one_in` of a utility row gets +-magnitude, which sends (scale * reach) * (u - util) beyond 2^31: the exact i64 branch of the clamp update
+__global__ __launch_bounds__(kBlock) void k_plant_outliers(float *__restrict__ dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const uint64_t h = splitmix64((seed ^ 0x4F55544C49455253ull) ^ (i * 0x9E3779B97F4A7C15ull));
+        if (h % one_in == 0) dst[i] = (h >> 63) ? -magnitude : magnitude;
+    }
+}
+hipError_t launch_plant_saturating(void *regrets, size_t n_cells, uint64_t seed, uint32_t one_in, hipStream_t stream) {
+    hipLaunchKernelGGL(k_plant_saturating, dim3(grid_for(n_cells)), dim3(kBlock), 0, stream, (int32_t *)regrets, n_cells, seed, one_in);
+    return hipGetLastError();
+}
+hipError_t launch_plant_outliers(float *dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude, hipStream_t stream) {
+    hipLaunchKernelGGL(k_plant_outliers, dim3(grid_for(n)), dim3(kBlock), 0, stream, dst, n, seed, one_in, magnitude);
+    return hipGetLastError();
+}
+
 // replicated-round deltas for the multi-GPU all-reduce: x -= snap / x += snap (wrapping for i32)
 template <int DT, int SIGN>
 __global__ __launch_bounds__(kBlock) void k_delta(void *__restrict__ x, const void *__restrict__ snap, size_t n) {

@@ -477,6 +477,19 @@ int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, i
            "fill_random(ssum)");
     return RS_OK;
 }
+int rs_table_plant_saturating(rs_table *t, uint64_t seed, uint32_t one_in) {
+    if (!t || one_in == 0) return fail(RS_ERR_INVALID, "rs_table_plant_saturating: bad argument");
+    if (t->dtype != RS_I32) return fail(RS_ERR_UNSUPPORTED, "rs_table_plant_saturating: i32 tables (the saturating range is the i32 range)");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(launch_plant_saturating(t->d_regrets, t->n_cells, seed, one_in, t->stream), "plant_saturating");
+    return RS_OK;
+}
+int rs_plant_outliers_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude) {
+    if (!t || !d_dst || one_in == 0) return fail(RS_ERR_INVALID, "rs_plant_outliers_f32: bad argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(launch_plant_outliers(d_dst, n, seed, one_in, magnitude, t->stream), "plant_outliers");
+    return RS_OK;
+}
 int rs_fill_uniform_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, float lo, float hi) {
     if (!t || !d_dst) return fail(RS_ERR_INVALID, "rs_fill_uniform_f32: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
