@@ -244,8 +244,8 @@ def cpu_baseline(n_clusters, mode, seconds):
 def cpu_config3(mode, seconds):
     """The CPU side of config 3 (>= 6x node-vs-host on the 706-node, 5 000-bucket tree): the enumerating cfr() (cfr.rs:481-627, boards
     enumerated at the public chance nodes, :502-522) on the three-street tree with 5 000 clusters per round and a board SUBSET that still leaves the caches,
-    (a) the literal per-lane restatement in reference layout with 8 threads (cfr.rs:195) and with every core, (b) `cpu_soa`: block-major SoA, 16 clusters per
-    unit, vectorised (oracle/cpu_soa.c soae_*), compared bit for bit with (a)'s code on a small table before it is timed.  Rates are river-board-iterations/s:
+    (a) the literal per-lane restatement in reference layout with 8 threads (cfr.rs:195) and with every core, (b) `cpu_soa`: block-major SoA, 20 clusters per
+    unit, the sibling river boards of a unit walked together, vectorised (oracle/cpu_soa.c soae_*), compared bit for bit with (a)'s code on a small table before it is timed.  Rates are river-board-iterations/s:
     the unit the GPU leg reports, and per river board the work is the same whatever the fan."""
     import numpy as np
     from oracle import orc
@@ -313,8 +313,8 @@ def cpu_config3(mode, seconds):
     iters3, dt3 = _timed_iterations(lambda k: soa.run(k, allc), seconds * 0.4)
     out["cpu_soa"] = {"value": sb[2] * iters3 / dt3, "unit": "river-board-iterations/s", "cores": used, "host_cores": allc, "kind": "port",
                       "table_bytes": soa.table_bytes, "identical_to_per_lane_oracle": same,
-                      "sample": "%d iterations of the 706-node tree, %d clusters per round, boards %s, ENUM chance, block-major SoA, units of 16 clusters walked through the whole "
-                                "tree, gcc -O3 -march=native, %d threads (one per unit at most: 313 units), %.1f s" % (iters3, C_, "/".join(map(str, sb)), used, dt3)}
+                      "sample": "%d iterations of the 706-node tree, %d clusters per round, boards %s, ENUM chance, block-major SoA, units of 20 clusters walked through the whole "
+                                "tree (sibling river boards together), gcc -O3 -march=native, %d threads (one per unit at most: 250 units), %.1f s" % (iters3, C_, "/".join(map(str, sb)), used, dt3)}
     soa.destroy()
     return out
 

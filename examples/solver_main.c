@@ -6,6 +6,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #include "rustsolver_amd.h"
@@ -53,6 +54,7 @@ int main(int argc, char **argv) {
     printf("%zu combos per range, %zu / %zu river clusters, %d action nodes\n", n_hands, rs_card_abs_size(river, 0), rs_card_abs_size(river, 1),
            rs_tree_n_action_nodes(tree));
     rs_deal_trainer_params params;
+    memset(&params, 0, sizeof(params));   /* every field this program does not name -- the kernel-form choices (rs_kernel_forms) among them -- means "the engine's own choice" */
     params.board_mask = board_mask;
     params.deals_per_batch = deals_per_batch;
     params.seed = (uint64_t)time(NULL);

@@ -19,6 +19,14 @@ int rs_table_fill_random(rs_table *table, uint64_t seed, int64_t regret_lo, int6
                          int64_t ssum_hi);
 /* dst[i] = lo + (hi - lo) * u(seed, i), u in [0,1) from the same hash; i < n */
 int rs_fill_uniform_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi);
+/* the same with element i hashed as index_offset + i: a rank's slice of a per-lane row gets the values the whole row would hold there */
+int rs_fill_uniform_f32_at(rs_table *table, float *d_dst, size_t n, uint64_t seed, float lo, float hi, uint64_t index_offset);
+/* Fill and checksum keyed by the LOGICAL cell (action node, action, global lane) rather than the element index, for tests that emulate the ranks of a board-sharded sweep
+ * one after another: lane_off[round_idx] = global index of the table's first lane on that round (0 for an unsharded table or a replicated round).  The fill writes
+ * lo + hash % span (i32 and binary16 tables); the checksum adds, per round, an order-independent sum over the real cells to out[2 * round_idx] (regrets) and
+ * out[2 * round_idx + 1] (strategy sums): the sums of the ranks' slices of a round equal the unsharded table's, whatever the pitches and tilings are */
+int rs_table_fill_random_logical(rs_table *table, uint64_t seed, int64_t regret_lo, int64_t regret_hi, int64_t ssum_lo, int64_t ssum_hi, const uint64_t *lane_off /* [RS_MAX_ROUNDS] */);
+int rs_table_checksum_logical(rs_table *table, const uint64_t *lane_off /* [RS_MAX_ROUNDS] */, uint64_t *out /* [RS_MAX_ROUNDS][2] */);
 /* SURVEY.md 8(d) "value-range note": one regret cell in `one_in` (hashed) is overwritten with a value of magnitude 2 100 000 000 .. 2 147 000 000 (either sign), so that the
  * saturating adds of the clamp update (cfr.rs:445-461) are exercised; i32 tables */
 int rs_table_plant_saturating(rs_table *table, uint64_t seed, uint32_t one_in);

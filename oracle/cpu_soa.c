@@ -255,11 +255,12 @@ size_t soa_table_bytes(const soa_ctx *c) {
  * src/solver/cfr.rs:502-522): `soae_*`.  The sweep decomposes by cluster -- cfr() enumerates boards, never clusters -- so the unit of work is a block of
  * SOAE_BL consecutive clusters walked through the WHOLE tree, boards enumerated in deal order at the public chance nodes exactly as orc_traverse does
  * (reach * (1.0 / len) down, util = util + u up).  Layout: per action node [cluster block][A][boards of the node's round][SOAE_BL] -- everything a unit
- * touches is contiguous, first-touched by the thread that owns the unit.  Blocks are narrow (one 64-byte vector of f32) so that a 5 000-cluster table
- * yields 313 units for the host's threads; units are dealt out round-robin and stay with their thread for every iteration.
+ * touches is contiguous, first-touched by the thread that owns the unit.  Blocks are narrow (20 clusters) so that a 5 000-cluster table yields 250 units for
+ * the host's threads, dealt out round-robin and kept for every iteration; below the last chance level the sibling boards of a unit are contiguous and are
+ * walked together, so the inner loops there -- 99 % of the work -- run over up to 1 280 lanes.
  * bench.py asserts identity with the per-lane restatement (orc_traverse, ORC_CHANCE_ENUM) on a small table before timing.
  * ==================================================================================================================================== */
-#define SOAE_BL 16
+#define SOAE_BL 20   /* 5 000 clusters = 250 units: one per thread on a 256-thread host */
 
 typedef struct {
     const orc_tree *tree;
@@ -272,21 +273,31 @@ typedef struct {
     int mode;
 } soae_ctx;
 
-static void ewalk(const soae_ctx *c, int node, int p, int r, size_t b, size_t blk, const float *restrict reach, float *restrict util) {
+/* util[0 .. nb * SOAE_BL) of `node` for traverser p over boards [b, b + nb) of round r, cluster block blk: the lanes of consecutive boards are contiguous in this
+ * layout, so the subtrees below the LAST chance level are walked for up to SOAE_NB sibling boards at once (inner loops of up to 1 024 lanes); above it nb == 1 */
+#define SOAE_NB 64
+#define SOAE_LMAX (SOAE_NB * SOAE_BL)
+static void ewalk(const soae_ctx *c, int node, int p, int r, size_t b, size_t nb, size_t blk, const float *restrict reach, float *restrict util) {
     const orc_node *nd = &c->tree->nodes[node];
+    const size_t L = nb * SOAE_BL;
     if (nd->kind == ORC_PRIVATE_CHANCE) {
-        ewalk(c, nd->children[0], p, r, b, blk, reach, util);
+        ewalk(c, nd->children[0], p, r, b, nb, blk, reach, util);
         return;
     }
-    if (nd->kind == ORC_PUBLIC_CHANCE) {   /* cfr.rs:502-522 */
+    if (nd->kind == ORC_PUBLIC_CHANCE) {   /* cfr.rs:502-522; only ever entered with nb == 1 */
         const uint32_t fan = c->boards[r + 1] / c->boards[r];
         const float inv = 1.0f / (float)fan;
-        float child_reach[SOAE_BL], u[SOAE_BL];
-        for (int i = 0; i < SOAE_BL; i++) child_reach[i] = (reach ? reach[i] : 1.0f) * inv;
+        float child_reach[SOAE_LMAX], u[SOAE_LMAX];
         for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
-        for (uint32_t d = 0; d < fan; d++) {
-            ewalk(c, nd->children[0], p, r + 1, b * fan + d, blk, child_reach, u);
-            for (int i = 0; i < SOAE_BL; i++) util[i] = util[i] + u[i];
+        const int last = (r + 2 == c->n_rounds);   /* the child round has no chance node below: its boards can be walked together */
+        const size_t step = last ? SOAE_NB : 1;
+        for (size_t d0 = 0; d0 < fan; d0 += step) {
+            const size_t n = (fan - d0) < step ? (fan - d0) : step;
+            for (size_t k = 0; k < n; k++)
+                for (int i = 0; i < SOAE_BL; i++) child_reach[k * SOAE_BL + i] = (reach ? reach[i] : 1.0f) * inv;
+            ewalk(c, nd->children[0], p, r + 1, b * fan + d0, n, blk, child_reach, u);
+            for (size_t k = 0; k < n; k++)   /* util = util + u, deal by deal in index order (cfr.rs:519) */
+                for (int i = 0; i < SOAE_BL; i++) util[i] = util[i] + u[k * SOAE_BL + i];
         }
         return;
     }
@@ -294,58 +305,58 @@ static void ewalk(const soae_ctx *c, int node, int p, int r, size_t b, size_t bl
         const float pot = (float)nd->value;
         if (nd->ttype == ORC_UNCONTESTED) {
             const float v = (p == nd->last_to_act) ? -1.0f * pot : 1.0f * pot;
-            for (int i = 0; i < SOAE_BL; i++) util[i] = v;
+            for (size_t i = 0; i < L; i++) util[i] = v;
         } else {
             const float *s = c->sign[r] + (blk * c->boards[r] + b) * SOAE_BL;
             const float win0 = (p == 0) ? pot : -pot;
-            for (int i = 0; i < SOAE_BL; i++) util[i] = s[i] == 0.0f ? 0.0f : (s[i] > 0.0f ? win0 : -win0);
+            for (size_t i = 0; i < L; i++) util[i] = s[i] == 0.0f ? 0.0f : (s[i] > 0.0f ? win0 : -win0);
         }
         return;
     }
     const int A = nd->n_children;
     const size_t B = c->boards[r], P = B * SOAE_BL;   /* P: elements between two actions' rows of this block */
-    float sigma[ORC_MAX_ACTIONS][SOAE_BL], u[ORC_MAX_ACTIONS][SOAE_BL], norm[SOAE_BL];
+    float sigma[ORC_MAX_ACTIONS][SOAE_LMAX], u[ORC_MAX_ACTIONS][SOAE_LMAX], norm[SOAE_LMAX];
     int32_t *restrict R = c->reg[nd->index] + (blk * (size_t)A * B + b) * SOAE_BL, *restrict S = c->ssm[nd->index] + (blk * (size_t)A * B + b) * SOAE_BL;
-    for (int i = 0; i < SOAE_BL; i++) norm[i] = 0.0f;
+    for (size_t i = 0; i < L; i++) norm[i] = 0.0f;
     for (int a = 0; a < A; a++)
-        for (int i = 0; i < SOAE_BL; i++) {
+        for (size_t i = 0; i < L; i++) {
             const int32_t x = R[a * P + i];
             norm[i] += x > 0 ? (float)x : 0.0f;
         }
     const float uni = 1.0f / (float)A;
     for (int a = 0; a < A; a++)
-        for (int i = 0; i < SOAE_BL; i++) {
+        for (size_t i = 0; i < L; i++) {
             const int32_t x = R[a * P + i];
             sigma[a][i] = norm[i] > 0.0f ? (x > 0 ? (float)x / norm[i] : 0.0f) : uni;
         }
     if (nd->player == p) {
-        for (int a = 0; a < A; a++) ewalk(c, nd->children[a], p, r, b, blk, reach, u[a]);
-        for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
+        for (int a = 0; a < A; a++) ewalk(c, nd->children[a], p, r, b, nb, blk, reach, u[a]);
+        for (size_t i = 0; i < L; i++) util[i] = 0.0f;
         for (int a = 0; a < A; a++)
-            for (int i = 0; i < SOAE_BL; i++) util[i] += u[a][i] * sigma[a][i];
+            for (size_t i = 0; i < L; i++) util[i] += u[a][i] * sigma[a][i];
         const float scale = c->scale;
         if (c->mode == ORC_UPD_CLAMP_I64) {
             for (int a = 0; a < A; a++)
-                for (int i = 0; i < SOAE_BL; i++) {
+                for (size_t i = 0; i < L; i++) {
                     const float sr = scale * (reach ? reach[i] : 1.0f);
                     R[a * P + i] = add_clamp(R[a * P + i], sr * (u[a][i] - util[i]));
                     S[a * P + i] = add_clamp(S[a * P + i], sr * sigma[a][i]);
                 }
         } else {
             for (int a = 0; a < A; a++)
-                for (int i = 0; i < SOAE_BL; i++) {
+                for (size_t i = 0; i < L; i++) {
                     const float sr = scale * (reach ? reach[i] : 1.0f);
                     R[a * P + i] = add_wrap(R[a * P + i], sr * (u[a][i] - util[i]));
                     S[a * P + i] = add_wrap(S[a * P + i], sr * sigma[a][i]);
                 }
         }
     } else {
-        float child_reach[SOAE_BL];
-        for (int i = 0; i < SOAE_BL; i++) util[i] = 0.0f;
+        float child_reach[SOAE_LMAX];
+        for (size_t i = 0; i < L; i++) util[i] = 0.0f;
         for (int a = 0; a < A; a++) {
-            for (int i = 0; i < SOAE_BL; i++) child_reach[i] = sigma[a][i] * (reach ? reach[i] : 1.0f);
-            ewalk(c, nd->children[a], p, r, b, blk, child_reach, u[a]);
-            for (int i = 0; i < SOAE_BL; i++) util[i] += u[a][i] * sigma[a][i];
+            for (size_t i = 0; i < L; i++) child_reach[i] = sigma[a][i] * (reach ? reach[i] : 1.0f);
+            ewalk(c, nd->children[a], p, r, b, nb, blk, child_reach, u[a]);
+            for (size_t i = 0; i < L; i++) util[i] += u[a][i] * sigma[a][i];
         }
     }
 }
@@ -382,10 +393,10 @@ static void *soae_worker(void *arg) {
             }
         return NULL;
     }
-    float util[SOAE_BL];
+    float util[SOAE_LMAX];
     for (size_t it = 0; it < j->iterations; it++)
         for (int p = 0; p < 2; p++)
-            for (size_t blk = (size_t)j->tid; blk < c->n_blocks; blk += (size_t)j->n_threads) ewalk(c, 0, p, 0, 0, blk, NULL, util);
+            for (size_t blk = (size_t)j->tid; blk < c->n_blocks; blk += (size_t)j->n_threads) ewalk(c, 0, p, 0, 0, 1, blk, NULL, util);
     return NULL;
 }
 
@@ -394,13 +405,17 @@ static int soae_run_threads(soae_ctx *c, soae_job proto, int n_threads) {
     if ((size_t)n_threads > c->n_blocks) n_threads = (int)c->n_blocks;
     pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
     soae_job *jobs = (soae_job *)malloc((size_t)n_threads * sizeof(soae_job));
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, (size_t)64 << 20);   /* the walk keeps ~100 KB of per-lane vectors per tree level on the stack */
     for (int i = 0; i < n_threads; i++) {
         jobs[i] = proto;
         jobs[i].c = c;
         jobs[i].tid = i;
         jobs[i].n_threads = n_threads;
-        pthread_create(&th[i], NULL, soae_worker, &jobs[i]);
+        pthread_create(&th[i], &attr, soae_worker, &jobs[i]);
     }
+    pthread_attr_destroy(&attr);
     for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
     free(th);
     free(jobs);

@@ -319,6 +319,27 @@ class OracleTree:
         self.n_nodes = self.t.n_nodes
         self.n_action_nodes = self.t.n_action_nodes
 
+    @classmethod
+    def from_nodes(cls, nodes):
+        """a tree adopted from plain node records (the fields of rs_tree_node / orc_node: kind, parent, children, index, player, round_idx, value, ttype, last_to_act,
+        round) instead of built from Options -- what rs_tree_from_nodes takes"""
+        self = cls.__new__(cls)
+        self._arr = (Node * len(nodes))()
+        n_act = 0
+        for i, src in enumerate(nodes):
+            d = self._arr[i]
+            d.kind, d.parent, d.n_children = int(src.kind), int(src.parent), int(src.n_children)
+            for k in range(d.n_children):
+                d.children[k] = int(src.children[k])
+            d.index, d.player, d.round_idx = int(src.index), int(src.player), int(src.round_idx)
+            d.value, d.ttype, d.last_to_act, d.round = int(src.value), int(src.ttype), int(src.last_to_act), int(src.round)
+            n_act += 1 if d.kind == ACTION else 0
+        self.t = Tree()
+        self.t.nodes, self.t.n_nodes, self.t.cap, self.t.n_action_nodes = C.cast(self._arr, C.POINTER(Node)), len(nodes), len(nodes), n_act
+        self.n_nodes, self.n_action_nodes = len(nodes), n_act
+        self._borrowed = True   # the node array belongs to Python: orc_tree_free must not see it
+        return self
+
     def node(self, i):
         return self.t.nodes[i]
 
@@ -339,7 +360,8 @@ class OracleTree:
 
     def __del__(self):
         try:
-            lib().orc_tree_free(C.byref(self.t))
+            if not getattr(self, "_borrowed", False):
+                lib().orc_tree_free(C.byref(self.t))
         except Exception:
             pass
 

@@ -122,6 +122,9 @@ SYMBOLS = {
     "rs_table_fill_random": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "rs_fill_uniform_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_float, C.c_float]),
     "rs_table_plant_saturating": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
+    "rs_fill_uniform_f32_at": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_float, C.c_float, C.c_uint64]),
+    "rs_table_fill_random_logical": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_uint64)]),
+    "rs_table_checksum_logical": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rs_plant_outliers_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_uint32, C.c_float]),
     "rs_dmalloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rs_dfree": (C.c_int, [_P, _P]),

@@ -179,7 +179,10 @@ hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_
 hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, int dtype, hipStream_t stream);
 hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t lo, int64_t hi, int dtype,
                               hipStream_t stream);
-hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream);
+hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream, size_t index_offset = 0);
+// op 0: fill i32 / binary16 cells with lo + hash(seed, node, action, lane_off + lane) % span; op 1: add the order-independent checksum of the same keys and the cells' bits to *d_out
+hipError_t launch_logical(void *x, size_t n, uint32_t node, uint32_t A, size_t tile, size_t lanes, size_t lane_off, size_t es, int op, uint64_t seed, int64_t lo, int64_t hi,
+                          unsigned long long *d_out, hipStream_t stream);
 hipError_t launch_plant_saturating(void *regrets, size_t n_cells, uint64_t seed, uint32_t one_in, hipStream_t stream);
 hipError_t launch_plant_outliers(float *dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude, hipStream_t stream);
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream);  // x -= snap

@@ -676,9 +676,9 @@ __global__ __launch_bounds__(kBlock) void k_fill_random(void *__restrict__ dst, 
     }
 }
 __global__ __launch_bounds__(kBlock) void k_fill_uniform(float *__restrict__ dst, size_t n, uint64_t seed, float lo,
-                                                         float width) {
+                                                         float width, size_t index_offset) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        const uint64_t h = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+        const uint64_t h = splitmix64(seed ^ ((i + index_offset) * 0x9E3779B97F4A7C15ull));
         const float u = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-08f;  // 24 bits * 2^-24 -> [0,1)
         dst[i] = lo + width * u;
     }
@@ -994,9 +994,39 @@ hipError_t launch_fill_random(void *dst, size_t n_cells, uint64_t seed, int64_t 
     else hipLaunchKernelGGL((k_fill_random<RS_F16>), grid, block, 0, stream, dst, n_cells, seed, lo, span);
     return hipGetLastError();
 }
-hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream) {
+hipError_t launch_fill_uniform(float *dst, size_t n, uint64_t seed, float lo, float hi, hipStream_t stream, size_t index_offset) {
     dim3 grid(grid_for(n)), block(kBlock);
-    hipLaunchKernelGGL(k_fill_uniform, grid, block, 0, stream, dst, n, seed, lo, hi - lo);
+    hipLaunchKernelGGL(k_fill_uniform, grid, block, 0, stream, dst, n, seed, lo, hi - lo, index_offset);
+    return hipGetLastError();
+}
+// fill and checksum keyed by the LOGICAL cell (node, action, global lane) instead of the element index: a rank that holds a slice of a round's boards (lane_off = first global
+// lane of its slice) fills and sums exactly what the unsharded table holds for those cells, whatever the pitches and tilings are
+template <typename E>
+__global__ __launch_bounds__(kBlock) void k_logical(E *__restrict__ x, size_t n, uint32_t node, uint32_t A, uint32_t T, size_t lanes, size_t lane_off, int op, uint64_t seed,
+                                                    int64_t lo, uint64_t span, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    const size_t tile_cells = (size_t)A * T;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const size_t lane = (i / tile_cells) * T + i % T, a = (i % tile_cells) / T;
+        if (lane >= lanes) continue;
+        const uint64_t key = ((uint64_t)node << 44) ^ ((uint64_t)a << 40) ^ (uint64_t)(lane_off + lane);
+        if (op == 0) {
+            const int64_t val = lo + (int64_t)(splitmix64(seed ^ (key * 0x9E3779B97F4A7C15ull)) % span);
+            if constexpr (sizeof(E) == 4) x[i] = (E)(int32_t)val;
+            else x[i] = (E)__builtin_bit_cast(uint16_t, (_Float16)(float)val);
+        } else acc += splitmix64(key ^ ((uint64_t)x[i] * 0x9E3779B97F4A7C15ull));
+    }
+    if (op != 0) {
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+    }
+}
+hipError_t launch_logical(void *x, size_t n, uint32_t node, uint32_t A, size_t tile, size_t lanes, size_t lane_off, size_t es, int op, uint64_t seed, int64_t lo, int64_t hi,
+                          unsigned long long *d_out, hipStream_t stream) {
+    dim3 grid(grid_for(n)), block_(kBlock);
+    const uint64_t span = (uint64_t)(hi - lo) + 1;
+    if (es == 4) hipLaunchKernelGGL((k_logical<uint32_t>), grid, block_, 0, stream, (uint32_t *)x, n, node, A, (uint32_t)tile, lanes, lane_off, op, seed, lo, span, d_out);
+    else hipLaunchKernelGGL((k_logical<uint16_t>), grid, block_, 0, stream, (uint16_t *)x, n, node, A, (uint32_t)tile, lanes, lane_off, op, seed, lo, span, d_out);
     return hipGetLastError();
 }
 hipError_t launch_delta_sub(void *x, const void *snap, size_t n, int dtype, hipStream_t stream) {

@@ -490,6 +490,47 @@ int rs_plant_outliers_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, ui
     RS_HIP(launch_plant_outliers(d_dst, n, seed, one_in, magnitude, t->stream), "plant_outliers");
     return RS_OK;
 }
+int rs_fill_uniform_f32_at(rs_table *t, float *d_dst, size_t n, uint64_t seed, float lo, float hi, uint64_t index_offset) {
+    if (!t || !d_dst) return fail(RS_ERR_INVALID, "rs_fill_uniform_f32_at: NULL argument");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    RS_HIP(launch_fill_uniform(d_dst, n, seed, lo, hi, t->stream, size_t(index_offset)), "fill_uniform");
+    return RS_OK;
+}
+static int logical_sweep(rs_table *t, const uint64_t *lane_off, int op, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, uint64_t *out, const char *fn) {
+    if (!t || !lane_off) return fail(RS_ERR_INVALID, std::string(fn) + ": NULL argument");
+    if (op == 0 && t->dtype == RS_F32) return fail(RS_ERR_UNSUPPORTED, std::string(fn) + ": i32 and binary16 tables");
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    unsigned long long *d = nullptr;
+    hipError_t e = hipSuccess;
+    if (op == 1) {
+        e = hipMalloc((void **)&d, RS_MAX_ROUNDS * 2 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d, 0, RS_MAX_ROUNDS * 2 * sizeof(unsigned long long), t->stream);
+    }
+    for (int n = 0; n < int(t->nodes.size()) && e == hipSuccess; ++n) {
+        const rs_node_desc &nd = t->nodes[size_t(n)];
+        if (nd.n_actions == 0) continue;
+        const size_t cells = t->pitch[size_t(n)] * nd.n_actions, lanes = size_t(nd.n_boards) * nd.n_clusters;
+        const size_t off = size_t(lane_off[nd.round_idx]);
+        e = launch_logical(t->regrets_ptr(n), cells, uint32_t(n), nd.n_actions, t->tile[size_t(n)], lanes, off, elem_size(t->dtype), op, seed, rlo, rhi,
+                           d ? d + 2 * nd.round_idx : nullptr, t->stream);
+        if (e == hipSuccess)
+            e = launch_logical(t->ssum_ptr(n), cells, uint32_t(n), nd.n_actions, t->tile[size_t(n)], lanes, off, elem_size(t->dtype), op, seed ^ 0x5353554Dull, slo, shi,
+                               d ? d + 2 * nd.round_idx + 1 : nullptr, t->stream);
+    }
+    if (op == 1 && e == hipSuccess) e = hipMemcpyAsync(out, d, RS_MAX_ROUNDS * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream);
+    if (op == 1 && e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (d) (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, fn);
+    return RS_OK;
+}
+int rs_table_fill_random_logical(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, const uint64_t *lane_off) {
+    if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random_logical: empty range");
+    return logical_sweep(t, lane_off, 0, seed, rlo, rhi, slo, shi, nullptr, "rs_table_fill_random_logical");
+}
+int rs_table_checksum_logical(rs_table *t, const uint64_t *lane_off, uint64_t *out) {
+    if (!out) return fail(RS_ERR_INVALID, "rs_table_checksum_logical: NULL argument");
+    return logical_sweep(t, lane_off, 1, 0, 0, 0, 0, 0, out, "rs_table_checksum_logical");
+}
 int rs_fill_uniform_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, float lo, float hi) {
     if (!t || !d_dst) return fail(RS_ERR_INVALID, "rs_fill_uniform_f32: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");

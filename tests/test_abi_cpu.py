@@ -228,11 +228,16 @@ def test_header_is_plain_c_and_the_example_driver_links(tmp_path):
     libdir = os.path.join(root, "rustsolver_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-D_POSIX_C_SOURCE=199309L", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "examples", "solver_main.c"), "-L" + libdir, "-lrustsolver_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    exe1 = str(tmp_path / "config1_main")   # BASELINE configs[0]: the 169-bucket two-action tree adopted with rs_tree_from_nodes
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "config1_main.c"), "-L" + libdir, "-lrustsolver_amd", "-Wl,-rpath," + libdir, "-o", exe1])
     import rustsolver_amd as rs
     if rs.device_count() > 0:
         pytest.skip("a GPU is visible: the run itself is covered by the GPU tests")
     r = subprocess.run([exe, "1000"], capture_output=True, text=True)
     assert r.returncode == 1 and "no usable HIP device" in r.stderr and "1081 / 1081 river clusters" in r.stdout
+    r = subprocess.run([exe1], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable HIP device" in r.stderr
 
 
 def test_rust_binding_covers_every_export():

@@ -251,3 +251,95 @@ def test_short_division_of_regret_matching_equals_the_compilers():
         L.check(L.load().rs_selftest_division(table._h, 1 << 28, seed, C.byref(bad), first))
         assert bad.value == 0, "div_exact_pos differs from a / b, first at a = %r b = %r" % (first[0], first[1])
     table.destroy()
+
+
+def _logical_setup(boards, lane_off, C, seed, dtype=rs.I32, shard=None, scale=10000.0, mode=None):
+    """three-street table + sign rows + solver whose contents are a function of the LOGICAL cell (node, action, global lane): rs_table_fill_random_logical /
+    rs_fill_uniform_f32_at with the slice's global lane offsets"""
+    from rustsolver_amd import _lib as L
+    import ctypes as C_
+    lib = L.load()
+    n, tree = rs.build_game_tree(rs.three_street_options())
+    table = rs.create_infosets(n, tree, [C], boards, dtype)
+    off = (C_.c_uint64 * 3)(*lane_off)
+    rng_r, rng_s = ((-10**6, 10**6), (0, 10**6)) if dtype == rs.I32 else ((-2000, 2000), (0, 2000))
+    L.check(lib.rs_table_fill_random_logical(table._h, seed, rng_r[0], rng_r[1], rng_s[0], rng_s[1], off))
+    signs, leaves = {}, {}
+    for i, nd in enumerate(tree.nodes):
+        if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+            parent = tree.nodes[nd.parent]
+            r = parent.round_idx
+            if r not in signs:
+                signs[r] = table.lane_buffer(parent.index, 1)
+                L.check(lib.rs_fill_uniform_f32_at(table._h, signs[r].ptr, boards[r] * C, seed + 17 + r, -1.0, 1.0, lane_off[r]))
+            leaves[i] = (rs.LEAF_SIGN, signs[r])
+    tr = rs.MCCFRTrainer(tree, table, leaves, scale=scale, mode=rs.UPD_WRAP_I32 if mode is None else mode, chance_mode=rs.CHANCE_ENUM, shard=shard)
+    return tree, table, tr, off
+
+
+def _logical_checksum(table, off):
+    from rustsolver_amd import _lib as L
+    import ctypes as C_
+    out = (C_.c_uint64 * 6)()
+    L.check(L.load().rs_table_checksum_logical(table._h, off, out))
+    return [int(x) for x in out]
+
+
+@pytest.mark.parametrize("dtype", ["i32", "f16"])
+def test_config4_shape_eight_emulated_ranks_equal_the_single_gpu_table(dtype):
+    """BASELINE configs[3] (and the 8-GPU half of configs[4]) at its real shape on ONE GPU: the 706-node tree, 5 000 clusters, boards 1 / 49 / 2 352 (i32; binary16: 1 / 98 /
+    4 704), first unsharded (135 GB), then as EIGHT ranks -- 6 or 7 turn boards and 288 or 336 river boards each (12 / 13 and 576 / 624 for binary16), flop replicated -- that
+    live side by side in the same GPU's memory and are driven phase by phase, the all-gather of the turn-root utility slots done by hand between phase 0 and phase 1 (in
+    production: one ncclAllGather over xGMI).  Contents are a function of the logical cell, so the union of the ranks' turn / river checksums must equal the unsharded table's
+    and every rank's replicated flop tables must equal its flop tables.  What this cannot show is the RCCL call itself on more than one physical GPU."""
+    from rustsolver_amd import _lib as L
+    from rustsolver_amd.dist import shard_boards
+    lib = L.load()
+    Cn, W, iters = 5000, 8, 2
+    G = [1, 49, 2352] if dtype == "i32" else [1, 98, 4704]
+    dt = rs.I32 if dtype == "i32" else rs.F16
+    scale, mode = (10000.0, rs.UPD_WRAP_I32) if dtype == "i32" else (2.0 ** -12, rs.UPD_CLAMP_I64)
+    fan = G[2] // G[1]
+    tree, table, tr, off = _logical_setup(G, [0, 0, 0], Cn, SEED, dt, None, scale, mode)
+    roots = []
+    for it in range(iters):
+        for player in (0, 1):
+            roots.append(tr.iterate(player, want_root_util=True).copy())
+    want = _logical_checksum(table, off)
+    tr.destroy()
+    table.destroy()
+    ranks = []
+    for g in range(W):
+        tlo, thi = shard_boards(G[1], g, W)
+        boards = [1, thi - tlo, (thi - tlo) * fan]
+        assert boards[1] in ((6, 7) if dtype == "i32" else (12, 13))
+        ranks.append(_logical_setup(boards, [0, tlo * Cn, tlo * fan * Cn], Cn, SEED, dt, (W, g, 1, G[1]), scale, mode))
+    k = 0
+    for it in range(iters):
+        for player in (0, 1):
+            for (_, tb, sv, _) in ranks:
+                sv.iterate_phase(player, 0)
+            slots = []
+            for g, (_, tb, sv, _) in enumerate(ranks):   # the all-gather by hand: rank g's slot goes to everybody
+                ptr, nbytes = sv.exchange_info(player)
+                host = np.empty(nbytes // 4, dtype=np.float32)
+                L.check(lib.rs_d2h(tb._h, host.ctypes.data, ptr + g * nbytes, nbytes))
+                slots.append(host)
+            for (_, tb, sv, _) in ranks:
+                ptr, nbytes = sv.exchange_info(player)
+                for g, host in enumerate(slots):
+                    L.check(lib.rs_h2d(tb._h, ptr + g * nbytes, host.ctypes.data, nbytes))
+            for (_, tb, sv, _) in ranks:
+                got = sv.iterate_phase(player, 1, want_root_util=True)
+                assert (bits(got) == bits(roots[k])).all(), "root utilities of a sharded rank, it=%d p=%d" % (it, player)
+            k += 1
+    union = [0] * 6
+    for g, (_, tb, sv, off_g) in enumerate(ranks):
+        cs = _logical_checksum(tb, off_g)
+        assert cs[0:2] == want[0:2], "rank %d: the replicated flop tables differ from the single-GPU run's" % g
+        for j in range(2, 6):
+            union[j] = (union[j] + cs[j]) & (2**64 - 1)
+    assert union[2:6] == want[2:6], "the union of the ranks' turn / river tables differs from the single-GPU table"
+    for (_, tb, sv, _) in ranks:
+        sv.destroy()
+        tb.destroy()

@@ -922,16 +922,20 @@ def test_checkpoint_roundtrip(tmp_path, table_layout, monkeypatch):
 
 # ---- sharded multi-round sweep (BASELINE configs[3]): W ranks emulated on one GPU ------------------------------------------
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("fuse", [1, 0])
-def test_sharded_enum_sweep_equals_single_gpu(world, fuse):
+@pytest.mark.parametrize("world,fuse,dtype", [(2, 1, "i32"), (3, 1, "i32"), (2, 0, "i32"), (3, 0, "i32"), (2, 1, "f32"), (3, 1, "f32"), (3, 0, "f32"), (2, 1, "f16"), (3, 1, "f16"),
+                                              (2, 0, "f16")])
+def test_sharded_enum_sweep_equals_single_gpu(world, fuse, dtype):
     """Turn and river boards sharded over `world` ranks, flop replicated; the ranks exchange the turn-root utility rows at the
     sharded chance nodes (here: copied by the test between the ranks' exchange buffers; in production one ncclAllGather).
-    Every rank must end up with the SAME flop table as the unsharded sweep and with its slice of the turn / river tables."""
+    Every rank must end up with the SAME flop table as the unsharded sweep and with its slice of the turn / river tables -- bit for bit for float tables too
+    (f32, and binary16 = the sharded half of BASELINE configs[4]): the all-gather design never splits an f32 sum over ranks."""
     from rustsolver_amd.dist import shard_boards
     Cn, G = 8, [1, 5, 10]                       # global boards per round; turn = sharded round (5 boards over 2 or 3 ranks)
     fan_river = G[2] // G[1]
-    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), G, Cn, 99)
+    dt_g, dt_o = {"i32": (rs.I32, orc.T_I32), "f32": (rs.F32, orc.T_F32), "f16": (rs.F16, orc.T_F16)}[dtype]
+    # float tables: utilities of an ENUM chance node are sums over its deals; scale 2^-6 keeps binary16 regrets (|x| <= 1000 at the start) far from its range limit
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if dtype == "i32" else (2.0 ** -6, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    tree, table, otree, otab, lg, lo = setup_pair(rs.three_street_options(), orc.options_three_street(), G, Cn, 99, dt_g, dt_o)
     full = {nd.index: table.download_node(nd.index) for nd in tree.action_nodes()}
     # global leaf signs per round, re-read from the full run's buffers
     signs = {}
@@ -940,15 +944,15 @@ def test_sharded_enum_sweep_equals_single_gpu(world, fuse):
             r = tree.nodes[nd.parent].round_idx
             if r not in signs:
                 signs[r] = table.read_lane_buffer(lg[i][1], tree.nodes[nd.parent].index)[0].copy()
-    ref = rs.MCCFRTrainer(tree, table, lg, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse)
-    osol = orc.OracleSolver(otree, otab, lo, scale=10000.0, mode=orc.UPD_WRAP_I32, chance_mode=orc.CHANCE_ENUM)
+    ref = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse)
+    osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, chance_mode=orc.CHANCE_ENUM)
 
     ranks = []
     for g in range(world):
         tlo, thi = shard_boards(G[1], g, world)
         boards = [1, thi - tlo, (thi - tlo) * fan_river]
         n_actions, tr_tree = rs.build_game_tree(rs.three_street_options())
-        tb = rs.create_infosets(n_actions, tr_tree, [Cn], boards)
+        tb = rs.create_infosets(n_actions, tr_tree, [Cn], boards, dt_g)
         cols = {0: slice(0, Cn), 1: slice(tlo * Cn, thi * Cn), 2: slice(tlo * fan_river * Cn, thi * fan_river * Cn)}
         for nd in tr_tree.action_nodes():
             R, S = full[nd.index]
@@ -961,7 +965,7 @@ def test_sharded_enum_sweep_equals_single_gpu(world, fuse):
                 if r not in bufs:
                     bufs[r] = tb.lane_buffer(parent.index, 1, signs[r][cols[r]])
                 leaves[i] = (rs.LEAF_SIGN, bufs[r])
-        sv = rs.MCCFRTrainer(tr_tree, tb, leaves, scale=10000.0, mode=rs.UPD_WRAP_I32, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse,
+        sv = rs.MCCFRTrainer(tr_tree, tb, leaves, scale=scale, mode=mg, chance_mode=rs.CHANCE_ENUM, fuse_subtrees=fuse,
                              shard=(world, g, 1, G[1]))
         ranks.append((tr_tree, tb, sv, cols))
 
@@ -991,7 +995,8 @@ def test_sharded_enum_sweep_equals_single_gpu(world, fuse):
         for nd in tr_tree.action_nodes():
             r, s2 = tb.download_node(nd.index)
             R, S = table.download_node(nd.index)
-            assert (r == R[:, cols[nd.round_idx]]).all() and (s2 == S[:, cols[nd.round_idx]]).all(), "node %d" % nd.index
+            assert r.tobytes() == np.ascontiguousarray(R[:, cols[nd.round_idx]]).tobytes() and s2.tobytes() == np.ascontiguousarray(S[:, cols[nd.round_idx]]).tobytes(), \
+                "node %d" % nd.index
     compare_tables(tree, table, otab)
 
 
@@ -1064,3 +1069,93 @@ def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
         r, s = table.download_node(nd.index)
         ro, so = otab.get_node(nd.index)
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
+def test_config1_plumbing_tree_through_rs_iterate():
+    """BASELINE configs[0], "preflop-only 169-iso buckets, 2-action tree": the reference has no preflop round (state.rs:8, :59-64), so this is build-side plumbing --
+    a tree adopted from plain node records (rs_tree_from_nodes) with ONE two-action node per player and 169 clusters (hand_indexer_s::init(1, [2]).size(0),
+    gen_abstraction/ehs.rs:30), swept by rs_iterate and compared with the oracle's walk of the same records: player 0 {fold -> player 1 wins the pot, continue -> player 1's
+    node}, player 1 {fold, call -> showdown}."""
+    C_, pot = 169, 3
+    nodes = [L.TreeNode() for _ in range(6)]
+
+    def fill(i, kind, parent, children=(), **kw):
+        nd = nodes[i]
+        nd.kind, nd.parent, nd.n_children = kind, parent, len(children)
+        for k, c in enumerate(children):
+            nd.children[k] = c
+        for key, v in kw.items():
+            setattr(nd, key, v)
+    fill(0, rs.NODE_PRIVATE_CHANCE, -1, (1,))
+    fill(1, rs.NODE_ACTION, 0, (2, 3), index=0, player=0, round_idx=0)
+    fill(2, rs.NODE_TERMINAL, 1, value=pot, ttype=rs.TERM_UNCONTESTED, last_to_act=0, round=0)
+    fill(3, rs.NODE_ACTION, 1, (4, 5), index=1, player=1, round_idx=0)
+    fill(4, rs.NODE_TERMINAL, 3, value=2 * pot, ttype=rs.TERM_UNCONTESTED, last_to_act=1, round=0)
+    fill(5, rs.NODE_TERMINAL, 3, value=2 * pot, ttype=rs.TERM_SHOWDOWN, last_to_act=1, round=0)
+    tree = rs.tree_from_nodes(nodes)
+    assert tree.n_action_nodes == 2
+    table = rs.create_infosets(2, tree, [C_], [1])
+    otree = orc.OracleTree.from_nodes(nodes)
+    otab = orc.OracleTable(otree, [1], C_)
+    rng = np.random.Generator(np.random.PCG64(1234))   # SURVEY 8(d) config 1: regrets ~ U{-1000..1000}, reach = 1
+    for idx in (0, 1):
+        R = rng.integers(-1000, 1001, size=(2, C_)).astype(np.int32)
+        S = rng.integers(0, 1001, size=(2, C_)).astype(np.int32)
+        table.upload_node(idx, R, S)
+        otab.set_node(idx, R, S)
+    sign = rng.integers(-1, 2, size=C_).astype(np.float32)
+    sbuf = table.lane_buffer(1, 1, sign)
+    tr = rs.MCCFRTrainer(tree, table, {5: (rs.LEAF_SIGN, sbuf)}, scale=100.0, mode=rs.UPD_CLAMP_I64)
+    osol = orc.OracleSolver(otree, otab, {5: (orc.LEAF_SIGN, sign)}, scale=100.0, mode=orc.UPD_CLAMP_I64)
+    for it in range(3):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+    for c in (0, 90, 168):   # get-infoset on the 169-bucket axis: `&self.infosets[an.index][cluster_idx]` and its two readers (infoset.rs:83-123)
+        for idx in (0, 1):
+            ro, so = otab.get_node(idx)
+            assert_bits(table[idx][c].get_strategy(), orc.get_strategy(ro[:, c]), "get_strategy node %d cluster %d" % (idx, c))
+            assert_bits(table[idx][c].get_final_strategy(), orc.get_final_strategy(so[:, c]), "get_final_strategy node %d cluster %d" % (idx, c))
+    with pytest.raises(IndexError):
+        table[0][169]
+
+
+def test_c_examples_run_through_the_c_abi(tmp_path):
+    """examples/*.c are plain C99 hosts of the C ABI: config1_main.c (BASELINE configs[0]: 169 buckets, a two-action tree adopted with rs_tree_from_nodes, three rs_iterate
+    sweeps from a zero table) must print what the oracle computes for the same records; solver_main.c (the reference's `solver` binary, main.rs:29-36) must train and report
+    an exploitability far below the uniform strategy's 77."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rustsolver_amd")
+    exes = {}
+    for name, extra in (("config1_main", []), ("solver_main", ["-D_POSIX_C_SOURCE=199309L"])):
+        exes[name] = str(tmp_path / name)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"] + extra + ["-I" + os.path.join(root, "include"),
+                               os.path.join(root, "examples", name + ".c"), "-L" + libdir, "-lrustsolver_amd", "-Wl,-rpath," + libdir, "-o", exes[name]])
+    r = subprocess.run([exes["config1_main"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [int(x) for x in re.search(r"regrets (-?\d+) (-?\d+), strategy_sum (-?\d+) (-?\d+)", r.stdout).groups()]
+    nodes = [L.TreeNode() for _ in range(6)]
+    spec = [(rs.NODE_PRIVATE_CHANCE, -1, (1,), {}), (rs.NODE_ACTION, 0, (2, 3), dict(index=0, player=0)), (rs.NODE_TERMINAL, 1, (), dict(value=3, ttype=rs.TERM_UNCONTESTED, last_to_act=0)),
+            (rs.NODE_ACTION, 1, (4, 5), dict(index=1, player=1)), (rs.NODE_TERMINAL, 3, (), dict(value=6, ttype=rs.TERM_UNCONTESTED, last_to_act=1)),
+            (rs.NODE_TERMINAL, 3, (), dict(value=6, ttype=rs.TERM_SHOWDOWN, last_to_act=1))]
+    for nd, (kind, parent, children, kw) in zip(nodes, spec):
+        nd.kind, nd.parent, nd.n_children = kind, parent, len(children)
+        for k, c in enumerate(children):
+            nd.children[k] = c
+        for key, v in kw.items():
+            setattr(nd, key, v)
+    otree = orc.OracleTree.from_nodes(nodes)
+    otab = orc.OracleTable(otree, [1], 169)
+    sign = np.array([0.0 if c % 3 == 0 else (-1.0 if c & 1 else 1.0) for c in range(169)], dtype=np.float32)
+    osol = orc.OracleSolver(otree, otab, {5: (orc.LEAF_SIGN, sign)}, scale=100.0, mode=orc.UPD_CLAMP_I64)
+    for it in range(3):
+        for player in (0, 1):
+            osol.iterate(player)
+    ro, so = otab.get_node(0)
+    assert got == [int(ro[0, 90]), int(ro[1, 90]), int(so[0, 90]), int(so[1, 90])], (got, r.stdout)
+    r = subprocess.run([exes["solver_main"], "4000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "1081 / 1081 river clusters" in r.stdout
+    assert float(re.search(r"exploitability (-?[\d.]+)", r.stdout).group(1)) < 20.0, r.stdout
