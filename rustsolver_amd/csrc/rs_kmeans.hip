@@ -232,42 +232,133 @@ __global__ __launch_bounds__(kKmBlock) void k_kmeans_reassign(const float *__res
     }
 }
 
-// Per-cluster sums of the member histograms, member counts and (growbatch) squared upper bounds, every sum in DATA ORDER like the reference's sequential
-// f32 `+=` (kmeans.rs:525-530, :393-400): ONE wave per cluster walks the assignment vector 256 entries at a time, a ballot per 64 marks its members, and they
-// are added one after the other -- lane b owns bin b.  Splitting a cluster's members over several waves would change the order of the f32 additions.
-__global__ __launch_bounds__(64) void k_kmeans_center_sums(const float *__restrict__ dataset, const unsigned *__restrict__ order, const unsigned *__restrict__ clusters,
-                                                           const float *__restrict__ bounds, size_t n, int n_bins, float *__restrict__ sums,
-                                                           float *__restrict__ counts, float *__restrict__ sq) {
-    const unsigned c = blockIdx.x, lane = threadIdx.x;
-    float acc = 0.0f, cnt = 0.0f, sqa = 0.0f;
-    for (size_t j0 = 0; j0 < n; j0 += 256) {
-        unsigned v[4];
+// ---- member lists: a STABLE counting sort of the data indices by cluster (histogram per tile -> exclusive scan -> stable scatter), once per training round.  Inside a
+// cluster the members keep their data order, which is the order of the reference's sequential f32 `+=` (kmeans.rs:525-530, :393-400).  Round 2 let ONE wave per
+// cluster scan the whole assignment vector for its members: k x n reads per round (500 x 1.29 M = 643 M), 267 ms per round at the reference's size.
+constexpr int kKmTile = 512;   // data per tile of the counting sort (kKmBlock threads x 2 consecutive data)
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_tile_hist(const unsigned *__restrict__ clusters, size_t n, int k, unsigned *__restrict__ tile_hist) {
+    extern __shared__ unsigned km_lds[];
+    for (int c = threadIdx.x; c < k; c += kKmBlock) km_lds[c] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kKmTile;
+    for (int q = threadIdx.x; q < kKmTile; q += kKmBlock)
+        if (base + q < n) atomicAdd(&km_lds[min(clusters[base + q], (unsigned)(k - 1))], 1u);
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += kKmBlock) tile_hist[(size_t)blockIdx.x * k + c] = km_lds[c];
+}
+// per cluster: members in the tiles before tile t (in place), and the cluster's total
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_tile_scan(unsigned *__restrict__ tile_hist, size_t n_tiles, int k, unsigned *__restrict__ total) {
+    const int c = blockIdx.x * kKmBlock + threadIdx.x;
+    if (c >= k) return;
+    unsigned run = 0;
+    size_t t = 0;
+    for (; t + 8 <= n_tiles; t += 8) {   // eight loads in flight, then the dependent adds
+        unsigned x[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t j = j0 + (size_t)q * 64 + lane;
-            v[q] = j < n ? clusters[j] : 0xffffffffu;
-        }
+        for (int q = 0; q < 8; ++q) x[q] = tile_hist[(t + q) * k + c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned long long m = __ballot(v[q] == c);
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                const size_t jj = j0 + (size_t)q * 64 + (size_t)b;
-                const size_t row = order ? (size_t)order[jj] : jj;
-                if ((int)lane < n_bins) acc += dataset[row * (size_t)n_bins + lane];
-                cnt += 1.0f;                                     // f32 `+= 1.0` (sticks at 2^24 exactly like the reference)
-                if (sq) {
-                    const float u = bounds[2 * jj + 1];
-                    sqa += u * u;                                // bounds[i].1.powf(2.0)
-                }
-            }
+        for (int q = 0; q < 8; ++q) {
+            tile_hist[(t + q) * k + c] = run;
+            run += x[q];
         }
     }
-    if ((int)lane < n_bins) sums[(size_t)c * n_bins + lane] = acc;
-    if (lane == 0) {
-        counts[c] = cnt;
-        if (sq) sq[c] = sqa;
+    for (; t < n_tiles; ++t) {
+        const unsigned x = tile_hist[t * k + c];
+        tile_hist[t * k + c] = run;
+        run += x;
+    }
+    total[c] = run;
+}
+// exclusive scan of the totals (one workgroup; k <= a few thousand), start[k] = n
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_start_scan(const unsigned *__restrict__ total, int k, unsigned *__restrict__ start) {
+    __shared__ unsigned part[kKmBlock];
+    const int per = (k + kKmBlock - 1) / kKmBlock, c0 = min(k, (int)threadIdx.x * per), c1 = min(k, c0 + per);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) sum += total[c];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < kKmBlock; d <<= 1) {
+        const unsigned x = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += x;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+    for (int c = c0; c < c1; ++c) {
+        start[c] = run;
+        run += total[c];
+    }
+    if (threadIdx.x == kKmBlock - 1) start[k] = part[kKmBlock - 1];
+}
+// stable scatter: datum i goes to start[c] + (members of c in earlier tiles) + (members of c earlier in its own tile)
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_scatter(const unsigned *__restrict__ clusters, size_t n, int k, const unsigned *__restrict__ tile_hist,
+                                                             const unsigned *__restrict__ start, unsigned *__restrict__ members) {
+    __shared__ unsigned key[kKmTile];
+    const size_t base = (size_t)blockIdx.x * kKmTile;
+    for (int q = threadIdx.x; q < kKmTile; q += kKmBlock) key[q] = base + q < n ? min(clusters[base + q], (unsigned)(k - 1)) : 0xffffffffu;
+    __syncthreads();
+    for (int q = threadIdx.x; q < kKmTile; q += kKmBlock) {
+        if (base + q >= n) continue;
+        const unsigned c = key[q];
+        unsigned rank = 0;
+        for (int e = 0; e < q; ++e) rank += key[e] == c ? 1u : 0u;   // earlier data of the same cluster inside the tile
+        members[start[c] + tile_hist[(size_t)blockIdx.x * k + c] + rank] = (unsigned)(base + q);
+    }
+}
+typedef float km_f32x4 __attribute__((ext_vector_type(4)));
+// The ordered sums are a chain of dependent f32 additions per (cluster, bin); what need NOT be ordered are the loads.  So the members' histograms are first copied,
+// by every CU at once, into a staging buffer laid out per cluster and BIN-major -- staged[start[c] * rows + b * count_c + m] = bin b of the cluster's m-th member (rows =
+// n_bins, + 1 row of upper bounds for growbatch) -- and then ONE wave per cluster streams it: lane b walks its own contiguous row with 16-byte loads and adds the values
+// strictly in member order (kmeans.rs:525-530, :393-400).  With the EMD heuristic a handful of clusters end up holding most of the data (kmeans.rs:287-334 as coded):
+// walking a 10^6-member list row by row was a chain of 10^6 dependent HBM round trips (79 ms per round at the reference's size).
+__global__ __launch_bounds__(kKmBlock) void k_kmeans_stage(const float *__restrict__ dataset, const unsigned *__restrict__ order, const unsigned *__restrict__ clusters,
+                                                           const unsigned *__restrict__ members, const unsigned *__restrict__ start, const float *__restrict__ bounds, size_t n,
+                                                           int n_bins, int k, int rows, float *__restrict__ staged) {
+    for (size_t j = (size_t)blockIdx.x * kKmBlock + threadIdx.x; j < n; j += (size_t)gridDim.x * kKmBlock) {
+        const unsigned jj = members[j];                               // position in the (shuffled) data
+        const unsigned c = min(clusters[jj], (unsigned)(k - 1));
+        const unsigned lo = start[c], cnt = start[c + 1] - lo, m = (unsigned)j - lo;
+        const size_t row = order ? (size_t)order[jj] : (size_t)jj;
+        float *__restrict__ out = staged + (size_t)lo * rows + m;
+        for (int b = 0; b < n_bins; ++b) out[(size_t)b * cnt] = dataset[row * (size_t)n_bins + b];
+        if (rows > n_bins) out[(size_t)n_bins * cnt] = bounds[2 * (size_t)jj + 1];
+    }
+}
+__global__ __launch_bounds__(64) void k_kmeans_center_sums(const float *__restrict__ staged, const unsigned *__restrict__ start, int n_bins, int rows, float *__restrict__ sums,
+                                                           float *__restrict__ counts, float *__restrict__ sq) {
+    const unsigned c = blockIdx.x, lane = threadIdx.x;
+    const unsigned lo = start[c], cnt = start[c + 1] - lo;
+    if ((int)lane < rows) {
+        const float *__restrict__ row = staged + (size_t)lo * rows + (size_t)lane * cnt;
+        const bool square = (int)lane == n_bins;                      // the growbatch row of upper bounds: sum of bounds[i].1.powf(2.0)
+        float acc = 0.0f, n_f = 0.0f;
+        unsigned m = 0;
+        for (; m < cnt && ((size_t)(row + m) & 15u) != 0; ++m) {      // up to the first 16-byte boundary of this lane's row
+            const float v = row[m];
+            acc += square ? v * v : v;
+            n_f += 1.0f;
+        }
+        for (; m + 32 <= cnt; m += 32) {                              // eight 16-byte loads in flight, then 32 ordered additions
+            km_f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const km_f32x4 *>(row + m + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc += square ? v[q].x * v[q].x : v[q].x;
+                acc += square ? v[q].y * v[q].y : v[q].y;
+                acc += square ? v[q].z * v[q].z : v[q].z;
+                acc += square ? v[q].w * v[q].w : v[q].w;
+                n_f += 1.0f; n_f += 1.0f; n_f += 1.0f; n_f += 1.0f;   // f32 `+= 1.0` per member (sticks at 2^24 exactly like the reference)
+            }
+        }
+        for (; m < cnt; ++m) {
+            const float v = row[m];
+            acc += square ? v * v : v;
+            n_f += 1.0f;
+        }
+        if ((int)lane < n_bins) sums[(size_t)c * n_bins + lane] = acc;
+        else if (sq) sq[c] = acc;
+        if (lane == 0) counts[c] = n_f;
     }
 }
 
@@ -477,9 +568,23 @@ namespace {
 
 struct KmDevice {   // per-call device workspace of the training loops
     float *raw = nullptr, *s = nullptr, *mv = nullptr, *sums = nullptr, *counts = nullptr, *sq = nullptr;
+    unsigned *members = nullptr, *tile_hist = nullptr, *total = nullptr, *start = nullptr;   // the member lists of a round (stable counting sort by cluster)
+    float *staged = nullptr;                                                                 // the members' histograms per cluster, bin-major
+    size_t n_tiles = 0, staged_floats = 0;
     ~KmDevice() {
         for (float *q : {raw, s, mv, sums, counts, sq})
             if (q) (void)hipFree(q);
+        for (unsigned *q : {members, tile_hist, total, start})
+            if (q) (void)hipFree(q);
+        if (staged) (void)hipFree(staged);
+    }
+    int alloc_lists(size_t n, int k) {
+        n_tiles = (n + kKmTile - 1) / kKmTile;
+        hipError_t e = hipMalloc((void **)&members, std::max<size_t>(n, 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&tile_hist, std::max<size_t>(n_tiles * size_t(k), 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&total, size_t(k) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&start, (size_t(k) + 1) * 4);
+        return e == hipSuccess ? RS_OK : hip_fail(e, "k-means member lists");
     }
     int alloc(int k, int n_bins) {
         hipError_t e = hipMalloc((void **)&raw, size_t(k) * n_bins * 4);
@@ -579,8 +684,27 @@ int fit_check(const char *who, const rs_table *t, int dist, const void *d_datase
 // growbatch: the `&& count > 0` form of the mean and the squared upper bounds per cluster.  new_centers / counts / sq are host outputs.
 int update_step(rs_table *t, int dist, const float *d_dataset, const uint32_t *d_order, size_t n, std::vector<float> &centers, int k, int n_bins, bool growbatch,
                 const uint32_t *d_clusters, float *d_bounds, KmDevice &w, std::vector<float> &mv, std::vector<float> &counts, std::vector<float> &sq) {
-    hipLaunchKernelGGL(k_kmeans_center_sums, dim3((unsigned)k), dim3(64), 0, t->stream, d_dataset, (const unsigned *)d_order, (const unsigned *)d_clusters,
-                       (const float *)d_bounds, n, n_bins, w.sums, w.counts, growbatch ? w.sq : (float *)nullptr);
+    if (!w.members || w.n_tiles != (n + kKmTile - 1) / kKmTile)
+        if (int rc = w.alloc_lists(n, k)) return rc;
+    if (size_t(k) * 4 > 64 * 1024) return fail(RS_ERR_UNSUPPORTED, "k-means training loops: at most 16 384 centers (the counting sort's LDS histogram)");
+    hipLaunchKernelGGL(k_kmeans_tile_hist, dim3((unsigned)w.n_tiles), dim3(kKmBlock), size_t(k) * 4, t->stream, (const unsigned *)d_clusters, n, k, w.tile_hist);
+    hipLaunchKernelGGL(k_kmeans_tile_scan, dim3((unsigned)((k + kKmBlock - 1) / kKmBlock)), dim3(kKmBlock), 0, t->stream, w.tile_hist, w.n_tiles, k, w.total);
+    hipLaunchKernelGGL(k_kmeans_start_scan, dim3(1), dim3(kKmBlock), 0, t->stream, (const unsigned *)w.total, k, w.start);
+    hipLaunchKernelGGL(k_kmeans_scatter, dim3((unsigned)w.n_tiles), dim3(kKmBlock), 0, t->stream, (const unsigned *)d_clusters, n, k, (const unsigned *)w.tile_hist,
+                       (const unsigned *)w.start, w.members);
+    RS_HIP(hipGetLastError(), "k-means member lists");
+    const int rows = n_bins + (growbatch ? 1 : 0);
+    if (rows > 64) return fail(RS_ERR_UNSUPPORTED, "k-means training loops: at most 63 bins (one lane of a wave per bin)");
+    if (w.staged_floats < n * size_t(rows) + 4) {
+        if (w.staged) (void)hipFree(w.staged);
+        w.staged = nullptr;
+        w.staged_floats = n * size_t(rows) + 4;
+        RS_HIP(hipMalloc((void **)&w.staged, w.staged_floats * 4), "k-means staging buffer");
+    }
+    hipLaunchKernelGGL(k_kmeans_stage, km_grid(n), dim3(kKmBlock), 0, t->stream, d_dataset, (const unsigned *)d_order, (const unsigned *)d_clusters, (const unsigned *)w.members,
+                       (const unsigned *)w.start, (const float *)d_bounds, n, n_bins, k, rows, w.staged);
+    hipLaunchKernelGGL(k_kmeans_center_sums, dim3((unsigned)k), dim3(64), 0, t->stream, (const float *)w.staged, (const unsigned *)w.start, n_bins, rows, w.sums, w.counts,
+                       growbatch ? w.sq : (float *)nullptr);
     RS_HIP(hipGetLastError(), "k_kmeans_center_sums");
     std::vector<float> mass(size_t(k) * n_bins);
     counts.assign(size_t(k), 0.0f);
