@@ -611,6 +611,27 @@ def solve_three_street_leg(rs, device):
            "exploitability_curve": curve, "seconds_training": train_s, "seconds_first_best_response": first_br_s, "seconds_best_response_both_players": br_s,
            "average_profile_values": [float(x) for x in ev], "table_bytes": int(tr.infosets.nbytes)}
     tr.destroy()
+    # the same game with the FULL 1 176-combo random ranges (lossless abstractions: 7.4 GB of table): what the rank-order showdowns (RS_BR_SORTED) are for -- the pair loop
+    # of cfr.rs:323-347 took 3.1 s per exploitability call at this size
+    try:
+        hands_f = ab.random_range(mask)
+        abs_f = [ab.CardAbstraction.init([hands_f, hands_f], mask, r, None) for r in range(3)]
+        trf = rs.DealTrainer(tree, abs_f, [hands_f, hands_f], mask, n, seed=1, use_graph=True, device=device)
+        trf.exploitability()                       # the first call computes and caches the cluster ids of every (board prefix, hand)
+        t0 = time.perf_counter()
+        ef0 = trf.exploitability()
+        brf_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        trf.train(1024)
+        trf.status()
+        trainf_s = time.perf_counter() - t0
+        out["full_ranges"] = {"what": "the same game with both full %d-combo ranges (%s clusters per player), 1 024 batches of %d deals"
+                                      % (len(hands_f), "/".join(str(a_.get_size(0)) for a_ in abs_f), n),
+                              "exploitability_curve": [[0, ef0], [1024 * n, trf.exploitability()]], "seconds_training": trainf_s,
+                              "seconds_best_response_both_players": brf_s, "table_bytes": int(trf.infosets.nbytes)}
+        trf.destroy()
+    except Exception as e:
+        out["full_ranges"] = {"error": str(e)}
     return out
 
 
@@ -991,6 +1012,9 @@ def compact_line(out):
         "solve_expl": [g(out, "solve", "exploitability_before"), g(out, "solve", "exploitability_after")], "solve_s": g(out, "solve", "seconds_training"),
         "solve_3s_expl": [x[1] for x in (g(out, "solve_three_street", "exploitability_curve") or [])] or None, "solve_3s_s": g(out, "solve_three_street", "seconds_training"),
         "solve_3s_br_s": g(out, "solve_three_street", "seconds_best_response_both_players"),
+        "solve_3s_full_expl": [x[1] for x in (g(out, "solve_three_street", "full_ranges", "exploitability_curve") or [])] or None,
+        "solve_3s_full_br_s": g(out, "solve_three_street", "full_ranges", "seconds_best_response_both_players"),
+        "solve_3s_full_s": g(out, "solve_three_street", "full_ranges", "seconds_training"),
         "kmeans_predict_ms": (g(out, "kmeans_predict", "seconds_per_sweep") or 0) * 1e3 or None, "kmeans_fit_regular_s": g(out, "kmeans_predict", "fit_regular", "seconds"),
         "dp_deals_Mps": (g(out, "dp_deals", "value") or 0) / 1e6 or None,
     }

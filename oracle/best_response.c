@@ -256,7 +256,141 @@ typedef struct {
     const uint64_t *bmask;                      /* [NB] the new cards of a run-out */
     uint32_t *score[2];                         /* [NB * n_p] */
     double *pw[2];                              /* [NB * n_p] traverser weights */
+    /* sorted mode (RS_BR_SORTED, rs_br.hip): per traverser side pl, per run-out: the opponent's valid hands sorted by (score, index), the holders of every card in that
+     * order, and where every traverser hand stands in both */
+    int sorted;
+    const uint8_t *hands[2];
+    uint16_t *ord[2], *nv[2], *cl[2], *nl[2], *nle[2];
+    uint8_t *cc[2], *kl[2], *kle[2];
+    int16_t *same[2];
 } brr_ctx;
+
+#define BRR_HOLDERS 51
+typedef struct { uint32_t score; uint16_t hand; } brr_key;
+static int brr_key_cmp(const void *a, const void *b) {
+    const brr_key *x = (const brr_key *)a, *y = (const brr_key *)b;
+    if (x->score != y->score) return x->score < y->score ? -1 : 1;
+    return x->hand < y->hand ? -1 : (x->hand > y->hand ? 1 : 0);
+}
+static void brr_build_index(brr_ctx *c, int pl) {
+    const int o = 1 - pl;
+    const size_t np = c->n[pl], no = c->n[o], NB = c->NB;
+    size_t b, h, g;
+    brr_key *keys = (brr_key *)malloc((no ? no : 1) * sizeof(brr_key));
+    uint32_t *hs = (uint32_t *)malloc(52 * BRR_HOLDERS * sizeof(uint32_t));
+    c->ord[pl] = (uint16_t *)calloc(NB * no + 1, 2); c->nv[pl] = (uint16_t *)calloc(NB + 1, 2);
+    c->cl[pl] = (uint16_t *)calloc(NB * 52 * BRR_HOLDERS, 2); c->cc[pl] = (uint8_t *)calloc(NB * 52, 1);
+    c->nl[pl] = (uint16_t *)calloc(NB * np + 1, 2); c->nle[pl] = (uint16_t *)calloc(NB * np + 1, 2);
+    c->kl[pl] = (uint8_t *)calloc(NB * np * 2 + 1, 1); c->kle[pl] = (uint8_t *)calloc(NB * np * 2 + 1, 1);
+    c->same[pl] = (int16_t *)malloc((np ? np : 1) * sizeof(int16_t));
+    for (h = 0; h < np; h++) {
+        c->same[pl][h] = -1;
+        for (g = 0; g < no; g++)
+            if (c->hmask[pl][h] == c->hmask[o][g]) c->same[pl][h] = (int16_t)g;
+    }
+    for (b = 0; b < NB; b++) {
+        size_t nv = 0, i;
+        int cd;
+        for (g = 0; g < no; g++)
+            if (!(c->hmask[o][g] & c->bmask[b])) { keys[nv].score = c->score[o][b * no + g]; keys[nv].hand = (uint16_t)g; nv++; }
+        qsort(keys, nv, sizeof(brr_key), brr_key_cmp);
+        c->nv[pl][b] = (uint16_t)nv;
+        for (i = 0; i < nv; i++) c->ord[pl][b * no + i] = keys[i].hand;
+        for (cd = 0; cd < 52; cd++) {
+            size_t cnt = 0;
+            for (i = 0; i < nv; i++) {
+                const size_t gg = keys[i].hand;
+                if (c->hands[o][2 * gg] == cd || c->hands[o][2 * gg + 1] == cd) {
+                    c->cl[pl][(b * 52 + (size_t)cd) * BRR_HOLDERS + cnt] = (uint16_t)gg;
+                    hs[cd * BRR_HOLDERS + cnt] = keys[i].score;
+                    cnt++;
+                }
+            }
+            c->cc[pl][b * 52 + (size_t)cd] = (uint8_t)cnt;
+        }
+        for (h = 0; h < np; h++) {
+            const size_t lane = b * np + h;
+            uint32_t sp;
+            size_t a = 0, e = 0;
+            int t;
+            if (c->hmask[pl][h] & c->bmask[b]) continue;
+            sp = c->score[pl][lane];
+            for (i = 0; i < nv; i++) { a += keys[i].score < sp; e += keys[i].score <= sp; }
+            c->nl[pl][lane] = (uint16_t)a;
+            c->nle[pl][lane] = (uint16_t)e;
+            for (t = 0; t < 2; t++) {
+                const int cd2 = c->hands[pl][2 * h + t];
+                size_t j, aa = 0, ee = 0;
+                for (j = 0; j < c->cc[pl][b * 52 + (size_t)cd2]; j++) { aa += hs[cd2 * BRR_HOLDERS + j] < sp; ee += hs[cd2 * BRR_HOLDERS + j] <= sp; }
+                c->kl[pl][2 * lane + t] = (uint8_t)aa;
+                c->kle[pl][2 * lane + t] = (uint8_t)ee;
+            }
+        }
+    }
+    free(keys); free(hs);
+}
+/* a terminal by rank order, every sum in the order rs_br.hip k_br_terminal_sorted uses: P in 64 chunks of ceil(nv / 64) sorted positions (chunk sums from 0.0, offsets
+ * sequential over the chunks, P[i] = offset + the sum inside the chunk up to i), Pc sequential per card */
+static void brr_terminal_sorted(const brr_ctx *c, const orc_node *n, const double *q, double *v) {
+    const int p = c->p, o = 1 - c->p;
+    const size_t np = c->n[p], no = c->n[o], NB = c->NB;
+    const double pot = (double)(float)n->value;
+    const int unc = n->ttype == ORC_UNCONTESTED;
+    const double value = unc ? ((p == (int)n->last_to_act) ? -pot : pot) : pot;
+    double *P = (double *)malloc((no + 1) * sizeof(double)), *Pc = (double *)malloc(52 * BRR_HOLDERS * sizeof(double)), O[65];
+    size_t b, h;
+    for (b = 0; b < NB; b++) {
+        const size_t nv = c->nv[p][b], len = (nv + 63) / 64;
+        const double *qb = q + b * no;
+        const uint16_t *ord = c->ord[p] + b * no;
+        size_t k, i;
+        int cd;
+        double run = 0.0, T;
+        for (k = 0; k < 64; k++) {
+            const size_t i0 = k * len < nv ? k * len : nv, i1 = i0 + len < nv ? i0 + len : nv;
+            double sum = 0.0;
+            for (i = i0; i < i1; i++) sum += qb[ord[i]];
+            O[k] = sum;
+        }
+        for (k = 0; k < 64; k++) { const double cs = O[k]; O[k] = run; run += cs; }
+        O[64] = run;
+        for (k = 0; k < 64; k++) {
+            const size_t i0 = k * len < nv ? k * len : nv, i1 = i0 + len < nv ? i0 + len : nv;
+            double local = 0.0;
+            for (i = i0; i < i1; i++) { local += qb[ord[i]]; P[i] = O[k] + local; }
+        }
+        for (cd = 0; cd < 52; cd++) {
+            const size_t cnt = c->cc[p][b * 52 + (size_t)cd];
+            double r2 = 0.0;
+            for (i = 0; i < cnt; i++) { r2 += qb[c->cl[p][(b * 52 + (size_t)cd) * BRR_HOLDERS + i]]; Pc[cd * BRR_HOLDERS + i] = r2; }
+        }
+        T = O[64];
+        for (h = 0; h < np; h++) {
+            const size_t lane = b * np + h;
+            size_t c0, c1, n0, n1;
+            double T0, T1, acc;
+            if (c->hmask[p][h] & c->bmask[b]) { v[lane] = 0.0; continue; }
+            c0 = c->hands[p][2 * h]; c1 = c->hands[p][2 * h + 1];
+            n0 = c->cc[p][b * 52 + c0]; n1 = c->cc[p][b * 52 + c1];
+            T0 = n0 ? Pc[c0 * BRR_HOLDERS + n0 - 1] : 0.0; T1 = n1 ? Pc[c1 * BRR_HOLDERS + n1 - 1] : 0.0;
+            if (unc) {
+                const int sm = c->same[p][h];
+                acc = value * (((T - T0) - T1) + (sm >= 0 ? qb[sm] : 0.0));
+            } else {
+                const size_t nl = c->nl[p][lane], nle = c->nle[p][lane];
+                const size_t a0 = c->kl[p][2 * lane], a1 = c->kl[p][2 * lane + 1], e0 = c->kle[p][2 * lane], e1 = c->kle[p][2 * lane + 1];
+                const double L = nl ? P[nl - 1] : 0.0, LE = nle ? P[nle - 1] : 0.0;
+                const double L0 = a0 ? Pc[c0 * BRR_HOLDERS + a0 - 1] : 0.0, L1 = a1 ? Pc[c1 * BRR_HOLDERS + a1 - 1] : 0.0;
+                const double E0 = e0 ? Pc[c0 * BRR_HOLDERS + e0 - 1] : 0.0, E1 = e1 ? Pc[c1 * BRR_HOLDERS + e1 - 1] : 0.0;
+                const double win = (L - L0) - L1;
+                const double lose = ((T - LE) - (T0 - E0)) - (T1 - E1);
+                acc = value * (win - lose);
+            }
+            v[lane] = c->pw[p][lane] * acc;
+        }
+    }
+    free(P); free(Pc);
+}
 
 static size_t brr_cluster(const brr_ctx *c, int r, int pl, size_t b, size_t h) { return c->cid[r][pl][(b / c->per_prefix[r]) * c->n[pl] + h]; }
 
@@ -266,6 +400,10 @@ static void brr_walk(const brr_ctx *c, int node_id, const double *q, double *v) 
     const size_t np = c->n[p], no = c->n[o], NB = c->NB;
     size_t b, h, g;
     int a;
+    if (n->kind == ORC_TERMINAL && c->sorted) {
+        brr_terminal_sorted(c, n, q, v);
+        return;
+    }
     if (n->kind == ORC_TERMINAL) {
         const double pot = (double)(float)n->value;
         for (b = 0; b < NB; b++)
@@ -389,7 +527,7 @@ int orc_best_response_rounds(const orc_tree *tree, const orc_table *tb, const ui
     NB = orc_br_runouts(board0, n_board0, NULL);
     cards = (uint8_t *)malloc(NB * 5);
     orc_br_runouts(board0, n_board0, cards);
-    c.tree = tree; c.tb = tb; c.mode = mode; c.n_rounds = n_rounds; c.NB = NB;
+    c.tree = tree; c.tb = tb; c.mode = mode & 0xff; c.sorted = (mode & 0x100) != 0; c.n_rounds = n_rounds; c.NB = NB;
     c.n[0] = n0; c.n[1] = n1;
     hands[0] = hands_p0; hands[1] = hands_p1;
     for (r = 0; r < n_rounds; r++) {   /* completions left after r new cards: P(D - r, K - r) */
@@ -437,6 +575,9 @@ int orc_best_response_rounds(const orc_tree *tree, const orc_table *tb, const ui
         }
     }
     c.pw[0] = w0; c.pw[1] = ones;
+    c.hands[0] = hands_p0; c.hands[1] = hands_p1;
+    if (c.sorted)
+        for (p = 0; p < 2; p++) brr_build_index(&c, p);
     v = (double *)malloc(NB * (n0 > n1 ? n0 : n1) * sizeof(double));
     for (p = 0; p < 2; p++) {
         double total = 0.0;
@@ -448,5 +589,7 @@ int orc_best_response_rounds(const orc_tree *tree, const orc_table *tb, const ui
     }
     free(v); free(w0); free(ones); free(bmask); free(cards);
     for (p = 0; p < 2; p++) { free(hm[p]); free(c.score[p]); }
+    if (c.sorted)
+        for (p = 0; p < 2; p++) { free(c.ord[p]); free(c.nv[p]); free(c.cl[p]); free(c.cc[p]); free(c.nl[p]); free(c.nle[p]); free(c.kl[p]); free(c.kle[p]); free(c.same[p]); }
     return 0;
 }

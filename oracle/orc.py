@@ -14,6 +14,7 @@ _SO = os.path.join(_HERE, "librs_oracle.so")
 
 MAX_ACTIONS, MAX_ROUNDS, MAX_SIZES = 8, 3, 4
 PRIVATE_CHANCE, PUBLIC_CHANCE, ACTION, TERMINAL = 0, 1, 2, 3
+BR_SORTED = 0x100   # orc_best_response_rounds: | into the mode for the rank-order showdowns of rs_br.hip (same sums in the same order)
 ALLIN, SHOWDOWN, UNCONTESTED = 0, 1, 2
 ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
 UPD_CLAMP_I64, UPD_WRAP_I32 = 0, 1

@@ -18,6 +18,7 @@ LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
 CHANCE_PASS, CHANCE_ENUM = 0, 1
 OPP_FULL, OPP_SAMPLE = 0, 1
 BR_MAX, BR_AVERAGE = 0, 1   # rs_best_response modes
+BR_SORTED = 0x100           # | into the mode: showdowns by rank order (O(n log n) per run-out), sums in a fixed order of their own
 DIST_EMD, DIST_L2 = 0, 1
 K_UPDATE, K_NODE_UTIL, K_REACH, K_CHANCE, K_DISCOUNT, K_STRATEGY, K_TREE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 

@@ -368,6 +368,191 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards(const uint64_t 
     v[lane] = pw[lane] * acc;
 }
 
+// ---- showdowns by rank order (RS_BR_SORTED): O(n log n) per run-out instead of the O(n^2) pair loop of cfr.rs:323-347 ------------------------------------------------
+// For a showdown leaf, a traverser hand h collects value * (sum of q over the opponent hands it beats - sum over those that beat it), over the opponent hands that share
+// no card with h or the run-out.  With the opponent's hands of a run-out SORTED by (score, index) -- the scores do not depend on the tree node, so the order and every
+// position below are computed once per call (k_br_index) -- that is a difference of prefix sums P over the sorted order, corrected for the at most 2 x 51 opponent hands
+// that hold one of h's cards through per-card prefix sums Pc:
+//     win  = (P[nl - 1] - Pc[c0][kl0 - 1]) - Pc[c1][kl1 - 1]                     nl  = opponent hands with a smaller score, kl_t = those among the holders of h's card t
+//     lose = ((T - P[nle - 1]) - (Tc[c0] - Pc[c0][kle0 - 1])) - (Tc[c1] - Pc[c1][kle1 - 1])      nle, kle_t = ... with a smaller or equal score; T, Tc = totals
+//     acc  = value * (win - lose)
+// (a hand holding BOTH cards is the same hand: equal score, in neither sum).  An uncontested leaf is value * (((T - Tc[c0]) - Tc[c1]) + q[same hand]).
+// Every sum has ONE fixed order, which the oracle (orc_best_response_rounds, sorted mode) follows to the bit: P in 64 chunks of ceil(n / 64) consecutive sorted positions --
+// chunk sums sequential from 0.0, chunk offsets sequential over the chunks, P[i] = offset + the sequential sum inside the chunk up to i -- and Pc sequential per card.
+constexpr int kBrCardHolders = 51, kBrSortN = 2048;   // a card is held by at most 51 two-card hands; 1 326 hands at most, padded to a power of two for the sort
+struct BrIndex {   // of one side as the OPPONENT (sorted hands, holders of every card) and of the other side's hands as the traverser (positions), all per run-out
+    uint16_t *ord = nullptr;       // [NB][n_o] opponent hand at sorted position i (i < nv[b])
+    uint16_t *nv = nullptr;        // [NB] opponent hands that avoid the run-out
+    uint16_t *cl = nullptr;        // [NB][52][51] holders of card c in sorted order
+    uint8_t *cc = nullptr;         // [NB][52] their number
+    uint16_t *nl = nullptr, *nle = nullptr;   // [NB][n_p]
+    uint8_t *kl = nullptr, *kle = nullptr;    // [NB][n_p][2]
+    int16_t *same = nullptr;       // [n_p] the opponent's hand with the same two cards, -1 = none
+};
+__global__ __launch_bounds__(kBrBlock) void k_br_index(const uint8_t *__restrict__ hands_p, uint32_t n_p, const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p,
+                                                       const uint8_t *__restrict__ hands_o, uint32_t n_o, const uint64_t *__restrict__ mask_o,
+                                                       const uint32_t *__restrict__ score_o, const uint64_t *__restrict__ bmask, BrIndex ix) {
+    __shared__ unsigned long long key[kBrSortN];                 // (score << 16) | hand, ~0 = padding
+    __shared__ uint16_t lcl[52][kBrCardHolders];
+    __shared__ uint32_t lcs[52][kBrCardHolders];                 // the holders' scores
+    __shared__ uint32_t lcc[52];
+    __shared__ uint32_t lnv;
+    const uint32_t b = blockIdx.x;
+    const uint64_t bm = bmask[b];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kBrSortN; i += kBrBlock)
+        key[i] = (i < n_o && !(mask_o[i] & bm)) ? ((unsigned long long)score_o[(size_t)b * n_o + i] << 16 | i) : ~0ull;
+    if (threadIdx.x == 0) lnv = 0;
+    __syncthreads();
+    for (uint32_t k = 2; k <= (uint32_t)kBrSortN; k <<= 1)       // bitonic sort, ascending
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kBrSortN; i += kBrBlock) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = key[i], y = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        key[i] = y;
+                        key[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n_o; i += kBrBlock) {
+        if (key[i] != ~0ull) {
+            ix.ord[(size_t)b * n_o + i] = (uint16_t)(key[i] & 0xffffu);
+            if (i + 1 == n_o || key[i + 1] == ~0ull) lnv = i + 1;
+        } else ix.ord[(size_t)b * n_o + i] = 0;
+    }
+    __syncthreads();
+    const uint32_t nv = lnv;
+    if (threadIdx.x == 0) ix.nv[b] = (uint16_t)nv;
+    if (threadIdx.x < 52) {                                      // the holders of card c, in sorted order
+        const uint32_t c = threadIdx.x;
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < nv; ++i) {
+            const uint32_t g = (uint32_t)(key[i] & 0xffffu);
+            if (hands_o[2 * g] == c || hands_o[2 * g + 1] == c) {
+                if (cnt < (uint32_t)kBrCardHolders) {
+                    lcl[c][cnt] = (uint16_t)g;
+                    lcs[c][cnt] = (uint32_t)(key[i] >> 16);
+                    ix.cl[((size_t)b * 52 + c) * kBrCardHolders + cnt] = (uint16_t)g;
+                }
+                ++cnt;
+            }
+        }
+        lcc[c] = min(cnt, (uint32_t)kBrCardHolders);
+        ix.cc[(size_t)b * 52 + c] = (uint8_t)lcc[c];
+    }
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < n_p; h += kBrBlock) {     // where every traverser hand stands in the opponent's order
+        const size_t lane = (size_t)b * n_p + h;
+        if (mask_p[h] & bm) {
+            ix.nl[lane] = ix.nle[lane] = 0;
+            ix.kl[2 * lane] = ix.kl[2 * lane + 1] = ix.kle[2 * lane] = ix.kle[2 * lane + 1] = 0;
+            continue;
+        }
+        const unsigned long long sp = score_p[lane];
+        uint32_t lo = 0, hi = nv;                                // first position with score >= sp
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((key[mid] >> 16) < sp) lo = mid + 1; else hi = mid;
+        }
+        ix.nl[lane] = (uint16_t)lo;
+        hi = nv;                                                 // first position with score > sp
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((key[mid] >> 16) <= sp) lo = mid + 1; else hi = mid;
+        }
+        ix.nle[lane] = (uint16_t)lo;
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t c = hands_p[2 * h + t];
+            uint32_t a = 0, e = 0;
+            for (uint32_t j = 0; j < lcc[c]; ++j) {
+                a += lcs[c][j] < sp ? 1u : 0u;
+                e += lcs[c][j] <= sp ? 1u : 0u;
+            }
+            ix.kl[2 * lane + t] = (uint8_t)a;
+            ix.kle[2 * lane + t] = (uint8_t)e;
+        }
+    }
+}
+// one workgroup per run-out: wave 0 builds P (chunked, see above) and the per-card prefixes in LDS, then all threads evaluate the traverser's hands
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
+                                                                 uint32_t n_p, const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
+                                                                 int uncontested, double value, double *__restrict__ v) {
+    extern __shared__ unsigned char br_lds[];
+    double *P = (double *)br_lds;                                // [n_o]
+    double *Pc = P + n_o;                                        // [52][51]
+    double *O = Pc + 52 * kBrCardHolders;                        // [65] chunk offsets, O[64] = total
+    const uint32_t b = blockIdx.x;
+    const uint32_t nv = ix.nv[b];
+    const double *__restrict__ qb = q + (size_t)b * n_o;
+    const uint16_t *__restrict__ ord = ix.ord + (size_t)b * n_o;
+    const uint32_t len = (nv + 63u) / 64u;
+    if (threadIdx.x < 64) {
+        const uint32_t k = threadIdx.x, i0 = min(nv, k * len), i1 = min(nv, i0 + len);
+        double sum = 0.0;
+        for (uint32_t i = i0; i < i1; ++i) sum += qb[ord[i]];
+        O[k] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                      // offsets: sequential over the chunks
+        double run = 0.0;
+        for (uint32_t k = 0; k < 64; ++k) {
+            const double c = O[k];
+            O[k] = run;
+            run += c;
+        }
+        O[64] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t k = threadIdx.x, i0 = min(nv, k * len), i1 = min(nv, i0 + len);
+        double local = 0.0;
+        for (uint32_t i = i0; i < i1; ++i) {
+            local += qb[ord[i]];
+            P[i] = O[k] + local;
+        }
+    } else if (threadIdx.x < 64 + 52) {
+        const uint32_t c = threadIdx.x - 64, cnt = ix.cc[(size_t)b * 52 + c];
+        const uint16_t *__restrict__ cl = ix.cl + ((size_t)b * 52 + c) * kBrCardHolders;
+        double run = 0.0;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            run += qb[cl[j]];
+            Pc[c * kBrCardHolders + j] = run;
+        }
+    }
+    __syncthreads();
+    const double T = O[64];
+    const uint64_t bm = bmask[b];
+    for (uint32_t h = threadIdx.x; h < n_p; h += kBrBlock) {
+        const size_t lane = (size_t)b * n_p + h;
+        if (mask_p[h] & bm) {
+            v[lane] = 0.0;
+            continue;
+        }
+        const uint32_t c0 = hands_p[2 * h], c1 = hands_p[2 * h + 1];
+        const uint32_t n0 = ix.cc[(size_t)b * 52 + c0], n1 = ix.cc[(size_t)b * 52 + c1];
+        const double T0 = n0 ? Pc[c0 * kBrCardHolders + n0 - 1] : 0.0, T1 = n1 ? Pc[c1 * kBrCardHolders + n1 - 1] : 0.0;
+        double acc;
+        if (uncontested) {
+            const int sm = ix.same[h];
+            acc = value * (((T - T0) - T1) + (sm >= 0 ? qb[sm] : 0.0));
+        } else {
+            const uint32_t nl = ix.nl[lane], nle = ix.nle[lane];
+            const uint32_t a0 = ix.kl[2 * lane], a1 = ix.kl[2 * lane + 1], e0 = ix.kle[2 * lane], e1 = ix.kle[2 * lane + 1];
+            const double L = nl ? P[nl - 1] : 0.0, LE = nle ? P[nle - 1] : 0.0;
+            const double L0 = a0 ? Pc[c0 * kBrCardHolders + a0 - 1] : 0.0, L1 = a1 ? Pc[c1 * kBrCardHolders + a1 - 1] : 0.0;
+            const double E0 = e0 ? Pc[c0 * kBrCardHolders + e0 - 1] : 0.0, E1 = e1 ? Pc[c1 * kBrCardHolders + e1 - 1] : 0.0;
+            const double win = (L - L0) - L1;
+            const double lose = ((T - LE) - (T0 - E0)) - (T1 - E1);
+            acc = value * (win - lose);
+        }
+        v[lane] = pw[lane] * acc;
+    }
+}
+
 struct BrSide {
     uint32_t n_hands = 0;
     uint32_t n = 0, n_pad = 0;     // lanes = NB * n_hands
@@ -377,12 +562,15 @@ struct BrSide {
     uint32_t *d_cid[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_start[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_order[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
     double *d_init_q = nullptr;    // this side's lanes as the OPPONENT's initial reach (its share of the deal probability)
     double *d_pw = nullptr;        // this side's lanes as the TRAVERSER's weight
+    uint8_t *d_hands = nullptr;    // [n_hands][2]
+    BrIndex index;                 // RS_BR_SORTED: this side as the TRAVERSER against the other side's sorted hands
 };
 
 struct BrRun {
     rs_table *t = nullptr;
     const rs_tree *tree = nullptr;
     int mode = RS_BR_MAX;
+    bool sorted = false;           // RS_BR_SORTED: showdowns by rank order
     int p = 0;
     uint32_t NB = 1;
     uint64_t *d_bmask = nullptr;
@@ -414,6 +602,13 @@ struct BrRun {
             const int unc = n.ttype == RS_TERM_UNCONTESTED;
             const double pot = double(float(n.value));   // tn.value as f32 (cfr.rs:316)
             const double value = unc ? (p == int(n.last_to_act) ? -pot : pot) : pot;
+            if (sorted) {
+                const size_t lds = (size_t(op.n_hands) + 52 * kBrCardHolders + 65) * sizeof(double);
+                hipLaunchKernelGGL(k_br_terminal_sorted, dim3(NB), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, q, op.n_hands, d_bmask, me.index,
+                                   unc, value, v_out);
+                err = hipGetLastError();
+                return;
+            }
             const size_t lds = size_t(op.n_hands) * (sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t));
             hipLaunchKernelGGL(k_br_terminal_boards, dim3(grid1(me.n_hands), NB), dim3(kBrBlock), lds, t->stream, me.d_mask, me.d_score, me.d_pw, me.n_hands, op.d_mask,
                                op.d_score, q, op.n_hands, d_bmask, unc, value, v_out);
@@ -499,7 +694,9 @@ size_t rs_br_runouts(const uint8_t *board0, int n_board0, uint8_t *out_cards) {
 int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
                             size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, int mode, double *out) {
     if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
-    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE");
+    const bool sorted = (mode & RS_BR_SORTED) != 0;
+    mode &= ~RS_BR_SORTED;
+    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE (| RS_BR_SORTED)");
     if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_best_response: empty tree");
     if (n_board0 < 3 || n_board0 > 5) return fail(RS_ERR_INVALID, "rs_best_response: the initial board has 3, 4 or 5 cards (state.rs:59-64)");
     const int K = 5 - n_board0, D = 52 - n_board0;
@@ -554,6 +751,7 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
     run.t = t;
     run.tree = tree;
     run.mode = mode;
+    run.sorted = sorted;
     run.NB = uint32_t(NB);
     run.d_bmask = run.upload(bmask);
     uint8_t *d_boards = run.upload(cards);
@@ -565,6 +763,7 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
         s.n_pad = uint32_t(round_up(size_t(s.n), 64));
         std::vector<uint8_t> hv(hands[p], hands[p] + 2 * n_hands[p]);
         uint8_t *d_hands = run.upload(hv);
+        s.d_hands = d_hands;
         s.d_mask = run.upload(mask[p]);
         s.d_score = run.dalloc<uint32_t>(s.n);
         if (run.err == hipSuccess) {
@@ -600,6 +799,29 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
             s.d_order[r] = run.upload(order);
         }
     }
+    if (sorted)   // the node-independent half of the rank-order showdowns: once per call
+        for (int p = 0; p < 2; ++p) {
+            BrSide &me = run.side[p], &op = run.side[1 - p];
+            BrIndex &ix = me.index;
+            ix.ord = run.dalloc<uint16_t>(NB * op.n_hands);
+            ix.nv = run.dalloc<uint16_t>(NB);
+            ix.cl = run.dalloc<uint16_t>(NB * 52 * kBrCardHolders);
+            ix.cc = run.dalloc<uint8_t>(NB * 52);
+            ix.nl = run.dalloc<uint16_t>(NB * me.n_hands);
+            ix.nle = run.dalloc<uint16_t>(NB * me.n_hands);
+            ix.kl = run.dalloc<uint8_t>(NB * me.n_hands * 2);
+            ix.kle = run.dalloc<uint8_t>(NB * me.n_hands * 2);
+            std::vector<int16_t> same(n_hands[p], -1);
+            for (size_t h = 0; h < n_hands[p]; ++h)
+                for (size_t g = 0; g < n_hands[1 - p]; ++g)
+                    if (mask[p][h] == mask[1 - p][g]) same[h] = int16_t(g);
+            ix.same = run.upload(same);
+            if (run.err == hipSuccess) {
+                hipLaunchKernelGGL(k_br_index, dim3(uint32_t(NB)), dim3(kBrBlock), 0, t->stream, me.d_hands, me.n_hands, me.d_mask, me.d_score, op.d_hands, op.n_hands, op.d_mask,
+                                   op.d_score, run.d_bmask, ix);
+                run.err = hipGetLastError();
+            }
+        }
     // the deal distribution of generate_hand (cfr.rs:100-143): the run-out uniform over ordered completions, player 0's combo uniform over the combos of its range
     // that avoid the full board, player 1's over those that avoid board and player 0: P = P(B) [disjoint] / (N0(B) N1(B, h0)); the whole weight rides on player 0's lane
     double pb = 1.0;

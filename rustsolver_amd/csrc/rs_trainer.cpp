@@ -30,6 +30,7 @@ struct rs_deal_trainer {
     uint64_t batches = 0;
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
     std::vector<uint32_t> br_cluster[RS_MAX_ROUNDS][2];   // cluster ids of every (board prefix, hand) of every round: they never change, computed at the first best response
+    bool br_cluster_ready = false;                        // ... and valid only once every (round, player) has been filled
     // train()'s prune schedule (cfr.rs:213-221): with a finite prune_threshold the solver runs in RS_UPD_PRUNE mode from the start and every
     // traverser visit honours the deal's flag byte -- all zero (= unpruned, bit for bit) until a batch reaches beyond the threshold
     uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
@@ -328,12 +329,11 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
     std::vector<uint8_t> runouts(NB * 5);
     rs_br_runouts(board, n_board0, runouts.data());
     const int K = 5 - n_board0, D = 52 - n_board0;
-    std::vector<uint32_t> (&cluster)[RS_MAX_ROUNDS][2] = tr->br_cluster;
+    // the ids are a function of ranges, board and abstractions, all fixed for the trainer's life: computed once.  They are built into locals and handed to the trainer only
+    // when EVERY (round, player) succeeded -- a failing get_cluster must not leave a half-filled cache behind that the next call would take for the real thing
     const uint32_t *ptrs[RS_MAX_ROUNDS * 2] = {};
-    const bool cached = !cluster[0][0].empty();
-    for (int r = 0; r < tr->n_rounds && cached; ++r)
-        for (int p = 0; p < 2; ++p) ptrs[r * 2 + p] = cluster[r][p].data();
-    for (int r = 0; r < tr->n_rounds && !cached; ++r) {
+    std::vector<uint32_t> cluster[RS_MAX_ROUNDS][2];
+    for (int r = 0; r < tr->n_rounds && !tr->br_cluster_ready; ++r) {
         size_t per_prefix = 1;
         for (int i = r; i < K; ++i) per_prefix *= size_t(D - i);
         const size_t n_prefix = NB / per_prefix, nc = size_t(2 + n_board0 + r);
@@ -359,9 +359,15 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
             if (int rc = rs_card_abs_get_cluster(tr->abs[r], cards.data(), where.size(), p, ids.data())) return rc;
             for (size_t i = 0; i < where.size(); ++i) cluster[r][p][where[i]] = ids[i];
             (void)nc;
-            ptrs[r * 2 + p] = cluster[r][p].data();
         }
     }
+    if (!tr->br_cluster_ready) {
+        for (int r = 0; r < tr->n_rounds; ++r)
+            for (int p = 0; p < 2; ++p) tr->br_cluster[r][p] = std::move(cluster[r][p]);
+        tr->br_cluster_ready = true;
+    }
+    for (int r = 0; r < tr->n_rounds; ++r)
+        for (int p = 0; p < 2; ++p) ptrs[r * 2 + p] = tr->br_cluster[r][p].data();
     return rs_best_response_rounds(tr->table, tr->tree, board, n_board0, tr->h_hands[0].data(), tr->n_hands[0], tr->h_hands[1].data(), tr->n_hands[1], ptrs, tr->n_rounds,
                                    mode, out);
 }

@@ -714,9 +714,10 @@ class DealTrainer:
         L.check(L.load().rs_deal_trainer_best_response(self._h, mode, _vp(out)))
         return out
 
-    def exploitability(self):
-        """(BR value of player 0 + BR value of player 1) / 2 against the current average strategies, per deal, in pot units of the leaves"""
-        return float(self.best_response(L.BR_MAX).sum() / 2.0)
+    def exploitability(self, sorted_showdowns=True):
+        """(BR value of player 0 + BR value of player 1) / 2 against the current average strategies, per deal, in pot units of the leaves.  sorted_showdowns: the leaves by
+        rank order (RS_BR_SORTED: O(n log n) per run-out, equal to the pair loop of cfr.rs:323-347 within f64 rounding)"""
+        return float(self.best_response(L.BR_MAX | (L.BR_SORTED if sorted_showdowns else 0)).sum() / 2.0)
 
     def _download(self, ptr, dtype, count):
         out = np.empty(count, dtype=dtype)

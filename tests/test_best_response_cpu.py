@@ -225,3 +225,21 @@ def test_multi_round_best_response_properties(board0, n_clusters):
     assert abs(ev.sum()) < 1e-9
     assert (br >= ev - 1e-9).all()
     assert br.sum() / 2 > 0
+
+
+@pytest.mark.parametrize("board0,n_clusters,n0,n1", [([4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3], [3, 4, 5], 40, 33), ([4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3, 4 * 1 + 0], [6, 2], 90, 120),
+                                                      ([4 * 2 + 1, 4 * 3 + 1, 4 * 12 + 3, 4 * 1 + 0, 4 * 7 + 2], [9], 300, 280)])
+def test_sorted_showdowns_equal_the_pair_loop(board0, n_clusters, n0, n1):
+    """RS_BR_SORTED restated (orc_best_response_rounds, mode | 0x100): the opponent's hands of a run-out sorted by (score, index), a leaf = a difference of prefix sums of
+    its reach corrected for the holders of the traverser's two cards.  A different summation order from the pair loop of cfr.rs:323-347, hence pinned to it within f64
+    rounding -- on ranges with plenty of shared cards, equal scores (ties), hands blocked by the run-out and the same hand in both ranges -- and, through it, to the deal-by-deal
+    enumeration the pair loop is pinned by."""
+    rng = np.random.Generator(np.random.PCG64(77 + len(board0)))
+    K = 5 - len(board0)
+    ot, tb, fs, h, cids, runouts = multi_round_game(rng, board0, n0, n1, ((0.5,),) * (K + 1), ((),) * (K + 1), n_clusters)
+    if n0 >= 90:
+        assert len(set(map(tuple, h[0])) & set(map(tuple, h[1]))) > 0      # the same hand on both sides exists (uncontested leaves add it back)
+    for mode in (0, 1):
+        pair = tb.best_response_rounds(board0, h[0], h[1], cids, mode)
+        srt = tb.best_response_rounds(board0, h[0], h[1], cids, mode | orc.BR_SORTED)
+        assert np.allclose(srt, pair, rtol=1e-11, atol=1e-12), (mode, pair, srt)

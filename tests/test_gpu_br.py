@@ -199,7 +199,47 @@ def test_multi_round_best_response_equals_oracle_bit_for_bit(board0, n0, n1, bet
         want = otab.best_response_rounds(board0, h[0], h[1], cids, mode)
         assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist(), (mode, got, want)
         vals[mode] = got
+        # showdowns by rank order (RS_BR_SORTED): a summation order of its own, identical to the oracle's sorted mode bit for bit and equal to the pair loop within rounding
+        got_s = table.best_response_rounds(tree, board0, h[0], h[1], cids, mode | L.BR_SORTED)
+        want_s = otab.best_response_rounds(board0, h[0], h[1], cids, mode | orc.BR_SORTED)
+        assert got_s.view(np.uint64).tolist() == want_s.view(np.uint64).tolist(), (mode, got_s, want_s)
+        assert np.allclose(got_s, got, rtol=1e-11, atol=1e-12), (mode, got_s, got)
     assert abs(vals[L.BR_AVERAGE].sum()) < 1e-9
+
+
+def test_sorted_showdowns_full_ranges_from_a_flop():
+    """the case the rank-order showdowns exist for: both full 1 176-combo ranges from a flop (2 352 run-outs, the reference's three-street tree with one bet size): the
+    exploitability of a random table through RS_BR_SORTED within a fraction of a second, zero-sum average profile, best response >= average -- and equal to the pair loop
+    (3 s per call at this size) where the test can afford it: on the turn-start game below"""
+    import time
+    mask = ab.card_mask("7h8hQc")
+    hands = ab.random_range(mask)
+    assert len(hands) == 1176
+    n_actions, tree = rs.build_game_tree(rs.Options(n_board_cards=3, bet_sizes=((1.0,),) * 3, raise_sizes=((),) * 3))
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, None) for r in range(3)]
+    tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, 1 << 16, seed=5, discount_interval=0)
+    tr.train(8)
+    tr.status()
+    tr.best_response(L.BR_AVERAGE | L.BR_SORTED)          # the first call computes and caches the cluster ids of every (prefix, hand)
+    t0 = time.perf_counter()
+    ev = tr.best_response(L.BR_AVERAGE | L.BR_SORTED)
+    br = tr.best_response(L.BR_MAX | L.BR_SORTED)
+    dt = (time.perf_counter() - t0) / 2
+    assert abs(ev.sum()) < 1e-9 and (br >= ev - 1e-9).all() and br.sum() / 2 > 0
+    assert dt < 1.0, "one full-range best response took %.2f s" % dt
+    tr.destroy()
+    # turn start, full ranges (1 128 combos, 48 run-outs): sorted against the pair loop
+    mask4 = ab.card_mask("7h8hQc2d")
+    hands4 = ab.random_range(mask4)
+    n4, tree4 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5, 1.0), (0.5, 1.0)), raise_sizes=((3.0,), (3.0,))))
+    abs4 = [ab.CardAbstraction.init([hands4, hands4], mask4, r, None) for r in (ab.TURN, ab.RIVER)]
+    tr4 = rs.DealTrainer(tree4, abs4, [hands4, hands4], mask4, 1 << 16, seed=6, discount_interval=0)
+    tr4.train(20)
+    tr4.status()
+    for mode in (L.BR_MAX, L.BR_AVERAGE):
+        pair, srt = tr4.best_response(mode), tr4.best_response(mode | L.BR_SORTED)
+        assert np.allclose(srt, pair, rtol=1e-10, atol=1e-12), (mode, pair, srt)
+    tr4.destroy()
 
 
 def test_three_street_trainer_is_solving_the_game():
