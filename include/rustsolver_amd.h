@@ -356,8 +356,9 @@ int rs_comm_allgather(rs_comm *comm, rs_table *table, void *d_buf, size_t bytes_
 int rs_comm_allreduce_deltas(rs_comm *comm, rs_table *table);   /* in-place ncclInt32 sum of the table's two delta arrays */
 /* the delta tables of a deal-batch table: two DEVICE i32 arrays of rs_table_cells() elements laid out like the table itself */
 int rs_table_deltas(rs_table *table, int32_t **d_dregrets, int32_t **d_dstrategy_sum);
-/* device memory a solver holds beside the table: the utility / reach arena and, for sampled deal sweeps over multi-round trees, the live-deal lists and
-   the reach rows between the round subtrees (both traversers) */
+/* device memory a solver holds beside the table, EVERYTHING it allocated: the utility / reach arena; for deal sweeps the AoS shadow of the table, the packed (or ordered)
+   per-deal records, the live-deal lists with their reach / position rows and counters, the work lists; the job descriptors of every launch; the exchange buffer of a
+   sharded sweep.  (The table's own delta arrays of a deal solver belong to the table: rs_table_deltas.) */
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 int rs_solver_n_launches(const rs_solver *solver, int traverser);

@@ -272,15 +272,16 @@ def splitmix64(x):
 
 
 def sample_bits(seed, node_index, lanes):
-    """the 32-bit counter hash of the opponent sampler (rs_device.hpp sample_bits): seed, node and lane words xor-ed, lowbias32 finisher"""
+    """the 32-bit counter hash of the opponent sampler (rs_device.hpp sample_bits): node and lane words xor-ed, the upper seed half added to the lane before its multiply,
+    the lower one xor-ed in, lowbias32 finisher"""
     lanes = np.asarray(lanes, dtype=np.uint64)
     M = np.uint64(0xFFFFFFFF)
     seed = np.uint64(seed)
     with np.errstate(over="ignore"):
-        s_mix = (seed & M) ^ (((seed >> np.uint64(32)) * np.uint64(0x85EBCA6B)) & M)
+        s_lo, s_hi = seed & M, seed >> np.uint64(32)
         n_mix = (np.uint64(node_index + 1) * np.uint64(0xC2B2AE35)) & M
-        l_mix = (((lanes & M) * np.uint64(0x9E3779B9)) & M) ^ (((lanes >> np.uint64(32)) * np.uint64(0x27D4EB2F)) & M)
-        x = (s_mix ^ n_mix ^ l_mix) & M
+        l_mix = (((((lanes & M) + s_hi) & M) * np.uint64(0x9E3779B9)) & M) ^ (((lanes >> np.uint64(32)) * np.uint64(0x27D4EB2F)) & M)
+        x = (s_lo ^ n_mix ^ l_mix) & M
         x ^= x >> np.uint64(16)
         x = (x * np.uint64(0x7FEB352D)) & M
         x ^= x >> np.uint64(15)

@@ -628,11 +628,12 @@ uint64_t orc_splitmix64(uint64_t x) {
 }
 
 uint32_t orc_sample_bits(uint64_t seed, uint32_t node_index, uint64_t lane) {
-    /* the 32-bit counter hash of rs_device.hpp sample_bits (lowbias32 finisher over seed, node and lane words) */
-    uint32_t s_mix = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    /* the 32-bit counter hash of rs_device.hpp sample_bits (lowbias32 finisher over seed, node and lane words; the upper seed half is added to the lane before its
+     * multiply, so that which (node, lane) pairs collide depends on the sweep seed) */
+    uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
     uint32_t n_mix = (node_index + 1u) * 0xC2B2AE35u;
-    uint32_t l_mix = ((uint32_t)lane * 0x9E3779B9u) ^ ((uint32_t)(lane >> 32) * 0x27D4EB2Fu);
-    uint32_t x = s_mix ^ n_mix ^ l_mix;
+    uint32_t l_mix = (((uint32_t)lane + s_hi) * 0x9E3779B9u) ^ ((uint32_t)(lane >> 32) * 0x27D4EB2Fu);
+    uint32_t x = s_lo ^ n_mix ^ l_mix;
     x ^= x >> 16;
     x *= 0x7FEB352Du;
     x ^= x >> 15;

@@ -436,12 +436,15 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 }
 __device__ __forceinline__ unsigned sample_bits(unsigned long long seed, unsigned node_index, unsigned long long lane) {
     // A 32-bit counter hash (round 2; round 1 ran splitmix64 here: two 64-bit multiplies, about 40 vector instructions per opponent node and lane, a fifth of a deal
-    // kernel's VALU work).  The sweep seed and the node fold into wave-uniform words (scalar ALU), the lane into one 32-bit multiply that the compiler shares between
-    // all opponent nodes of a kernel; the finisher is the two-multiply "lowbias32" mixer.  23 of the 32 bits reach the sampler (u01 = (bits >> 9) * 2^-23).
-    const unsigned s_mix = (unsigned)seed ^ ((unsigned)(seed >> 32) * 0x85EBCA6Bu);
+    // kernel's VALU work).  The node folds into a wave-uniform word (scalar ALU), the lane into one add and one 32-bit multiply that the compiler shares between all
+    // opponent nodes of a kernel; the finisher is the two-multiply "lowbias32" mixer.  23 of the 32 bits reach the sampler (u01 = (bits >> 9) * 2^-23).
+    // The upper seed half is ADDED to the lane before the multiply (round 3): with the seed only xor-ed in, two (node, lane) pairs whose 32-bit keys collide drew the same
+    // bits in EVERY sweep whatever the seed (at 4 M deals x 700 nodes most keys have such a partner); (lane + s) * M is not xor-linear in s, so which pairs collide now
+    // changes with every sweep seed.
+    const unsigned s_lo = (unsigned)seed, s_hi = (unsigned)(seed >> 32);
     const unsigned n_mix = (node_index + 1u) * 0xC2B2AE35u;
-    const unsigned l_mix = ((unsigned)lane * 0x9E3779B9u) ^ ((unsigned)(lane >> 32) * 0x27D4EB2Fu);
-    unsigned x = s_mix ^ n_mix ^ l_mix;
+    const unsigned l_mix = (((unsigned)lane + s_hi) * 0x9E3779B9u) ^ ((unsigned)(lane >> 32) * 0x27D4EB2Fu);
+    unsigned x = s_lo ^ n_mix ^ l_mix;
     x ^= x >> 16;
     x *= 0x7FEB352Du;
     x ^= x >> 15;

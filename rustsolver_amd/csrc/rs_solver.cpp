@@ -104,6 +104,7 @@ struct rs_solver {
     Plan plan[2];
     char *d_arena = nullptr;
     size_t arena_bytes = 0;
+    size_t other_bytes = 0;             // every other device allocation of the solver: table shadow, packed / ordered per-deal records, job blobs, work lists, counters, exchange buffer
     uint32_t n_boards[RS_MAX_ROUNDS] = {0, 0, 0};
     uint32_t n_clusters = 0;
     size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
@@ -1635,6 +1636,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
             }
         }
+        s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256);
         e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
         if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
         {
@@ -1686,6 +1688,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus) * 2, (size_t(n) + kOrderThreads - 1) / kOrderThreads));
                 const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, kOrderThreads));
                 const uint32_t max_bins = std::max(bins[0], bins[1]);
+                s->other_bytes += pitch * 32 + size_t(2) * max_bins * sizeof(uint32_t);
                 e = hipMalloc(&s->d_arec, pitch * 32);
                 if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
                 if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(2) * max_bins * sizeof(uint32_t));
@@ -1717,6 +1720,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             std::vector<PackJob> jobs;
             const size_t pitch = round_up(s->deals.n_deals, kLanePad);
             for (int r = 0; r < s->n_rounds && e == hipSuccess; ++r) {
+                s->other_bytes += pitch * 16;
                 e = hipMalloc(&s->d_attr[r], pitch * 16);
                 if (e == hipSuccess) e = hipMemsetAsync(s->d_attr[r], 0, pitch * 16, table->stream);
                 PackJob j{};
@@ -1759,6 +1763,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             } else {
                 (void)hipFree(s->d_attr[r]);
                 s->d_attr[r] = nullptr;
+                s->other_bytes -= round_up(s->deals.n_deals, kLanePad) * 16;
             }
         }
         if (int(keep.size()) != s->n_pack_jobs) {
@@ -1801,6 +1806,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         const size_t nb = size_t(std::max(s->plan[0].n_boundary, s->plan[1].n_boundary));
         s->exchange_floats_per_rank = nb * s->slot_lanes;
         const size_t bytes = std::max<size_t>(size_t(s->params.shard_world) * s->exchange_floats_per_rank * sizeof(float), 256);
+        s->other_bytes += bytes;
         if ((e = hipMalloc((void **)&s->d_exchange, bytes)) != hipSuccess || (e = hipMemsetAsync(s->d_exchange, 0, bytes, table->stream)) != hipSuccess) {
             rc = hip_fail(e, "rs_solver_create: exchange buffer");
             rs_solver_destroy(s);
@@ -1814,6 +1820,9 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     for (int p = 0; p < 2; ++p) {
         Plan &pl = s->plan[p];
         const size_t bytes = std::max<size_t>(pl.jobs.size(), 1) * sizeof(NodeJob);
+        s->other_bytes += bytes + std::max<size_t>(pl.chance_jobs.size(), 1) * sizeof(ChanceJob) + pl.n_count_words * sizeof(uint32_t) + pl.compact_jobs.size() * sizeof(CompactJob) +
+                          size_t(pl.n_apply_jobs) * sizeof(ApplyJob);
+        for (const JitLaunch &JL : pl.jit) s->other_bytes += JL.blob.size() + (JL.worklist ? (size_t(JL.n_jobs) + 3) * sizeof(uint32_t) : 0);
         if ((e = hipMalloc((void **)&pl.d_jobs, bytes)) != hipSuccess) {
             rc = hip_fail(e, "rs_solver_create: job allocation");
             rs_solver_destroy(s);
@@ -1940,7 +1949,7 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
     return RS_OK;
 }
 
-size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes : 0; }
+size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes + s->other_bytes : 0; }
 
 int rs_jit_available(void) { return jit_available() ? 1 : 0; }
 

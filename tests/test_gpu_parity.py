@@ -1159,3 +1159,31 @@ def test_c_examples_run_through_the_c_abi(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "1081 / 1081 river clusters" in r.stdout
     assert float(re.search(r"exploitability (-?[\d.]+)", r.stdout).group(1)) < 20.0, r.stdout
+
+
+@pytest.mark.parametrize("shadow", ["rule-mixed", "all"])
+def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
+    """sampled sweeps read a node through its AoS shadow (rebuilt per sweep) only where the batch is likely to read the record at all (rs_solver.cpp: n_deals * 8 >= clusters *
+    actions * round subtrees); elsewhere the kernels gather the table's own rows (gather_node / gather_node2 with a null shadow).  3 000 deals against 30 / 300 / 140 clusters:
+    every flop and turn node keeps its shadow, on the river the two-action nodes keep theirs (140 * 2 * 72 < 24 000) and the three-action nodes lose it -- both kinds inside
+    ONE generated subtree.  "all" (RS_SHADOW_ALL) shadows everything.  Same bits as the oracle either way, and the workspace figure shows the difference."""
+    if shadow == "all":
+        monkeypatch.setenv("RS_JIT_SHADOW_ALL", "1")
+    n_deals = 3000
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(30, 28), (300, 280), (140, 140)], n_deals, 93)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=14)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=True, opp_mode=orc.OPP_SAMPLE, base_seed=14)
+    test_deal_sweeps_with_and_without_table_shadows.workspace[shadow] = tr.workspace_bytes
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+    ws = test_deal_sweeps_with_and_without_table_shadows.workspace
+    if len(ws) == 2:   # rs_solver_workspace_bytes counts the shadow: shadowing every node costs the river's three-action records (16 + 32 bytes per cluster and traverser sweep)
+        assert ws["all"] > ws["rule-mixed"]
+
+
+test_deal_sweeps_with_and_without_table_shadows.workspace = {}
