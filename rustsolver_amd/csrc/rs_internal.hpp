@@ -266,6 +266,13 @@ void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, c
                       bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
+uint64_t jit_source_key(const std::string &source);   // what the caches are keyed by (source + compiler version + options)
+struct JitRequest {
+    const std::string *source, *entry;
+    hipFunction_t fn;
+};
+// the same for many kernels: the ones no cache holds are compiled concurrently on host threads, then loaded one after the other
+int jit_get_kernels(std::vector<JitRequest> &reqs, int device, bool dump = false);
 int jit_compile_only(const std::string &source, bool dump = false);
 const char *jit_device_source();
 

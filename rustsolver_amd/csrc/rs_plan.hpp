@@ -1,0 +1,161 @@
+// rs_plan.hpp -- what the plan builder (rs_plan.cpp) and the executor (rs_solver.cpp) share: the launch plan of one traverser and the solver object.  Not part of the ABI.
+#pragma once
+
+#include <map>
+#include <vector>
+
+#include "rs_internal.hpp"
+
+namespace rs {
+
+constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
+constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
+constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER };
+
+struct Launch {
+    int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
+    int kind;
+    int n_actions = 0;
+    int first_job = 0, n_jobs = 0;
+    uint32_t max_n_vec = 0;
+    size_t max_lanes = 0;   // chance launches: largest lane count among the jobs
+    double bytes = 0.0;
+};
+
+struct ReachSrc {
+    const float *ptr = nullptr;
+    float cst = 1.0f;
+    bool valid = false;
+};
+
+// one launch of a tree-specialised (hipRTC) kernel: blockIdx.y indexes the argument blobs
+struct JitLaunch {
+    hipFunction_t fn = nullptr;         // resolved by rs_solver_create once the whole plan is known (all kernels compiled together)
+    std::string source, entry;          // the generated source and its entry point (released after the compile)
+    std::vector<unsigned char> blob;   // n_jobs * stride bytes, layout = JArgs of the generated source
+    size_t stride = 0;
+    int n_jobs = 0;
+    uint32_t max_n_vec = 0;
+    unsigned char *d_blob = nullptr;
+    double bytes = 0.0;
+    int threads = 256;
+    size_t lds_bytes = 0;
+    bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
+    bool seg = false;                   // ordered sweeps, last round: no LDS, 256-thread workgroups, many per CU
+    bool worklist = false;              // list-walking kernels with LDS tiles: a 1-D grid of resident workgroups pulls (job, trip) items; k_worklist runs right before
+    uint32_t *d_wl = nullptr;           // [2 + n_jobs + 1]
+    uint32_t off_count = 0, deals_per_trip = 0;
+};
+
+struct Plan {
+    std::vector<ChanceJob> chance_jobs;   // L_EXPAND / L_REDUCE launches index into this (first_job, n_jobs)
+    ChanceJob *d_chance_jobs = nullptr;
+    std::vector<JitLaunch> jit;
+    std::vector<NodeJob> jobs;
+    NodeJob *d_jobs = nullptr;
+    std::vector<Launch> launches;
+    // sparse deal sweeps: per subtree root the list of live deals (reach not NaN), rebuilt by k_compact_live after the top-down pass
+    uint32_t *d_lists = nullptr;        // [n_compact][pitch]
+    float *d_rlists = nullptr;          // position-indexed rows: the reach of every list entry, same shape as d_lists
+    uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
+    ApplyJob *d_apply_jobs = nullptr;   // deal sweeps: the cell ranges of the traverser's own nodes (where its deltas are)
+    int n_apply_jobs = 0;
+    size_t apply_max_vec = 0;
+    size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees
+    size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
+    uint32_t *d_counts = nullptr;       // [n_compact]
+    CompactJob *d_compact_jobs = nullptr;
+    std::vector<CompactJob> compact_jobs;
+    std::vector<size_t> count_off;      // per compact job: index of its first counter (a job has one per cluster range)
+    uint32_t compact_max_lanes = 0;
+    float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep
+    size_t reach_nan_bytes = 0;
+    size_t split = 0;                   // sharded sweeps: launches [0, split) = phase 0, [split, end) = phase 1
+    int n_boundary = 0;                 // chance nodes entering the sharded round
+    size_t arena_bytes = 0;
+    const float *root_util = nullptr;   // inside the arena
+    size_t root_lanes = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+};
+
+
+}  // namespace rs
+
+using rs::Knobs;
+using rs::OrderJob;
+using rs::PackJob;
+using rs::Plan;
+using rs::ShadowJob;
+
+struct rs_solver {
+    rs_table *table = nullptr;
+    rs_tree tree;
+    rs_solver_params params{};
+    Knobs knobs;                        // kernel-form switches, resolved once at creation (rs_knobs.cpp)
+    int lds_limit = 64 * 1024;          // LDS bytes the device gives ONE workgroup (MI355X: 160 KiB), queried at creation
+    std::vector<rs_leaf_desc> leaves[2];
+    Plan plan[2];
+    char *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t other_bytes = 0;             // every other device allocation of the solver: table shadow, packed / ordered per-deal records, job blobs, work lists, counters, exchange buffer
+    uint32_t n_boards[RS_MAX_ROUNDS] = {0, 0, 0};
+    uint32_t n_clusters = 0;
+    size_t pitch[RS_MAX_ROUNDS] = {0, 0, 0};
+    int n_rounds = 0;
+    // multi-GPU sharding (rs_solver_params.shard_*)
+    bool sharded = false;
+    uint32_t shard_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // first global board of every rank at shard_round, then the total
+    size_t slot_lanes = 0;              // floats per (rank, boundary node) in the exchange buffer
+    float *d_exchange = nullptr;        // [world][n_boundary][slot_lanes]
+    size_t exchange_floats_per_rank = 0;
+    rs_comm *comm = nullptr;
+    int n_cus = 256;                    // multiprocessors of the device (grid of the persistent deal kernels)
+    // round subtrees of one round are independent: their launches are spread over a few auxiliary streams (fork / join with events)
+    static constexpr int kAux = 4;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    // deal sweeps through tree-specialised kernels read the table from an AoS shadow rebuilt at the start of every sweep
+    int32_t *d_shadow = nullptr;
+    ShadowJob *d_shadow_jobs = nullptr;   // the jobs of traverser 0's sweep, then those of traverser 1's (the same nodes, different record widths)
+    int n_shadow_jobs = 0;                // per traverser
+    std::vector<size_t> shadow_off_p[2];  // per traverser and table node, in ints (SIZE_MAX: no shadow)
+    std::vector<uint32_t> shadow_stride_p[2];
+    uint32_t shadow_max_clusters = 0;
+    // sparse deal sweeps fetch the per-deal inputs of a round (both cluster ids, leaf value, prune flag) as ONE packed 16-byte record per live deal
+    void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
+    PackJob *d_pack_jobs = nullptr;
+    int n_pack_jobs = 0;
+    unsigned attr_used = 0;             // bit r: some generated kernel reads the packed records of round r (only the list-walking forms do)
+    // ordered sweeps (rs_kernel_forms.deal_order): traverser p's sweep walks the batch sorted by p's cluster id on the last round; d_arec holds the 32-byte per-deal
+    // records in that order (rebuilt at the start of every sweep by k_order_*), d_attr[r] all point at it
+    bool ordered = false;
+    int order_round = 0;                // the last betting round of the tree
+    void *d_arec = nullptr;
+    uint32_t *d_order_tot = nullptr;    // [2][n_bins]: counts and cursors of the counting sort
+    OrderJob order_job[2];              // per traverser
+    bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
+    rs_deal_batch deals{};
+    uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
+    const uint64_t *d_seed() const { return d_seed_state ? d_seed_state + 2 : nullptr; }
+};
+
+namespace rs {
+
+#define RS_HIP(call, what)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return rs::hip_fail(e_, what); \
+    } while (0)
+
+// rs_plan.cpp: shapes and sharding derived from table + tree (validation included), then one PlanBuilder per traverser: layout() decides which buffers exist
+// (offsets into the arena the caller then allocates), emit() writes the jobs and launches
+int derive_geometry(rs_solver *s);
+struct PlanBuilder;
+PlanBuilder *plan_builder_new(rs_solver *s, int traverser);
+int plan_builder_layout(PlanBuilder *b);
+int plan_builder_emit(PlanBuilder *b);
+void plan_builder_free(PlanBuilder *b);
+
+}  // namespace rs

@@ -1,0 +1,294 @@
+// rs_plan_deals.cpp -- the host-side traversal scheduler, part 1b: what only DEAL sweeps need (rs_solver_create_deals: lanes are sampled deals, mccfr() as the reference
+// runs it, cfr.rs:299-479).  A deal has one run-out, so the tree is cut at the chance nodes into ONE generated subtree per betting round and root, each with a reach-down
+// kernel and a walk that updates the table; below a sampled opponent node most deals are off their path, so every round subtree walks a compacted list of its LIVE deals;
+// where the LDS delta tiles of a subtree's traverser nodes do not fit one workgroup together the cluster axis is cut into ranges (one list and one kernel job per range);
+// list-walking kernels with tiles pull (job, trip) items from a device-built work list; after the sweep the i32 deltas are applied over the traverser's own nodes.
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "rs_plan_builder.hpp"
+
+using namespace rs;
+
+namespace rs {
+
+PlanBuilder::Parts PlanBuilder::parts_of(int root) const {
+    const rs_table *t = s->table;
+    size_t sum_a = 0;
+    uint32_t n_cl = 0, pitch = 0;
+    std::vector<int> stack{root};
+    while (!stack.empty()) {
+        const int q = stack.back();
+        stack.pop_back();
+        const rs_tree_node &qn = nodes[q];
+        if (qn.kind == RS_NODE_ACTION && qn.player == p && qn.n_children > 0) {
+            sum_a += size_t(qn.n_children);
+            n_cl = t->nodes[size_t(qn.index)].n_clusters;
+            pitch = uint32_t(t->pitch[size_t(qn.index)]);
+        }
+        for (int k = 0; k < qn.n_children; ++k) {
+            const int c = qn.children[k];
+            if (nodes[c].kind != RS_NODE_PRIVATE_CHANCE && nodes[c].kind != RS_NODE_PUBLIC_CHANCE) stack.push_back(c);
+        }
+    }
+    const size_t limit = size_t(lds_limit) / 4;
+    if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit || seg_root(root)) return Parts{1u, pitch, n_cl, pitch};
+    // Partitioning costs list indirection (gathers instead of row loads, a bucketing pass).  When most tiles would be resident anyway --
+    // 1 081 clusters miss the budget by 1 % and keep 5 of 7 -- it loses (measured 1.33 against 0.84 ms per batch): only partition when
+    // fewer than half of the tile bytes fit.
+    if (limit * 2 >= 2 * sum_a * pitch) return Parts{1u, pitch, n_cl, pitch};
+    const uint32_t r = uint32_t(limit / (2 * sum_a)) / 64u * 64u;
+    if (r < 64u || (n_cl + r - 1) / r > 64u) return Parts{1u, pitch, n_cl, pitch};   // k_compact_live handles up to 64 ranges
+    return Parts{(n_cl + r - 1) / r, r, n_cl, pitch};
+}
+
+void PlanBuilder::mark_round_inside(int root, int id) {
+    for (int k = 0; k < nodes[id].n_children; ++k) {
+        int c = nodes[id].children[k];
+        bool through_chance = false;
+        while (nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE) {
+            inside[c] = 1;   // nothing is launched for a pass-through chance node
+            through_chance = true;
+            c = nodes[c].children[0];
+        }
+        if (through_chance && nodes[c].kind == RS_NODE_ACTION && nodes[c].n_children > 0) {
+            bnd[size_t(root)].push_back(c);
+            mark_round(c);
+        } else {
+            inside[c] = 1;
+            if (nodes[c].kind == RS_NODE_ACTION) mark_round_inside(root, c);
+        }
+    }
+}
+
+void PlanBuilder::mark_round(int root) {
+    fused_root[root] = 1;
+    mark_round_inside(root, root);
+}
+
+// `segments`: the utility row of a root below a LISTED parent is addressed by the parent's list position, one segment per cluster range of the parent (pos_rows)
+void PlanBuilder::layout_round(int root, size_t segments) {
+    util_off[root] = alloc(lane_round[root], segments);
+    const size_t below = (pos_rows && listed_root(root)) ? size_t(parts_of(root).first) : size_t(1);
+    for (int b : bnd[size_t(root)]) {
+        nan_slot[size_t(b)] = n_nan++;
+        layout_round(b, below);
+    }
+}
+
+int PlanBuilder::emit_deal_lists() {
+    const size_t n = nodes.size();
+    const rs_table *t = s->table;
+    // ---- sparse deal sweeps: which subtree roots get a compacted list of their live deals ---------------------------------
+    // mccfr() follows ONE opponent action per node (cfr.rs:467-476): below a sampled node most deals are off their path (NaN reach).  A
+    // subtree kernel that walks every deal would compute nothing for them; instead the live ones are compacted and only they are walked.
+    sparse_slot.assign(n, -1);
+    // the compact jobs of `ids` (in that order); reach_of(id) = the buffer whose non-NaN lanes are the live deals
+    auto make_lists = [&](const std::vector<int> &ids, auto reach_of) -> int {
+        const size_t n_sparse = ids.size();
+        if (!n_sparse) return RS_OK;
+        size_t list_elems = 0, n_counts = 0;
+        std::vector<uint32_t> n_parts(n_sparse, 1), part_size(n_sparse, 0);
+        for (size_t k = 0; k < n_sparse; ++k) {
+            const Parts pr = parts_of(ids[k]);
+            n_parts[k] = pr.first;
+            part_size[k] = pr.second;
+            list_elems += size_t(pr.first) * s->pitch[lane_round[ids[k]]];
+            n_counts += pr.first;
+        }
+        hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
+        if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
+        if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_plists, list_elems * sizeof(uint32_t));
+        plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + (pos_rows ? 2 : 0));
+        plan.n_count_words = n_counts * kCountStride;
+        if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
+        if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
+        if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+        plan.compact_jobs.resize(n_sparse);
+        plan.count_off.assign(n_sparse + 1, 0);
+        size_t at = 0, cat = 0;
+        for (size_t k = 0; k < n_sparse; ++k) {
+            const int id = ids[k];
+            sparse_slot[id] = int(k);
+            CompactJob &cj = plan.compact_jobs[k];
+            cj = CompactJob{};
+            cj.reach = reach_of(id);
+            cj.list = plan.d_lists + at;
+            cj.count = plan.d_counts + cat * kCountStride;   // one cache line each: atomics on neighbours would serialise
+            cj.n_lanes = s->deals.n_deals;
+            cj.n_parts = n_parts[k];
+            cj.part_size = std::max<uint32_t>(1, part_size[k]);
+            cj.list_stride = uint32_t(s->pitch[lane_round[id]]);
+            cj.count_stride = uint32_t(kCountStride);
+            cj.key = n_parts[k] > 1 ? s->deals.d_cluster[nodes[id].round_idx][p] : nullptr;   // the traverser's cluster on this round
+            cj.key_stride = 1;
+            if (cj.key && s->ordered) {   // list entries are ranks: the key sits in the rank's record
+                cj.key = static_cast<const uint32_t *>(s->d_arec) + 2 * nodes[id].round_idx + p;
+                cj.key_stride = 8;
+            }
+            plan.count_off[k] = cat;
+            at += size_t(n_parts[k]) * s->pitch[lane_round[id]];
+            cat += n_parts[k];
+            plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
+        }
+        plan.count_off[n_sparse] = cat;
+        // a deal can only be live in a round subtree if its PARENT subtree walked it: scan the parent's live lists rather than the whole batch (the parent's reach-down
+        // kernel writes every boundary row for every deal it walks -- reach or NaN -- so nothing stale is ever read and the rows need no NaN fill per sweep)
+        if (scan_parent)
+            for (size_t k = 0; k < n_sparse; ++k) {
+                const int par = parent_root_.empty() ? -1 : parent_root_[size_t(ids[k])];
+                if (par < 0 || sparse_slot[size_t(par)] < 0) continue;
+                const CompactJob &pj = plan.compact_jobs[size_t(sparse_slot[size_t(par)])];
+                CompactJob &cj = plan.compact_jobs[k];
+                cj.src_list = pj.list;
+                cj.src_count = pj.count;
+                cj.src_parts = pj.n_parts;
+                cj.src_list_stride = pj.list_stride;
+                cj.src_count_stride = pj.count_stride;
+                cj.pos_rows = pos_rows ? 1u : 0u;
+            }
+        if (pos_rows)   // every list but the first root's carries the reach of its entries (the first root's deals are all live, with the constant root reach)
+            for (size_t k = 0; k < n_sparse; ++k)
+                if (ids[k] != first_root) {
+                    plan.compact_jobs[k].rlist = plan.d_rlists + (plan.compact_jobs[k].list - plan.d_lists);
+                    plan.compact_jobs[k].plist = plan.d_plists + (plan.compact_jobs[k].list - plan.d_lists);
+                }
+        ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
+        if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
+        return RS_OK;
+    };
+    auto push_compact = [&](int first, int count) {
+        if (count <= 0) return;
+        Launch L;
+        L.kind = L_COMPACT;
+        L.first_job = first;
+        L.n_jobs = count;
+        L.bytes = 8.0 * double(s->deals.n_deals) * count;
+        plan.launches.push_back(L);
+    };
+    if (round_mode) {
+        // ---- round subtrees, top-down: NaN-fill every root's reach buffer, then round by round compact the live deals of the round's
+        // roots and let their DOWN kernels hand reach to the next round's roots
+        roots_of_round.assign(1, std::vector<int>{first_root});
+        for (size_t r = 0; r < roots_of_round.size(); ++r)
+            for (int root : roots_of_round[r])
+                for (int b : bnd[size_t(root)]) {
+                    if (roots_of_round.size() <= r + 1) roots_of_round.emplace_back();
+                    roots_of_round[r + 1].push_back(b);
+                }
+        std::vector<int> &parent_root = parent_root_;
+        parent_root.assign(n, -1);
+        for (size_t r = 0; r < roots_of_round.size(); ++r)
+            for (int root : roots_of_round[r])
+                for (int b : bnd[size_t(root)]) parent_root[size_t(b)] = root;
+        nan_off.assign(size_t(n_nan) + 1, 0);
+        for (size_t b = 0; b < n; ++b)
+            if (nan_slot[b] >= 0) {   // rows of a listed parent hold one list-position segment per cluster range of the parent
+                const int par = parent_root[b];
+                nan_off[size_t(nan_slot[b]) + 1] = s->pitch[0] * ((pos_rows && par >= 0 && listed_root(par)) ? size_t(parts_of(par).first) : size_t(1));
+            }
+        for (size_t k = 0; k < size_t(n_nan); ++k) nan_off[k + 1] += nan_off[k];
+        if (n_nan) {
+            plan.reach_nan_bytes = nan_off[size_t(n_nan)] * sizeof(float);
+            plan.aux_bytes += plan.reach_nan_bytes;
+            hipError_t en = hipMalloc((void **)&plan.d_reach_nan, plan.reach_nan_bytes);
+            if (en == hipSuccess) en = hipMemsetAsync(plan.d_reach_nan, 0xff, plan.reach_nan_bytes, t->stream);
+            if (en != hipSuccess) return hip_fail(en, "rs_solver_create: reach buffers of the round subtrees");
+            // dense sweeps read every lane of a root's row: lanes nobody handed a reach to must hold NaN.  List sweeps only ever read what the parent's reach-down
+            // kernel wrote in THIS sweep (the compaction scans the parent's lists), so they need no fill -- unless the old whole-batch scan is asked for
+            if (!scan_parent) {
+                Launch L;
+                L.kind = L_NANFILL;
+                plan.launches.push_back(L);
+            }
+        }
+        std::vector<int> listed;
+        std::vector<std::pair<int, int>> slots_of_round(roots_of_round.size(), {0, 0});   // (first compact job, count)
+        if (want_lists && parts_of(first_root).first > 1) {   // its tiles had to be partitioned: every deal is live, listed by cluster range
+            slots_of_round[0] = {0, 1};
+            listed.push_back(first_root);
+        }
+        if (want_lists)
+            for (size_t r = 1; r < roots_of_round.size(); ++r) {
+                slots_of_round[r] = {int(listed.size()), int(roots_of_round[r].size())};
+                listed.insert(listed.end(), roots_of_round[r].begin(), roots_of_round[r].end());
+            }
+        if (int rc = make_lists(listed, [&](int id) { return id == first_root ? (const float *)nullptr : (const float *)nan_ptr(id); })) return rc;
+        for (size_t r = 0; r < roots_of_round.size(); ++r) {
+            push_compact(slots_of_round[r].first, slots_of_round[r].second);
+            std::map<uint64_t, int> by_fn;
+            for (int root : roots_of_round[r]) {
+                if (bnd[size_t(root)].empty()) continue;
+                for (int b : bnd[size_t(root)]) reach[b] = ReachSrc{nan_ptr(b), 0.0f, true};
+                if (int rc = add_jit_job(root, true, sparse_slot, by_fn)) return rc;
+            }
+            const int group = ++next_group;   // the DOWN kernels of one round write different reach buffers
+            for (auto &kv : by_fn) {
+                Launch L;
+                L.kind = L_TREE;
+                L.group = group;
+                L.first_job = kv.second;
+                L.bytes = plan.jit[kv.second].bytes;
+                plan.launches.push_back(L);
+            }
+        }
+    } else if (want_lists) {
+        std::vector<int> listed;
+        for (size_t id = 0; id < n; ++id)
+            if (fused_root[id] && !inside[id] && !dead_end(int(id)) && reach[id].ptr) listed.push_back(int(id));
+        if (int rc = make_lists(listed, [&](int id) { return reach[id].ptr; })) return rc;
+        push_compact(0, int(listed.size()));
+    }
+    return RS_OK;
+}
+
+int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last round first; the subtrees of one round are independent of each other
+    if (round_mode)
+        for (size_t r = roots_of_round.size(); r-- > 0;) {
+            std::map<uint64_t, int> by_fn;
+            for (int root : roots_of_round[r])
+                if (int rc = add_jit_job(root, false, sparse_slot, by_fn)) return rc;
+            const int group = ++next_group;
+            for (auto &kv : by_fn) {
+                Launch L;
+                L.kind = L_TREE;
+                L.group = group;
+                L.first_job = kv.second;
+                L.bytes = plan.jit[kv.second].bytes;
+                plan.launches.push_back(L);
+            }
+        }
+    return RS_OK;
+}
+
+int PlanBuilder::emit_apply() {
+    const rs_table *t = s->table;
+    if (s->deal_mode) {   // table += delta, delta = 0: over the traverser's own nodes (nobody else's deltas were written: the other half of the delta arrays stays unread)
+        std::vector<ApplyJob> aj;
+        double cells = 0.0;
+        for (size_t i = 0; i < t->nodes.size(); ++i) {
+            const rs_node_desc &d = t->nodes[i];
+            if (d.n_actions == 0 || d.player != p) continue;
+            const size_t nc = size_t(d.n_actions) * t->pitch[i];
+            if ((t->cell_off[i] % kVec) || (nc % kVec)) { aj.clear(); break; }   // never with 64-lane padded pitches; the whole-table form is the fallback
+            aj.push_back(ApplyJob{t->cell_off[i] / kVec, nc / kVec});
+            plan.apply_max_vec = std::max(plan.apply_max_vec, nc / kVec);
+            cells += double(nc);
+        }
+        if (!aj.empty() && !s->knobs.apply_whole_table) {
+            hipError_t ea = hipMalloc((void **)&plan.d_apply_jobs, aj.size() * sizeof(ApplyJob));
+            if (ea == hipSuccess) ea = hipMemcpy(plan.d_apply_jobs, aj.data(), aj.size() * sizeof(ApplyJob), hipMemcpyHostToDevice);
+            if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");
+            plan.n_apply_jobs = int(aj.size());
+        }
+        Launch L;
+        L.kind = L_APPLY;
+        L.bytes = (plan.n_apply_jobs ? cells : double(t->n_cells)) * 32.0;
+        plan.launches.push_back(L);
+    }
+    return RS_OK;
+}
+
+}  // namespace rs
