@@ -522,18 +522,18 @@ class OracleSolver:
 class OracleDealTable(OracleTable):
     """The reference's own table shape: [action_node][cluster], sizes per (round_idx, player) (infoset.rs:28-32)."""
 
-    def __init__(self, tree, sizes):
+    def __init__(self, tree, sizes, dtype=T_I32):
         """sizes[round_idx] = (size_p0, size_p1)"""
         self.tree = tree
         self.sizes = [tuple(s) for s in sizes] + [(0, 0)] * (MAX_ROUNDS - len(sizes))
         self.n_boards = [1] * MAX_ROUNDS
         self.n_clusters = 0
-        self.dtype = T_I32
+        self.dtype = dtype
         self.tb = Table()
         arr = ((C.c_uint32 * 2) * MAX_ROUNDS)()
         for r in range(MAX_ROUNDS):
             arr[r][0], arr[r][1] = self.sizes[r]
-        if lib().orc_table_create_sizes(C.byref(tree.t), C.byref(arr), T_I32, C.byref(self.tb)) != 0:
+        if lib().orc_table_create_sizes(C.byref(tree.t), C.byref(arr), dtype, C.byref(self.tb)) != 0:
             raise MemoryError
         self._node_by_index = {}
         for i in range(tree.n_nodes):
@@ -553,7 +553,7 @@ class OracleDealSolver(OracleSolver):
         """cidx: dict (round_idx, player) -> uint32 array [n_deals]; lane_base: global index of deal 0 (data-parallel batches);
         prune_deal: uint8 [n_deals] read at every sweep, 1 = the deal is traversed with prune = true (needs prune=True; cfr.rs:213-221)"""
         super().__init__(tree, table, leaves, chance_mode=CHANCE_PASS, **kw)
-        self.delta = OracleDealTable(tree, table.sizes)
+        self.delta = OracleDealTable(tree, table.sizes, table.dtype)
         self.n_deals = n_deals
         dc = DealCtx()
         dc.ctx = C.pointer(self.ctx)

@@ -786,6 +786,31 @@ float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t 
         orc_infoset *dinfo = &dc->delta->rows[nd->index][cluster_idx];
         float utils[ORC_MAX_ACTIONS], strategy[ORC_MAX_ACTIONS], util = 0.0f;
         const int prune = ctx->prune && (!dc->prune_deal || dc->prune_deal[deal]);   /* the `prune` argument of mccfr(), cfr.rs:219-221 */
+        if (ctx->table->dtype == ORC_T_F32) {
+            /* f32 tables (extension): every deal reads the table as of sweep start; its visit contributes dr = (scale*reach)*(u-util), ds = (scale*reach)*sigma, which
+             * are added to the cell's delta IN DEAL ORDER (this loop runs deals 0, 1, 2, ..), each delta starting the sweep at 0.0; orc_iterate_deals then adds the deltas
+             * to the table.  No prune, no RM+ (the device refuses them for f32 deal batches) */
+            orc_get_strategy_f32(infoset->fregrets, n_actions, strategy);
+            if (nd->player == player) {
+                float k;
+                for (i = 0; i < n_actions; i++) utils[i] = orc_traverse_deal(dc, nd->children[i], player, deal, cfr_reach);
+                for (i = 0; i < n_actions; i++) util += utils[i] * strategy[i];
+                k = ctx->scale * cfr_reach;
+                for (i = 0; i < n_actions; i++) {
+                    dinfo->fregrets[i] = dinfo->fregrets[i] + k * (utils[i] - util);
+                    dinfo->fstrategy_sum[i] = dinfo->fstrategy_sum[i] + k * strategy[i];
+                }
+            } else if (ctx->opp_mode == ORC_OPP_SAMPLE) {
+                int a_idx = orc_weighted_index(strategy, n_actions, orc_sample_bits(ctx->sample_seed, (uint32_t)nd->index, dc->lane_base + deal));
+                util = orc_traverse_deal(dc, nd->children[a_idx], player, deal, cfr_reach * strategy[a_idx]);
+            } else {
+                for (i = 0; i < n_actions; i++) {
+                    utils[i] = orc_traverse_deal(dc, nd->children[i], player, deal, strategy[i] * cfr_reach);
+                    util += utils[i] * strategy[i];
+                }
+            }
+            return util;
+        }
         orc_get_strategy(infoset->regrets, n_actions, strategy);
         if (nd->player == player) {
             int32_t r[ORC_MAX_ACTIONS], s[ORC_MAX_ACTIONS];
@@ -828,6 +853,15 @@ void orc_iterate_deals(const orc_deal_ctx *dc, int player, float *root_util) {
     for (i = 0; i < dc->ctx->table->n_rows; i++)
         for (j = 0; j < dc->ctx->table->row_len[i]; j++) {
             orc_infoset *is = &dc->ctx->table->rows[i][j], *di = &dc->delta->rows[i][j];
+            if (dc->ctx->table->dtype == ORC_T_F32) {
+                for (k = 0; k < is->n_actions; k++) {
+                    is->fregrets[k] = is->fregrets[k] + di->fregrets[k];
+                    is->fstrategy_sum[k] = is->fstrategy_sum[k] + di->fstrategy_sum[k];
+                    di->fregrets[k] = 0.0f;
+                    di->fstrategy_sum[k] = 0.0f;
+                }
+                continue;
+            }
             for (k = 0; k < is->n_actions; k++) {
                 is->regrets[k] = wrapping_add_i32(is->regrets[k], di->regrets[k]);
                 is->strategy_sum[k] = wrapping_add_i32(is->strategy_sum[k], di->strategy_sum[k]);

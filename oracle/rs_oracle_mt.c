@@ -117,9 +117,15 @@ static int create_sizes_rec(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUN
         for (k = 0; k < n; k++) {
             orc_infoset *is = &tb->rows[nd->index][k];
             is->n_actions = nd->n_children;
-            is->regrets = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
-            is->strategy_sum = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
-            if (!is->regrets || !is->strategy_sum) return -1;
+            if (tb->dtype == ORC_T_I32) {
+                is->regrets = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
+                is->strategy_sum = (int32_t *)calloc((size_t)nd->n_children, sizeof(int32_t));
+                if (!is->regrets || !is->strategy_sum) return -1;
+            } else {   /* f32 deal tables (extension) */
+                is->fregrets = (float *)calloc((size_t)nd->n_children, sizeof(float));
+                is->fstrategy_sum = (float *)calloc((size_t)nd->n_children, sizeof(float));
+                if (!is->fregrets || !is->fstrategy_sum) return -1;
+            }
         }
     }
     for (i = 0; i < nd->n_children; i++)
@@ -131,7 +137,7 @@ int orc_table_create_sizes(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUND
     out->dtype = dtype;
     out->rows = (orc_infoset **)calloc((size_t)out->n_rows, sizeof(orc_infoset *));
     out->row_len = (size_t *)calloc((size_t)out->n_rows, sizeof(size_t));
-    if (!out->rows || !out->row_len || dtype != ORC_T_I32) return -1;
+    if (!out->rows || !out->row_len || (dtype != ORC_T_I32 && dtype != ORC_T_F32)) return -1;
     return create_sizes_rec(t, sizes, out, 0);
 }
 

@@ -171,8 +171,9 @@ __device__ __forceinline__ void load_u32_row(const unsigned *base, unsigned v, u
     for (int j = 0; j < kVecD; j++) out[j] = *(as_global<unsigned>(base) + v * kVecD + j);
 #endif
 }
-__device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, const unsigned (&idx)[kVecD], int (&out)[kVecD]) {
-    const RS_GLOBAL int *p = as_global<int>((const int *)base + row_off);
+template <typename V>
+__device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, const unsigned (&idx)[kVecD], V (&out)[kVecD]) {   // V = int or float: a 4-byte table element
+    const RS_GLOBAL V *p = as_global<V>((const V *)base + row_off);
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = p[idx[j]];
 }
@@ -215,19 +216,29 @@ __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (
 }
 // A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
 // from the table's own [A][pitch] rows, one 4-byte gather per (action, array).  `shadow` is a kernel argument: the branch is uniform.
-template <int A>
-__device__ __forceinline__ void gather_node(const void *shadow, unsigned stride, const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {
-    if (shadow) gather_rec<A>(shadow, stride, idx, r);
-    else {
+template <int A, typename V>
+__device__ __forceinline__ void gather_node(const void *shadow, unsigned stride, const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], V (&r)[A][kVecD]) {
+    if constexpr (sizeof(V) == sizeof(int) && (V)0.5 == (V)0) {
+        if (shadow) {
+            gather_rec<A>(shadow, stride, idx, r);
+            return;
+        }
+    }
+    {   // f32 tables have no shadow (the solver builds none)
 #pragma unroll
         for (int a = 0; a < A; a++) gather_i32(reg, a * tpitch, idx, r[a]);
     }
 }
-template <int A>
-__device__ __forceinline__ void gather_node2(const void *shadow, const void *reg, const void *ssm, unsigned tpitch, const unsigned (&idx)[kVecD], int (&r)[A][kVecD],
-                                             int (&s)[A][kVecD]) {
-    if (shadow) gather_rec2<A>(shadow, idx, r, s);
-    else {
+template <int A, typename V>
+__device__ __forceinline__ void gather_node2(const void *shadow, const void *reg, const void *ssm, unsigned tpitch, const unsigned (&idx)[kVecD], V (&r)[A][kVecD],
+                                             V (&s)[A][kVecD]) {
+    if constexpr (sizeof(V) == sizeof(int) && (V)0.5 == (V)0) {
+        if (shadow) {
+            gather_rec2<A>(shadow, idx, r, s);
+            return;
+        }
+    }
+    {
 #pragma unroll
         for (int a = 0; a < A; a++) {
             gather_i32(reg, a * tpitch, idx, r[a]);
@@ -421,6 +432,39 @@ __device__ __forceinline__ float visit_f32(float (&r)[A], float (&s)[A], const f
         }
     }
     return util;
+}
+
+// f32 tables under DEAL sweeps: several deals of a batch may address one info set, and f32 sums do not commute, so a visit does not add into anything: it hands out its
+// two delta vectors, dr = (scale*reach)*(u-util) and ds = (scale*reach)*sigma (0 for a lane that is not on its deal's path), which the sweep stores per deal; after the
+// sweep every cell's deltas are summed IN DEAL ORDER from 0.0 and added to the table (k_apply_f32_rows) -- the order the oracle's sequential loop over the deals has.
+template <int A>
+__device__ __forceinline__ float visit_f32_delta(const float (&r)[A], const float (&u)[A], float reach, float scale, float (&dr)[A], float (&ds)[A]) {
+    float sig[A];
+    regret_match<A, float>(r, sig);
+    float util = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) util += u[a] * sig[a];
+    const bool active = !(reach != reach);
+    const float k = scale * reach;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        dr[a] = active ? k * (u[a] - util) : 0.0f;
+        ds[a] = active ? k * sig[a] : 0.0f;
+    }
+    return util;
+}
+template <int A>
+__device__ __forceinline__ void lanes_visit_delta(const float (&r)[A][kVecD], const float (&u)[A][kVecD], const float (&reach)[kVecD], float scale, float (&dr)[A][kVecD],
+                                                  float (&ds)[A][kVecD], float (&dest)[kVecD]) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        float rl[A], ul[A], d1[A], d2[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) { rl[a] = r[a][j]; ul[a] = u[a][j]; }
+        dest[j] = visit_f32_delta<A>(rl, ul, reach[j], scale, d1, d2);
+#pragma unroll
+        for (int a = 0; a < A; a++) { dr[a][j] = d1[a]; ds[a][j] = d2[a]; }
+    }
 }
 
 // ---- opponent sampling: mccfr's `WeightedIndex::new(&strategy)` + `dist.sample(rng)` (cfr.rs:471-472) ------------

@@ -167,6 +167,19 @@ struct ApplyJob {
     size_t n_vec;
 };
 hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, void *dssum, const ApplyJob *d_jobs, int n_jobs, size_t max_vec, hipStream_t stream);
+// deal sweeps on f32 tables: the per-deal delta rows of one traverser node ([2A][pitch]: regret deltas, then strategy-sum deltas) are summed per cluster over the cluster's
+// deals IN DEAL ORDER (members[start[c] .. start[c + 1]) ascending) from 0.0 and the sums added to the node's table rows
+struct ApplyF32Job {
+    float *reg, *ssm;          // [A][tpitch]
+    const float *rows;         // [2A][pitch]
+    const uint32_t *start, *members;
+    uint32_t n_actions, tpitch, n_clusters, pad_;
+};
+hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, hipStream_t stream);
+// stable counting sort of 0 .. n-1 by key (rs_kmeans.hip): members[start[c] .. start[c + 1]) = the indices with key c, ascending; scratch: tile_hist [ceil(n / 512)][k], total [k]
+hipError_t launch_member_lists(const uint32_t *keys, size_t n, int k, uint32_t *tile_hist, uint32_t *total, uint32_t *start /* [k + 1] */, uint32_t *members /* [n] */,
+                               hipStream_t stream);
+size_t member_list_tiles(size_t n);
 hipError_t launch_showdown_sign(const uint8_t *cards, float *sign, uint32_t n, uint32_t pitch, hipStream_t stream);
 hipError_t launch_next_seed(uint64_t *d_state /* {base, call_index, seed} */, hipStream_t stream);
 hipError_t launch_probe_copy(const void *in, void *out, size_t bytes, unsigned blocks, hipStream_t stream);   // rs_stream_probe

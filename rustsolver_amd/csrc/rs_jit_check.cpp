@@ -138,6 +138,15 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                         if (int rc = jit_compile_only(jo.source, knobs.dump != 0)) return rc;
                     }
                 }
+                if (f6 == 0 || f6 == 4) {   // deal sweeps on RS_F32 tables: the dense reach-down half and the dense walk that stores its deltas per deal (no prune on floats)
+                    JitSubtree jf;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_F32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, false, down, false, lanes,
+                                     &root, jf, knobs, 0, false);
+                    if (!(down && jf.boundary_roots.empty()) && !seen.count(jf.source)) {
+                        seen[jf.source] = 1;
+                        if (int rc = jit_compile_only(jf.source, knobs.dump != 0)) return rc;
+                    }
+                }
                 if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
                     JitSubtree jw;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,

@@ -926,6 +926,25 @@ hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *d
                        (int32_t *)dssum, n_vec);
     return hipGetLastError();
 }
+// deal sweeps on f32 tables: one thread per (cluster, row of the node's [2A] delta rows) adds the deltas of the cluster's deals one after the other, in deal order
+__global__ __launch_bounds__(kBlock) void k_apply_f32_rows(const ApplyF32Job *__restrict__ jobs, uint32_t pitch) {
+    const ApplyF32Job job = jobs[blockIdx.y];
+    const uint32_t rows = 2 * job.n_actions, n = job.n_clusters * rows;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t x = i / job.n_clusters, c = i - x * job.n_clusters;   // consecutive threads: consecutive clusters of one row
+        const float *__restrict__ row = job.rows + (size_t)x * pitch;
+        float acc = 0.0f;
+        for (uint32_t m = job.start[c]; m < job.start[c + 1]; ++m) acc += row[job.members[m]];
+        float *cell = (x < job.n_actions ? job.reg + (size_t)x * job.tpitch : job.ssm + (size_t)(x - job.n_actions) * job.tpitch) + c;
+        *cell = *cell + acc;
+    }
+}
+hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) * 2 * RS_MAX_ACTIONS + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_apply_f32_rows, grid, block, 0, stream, d_jobs, pitch);
+    return hipGetLastError();
+}
 hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, void *dssum, const ApplyJob *d_jobs, int n_jobs, size_t max_vec, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((max_vec + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);

@@ -306,6 +306,18 @@ __global__ __launch_bounds__(kKmBlock) void k_kmeans_scatter(const unsigned *__r
     }
 }
 typedef float km_f32x4 __attribute__((ext_vector_type(4)));
+size_t member_list_tiles(size_t n) { return (n + kKmTile - 1) / kKmTile; }
+hipError_t launch_member_lists(const uint32_t *keys, size_t n, int k, uint32_t *tile_hist, uint32_t *total, uint32_t *start, uint32_t *members, hipStream_t stream) {
+    if (size_t(k) * 4 > 64 * 1024) return hipErrorInvalidValue;
+    const size_t n_tiles = member_list_tiles(n);
+    hipLaunchKernelGGL(k_kmeans_tile_hist, dim3((unsigned)n_tiles), dim3(kKmBlock), size_t(k) * 4, stream, (const unsigned *)keys, n, k, (unsigned *)tile_hist);
+    hipLaunchKernelGGL(k_kmeans_tile_scan, dim3((unsigned)((k + kKmBlock - 1) / kKmBlock)), dim3(kKmBlock), 0, stream, (unsigned *)tile_hist, n_tiles, k, (unsigned *)total);
+    hipLaunchKernelGGL(k_kmeans_start_scan, dim3(1), dim3(kKmBlock), 0, stream, (const unsigned *)total, k, (unsigned *)start);
+    hipLaunchKernelGGL(k_kmeans_scatter, dim3((unsigned)n_tiles), dim3(kKmBlock), 0, stream, (const unsigned *)keys, n, k, (const unsigned *)tile_hist, (const unsigned *)start,
+                       (unsigned *)members);
+    return hipGetLastError();
+}
+
 // The ordered sums are a chain of dependent f32 additions per (cluster, bin); what need NOT be ordered are the loads.  So the members' histograms are first copied,
 // by every CU at once, into a staging buffer laid out per cluster and BIN-major -- staged[start[c] * rows + b * count_c + m] = bin b of the cluster's m-th member (rows =
 // n_bins, + 1 row of upper bounds for growbatch) -- and then ONE wave per cluster streams it: lane b walks its own contiguous row with 16-byte loads and adds the values

@@ -307,7 +307,9 @@ int PlanBuilder::build() {
         round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
                      nodes[first_root].n_children > 0;
         const bool sparse_off = kn.no_sparse != 0, parts_off = kn.no_parts != 0;
-        want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off;
+        if (s->deal_mode && s->table->dtype == RS_F32 && !round_mode)
+            return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables run through the generated round subtrees only (the first node below the root must be an action node)");
+        want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off && s->table->dtype == RS_I32;   // f32 deal sweeps walk every deal (their delta rows are per deal)
         want_parts = round_mode && want_lists && !parts_off;
         // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
         // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
@@ -398,7 +400,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
     const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
     if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
     const bool seg = seg_root(id) && !down && t->dtype == RS_I32;
-    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg;
+    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
     JitSubtree js;
     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
@@ -478,10 +480,16 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         uint32_t tp[2] = {0, 0};
         for (size_t k = 0; k < js.node_ids.size(); ++k) {
             const rs_tree_node &an = nodes[js.node_ids[k]];
-            put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
-            put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
-            put_ptr(js.off_shd + 8 * k, s->shadow_off_p[p][an.index] == SIZE_MAX ? nullptr : s->d_shadow + s->shadow_off_p[p][an.index]);
-            put_u32(js.off_sstride + 4 * k, s->shadow_stride_p[p][an.index]);
+            if (t->dtype == RS_F32) {   // the node's per-deal delta rows [2A][pitch] (traverser nodes only)
+                put_ptr(js.off_dreg + 8 * k, (an.player == p && an.n_children > 0) ? plan.d_frows + plan.frow_off[size_t(an.index)] : nullptr);
+                put_ptr(js.off_dssm + 8 * k, nullptr);
+            } else {
+                put_ptr(js.off_dreg + 8 * k, (char *)t->d_dregrets + t->cell_off[an.index] * 4);
+                put_ptr(js.off_dssm + 8 * k, (char *)t->d_dssum + t->cell_off[an.index] * 4);
+            }
+            const bool shadowed = !s->shadow_off_p[p].empty() && s->shadow_off_p[p][an.index] != SIZE_MAX;   // f32 tables have no shadow at all
+            put_ptr(js.off_shd + 8 * k, shadowed ? s->d_shadow + s->shadow_off_p[p][an.index] : nullptr);
+            put_u32(js.off_sstride + 4 * k, shadowed ? s->shadow_stride_p[p][an.index] : 0u);
             tp[an.player] = uint32_t(t->pitch[an.index]);
         }
         for (int q = 0; q < 2; ++q)   // a player without nodes in this subtree: any valid vector will do
@@ -560,6 +568,20 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
 int PlanBuilder::emit() {
     const size_t n = nodes.size();
     const rs_table *t = s->table;
+    if (s->deal_mode && t->dtype == RS_F32) {   // per-deal delta rows of this traverser's nodes: [2A][deal pitch] floats each
+        plan.frow_off.assign(t->nodes.size(), SIZE_MAX);
+        size_t floats = 0;
+        for (size_t i = 0; i < t->nodes.size(); ++i) {
+            const rs_node_desc &d = t->nodes[i];
+            if (d.n_actions == 0 || d.player != p) continue;
+            plan.frow_off[i] = floats;
+            floats += size_t(2) * d.n_actions * s->pitch[0];
+        }
+        hipError_t ef = hipMalloc((void **)&plan.d_frows, std::max<size_t>(floats, 64) * sizeof(float));
+        if (ef == hipSuccess) ef = hipMemsetAsync(plan.d_frows, 0, std::max<size_t>(floats, 64) * sizeof(float), t->stream);
+        if (ef != hipSuccess) return hip_fail(ef, "rs_solver_create_deals: per-deal delta rows");
+        plan.aux_bytes += floats * sizeof(float);
+    }
     const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
     const double es = double(elem_size(t->dtype));
     // The plan walks the tree in dependency order: by tree depth for the level plan -- or, when every action node lives in a generated subtree (lane round

@@ -60,6 +60,14 @@ struct Plan {
     float *d_rlists = nullptr;          // position-indexed rows: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
     ApplyJob *d_apply_jobs = nullptr;   // deal sweeps: the cell ranges of the traverser's own nodes (where its deltas are)
+    // deal sweeps on f32 tables: per-deal delta rows of every traverser node, the traverser's deals listed per cluster and round (rebuilt every sweep), the ordered apply
+    float *d_frows = nullptr;
+    std::vector<size_t> frow_off;       // per table node: float offset of its [2A][pitch] rows inside d_frows (SIZE_MAX: not this traverser's)
+    ApplyF32Job *d_f32_jobs = nullptr;
+    int n_f32_jobs = 0;
+    uint32_t f32_max_clusters = 0;
+    uint32_t *d_member_start[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_members[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
+    uint32_t *d_member_scratch = nullptr;   // tile histograms, then totals
     int n_apply_jobs = 0;
     size_t apply_max_vec = 0;
     size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees

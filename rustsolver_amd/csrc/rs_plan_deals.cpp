@@ -265,6 +265,51 @@ int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last 
 
 int PlanBuilder::emit_apply() {
     const rs_table *t = s->table;
+    if (s->deal_mode && t->dtype == RS_F32) {   // the ordered apply: member lists per round of the traverser's cluster ids, then one job per traverser node
+        std::vector<ApplyF32Job> jobs;
+        const uint32_t n = s->deals.n_deals;
+        size_t scratch = 0;
+        for (int r = 0; r < s->n_rounds; ++r) {
+            uint32_t k = 0;
+            for (size_t i = 0; i < t->nodes.size(); ++i)
+                if (t->nodes[i].round_idx == r && t->nodes[i].player == p && t->nodes[i].n_actions > 0) k = std::max(k, t->nodes[i].n_clusters);
+            if (!k) continue;
+            if (size_t(k) * 4 > 64 * 1024) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: f32 tables take at most 16 384 clusters per node (the member lists' LDS histogram)");
+            hipError_t e = hipMalloc((void **)&plan.d_member_start[r], (size_t(k) + 1) * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&plan.d_members[r], std::max<size_t>(n, 1) * 4);
+            if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: member lists");
+            plan.aux_bytes += (size_t(k) + 1) * 4 + size_t(n) * 4;
+            scratch = std::max(scratch, (member_list_tiles(n) + 1) * size_t(k));
+        }
+        if (hipMalloc((void **)&plan.d_member_scratch, std::max<size_t>(scratch, 1) * 4) != hipSuccess) return fail(RS_ERR_OOM, "rs_solver_create_deals: member-list scratch");
+        plan.aux_bytes += scratch * 4;
+        for (size_t i = 0; i < t->nodes.size(); ++i) {
+            const rs_node_desc &d = t->nodes[i];
+            if (d.n_actions == 0 || d.player != p) continue;
+            ApplyF32Job j{};
+            j.reg = static_cast<float *>(t->regrets_ptr(int(i)));
+            j.ssm = static_cast<float *>(t->ssum_ptr(int(i)));
+            j.rows = plan.d_frows + plan.frow_off[i];
+            j.start = plan.d_member_start[d.round_idx];
+            j.members = plan.d_members[d.round_idx];
+            j.n_actions = d.n_actions;
+            j.tpitch = uint32_t(t->pitch[i]);
+            j.n_clusters = d.n_clusters;
+            jobs.push_back(j);
+            plan.f32_max_clusters = std::max(plan.f32_max_clusters, d.n_clusters);
+        }
+        if (!jobs.empty()) {
+            hipError_t e = hipMalloc((void **)&plan.d_f32_jobs, jobs.size() * sizeof(ApplyF32Job));
+            if (e == hipSuccess) e = hipMemcpy(plan.d_f32_jobs, jobs.data(), jobs.size() * sizeof(ApplyF32Job), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: f32 apply jobs");
+            plan.n_f32_jobs = int(jobs.size());
+        }
+        Launch L;
+        L.kind = L_APPLY;
+        L.bytes = double(plan.n_f32_jobs) * 0.0;
+        plan.launches.push_back(L);
+        return RS_OK;
+    }
     if (s->deal_mode) {   // table += delta, delta = 0: over the traverser's own nodes (nobody else's deltas were written: the other half of the delta arrays stays unread)
         std::vector<ApplyJob> aj;
         double cells = 0.0;

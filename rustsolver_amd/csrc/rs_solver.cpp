@@ -19,6 +19,23 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     rs_table *t = s->table;
     if (!tree_stream) tree_stream = t->stream;
     static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
+    if (L.kind == L_APPLY && t->dtype == RS_F32) {   // every cell's deltas summed in deal order: the traverser's deals listed per cluster, round by round, then the node jobs
+        const int pl = &plan == &s->plan[1] ? 1 : 0;
+        prof_begin(t, RS_K_DISCOUNT, L.bytes);
+        hipError_t ef = hipSuccess;
+        for (int r = 0; r < s->n_rounds && ef == hipSuccess; ++r) {
+            if (!plan.d_members[r]) continue;
+            uint32_t k = 0;
+            for (size_t i = 0; i < t->nodes.size(); ++i)
+                if (t->nodes[i].round_idx == r && t->nodes[i].player == pl && t->nodes[i].n_actions > 0) k = std::max(k, t->nodes[i].n_clusters);
+            ef = launch_member_lists(s->deals.d_cluster[r][pl], s->deals.n_deals, int(k), plan.d_member_scratch, plan.d_member_scratch + member_list_tiles(s->deals.n_deals) * size_t(k),
+                                     plan.d_member_start[r], plan.d_members[r], t->stream);
+        }
+        if (ef == hipSuccess) ef = launch_apply_f32_rows(plan.d_f32_jobs, plan.n_f32_jobs, plan.f32_max_clusters, uint32_t(s->pitch[0]), t->stream);
+        prof_end(t);
+        RS_HIP(ef, "k_apply_f32_rows");
+        return RS_OK;
+    }
     if (L.kind == L_APPLY) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         hipError_t ea = plan.n_apply_jobs ? launch_apply_delta_jobs(t->d_regrets, t->d_dregrets, t->d_ssum, t->d_dssum, plan.d_apply_jobs, plan.n_apply_jobs, plan.apply_max_vec, t->stream)
@@ -189,8 +206,14 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
 int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                            const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!deals || deals->n_deals == 0) return fail(RS_ERR_INVALID, "rs_solver_create_deals: empty deal batch");
-    if (table && table->dtype != RS_I32)
-        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: deal batches accumulate i32 deltas; use an RS_I32 table");
+    if (table && table->dtype == RS_F16)
+        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: deal batches run on RS_I32 tables (i32 deltas, atomics) or RS_F32 tables (per-deal deltas summed in deal order)");
+    if (table && table->dtype == RS_F32) {   // the float form: dense walks, no atomics, every cell's deltas added in deal order (bit-identical to the oracle's sequential loop)
+        if (!params || !params->fuse_subtrees) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables need fuse_subtrees = 1 (the generated kernels)");
+        if (params->mode & (RS_UPD_PRUNE | RS_UPD_RMPLUS)) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables take neither RS_UPD_PRUNE nor RS_UPD_RMPLUS");
+        if (params->chance_mode != RS_CHANCE_PASS) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: a deal has one run-out: use RS_CHANCE_PASS (cfr.rs:306-313)");
+        return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out);
+    }
     if (params && params->chance_mode != RS_CHANCE_PASS)
         return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: a deal has one run-out: use RS_CHANCE_PASS (cfr.rs:306-313)");
     if (table && (!table->d_dregrets || !table->d_dssum)) {
@@ -223,6 +246,13 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
         if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);
+        if (pl.d_frows) (void)hipFree(pl.d_frows);
+        if (pl.d_f32_jobs) (void)hipFree(pl.d_f32_jobs);
+        if (pl.d_member_scratch) (void)hipFree(pl.d_member_scratch);
+        for (int r = 0; r < RS_MAX_ROUNDS; ++r) {
+            if (pl.d_member_start[r]) (void)hipFree(pl.d_member_start[r]);
+            if (pl.d_members[r]) (void)hipFree(pl.d_members[r]);
+        }
         if (pl.d_counts) (void)hipFree(pl.d_counts);
         if (pl.d_compact_jobs) (void)hipFree(pl.d_compact_jobs);
         for (JitLaunch &JL : pl.jit) {
@@ -348,7 +378,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    if (s->deal_mode && s->params.fuse_subtrees) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
+    if (s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
         std::vector<ShadowJob> jobs;
         size_t ints = 0;
         // A record is worth transposing when the sweep reads it: sampled sweeps reach a node of a later round with probability ~ 1 / (round subtrees of that round), so a
@@ -410,7 +440,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     }
     // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
     // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
-    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack) {
+    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
         const float *leaf = nullptr;
         bool one = true;
         for (size_t i = 0; i < n && one; ++i) {
@@ -675,6 +705,8 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
         if (int rc = run_plan(s, traverser, 1)) return rc;
         return copy_root(s, traverser, d_root_util);
     }
+    if (s->deal_mode && s->comm && s->table->dtype != RS_I32)
+        return fail(RS_ERR_UNSUPPORTED, "rs_iterate: data-parallel deal batches all-reduce i32 deltas; an RS_F32 deal solver runs on one GPU");
     if (s->deal_mode && s->comm) {   // data-parallel deal batches: sweep, sum the deltas over the ranks, apply the union
         if (int rc = run_plan(s, traverser, 0)) return rc;
         if (int rc = rs_comm_allreduce_deltas(s->comm, s->table)) return rc;

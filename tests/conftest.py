@@ -23,9 +23,10 @@ def golden_dir():
 DEALS_PER_THREAD_TESTS = {
     "test_deal_batches_vs_oracle", "test_deal_batches_large_cluster_counts", "test_deal_batches_many_trips_per_workgroup",
     "test_sparse_subtree_sweeps_three_streets_many_deals", "test_wide_nodes_in_deal_batches", "test_deal_trainer_reference_as_coded",
-    "test_deal_trainer_prune_schedule", "test_deal_trainer_three_streets_from_a_flop_with_bucket_files", "test_deal_trainer_ragged_batches",
-    "test_data_parallel_ranks_equal_one_gpu_with_the_union_batch",
+    "test_deal_trainer_ragged_batches", "test_data_parallel_ranks_equal_one_gpu_with_the_union_batch",
 }
+# (round 3: the two heaviest trainer tests -- the prune schedule and the flop-start game with bucket files, 50 s between them -- run the engine's own choice only; the
+# four-deal forms of their kernels are the ones test_deal_batches_vs_oracle, test_sparse_subtree_sweeps_three_streets_many_deals and the ragged-batch test force)
 # the two-deal forms are one more value of the same template parameter: the cheaper half of the list runs them too
 TWO_DEALS_PER_THREAD_TESTS = {
     "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup", "test_sparse_subtree_sweeps_three_streets_many_deals",
@@ -51,8 +52,9 @@ TABLE_LAYOUT_TESTS = {
 # reach-down and a walk-up kernel each (`_lanes_down`, `_lanes_round`) unless RS_JIT_NO_LANE_ROUNDS keeps them on the level plan: these tests run in all four forms.
 FAN_LOOP_TESTS = {
     "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu", "test_config3_cluster_count_whole_table_on_few_boards",
-    "test_randomised_differential", "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
+    "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
 }
+# (test_randomised_differential draws its own form per seed: 48 cases instead of 192, every form still met a dozen times)
 
 
 def pytest_generate_tests(metafunc):

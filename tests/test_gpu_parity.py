@@ -642,8 +642,13 @@ def test_wide_nodes_in_deal_batches(fuse, sampled):
 
 
 @pytest.mark.parametrize("seed", range(48))
-def test_randomised_differential(seed):
-    """random game options x engine modes, GPU vs oracle, bit for bit"""
+def test_randomised_differential(seed, monkeypatch):
+    """random game options x engine modes, GPU vs oracle, bit for bit.  The form of the subtrees below ENUM chance nodes (rs_kernel_forms.lane_fan; conftest's fan_loop
+    fixture for the other lane tests) goes round with the seed."""
+    form = ["xr", "fan", "off", "levels"][seed % 4]
+    monkeypatch.setenv("RS_JIT_FAN", {"xr": "1", "fan": "2", "off": "0", "levels": "1"}[form])
+    if form == "levels":
+        monkeypatch.setenv("RS_JIT_NO_LANE_ROUNDS", "1")
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     nb = int(rng.choice([5, 5, 4, 3]))
     rounds = 6 - nb
@@ -1187,3 +1192,39 @@ def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
 
 
 test_deal_sweeps_with_and_without_table_shadows.workspace = {}
+
+
+@pytest.mark.parametrize("variant", ["river-sampled", "river-full", "three-street-sampled", "three-street-full", "river-sampled-4-per-thread"])
+def test_f32_deal_batches_vs_oracle(variant, monkeypatch):
+    """rs_solver_create_deals on an RS_F32 table (north_star: "f32 regrets"): deal sweeps whose sums are float.  f32 additions do not commute, so there are no atomics: every
+    deal walks its subtrees densely, a traverser visit stores its two delta vectors per deal, and after the sweep every cell's deltas are added IN DEAL ORDER from 0.0 and
+    then to the table -- exactly the oracle's sequential loop over the deals, hence bit-identical, with thousands of deals per info set.  Root utilities too."""
+    three, sampled = variant.startswith("three"), "sampled" in variant
+    if variant.endswith("4-per-thread"):
+        monkeypatch.setenv("RS_JIT_LANES", "4")
+    n_deals = 2003 if three else 5001
+    rng = np.random.Generator(np.random.PCG64(55))
+    sizes = [(7, 9), (11, 8), (13, 17)] if three else [(13, 17)]
+    n_actions, tree = rs.build_game_tree(rs.three_street_options() if three else rs.default_flop())
+    table = rs.create_infosets(n_actions, tree, sizes, [1] * len(sizes), rs.F32)
+    otree = orc.OracleTree(orc.options_three_street() if three else orc.options_default_river())
+    otab = orc.OracleDealTable(otree, sizes, orc.T_F32)
+    for nd in tree.action_nodes():
+        a, n = nd.n_children, sizes[nd.round_idx][nd.player]
+        R = rng.uniform(-1000, 1000, size=(a, n)).astype(np.float32)
+        S = rng.uniform(0, 1000, size=(a, n)).astype(np.float32)
+        table.upload_node(nd.index, R, S)
+        otab.set_node(nd.index, R, S)
+    cidx = {(r, p): rng.integers(0, sizes[r][p], size=n_deals).astype(np.uint32) for r in range(len(sizes)) for p in (0, 1)}
+    sign = rng.integers(-1, 2, size=n_deals).astype(np.float32)
+    sbuf = rs.deal_buffer(table, n_deals, sign)
+    lg = {i: (rs.LEAF_SIGN, sbuf) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
+    lo = {i: (orc.LEAF_SIGN, sign) for i in lg}
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=0.25, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=5)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=0.25, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=5)
+    for it in range(3):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    compare_tables(tree, table, otab)
+    with pytest.raises(rs.RsError):   # pruning compares i32 regrets with the threshold (cfr.rs:352): not on float tables
+        rs.MCCFRTrainer(tree, table, lg, scale=0.25, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=5)
