@@ -282,7 +282,10 @@ typedef struct rs_kernel_forms {
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
                                    sum their deltas by wave segments instead of LDS tiles (default: off -- measured slower at every batch size tried) */
-    int32_t reserved[3];        /* zero */
+    int32_t delta_rows;         /* RS_FORM_*: i32 deal sweeps keep no delta tiles and issue no atomics inside the walk: a visit stores its deltas at the deal's LIST POSITION
+                                   ([2A][batch pitch] i32 rows per traverser node, coalesced), and one streaming pass per sweep sums every row by cluster (LDS histogram of
+                                   one row at a time) into the delta tables.  Applies to the round subtrees whose traverser nodes have at most 16 384 clusters */
+    int32_t reserved[2];        /* zero */
 } rs_kernel_forms;
 
 typedef struct rs_solver_params {
@@ -362,7 +365,8 @@ int rs_table_deltas(rs_table *table, int32_t **d_dregrets, int32_t **d_dstrategy
 size_t rs_solver_workspace_bytes(const rs_solver *solver);
 int rs_jit_available(void);   /* 1 if libhiprtc.so can be loaded (needed for fuse_subtrees) */
 int rs_solver_n_launches(const rs_solver *solver, int traverser);
-/* which kernel forms the solver chose (rs_kernel_forms): bit 0 = deal sweeps walk the batch in last-round-cluster order (deal_order); negative = bad solver */
+/* which kernel forms the solver chose (rs_kernel_forms): bit 0 = deal sweeps walk the batch in last-round-cluster order (deal_order), bit 1 = some round subtree
+   stores delta rows (delta_rows); negative = bad solver */
 int rs_solver_forms(const rs_solver *solver);
 
 /* ---- card-abstraction plumbing in front of get-infoset (host only; card_abstraction.rs) -----------------------------

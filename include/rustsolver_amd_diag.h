@@ -34,6 +34,10 @@ int rs_table_plant_saturating(rs_table *table, uint64_t seed, uint32_t one_in);
  * of the clamp update (rs_device.hpp visit_i32) */
 int rs_plant_outliers_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed, uint32_t one_in, float magnitude);
 
+/* ---- deal sweeps: how many (deal, round subtree) walks did the LAST sweep of `traverser` make?  out[r] = live-list entries summed over the round subtrees of betting
+ * round r (a round whose subtrees walk the whole batch counts n_deals per subtree).  Synchronises.  The unit the deal kernels' costs are quoted per. */
+int rs_solver_walk_counts(rs_solver *solver, int traverser, uint64_t *out /* [RS_MAX_ROUNDS] */);
+
 /* ---- checks of the generated (hipRTC) kernels without a GPU ---------------------------------------------------------------------- */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */
 int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, int *n_kernels);

@@ -57,7 +57,7 @@ class DealBatch(C.Structure):
 
 class KernelForms(C.Structure):   # rs_kernel_forms: every field 0 = the engine's own choice
     _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("worklist", C.c_int32), ("shadow", C.c_int32),
-                ("deal_order", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("deal_order", C.c_int32), ("delta_rows", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class TableParams(C.Structure):
@@ -161,6 +161,7 @@ SYMBOLS = {
     "rs_deal_trainer_finish_batch": (C.c_int, [_P]),
     "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
+    "rs_solver_walk_counts": (C.c_int, [_P, C.c_int, _P]),
     "rs_solver_forms": (C.c_int, [_P]),
     "rs_jit_available": (C.c_int, []),
     "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -24,6 +24,7 @@ constexpr int kARITH_CLAMP = 0, kARITH_WRAP = 1;           // == RS_UPD_CLAMP_I6
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -177,23 +178,31 @@ __device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, c
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = p[idx[j]];
 }
-// AoS shadow of one action node for deal sweeps: record c = [regrets 0..H) [strategy_sum 0..H)], H = 4 ints (A <= 4) or 8 (A <= 8), built from
-// the SoA table at the start of every sweep (k_build_shadow).  A deal then reads a node with one or two 16-byte loads per array instead of
-// one 4-byte load per (action, array): the gathers of a wave touch 64 random cache lines EACH, and with the SoA rows they were what bounded
-// the deal kernels (about 250 gathers per 4 deals and tree walk).
+// AoS shadow of one action node for deal sweeps: record c = [regrets 0..H) [strategy_sum 0..H)], H = 2 ints (A <= 2), 4 (A <= 4) or 8 (A <= 8), built from
+// the SoA table at the start of every sweep (k_build_shadow).  A deal then reads a node with ONE load where it can -- 8 bytes of regrets or the whole 16-byte record of a
+// two-action node -- instead of one 4-byte load per (action, array): the 64 lanes of a gather touch 64 different cache lines, every one of them a cycle of the CU's L1,
+// and those cycles are what the deal kernels run out of (round 3: 34 L1 accesses per walked deal and subtree, half a lookup per CU and cycle).
+template <int A>
+constexpr int shadow_half() { return A <= 2 ? 2 : (A <= 4 ? 4 : 8); }
 template <int A>
 __device__ __forceinline__ void gather_rec_half(const RS_GLOBAL int *rec, int (&out)[A][kVecD], int j) {
-    const i32x4 lo = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec);
-    out[0][j] = lo.x;
-    if (A > 1) out[1 < A ? 1 : 0][j] = lo.y;
-    if (A > 2) out[2 < A ? 2 : 0][j] = lo.z;
-    if (A > 3) out[3 < A ? 3 : 0][j] = lo.w;
-    if (A > 4) {
-        const i32x4 hi = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec + 4);
-        out[4 < A ? 4 : 0][j] = hi.x;
-        if (A > 5) out[5 < A ? 5 : 0][j] = hi.y;
-        if (A > 6) out[6 < A ? 6 : 0][j] = hi.z;
-        if (A > 7) out[7 < A ? 7 : 0][j] = hi.w;
+    if constexpr (A <= 2) {
+        const i32x2 lo = *reinterpret_cast<const RS_GLOBAL i32x2 *>(rec);
+        out[0][j] = lo.x;
+        if (A > 1) out[1 < A ? 1 : 0][j] = lo.y;
+    } else {
+        const i32x4 lo = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec);
+        out[0][j] = lo.x;
+        if (A > 1) out[1 < A ? 1 : 0][j] = lo.y;
+        if (A > 2) out[2 < A ? 2 : 0][j] = lo.z;
+        if (A > 3) out[3 < A ? 3 : 0][j] = lo.w;
+        if (A > 4) {
+            const i32x4 hi = *reinterpret_cast<const RS_GLOBAL i32x4 *>(rec + 4);
+            out[4 < A ? 4 : 0][j] = hi.x;
+            if (A > 5) out[5 < A ? 5 : 0][j] = hi.y;
+            if (A > 6) out[6 < A ? 6 : 0][j] = hi.z;
+            if (A > 7) out[7 < A ? 7 : 0][j] = hi.w;
+        }
     }
 }
 // `stride` (ints between two clusters' records): 2H where the record holds regrets and strategy_sum (the sweep's traverser nodes), H where it holds regrets only (the
@@ -206,12 +215,19 @@ __device__ __forceinline__ void gather_rec(const void *shadow, unsigned stride, 
 }
 template <int A>
 __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
-    constexpr int H = A <= 4 ? 4 : 8;
+    constexpr int H = shadow_half<A>();
     const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
 #pragma unroll
     for (int j = 0; j < kVecD; j++) {
-        gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
-        gather_rec_half<A>(p + (size_t)idx[j] * (2 * H) + H, s, j);
+        if constexpr (A <= 2) {   // one 16-byte record {r0, r1, s0, s1}
+            const i32x4 w = *reinterpret_cast<const RS_GLOBAL i32x4 *>(p + (size_t)idx[j] * 4);
+            r[0][j] = w.x;
+            s[0][j] = w.z;
+            if (A > 1) { r[1 < A ? 1 : 0][j] = w.y; s[1 < A ? 1 : 0][j] = w.w; }
+        } else {
+            gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
+            gather_rec_half<A>(p + (size_t)idx[j] * (2 * H) + H, s, j);
+        }
     }
 }
 // A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
@@ -253,6 +269,35 @@ __device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, co
     for (int j = 0; j < kVecD; j++) {
         const int delta = (int)((unsigned)now[j] - (unsigned)before[j]);
         if (delta != 0) __hip_atomic_fetch_add(p + idx[j], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// Delta rows (rs_kernel_forms.delta_rows): no sum inside the walk at all.  Row a of `rows` ([2A][pitch] ints) takes the regret delta of action a at the deal's list
+// position, row A + a its strategy-sum delta; k_row_sums adds every row up per cluster afterwards.  Positions the walk did not own (ok[j] false) are never read.
+template <int A>
+__device__ __forceinline__ void keep_deltas(const int (&r)[A][kVecD], const int (&q)[A][kVecD], const int (&s)[A][kVecD], const int (&t)[A][kVecD], int (&d)[2 * A][kVecD]) {
+#pragma unroll
+    for (int a = 0; a < A; a++)
+#pragma unroll
+        for (int j = 0; j < kVecD; j++) {
+            d[a][j] = (int)((unsigned)r[a][j] - (unsigned)q[a][j]);
+            d[A + a][j] = (int)((unsigned)s[a][j] - (unsigned)t[a][j]);
+        }
+}
+template <int A>
+__device__ __forceinline__ void store_delta_rows(int *rows, unsigned pitch, unsigned v, const bool (&ok)[kVecD], const int (&d)[2 * A][kVecD]) {
+    RS_GLOBAL int *p = as_global<int>(rows) + (size_t)v * kVecD;
+#pragma unroll
+    for (int x = 0; x < 2 * A; x++) {
+#if RS_LANES == 4
+        if (ok[0] && ok[1] && ok[2] && ok[3]) {
+            const i32x4 w = {d[x][0], d[x][1], d[x][2], d[x][3]};
+            *reinterpret_cast<RS_GLOBAL i32x4 *>(p + (size_t)x * pitch) = w;
+            continue;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < kVecD; j++)
+            if (ok[j]) p[(size_t)x * pitch + j] = d[x][j];
     }
 }
 // LDS-privatised form for deal batches: a workgroup first sums its deltas for one traverser node in LDS

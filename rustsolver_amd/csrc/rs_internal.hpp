@@ -176,6 +176,19 @@ struct ApplyF32Job {
     uint32_t n_actions, tpitch, n_clusters, pad_;
 };
 hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, hipStream_t stream);
+// i32 deal sweeps with delta rows: the walk of a round subtree stored, for every traverser node, [2A][pitch] i32 deltas at the list position of each walked deal (zero where
+// the deal did not come by).  One job = the A rows of one node and array + the key row beside them (the traverser's cluster of every position); a workgroup takes one chunk
+// of positions, sums it per cluster in an LDS tile [n_rows][n_clusters] and adds the non-zero cells to the delta table's rows -- integer adds: any order, same bits
+struct RowSumJob {
+    const int32_t *rows;       // [n_rows][pitch]
+    const uint32_t *key;       // [n]
+    const uint32_t *count;     // device count of list entries, or null: n_const
+    int32_t *dst;              // [n_rows][tpitch] inside the delta table
+    uint32_t n_rows, pitch, tpitch, n_clusters, n_const, pad_;
+};
+hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream);
+constexpr uint32_t kRowSumMaxCells = 16384;   // ints of one job's LDS tile (64 KiB: two workgroups per CU)
+constexpr uint32_t kRowSumChunk = 262144;     // list positions per workgroup
 // stable counting sort of 0 .. n-1 by key (rs_kmeans.hip): members[start[c] .. start[c + 1]) = the indices with key c, ascending; scratch: tile_hist [ceil(n / 512)][k], total [k]
 hipError_t launch_member_lists(const uint32_t *keys, size_t n, int k, uint32_t *tile_hist, uint32_t *total, uint32_t *start /* [k + 1] */, uint32_t *members /* [n] */,
                                hipStream_t stream);
@@ -218,6 +231,8 @@ struct Knobs {
     int shadow_all = 0;             // RS_JIT_SHADOW_ALL
     int shadow_wide = 0;            // RS_JIT_SHADOW_WIDE
     int ordered = kUnset;           // RS_JIT_ORDERED: 1 on / 0 off
+    int rows = kUnset;              // RS_JIT_ROWS: 1 on / 0 off (delta rows by list position + one summing pass per sweep)
+    int rows_chunk = kUnset;        // RS_JIT_ROWS_CHUNK: list entries one workgroup of the summing pass takes (tests: small values force several chunks per row)
     // generator switches (test-only)
     int distance = kUnset;          // RS_JIT_DISTANCE
     int threads = kUnset;           // RS_JIT_THREADS
@@ -269,6 +284,7 @@ struct JitSubtree {
     size_t off_attr = 0;                                                                  // sparse deal sweeps: packed per-deal inputs of the subtree's round, may be null
     size_t off_rlist = 0;                                                                 // the reach of every entry of the live list (position-indexed rows), may be null
     size_t off_plist = 0;                                                                 // the parent-subtree position of every entry of the live list, may be null
+    size_t off_klist = 0;                                                                 // delta rows: the key row of the job's list (the traverser's cluster of every entry), written by the walk
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
@@ -276,7 +292,7 @@ struct JitSubtree {
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
-                      bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false);
+                      bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false, bool rows = false);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
 uint64_t jit_source_key(const std::string &source);   // what the caches are keyed by (source + compiler version + options)

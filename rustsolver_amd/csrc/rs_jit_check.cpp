@@ -147,6 +147,15 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                         if (int rc = jit_compile_only(jf.source, knobs.dump != 0)) return rc;
                     }
                 }
+                if (f6 >= 4) {   // delta rows (rs_kernel_forms.delta_rows): the walk stores its deltas by position, dense and over a list
+                    JitSubtree jr;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, sparse, false,
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jr, knobs, 0, sparse, sparse, false, false, false, true);
+                    if (!seen.count(jr.source)) {
+                        seen[jr.source] = 1;
+                        if (int rc = jit_compile_only(jr.source, knobs.dump != 0)) return rc;
+                    }
+                }
                 if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
                     JitSubtree jw;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__rest
             rec[8 + a] = (both && a < A) ? ssm[(size_t)a * pitch + c] : 0;
         }
         i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * job->stride);
-        if (half == 4) {
+        if (half == 2) {   // two actions: 8 bytes of regrets, or one 16-byte record {r0, r1, s0, s1}
+            if (both) out[0] = i32x4{rec[0], rec[1], rec[8], rec[9]};
+            else *reinterpret_cast<i32x2 *>(dst + (size_t)c * job->stride) = i32x2{rec[0], rec[1]};
+        } else if (half == 4) {
             out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
             if (both) out[1] = i32x4{rec[8], rec[9], rec[10], rec[11]};
         } else {
@@ -943,6 +946,96 @@ hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t
     if (n_jobs <= 0) return hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) * 2 * RS_MAX_ACTIONS + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
     hipLaunchKernelGGL(k_apply_f32_rows, grid, block, 0, stream, d_jobs, pitch);
+    return hipGetLastError();
+}
+// i32 deal sweeps with delta rows (rs_kernel_forms.delta_rows): workgroup (x, y) sums positions [y * chunk, (y + 1) * chunk) of job x's rows per cluster (the JOB is the fast
+// grid axis: workgroups go to the 8 XCDs round-robin in launch order, most lists end after a few chunks, and with 16 chunks on the fast axis the working ones all landed on
+// three XCDs -- 3.0 against 0.97 ms per launch).  Streaming: every
+// position is read once (key + n_rows deltas, 16-byte loads), added to the LDS tile with ds_add where non-zero, and the tile's non-zero cells go to the delta table
+// with one global atomic each (consecutive threads: consecutive cells).  No order dependence anywhere: wrapping integer adds.
+constexpr int kRowSumBlock = 512;
+constexpr int kRowSumMaxRows = 8;   // RS_MAX_ACTIONS
+__global__ __launch_bounds__(kRowSumBlock) void k_row_sums(const RowSumJob *__restrict__ jobs, uint32_t chunk) {
+    const RowSumJob J = jobs[blockIdx.x];
+    const uint32_t n = J.count ? *J.count : J.n_const;
+    const uint32_t lo = blockIdx.y * chunk;   // chunk % 4 == 0
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + chunk);
+    extern __shared__ int row_tile[];
+    const uint32_t cells = J.n_rows * J.n_clusters;
+    for (uint32_t i = threadIdx.x; i < cells; i += kRowSumBlock) row_tile[i] = 0;
+    __syncthreads();
+    // every workgroup starts at its own place inside its chunk and wraps around: thousands of them stream rows laid out alike, and in step they would all sit on the
+    // same memory channels.  The loads of slot it + 1 are issued before slot it is added up (the adds are LDS atomics: nothing else would overlap the next round trip).
+    constexpr uint32_t kStep = 4 * kRowSumBlock;
+    const uint32_t n_it = (hi - lo + kStep - 1) / kStep, rot = (blockIdx.x * 7u + blockIdx.y * 3u) % n_it;
+    const __attribute__((address_space(1))) uint32_t *key = (const __attribute__((address_space(1))) uint32_t *)J.key;
+    const __attribute__((address_space(1))) int *rows = (const __attribute__((address_space(1))) int *)J.rows;
+    const bool key_vec = (reinterpret_cast<uintptr_t>(J.key) & 15) == 0;   // the key row of a dense job is the caller's cluster-id vector
+    auto place = [&](uint32_t it) {
+        uint32_t slot = it + rot;
+        if (slot >= n_it) slot -= n_it;
+        return lo + slot * kStep + 4 * threadIdx.x;
+    };
+    uint32_t kc[4], kn[4];
+    i32x4 dc[kRowSumMaxRows], dn[kRowSumMaxRows];
+    auto fetch = [&](uint32_t i, uint32_t (&k)[4], i32x4 (&d)[kRowSumMaxRows]) {   // a full vector of positions i .. i + 3 (< hi)
+        if (key_vec) {
+            const u32x4 kv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(key + i);
+            k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w;
+        } else {
+            for (int j = 0; j < 4; j++) k[j] = key[i + j];
+        }
+#pragma unroll
+        for (int r = 0; r < kRowSumMaxRows; ++r)
+            if (r < (int)J.n_rows) d[r] = *reinterpret_cast<const __attribute__((address_space(1))) i32x4 *>(rows + (size_t)r * J.pitch + i);
+    };
+    uint32_t i_cur = place(0);
+    bool full_cur = i_cur + 4 <= hi;
+    if (full_cur) fetch(i_cur, kc, dc);
+    for (uint32_t it = 0; it < n_it; ++it) {
+        const uint32_t i_next = it + 1 < n_it ? place(it + 1) : hi;
+        const bool full_next = i_next + 4 <= hi;
+        if (full_next) fetch(i_next, kn, dn);
+        if (full_cur) {
+#pragma unroll
+            for (int r = 0; r < kRowSumMaxRows; ++r)
+                if (r < (int)J.n_rows) {
+                    int *t = row_tile + r * J.n_clusters;
+                    if (dc[r].x) __hip_atomic_fetch_add(t + kc[0], dc[r].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (dc[r].y) __hip_atomic_fetch_add(t + kc[1], dc[r].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (dc[r].z) __hip_atomic_fetch_add(t + kc[2], dc[r].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (dc[r].w) __hip_atomic_fetch_add(t + kc[3], dc[r].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+        } else {
+            for (uint32_t q = i_cur; q < hi; ++q) {   // the ragged end of the list
+                const uint32_t k = key[q];
+                for (uint32_t r = 0; r < J.n_rows; ++r) {
+                    const int d = rows[(size_t)r * J.pitch + q];
+                    if (d) __hip_atomic_fetch_add(row_tile + r * J.n_clusters + k, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        i_cur = i_next;
+        full_cur = full_next;
+#pragma unroll
+        for (int j = 0; j < 4; j++) kc[j] = kn[j];
+#pragma unroll
+        for (int r = 0; r < kRowSumMaxRows; ++r) dc[r] = dn[r];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cells; i += kRowSumBlock) {
+        const int x = row_tile[i];
+        if (x == 0) continue;
+        const uint32_t r = i / J.n_clusters, c = i - r * J.n_clusters;
+        __hip_atomic_fetch_add(J.dst + (size_t)r * J.tpitch + c, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream) {
+    if (n_jobs <= 0 || max_entries == 0) return hipSuccess;
+    chunk = std::max<uint32_t>(std::max<uint32_t>(4, chunk / 4 * 4), (max_entries / 65535 + 4) / 4 * 4);   // grid.y <= 65535
+    dim3 grid((unsigned)n_jobs, (max_entries + chunk - 1) / chunk), block(kRowSumBlock);
+    hipLaunchKernelGGL(k_row_sums, grid, block, size_t(max_cells) * sizeof(int), stream, d_jobs, chunk);
     return hipGetLastError();
 }
 hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, void *dssum, const ApplyJob *d_jobs, int n_jobs, size_t max_vec, hipStream_t stream) {

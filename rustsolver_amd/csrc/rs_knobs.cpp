@@ -24,6 +24,8 @@ const Entry kEntries[] = {
     {"RS_JIT_SHADOW_ALL", FLAG, &Knobs::shadow_all, nullptr},
     {"RS_JIT_SHADOW_WIDE", FLAG, &Knobs::shadow_wide, nullptr},
     {"RS_JIT_ORDERED", INT, &Knobs::ordered, nullptr},
+    {"RS_JIT_ROWS", INT, &Knobs::rows, nullptr},
+    {"RS_JIT_ROWS_CHUNK", INT, &Knobs::rows_chunk, nullptr},
     {"RS_JIT_DISTANCE", INT, &Knobs::distance, nullptr},
     {"RS_JIT_THREADS", INT, &Knobs::threads, nullptr},
     {"RS_JIT_WAVES", INT, &Knobs::waves, nullptr},
@@ -61,6 +63,8 @@ Knobs knobs_resolve(const rs_kernel_forms *forms) {
         if (forms->shadow == RS_SHADOW_WIDE) k.shadow_wide = 1;
         if (forms->deal_order == RS_FORM_ON) k.ordered = 1;
         else if (forms->deal_order == RS_FORM_OFF) k.ordered = 0;
+        if (forms->delta_rows == RS_FORM_ON) k.rows = 1;
+        else if (forms->delta_rows == RS_FORM_OFF) k.rows = 0;
     }
     for (const Entry &e : kEntries) {   // then the test-only overrides
         const char *v = getenv(e.name);

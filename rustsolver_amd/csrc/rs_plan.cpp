@@ -400,13 +400,14 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
     const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
     if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
     const bool seg = seg_root(id) && !down && t->dtype == RS_I32;
-    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
+    const bool rows = s->deal_mode && rows_root(id) && !down;
+    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg && !rows && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
     JitSubtree js;
     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                      (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg);
+                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows);
     const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
     // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete, every distinct source at once on a pool of host threads
@@ -422,6 +423,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         plan.jit.back().threads = js.threads;
         plan.jit.back().worklist = js.worklist;
         plan.jit.back().seg = seg;
+        plan.jit.back().rows = rows;
         plan.jit.back().off_count = uint32_t(js.off_count);
         plan.jit.back().deals_per_trip = uint32_t(js.threads * js.lanes);
     }
@@ -480,7 +482,11 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         uint32_t tp[2] = {0, 0};
         for (size_t k = 0; k < js.node_ids.size(); ++k) {
             const rs_tree_node &an = nodes[js.node_ids[k]];
-            if (t->dtype == RS_F32) {   // the node's per-deal delta rows [2A][pitch] (traverser nodes only)
+            if (rows) {   // the node's delta rows [2A][batch pitch], indexed by this job's list position (traverser nodes only)
+                const bool own = an.player == p && an.n_children > 0;
+                put_ptr(js.off_dreg + 8 * k, own ? s->d_drows + plan.drow_off[size_t(an.index)] : nullptr);
+                put_ptr(js.off_dssm + 8 * k, nullptr);
+            } else if (t->dtype == RS_F32) {   // the node's per-deal delta rows [2A][pitch] (traverser nodes only)
                 put_ptr(js.off_dreg + 8 * k, (an.player == p && an.n_children > 0) ? plan.d_frows + plan.frow_off[size_t(an.index)] : nullptr);
                 put_ptr(js.off_dssm + 8 * k, nullptr);
             } else {
@@ -511,6 +517,39 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             // position-indexed rows: the entries of every list but the first root's (all of whose deals are live, with the constant root reach) carry their reach
             put_ptr(js.off_rlist, (pos_rows && id != first_root) ? plan.d_rlists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             put_ptr(js.off_plist, (pos_rows && id != first_root) ? plan.d_plists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
+            put_ptr(js.off_klist, rows ? plan.d_klists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
+        }
+        if (rows) {   // what k_row_sums adds up after the walks: per traverser node and array the A rows beside the job's key row (row by row where A tiles do not fit together)
+            const uint32_t bp = uint32_t(s->pitch[0] + kRowStagger);   // the delta rows' own pitch (JArgs.rp of this form)
+            const CompactJob *cj = sparse ? &plan.compact_jobs[size_t(sparse_slot[id])] : nullptr;
+            for (size_t k = 0; k < js.node_ids.size(); ++k) {
+                const rs_tree_node &an = nodes[js.node_ids[k]];
+                if (an.player != p || an.n_children == 0) continue;
+                const uint32_t A = uint32_t(an.n_children), ncl = t->nodes[size_t(an.index)].n_clusters, tpn = uint32_t(t->pitch[size_t(an.index)]);
+                for (int arr = 0; arr < 2; ++arr) {
+                    RowSumJob rj{};
+                    rj.key = cj ? plan.d_klists + (cj->list - plan.d_lists) : s->deals.d_cluster[r][p];
+                    rj.count = cj ? cj->count : nullptr;
+                    rj.n_const = s->deals.n_deals;
+                    rj.pitch = bp;
+                    rj.tpitch = tpn;
+                    rj.n_clusters = ncl;
+                    const int32_t *src = s->d_drows + plan.drow_off[size_t(an.index)] + size_t(arr) * A * bp;
+                    int32_t *dst = static_cast<int32_t *>(arr == 0 ? t->d_dregrets : t->d_dssum) + t->cell_off[an.index];
+                    if (A * ncl <= kRowSumMaxCells) {
+                        rj.rows = src;
+                        rj.dst = dst;
+                        rj.n_rows = A;
+                        plan.row_jobs.push_back(rj);
+                    } else
+                        for (uint32_t a = 0; a < A; ++a) {
+                            rj.rows = src + size_t(a) * bp;
+                            rj.dst = dst + size_t(a) * tpn;
+                            rj.n_rows = 1;
+                            plan.row_jobs.push_back(rj);
+                        }
+                }
+            }
         }
         // LDS tile placement: as many traverser nodes as fit keep a RESIDENT tile (zeroed / flushed once per workgroup), the
         // rest share one transient area.  Smallest tiles first; the transient area must hold the largest tile left out.
@@ -523,7 +562,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         const uint32_t n_cl = parts.n_clusters;
         put_u32(js.off_c0, c0);
         put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
-        put_u32(js.off_rp, rp);
+        put_u32(js.off_rp, rows ? uint32_t(s->pitch[0] + kRowStagger) : rp);
         put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
         put_ptr(js.off_attr, (sparse || s->ordered) ? s->d_attr[nodes[id].round_idx] : nullptr);
         if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
@@ -581,6 +620,22 @@ int PlanBuilder::emit() {
         if (ef == hipSuccess) ef = hipMemsetAsync(plan.d_frows, 0, std::max<size_t>(floats, 64) * sizeof(float), t->stream);
         if (ef != hipSuccess) return hip_fail(ef, "rs_solver_create_deals: per-deal delta rows");
         plan.aux_bytes += floats * sizeof(float);
+    }
+    if (s->rows) {   // delta rows: one buffer for both traversers' sweeps, offsets per traverser node of an eligible round
+        plan.drow_off.assign(t->nodes.size(), SIZE_MAX);
+        size_t ints = 0;
+        for (size_t i = 0; i < t->nodes.size(); ++i) {
+            const rs_node_desc &d = t->nodes[i];
+            if (d.n_actions == 0 || d.player != p || !rows_round_ok(s, p, d.round_idx)) continue;
+            plan.drow_off[i] = ints;
+            ints += size_t(2) * d.n_actions * (s->pitch[0] + kRowStagger);
+        }
+        if (!s->d_drows) {
+            const size_t need = std::max<size_t>(std::max(drows_ints(s, 0), drows_ints(s, 1)), 64);
+            hipError_t ed = hipMalloc((void **)&s->d_drows, need * sizeof(int32_t));
+            if (ed != hipSuccess) return hip_fail(ed, "rs_solver_create_deals: delta rows");
+            s->other_bytes += need * sizeof(int32_t);
+        }
     }
     const bool prune = (s->params.mode & RS_UPD_PRUNE) != 0;
     const double es = double(elem_size(t->dtype));
@@ -817,6 +872,7 @@ int PlanBuilder::emit() {
     }
     }   // pass
     if (int rc = emit_round_walks()) return rc;
+    if (int rc = emit_row_sums()) return rc;
     if (!s->sharded) plan.split = plan.launches.size();   // deal batches: phase 0 = the sweep, phase 1 = the apply below
     if (int rc = emit_apply()) return rc;
     // value returned at node 0

@@ -10,8 +10,11 @@ namespace rs {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
 constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
+// Rows that many workgroups stream at the same offsets at the same time (delta rows, live-deal lists) must not start a power of two apart: a 4 M-deal batch puts them 16 MiB
+// apart, every stream then sits on the same memory channel at the same moment, and the row-summing pass ran 4x slower than with 4 196 416 deals (12.7 against 8.9 ms per batch)
+constexpr size_t kRowStagger = 1088;   // elements between the natural pitch and the one used (4 352 B: off every power-of-two interleave up to 4 KiB, rows stay 256-B aligned)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
-enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER };
+enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER, L_ROWSUM };
 
 struct Launch {
     int group = 0;                      // > 0: consecutive launches of one group are independent of each other (round subtrees) and may overlap
@@ -43,6 +46,7 @@ struct JitLaunch {
     size_t lds_bytes = 0;
     bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
     bool seg = false;                   // ordered sweeps, last round: no LDS, 256-thread workgroups, many per CU
+    bool rows = false;                  // delta rows: no LDS, no barrier, 256-thread workgroups, many per CU
     bool worklist = false;              // list-walking kernels with LDS tiles: a 1-D grid of resident workgroups pulls (job, trip) items; k_worklist runs right before
     uint32_t *d_wl = nullptr;           // [2 + n_jobs + 1]
     uint32_t off_count = 0, deals_per_trip = 0;
@@ -59,6 +63,11 @@ struct Plan {
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
     float *d_rlists = nullptr;          // position-indexed rows: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
+    uint32_t *d_klists = nullptr;       // delta rows: the traverser's cluster of every list entry (the key row of k_row_sums), same shape as d_lists
+    std::vector<size_t> drow_off;       // delta rows: per table node the int offset of its [2A][batch pitch] rows inside the solver's d_drows (SIZE_MAX: none)
+    std::vector<RowSumJob> row_jobs;
+    RowSumJob *d_row_jobs = nullptr;
+    uint32_t row_max_cells = 0;
     ApplyJob *d_apply_jobs = nullptr;   // deal sweeps: the cell ranges of the traverser's own nodes (where its deltas are)
     // deal sweeps on f32 tables: per-deal delta rows of every traverser node, the traverser's deals listed per cluster and round (rebuilt every sweep), the ordered apply
     float *d_frows = nullptr;
@@ -76,6 +85,8 @@ struct Plan {
     CompactJob *d_compact_jobs = nullptr;
     std::vector<CompactJob> compact_jobs;
     std::vector<size_t> count_off;      // per compact job: index of its first counter (a job has one per cluster range)
+    std::vector<int> compact_round;     // per compact job: betting round of its root
+    int dense_roots[RS_MAX_ROUNDS] = {0, 0, 0};   // round subtrees that walk the whole batch, per round
     uint32_t compact_max_lanes = 0;
     float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep
     size_t reach_nan_bytes = 0;
@@ -94,6 +105,7 @@ struct Plan {
 using rs::Knobs;
 using rs::OrderJob;
 using rs::PackJob;
+using rs::RowSumJob;
 using rs::Plan;
 using rs::ShadowJob;
 
@@ -143,6 +155,9 @@ struct rs_solver {
     void *d_arec = nullptr;
     uint32_t *d_order_tot = nullptr;    // [2][n_bins]: counts and cursors of the counting sort
     OrderJob order_job[2];              // per traverser
+    // delta rows (rs_kernel_forms.delta_rows): one buffer for both traversers' sweeps (they never overlap), [2A][batch pitch] i32 per traverser node of an eligible round
+    bool rows = false;
+    int32_t *d_drows = nullptr;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};
     uint64_t *d_seed_state = nullptr;   // RS_OPP_SAMPLE: {base seed, call index, seed of the current sweep}
@@ -160,6 +175,8 @@ namespace rs {
 // rs_plan.cpp: shapes and sharding derived from table + tree (validation included), then one PlanBuilder per traverser: layout() decides which buffers exist
 // (offsets into the arena the caller then allocates), emit() writes the jobs and launches
 int derive_geometry(rs_solver *s);
+bool rows_round_ok(const rs_solver *s, int p, int round);   // rs_plan_deals.cpp: do traverser p's nodes of this round take the delta-rows form?
+size_t drows_ints(const rs_solver *s, int p);               // ints of delta rows traverser p's sweep needs
 struct PlanBuilder;
 PlanBuilder *plan_builder_new(rs_solver *s, int traverser);
 int plan_builder_layout(PlanBuilder *b);

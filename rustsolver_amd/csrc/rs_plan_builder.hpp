@@ -53,6 +53,11 @@ struct PlanBuilder {
         uint32_t n_clusters, pitch;   // of the TRAVERSER's nodes in this round subtree (the root may be the opponent's)
     };
     bool seg_root(int root) const { return s->ordered && nodes[size_t(root)].round_idx == s->order_round; }   // its deltas are summed by wave segments: no LDS tiles
+    // delta rows (rs_kernel_forms.delta_rows): the walk of this root stores its deltas by list position, k_row_sums adds them up per cluster: no tiles, no cluster ranges
+    // (the engine's choice, 1: the list walkers only -- the first round's dense walk keeps its tiles, four deals per thread; 2, tests: every round subtree)
+    bool rows_root(int root) const {
+        return round_mode && rows_round_ok(s, p, nodes[size_t(root)].round_idx) && (s->knobs.rows >= 2 || (want_lists && root != first_root));
+    }
     Parts parts_of(int root) const;
 
     PlanBuilder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
@@ -110,6 +115,7 @@ struct PlanBuilder {
     std::vector<int> sparse_slot;   // per tree node: index of its compact job (the list of its live deals), -1 = it walks every lane
     int emit_deal_lists();
     int emit_round_walks();
+    int emit_row_sums();
     int emit_apply();
 
     // pass 2 (after the arena exists): emit jobs and launches

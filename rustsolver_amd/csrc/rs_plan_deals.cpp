@@ -13,6 +13,25 @@ using namespace rs;
 
 namespace rs {
 
+bool rows_round_ok(const rs_solver *s, int p, int round) {
+    if (!s->rows || !s->deal_mode || s->table->dtype != RS_I32) return false;
+    const rs_table *t = s->table;
+    uint32_t k = 0;
+    for (size_t i = 0; i < t->nodes.size(); ++i)
+        if (t->nodes[i].round_idx == round && t->nodes[i].player == p && t->nodes[i].n_actions > 0) k = std::max(k, t->nodes[i].n_clusters);
+    return k > 0 && k <= kRowSumMaxCells;   // one row's LDS tile must fit
+}
+
+size_t drows_ints(const rs_solver *s, int p) {
+    const rs_table *t = s->table;
+    size_t ints = 0;
+    for (size_t i = 0; i < t->nodes.size(); ++i) {
+        const rs_node_desc &d = t->nodes[i];
+        if (d.n_actions > 0 && d.player == p && rows_round_ok(s, p, d.round_idx)) ints += size_t(2) * d.n_actions * (s->pitch[0] + kRowStagger);
+    }
+    return ints;
+}
+
 PlanBuilder::Parts PlanBuilder::parts_of(int root) const {
     const rs_table *t = s->table;
     size_t sum_a = 0;
@@ -33,7 +52,7 @@ PlanBuilder::Parts PlanBuilder::parts_of(int root) const {
         }
     }
     const size_t limit = size_t(lds_limit) / 4;
-    if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit || seg_root(root)) return Parts{1u, pitch, n_cl, pitch};
+    if (!want_parts || sum_a == 0 || 2 * sum_a * pitch <= limit || seg_root(root) || rows_root(root)) return Parts{1u, pitch, n_cl, pitch};
     // Partitioning costs list indirection (gathers instead of row loads, a bucketing pass).  When most tiles would be resident anyway --
     // 1 081 clusters miss the budget by 1 % and keep 5 of 7 -- it loses (measured 1.33 against 0.84 ms per batch): only partition when
     // fewer than half of the tile bytes fit.
@@ -94,13 +113,16 @@ int PlanBuilder::emit_deal_lists() {
             const Parts pr = parts_of(ids[k]);
             n_parts[k] = pr.first;
             part_size[k] = pr.second;
-            list_elems += size_t(pr.first) * s->pitch[lane_round[ids[k]]];
+            list_elems += size_t(pr.first) * s->pitch[lane_round[ids[k]]] + kRowStagger;
             n_counts += pr.first;
         }
         hipError_t ea = hipMalloc((void **)&plan.d_lists, list_elems * sizeof(uint32_t));
         if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_rlists, list_elems * sizeof(float));
         if (ea == hipSuccess && pos_rows) ea = hipMalloc((void **)&plan.d_plists, list_elems * sizeof(uint32_t));
-        plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + (pos_rows ? 2 : 0));
+        bool any_rows = false;
+        for (int id : ids) any_rows = any_rows || rows_root(id);
+        if (ea == hipSuccess && any_rows) ea = hipMalloc((void **)&plan.d_klists, list_elems * sizeof(uint32_t));
+        plan.aux_bytes += list_elems * sizeof(uint32_t) * (1 + (pos_rows ? 2 : 0) + (any_rows ? 1 : 0));
         plan.n_count_words = n_counts * kCountStride;
         if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
         if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
@@ -112,6 +134,7 @@ int PlanBuilder::emit_deal_lists() {
         for (size_t k = 0; k < n_sparse; ++k) {
             const int id = ids[k];
             sparse_slot[id] = int(k);
+            plan.compact_round.push_back(int(nodes[id].round_idx));
             CompactJob &cj = plan.compact_jobs[k];
             cj = CompactJob{};
             cj.reach = reach_of(id);
@@ -129,7 +152,7 @@ int PlanBuilder::emit_deal_lists() {
                 cj.key_stride = 8;
             }
             plan.count_off[k] = cat;
-            at += size_t(n_parts[k]) * s->pitch[lane_round[id]];
+            at += size_t(n_parts[k]) * s->pitch[lane_round[id]] + kRowStagger;   // the lists of different roots are walked at the same positions at the same time
             cat += n_parts[k];
             plan.compact_max_lanes = std::max(plan.compact_max_lanes, cj.n_lanes);
         }
@@ -248,8 +271,10 @@ int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last 
     if (round_mode)
         for (size_t r = roots_of_round.size(); r-- > 0;) {
             std::map<uint64_t, int> by_fn;
-            for (int root : roots_of_round[r])
+            for (int root : roots_of_round[r]) {
+                if (sparse_slot[size_t(root)] < 0) plan.dense_roots[nodes[size_t(root)].round_idx] += 1;
                 if (int rc = add_jit_job(root, false, sparse_slot, by_fn)) return rc;
+            }
             const int group = ++next_group;
             for (auto &kv : by_fn) {
                 Launch L;
@@ -260,6 +285,24 @@ int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last 
                 plan.launches.push_back(L);
             }
         }
+    return RS_OK;
+}
+
+int PlanBuilder::emit_row_sums() {   // delta rows: after all walks, one streaming pass adds every stored row up per cluster into the delta tables
+    if (plan.row_jobs.empty()) return RS_OK;
+    hipError_t e = hipMalloc((void **)&plan.d_row_jobs, plan.row_jobs.size() * sizeof(RowSumJob));
+    if (e == hipSuccess) e = hipMemcpy(plan.d_row_jobs, plan.row_jobs.data(), plan.row_jobs.size() * sizeof(RowSumJob), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: row-sum jobs");
+    plan.aux_bytes += plan.row_jobs.size() * sizeof(RowSumJob);
+    double entries = 0.0;
+    for (const RowSumJob &j : plan.row_jobs) {
+        entries += double(j.n_rows + 1) * (j.count ? double(s->deals.n_deals) / 8.0 : double(j.n_const));   // a list holds a share of the batch (an estimate for the profiling hooks)
+        plan.row_max_cells = std::max(plan.row_max_cells, j.n_rows * j.n_clusters);
+    }
+    Launch L;
+    L.kind = L_ROWSUM;
+    L.bytes = entries * 4.0;
+    plan.launches.push_back(L);
     return RS_OK;
 }
 

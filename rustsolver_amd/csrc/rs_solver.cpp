@@ -68,6 +68,14 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         RS_HIP(eo, "k_order");
         return RS_OK;
     }
+    if (L.kind == L_ROWSUM) {
+        prof_begin(t, RS_K_DISCOUNT, L.bytes);
+        const uint32_t chunk = s->knobs.rows_chunk != kUnset && s->knobs.rows_chunk > 0 ? uint32_t(s->knobs.rows_chunk) : kRowSumChunk;
+        hipError_t er = launch_row_sums(plan.d_row_jobs, int(plan.row_jobs.size()), s->deals.n_deals, chunk, plan.row_max_cells, t->stream);
+        prof_end(t);
+        RS_HIP(er, "k_row_sums");
+        return RS_OK;
+    }
     if (L.kind == L_PACK) {
         RS_HIP(launch_pack_attr(s->d_pack_jobs, s->n_pack_jobs, s->deals.n_deals, t->stream), "k_pack_attr");
         return RS_OK;
@@ -100,7 +108,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
         blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
         if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
-        if (JL.seg && JL.n_jobs > 1) blocks = std::min<size_t>(blocks, std::max<size_t>(64, size_t(s->n_cus) * 32 / size_t(JL.n_jobs) * 4));   // list walkers: a list holds a share of the batch
+        if ((JL.seg || JL.rows) && JL.n_jobs > 1) blocks = std::min<size_t>(blocks, std::max<size_t>(64, size_t(s->n_cus) * 32 / size_t(JL.n_jobs) * 4));   // list walkers: a list holds a share of the batch
         if (s->knobs.max_blocks != kUnset)   // tests: force several trips per workgroup
             blocks = std::max<size_t>(1, std::min<size_t>(blocks, size_t(std::max(1, s->knobs.max_blocks))));
         const void *d_blob = JL.d_blob;
@@ -245,6 +253,8 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_lists) (void)hipFree(pl.d_lists);
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
+        if (pl.d_klists) (void)hipFree(pl.d_klists);
+        if (pl.d_row_jobs) (void)hipFree(pl.d_row_jobs);
         if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);
         if (pl.d_frows) (void)hipFree(pl.d_frows);
         if (pl.d_f32_jobs) (void)hipFree(pl.d_f32_jobs);
@@ -277,6 +287,7 @@ void rs::solver_release_device(rs_solver *s) {
         s->d_attr[r] = nullptr;
     }
     if (s->d_arec) (void)hipFree(s->d_arec);
+    if (s->d_drows) (void)hipFree(s->d_drows);
     if (s->d_order_tot) (void)hipFree(s->d_order_tot);
     s->d_arec = nullptr;
     s->d_order_tot = nullptr;
@@ -403,7 +414,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 if (d.n_actions == 0) continue;
                 const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
                 if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
-                const uint32_t half = d.n_actions <= 4 ? 4 : 8;
+                const uint32_t half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
                 const uint32_t stride = (d.player == tp || s->knobs.shadow_wide) ? 2 * half : half;
                 s->shadow_off_p[tp][i] = ints;
                 s->shadow_stride_p[tp][i] = stride;
@@ -438,6 +449,9 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
+    // delta rows (rs_kernel_forms.delta_rows): the walks of a deal sweep store their deltas by list position and one streaming pass sums them (rs_plan_deals.cpp rows_round_ok
+    // says for which rounds); opt-in
+    s->rows = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds && s->knobs.rows != kUnset && s->knobs.rows != 0;
     // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
     // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
     if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
@@ -465,7 +479,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
             // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
             // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
-            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
+            s->ordered = round_mode && fits && !s->rows && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
             if (s->ordered) {
                 const size_t pitch = round_up(s->deals.n_deals, kLanePad);
                 const uint32_t n = s->deals.n_deals;
@@ -760,7 +774,23 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
 
 size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes + s->other_bytes : 0; }
 
-int rs_solver_forms(const rs_solver *s) { return s ? (s->ordered ? 1 : 0) : RS_ERR_INVALID; }
+int rs_solver_forms(const rs_solver *s) { return s ? ((s->ordered ? 1 : 0) | (s->rows ? 2 : 0)) : RS_ERR_INVALID; }
+int rs_solver_walk_counts(rs_solver *s, int traverser, uint64_t *out) {
+    if (!s || !s->table || !out || traverser < 0 || traverser > 1) return fail(RS_ERR_INVALID, "rs_solver_walk_counts: bad argument");
+    if (!s->deal_mode) return fail(RS_ERR_INVALID, "rs_solver_walk_counts: not a deal-batch solver");
+    const Plan &plan = s->plan[traverser];
+    for (int r = 0; r < RS_MAX_ROUNDS; ++r) out[r] = uint64_t(plan.dense_roots[r]) * s->deals.n_deals;
+    if (plan.n_count_words) {
+        std::vector<uint32_t> host(plan.n_count_words);
+        RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+        RS_HIP(hipStreamSynchronize(s->table->stream), "rs_solver_walk_counts: sync");
+        RS_HIP(hipMemcpy(host.data(), plan.d_counts, plan.n_count_words * sizeof(uint32_t), hipMemcpyDeviceToHost), "rs_solver_walk_counts: counters");
+        for (size_t k = 0; k < plan.compact_round.size(); ++k)
+            for (size_t c = plan.count_off[k]; c < plan.count_off[k + 1]; ++c) out[plan.compact_round[k]] += host[c * kCountStride];
+    }
+    return RS_OK;
+}
+
 int rs_solver_n_launches(const rs_solver *s, int traverser) {
     if (!s || traverser < 0 || traverser > 1) return RS_ERR_INVALID;
     return int(s->plan[traverser].launches.size());

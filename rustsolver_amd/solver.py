@@ -574,10 +574,19 @@ class MCCFRTrainer:
     def n_launches(self, player):
         return L.load().rs_solver_n_launches(self._h, player)
 
+    def walk_counts(self, player):
+        """(deal, round subtree) walks of the last sweep of `player`, per betting round (rs_solver_walk_counts)"""
+        return walk_counts(self._h, player)
+
     @property
     def ordered(self):
         """deal sweeps walk the batch in the order of the traverser's last-round cluster (rs_kernel_forms.deal_order)"""
         return bool(L.load().rs_solver_forms(self._h) & 1)
+
+    @property
+    def delta_rows(self):
+        """deal sweeps store their deltas by list position and sum them in one pass per sweep (rs_kernel_forms.delta_rows)"""
+        return bool(L.load().rs_solver_forms(self._h) & 2)
 
     def iterate(self, player, want_root_util=False):
         """`self.cfr(0, player, hand, 1f32, ..)` for every lane (cfr.rs:217)"""
@@ -627,6 +636,13 @@ class MCCFRTrainer:
             pass
 
 
+def walk_counts(solver_handle, player):
+    import ctypes as C
+    out = (C.c_uint64 * 3)()
+    L.check(L.load().rs_solver_walk_counts(solver_handle, player, out))
+    return [int(x) for x in out]
+
+
 class DealTrainer:
     """MCCFRTrainer::init + train (cfr.rs:159-297) with the whole deal pipeline on the GPU (rs_deal_trainer): generate_hand,
     get_cluster for every round and player, the showdown comparison and the sampled mccfr sweep, batch after batch."""
@@ -669,6 +685,10 @@ class DealTrainer:
     def iterate_phase(self, player, phase):
         """phase 0: the sweep (deltas accumulated), phase 1: table += delta; between them the ranks' deltas are summed"""
         L.check(L.load().rs_iterate_phase(L.load().rs_deal_trainer_solver(self._h), player, phase, None))
+
+    def walk_counts(self, player):
+        """(deal, round subtree) walks of the last batch's sweep of `player`, per betting round"""
+        return walk_counts(L.load().rs_deal_trainer_solver(self._h), player)
 
     def finish_batch(self):
         L.check(L.load().rs_deal_trainer_finish_batch(self._h))

@@ -1082,6 +1082,42 @@ def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("variant", ["river", "river-full-width", "river+graph", "river+prune-per-deal", "three-street", "three-street+prune-per-deal", "three-street-wrap",
+                                     "three-street-scan-parent", "three-street-full-width", "three-street-big-river", "three-street-lists-only",
+                                     "three-street+prune-per-deal-lists-only"])
+def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
+    """rs_kernel_forms.delta_rows (forced through its test override): no delta tiles, no atomics inside the walk -- a visit stores its two delta vectors at the deal's
+    list position ([2A][batch pitch] rows per traverser node), and k_row_sums adds every row up per cluster after the walks (a few hundred positions per workgroup here, so
+    that rows are cut into many chunks).  Dense walks (the first round; every round with a full-width opponent) index the rows by deal id.  "big-river": the river's
+    20 000 clusters exceed the summing pass's tile, so that round keeps its tiles while flop and turn store rows.  "lists-only": what rs_kernel_forms.delta_rows = RS_FORM_ON
+    gives -- the list walkers store rows, the first round's dense walk keeps its LDS tiles.  Same bits as the oracle."""
+    monkeypatch.setenv("RS_JIT_ROWS", "1" if "lists-only" in variant else "2")
+    monkeypatch.setenv("RS_JIT_ROWS_CHUNK", "1000")
+    three, prune, full = variant.startswith("three"), "prune" in variant, "full-width" in variant
+    if "scan-parent" in variant:
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    n_deals = (3001 if full else 20011) if three else 30005
+    flags = (np.random.Generator(np.random.PCG64(6)).integers(0, 3, n_deals) == 0).astype(np.uint8) if prune else None
+    if three:
+        last = (20000, 17000) if "big-river" in variant else (301, 250)
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (211, 190), last], n_deals, 41)
+    else:
+        tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(1013, 977)], n_deals, 42)
+    scale, mg, mo = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if "wrap" in variant else (100.0, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    og, oo = (rs.OPP_FULL, orc.OPP_FULL) if full else (rs.OPP_SAMPLE, orc.OPP_SAMPLE)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mg | (rs.UPD_PRUNE if prune else 0), fuse_subtrees=1, deals=cidx, opp_mode=og, sample_seed=99,
+                         use_graph="graph" in variant, prune_deal=flags)
+    assert tr.delta_rows
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune, prune_deal=flags, opp_mode=oo, base_seed=99)
+    for it in range(3):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_config1_plumbing_tree_through_rs_iterate():
     """BASELINE configs[0], "preflop-only 169-iso buckets, 2-action tree": the reference has no preflop round (state.rs:8, :59-64), so this is build-side plumbing --
     a tree adopted from plain node records (rs_tree_from_nodes) with ONE two-action node per player and 169 clusters (hand_indexer_s::init(1, [2]).size(0),
