@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -303,6 +304,7 @@ struct JitRequest {
 // the same for many kernels: the ones no cache holds are compiled concurrently on host threads, then loaded one after the other
 int jit_get_kernels(std::vector<JitRequest> &reqs, int device, bool dump = false);
 int jit_compile_only(const std::string &source, bool dump = false);
+int jit_compile_many(const std::map<std::string, int> &sources, bool dump = false);   // the keys, concurrently (hipRTC programs are independent objects)
 const char *jit_device_source();
 
 // ---- host-side objects ----------------------------------------------------------------------------

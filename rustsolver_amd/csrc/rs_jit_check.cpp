@@ -55,7 +55,6 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
                 if (down && js.boundary_roots.empty()) continue;
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
-                if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
             }
         }
         for (size_t i = 0; i < n; ++i) {
@@ -69,10 +68,10 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
                                  (mode & RS_UPD_PRUNE) != 0, 4, nullptr, js, knobs, fan);
                 if (seen.count(js.source)) continue;
                 seen[js.source] = 1;
-                if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
             }
         }
     }
+    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, on a pool of host threads
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }
@@ -123,7 +122,6 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (!seen.count(js.source)) {
                     seen[js.source] = 1;
-                    if (int rc = jit_compile_only(js.source, knobs.dump != 0)) return rc;
                 }
                 if (opp_mode == RS_OPP_SAMPLE && (f6 == 0 || f6 == 1 || f6 == 2 || f6 == 3) && (mode & RS_UPD_ARITH_MASK) == RS_UPD_CLAMP_I64) {
                     // ordered sweeps (rs_kernel_forms.deal_order): 32-byte records by rank; the last round's walk sums its deltas by wave segments instead of LDS tiles
@@ -135,7 +133,6 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      0, true, sparse, sparse && lds && !down, true, nodes[i].round_idx == last_round);
                     if (!(down && jo.boundary_roots.empty()) && !seen.count(jo.source)) {
                         seen[jo.source] = 1;
-                        if (int rc = jit_compile_only(jo.source, knobs.dump != 0)) return rc;
                     }
                 }
                 if (f6 == 0 || f6 == 4) {   // deal sweeps on RS_F32 tables: the dense reach-down half and the dense walk that stores its deltas per deal (no prune on floats)
@@ -144,7 +141,6 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      &root, jf, knobs, 0, false);
                     if (!(down && jf.boundary_roots.empty()) && !seen.count(jf.source)) {
                         seen[jf.source] = 1;
-                        if (int rc = jit_compile_only(jf.source, knobs.dump != 0)) return rc;
                     }
                 }
                 if (f6 >= 4) {   // delta rows (rs_kernel_forms.delta_rows): the walk stores its deltas by position, dense and over a list
@@ -153,7 +149,6 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      (mode & RS_UPD_PRUNE) != 0, lanes, &root, jr, knobs, 0, sparse, sparse, false, false, false, true);
                     if (!seen.count(jr.source)) {
                         seen[jr.source] = 1;
-                        if (int rc = jit_compile_only(jr.source, knobs.dump != 0)) return rc;
                     }
                 }
                 if (sparse && lds && !down) {   // the work-list form every list-walking kernel with LDS tiles is launched in
@@ -162,7 +157,6 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      (mode & RS_UPD_PRUNE) != 0, lanes, &root, jw, knobs, 0, sparse, true, true);
                     if (!seen.count(jw.source)) {
                         seen[jw.source] = 1;
-                        if (int rc = jit_compile_only(jw.source, knobs.dump != 0)) return rc;
                     }
                 }
                 if (sparse && !js.boundary_roots.empty()) {   // the forms that address the rows shared with the next round by list position (large batches)
@@ -171,12 +165,12 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      (mode & RS_UPD_PRUNE) != 0, lanes, &root, jp, knobs, 0, sparse, true);
                     if (!seen.count(jp.source)) {
                         seen[jp.source] = 1;
-                        if (int rc = jit_compile_only(jp.source, knobs.dump != 0)) return rc;
                     }
                 }
             }
         }
     }
+    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, on a pool of host threads
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }

@@ -52,7 +52,7 @@ struct PlanBuilder {
         uint32_t first, second;   // number of cluster ranges, clusters per range
         uint32_t n_clusters, pitch;   // of the TRAVERSER's nodes in this round subtree (the root may be the opponent's)
     };
-    bool seg_root(int root) const { return s->ordered && nodes[size_t(root)].round_idx == s->order_round; }   // its deltas are summed by wave segments: no LDS tiles
+    bool seg_root(int root) const { return s->ordered && nodes[size_t(root)].round_idx == s->order_round && !rows_root(root); }   // its deltas are summed by wave segments: no LDS tiles
     // delta rows (rs_kernel_forms.delta_rows): the walk of this root stores its deltas by list position, k_row_sums adds them up per cluster: no tiles, no cluster ranges
     // (the engine's choice, 1: the list walkers only -- the first round's dense walk keeps its tiles, four deals per thread; 2, tests: every round subtree)
     bool rows_root(int root) const {

@@ -268,14 +268,36 @@ int PlanBuilder::emit_deal_lists() {
 }
 
 int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last round first; the subtrees of one round are independent of each other
-    if (round_mode)
+    // delta rows: the rows a round's walks stored are summed while the NEXT launches of the walk run (the round above: gather-bound walks beside a streaming pass), so the
+    // summing launch of round r joins the group of round r - 1; the first round's comes last, on its own
+    auto push_row_sums = [&](size_t first, size_t end, int group) {
+        if (end <= first) return;
+        Launch L;
+        L.kind = L_ROWSUM;
+        L.group = group;
+        L.first_job = int(first);
+        L.n_jobs = int(end - first);
+        double entries = 0.0;
+        for (size_t k = first; k < end; ++k) {
+            const RowSumJob &j = plan.row_jobs[k];
+            entries += double(j.n_rows + 1) * (j.count ? double(s->deals.n_deals) / 8.0 : double(j.n_const));   // a list holds a share of the batch (an estimate for the profiling hooks)
+            plan.row_max_cells = std::max(plan.row_max_cells, j.n_rows * j.n_clusters);
+        }
+        L.bytes = entries * 4.0;
+        plan.launches.push_back(L);
+    };
+    if (round_mode) {
+        size_t pending = plan.row_jobs.size();   // row jobs [pending, size) wait for their summing launch
         for (size_t r = roots_of_round.size(); r-- > 0;) {
             std::map<uint64_t, int> by_fn;
+            const size_t before = plan.row_jobs.size();
             for (int root : roots_of_round[r]) {
                 if (sparse_slot[size_t(root)] < 0) plan.dense_roots[nodes[size_t(root)].round_idx] += 1;
                 if (int rc = add_jit_job(root, false, sparse_slot, by_fn)) return rc;
             }
             const int group = ++next_group;
+            push_row_sums(pending, before, group);   // the round below left rows: sum them beside this round's walks
+            pending = before;
             for (auto &kv : by_fn) {
                 Launch L;
                 L.kind = L_TREE;
@@ -285,24 +307,17 @@ int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last 
                 plan.launches.push_back(L);
             }
         }
+        push_row_sums(pending, plan.row_jobs.size(), 0);
+    }
     return RS_OK;
 }
 
-int PlanBuilder::emit_row_sums() {   // delta rows: after all walks, one streaming pass adds every stored row up per cluster into the delta tables
+int PlanBuilder::emit_row_sums() {   // delta rows: the job descriptors of the summing launches emit_round_walks placed
     if (plan.row_jobs.empty()) return RS_OK;
     hipError_t e = hipMalloc((void **)&plan.d_row_jobs, plan.row_jobs.size() * sizeof(RowSumJob));
     if (e == hipSuccess) e = hipMemcpy(plan.d_row_jobs, plan.row_jobs.data(), plan.row_jobs.size() * sizeof(RowSumJob), hipMemcpyHostToDevice);
     if (e != hipSuccess) return hip_fail(e, "rs_solver_create_deals: row-sum jobs");
     plan.aux_bytes += plan.row_jobs.size() * sizeof(RowSumJob);
-    double entries = 0.0;
-    for (const RowSumJob &j : plan.row_jobs) {
-        entries += double(j.n_rows + 1) * (j.count ? double(s->deals.n_deals) / 8.0 : double(j.n_const));   // a list holds a share of the batch (an estimate for the profiling hooks)
-        plan.row_max_cells = std::max(plan.row_max_cells, j.n_rows * j.n_clusters);
-    }
-    Launch L;
-    L.kind = L_ROWSUM;
-    L.bytes = entries * 4.0;
-    plan.launches.push_back(L);
     return RS_OK;
 }
 

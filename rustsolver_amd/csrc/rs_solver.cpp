@@ -71,7 +71,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     if (L.kind == L_ROWSUM) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         const uint32_t chunk = s->knobs.rows_chunk != kUnset && s->knobs.rows_chunk > 0 ? uint32_t(s->knobs.rows_chunk) : kRowSumChunk;
-        hipError_t er = launch_row_sums(plan.d_row_jobs, int(plan.row_jobs.size()), s->deals.n_deals, chunk, plan.row_max_cells, t->stream);
+        hipError_t er = launch_row_sums(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, chunk, plan.row_max_cells, tree_stream);
         prof_end(t);
         RS_HIP(er, "k_row_sums");
         return RS_OK;
@@ -449,9 +449,14 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    // delta rows (rs_kernel_forms.delta_rows): the walks of a deal sweep store their deltas by list position and one streaming pass sums them (rs_plan_deals.cpp rows_round_ok
-    // says for which rounds); opt-in
-    s->rows = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds && s->knobs.rows != kUnset && s->knobs.rows != 0;
+    // delta rows (rs_kernel_forms.delta_rows): the list walkers of a deal sweep store their deltas by list position and one streaming pass per round sums them
+    // (rs_plan_deals.cpp rows_round_ok says for which rounds).  Measured on one MI355X, three streets, 5 000-bucket files (profiles/r03_deals.md): 4 M deals per batch 8.34 -> 7.47 ms,
+    // 1 M 3.28 -> 2.99, 256 K 1.48 -> 1.31, 64 K 0.90 -> 0.92; lossless abstractions at 64 K 2.53 -> 2.37: the engine's choice beyond 64 K deals per batch
+    {
+        const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds;
+        const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->deals.n_deals > kRowsMinDeals;   // only sampled sweeps have list walkers
+        s->rows = can && (s->knobs.rows == kUnset ? engine : s->knobs.rows != 0);
+    }
     // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
     // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
     if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
@@ -479,7 +484,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
             // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
             // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
-            s->ordered = round_mode && fits && !s->rows && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
+            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
             if (s->ordered) {
                 const size_t pitch = round_up(s->deals.n_deals, kLanePad);
                 const uint32_t n = s->deals.n_deals;
