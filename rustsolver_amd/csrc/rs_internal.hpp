@@ -121,6 +121,11 @@ struct CompactJob {
     float *rlist;         // [n_parts][list_stride] or nullptr
     uint32_t *plist;      // [n_parts][list_stride] or nullptr: where the parent subtree will read this deal's utility (its list position; the deal id below an unlisted parent)
 };
+// compact jobs [first, first + n) scan one source for n sibling roots (k_compact_siblings): n <= 16, no cluster ranges
+struct CompactGroup {
+    uint32_t first, n;
+};
+hipError_t launch_compact_siblings(const CompactJob *d_jobs, const CompactGroup *d_groups, int n_groups, uint32_t max_lanes, hipStream_t stream);
 // deal sweeps: packed per-deal inputs of one round (rs_kernels.hip k_pack_attr)
 struct u32x4_host { uint32_t x, y, z, w; };
 struct PackJob {
@@ -259,6 +264,7 @@ struct Knobs {
     long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES
     long tile_min_lanes = kUnset;   // RS_TABLE_TILE_MIN_LANES
     int no_prefetch = 0;            // RS_TRAINER_NO_PREFETCH
+    int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
 std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), else ~/.cache/rustsolver_amd

@@ -862,6 +862,76 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_
 }
 
 
+// The roots below ONE parent subtree scan the same source -- the parent's live list, or the whole batch below the first root -- each for its own reach row.  One job per
+// root walks that source once per root (twelve turn roots: the 4 M-deal batch twelve times) and pays the two barriers and the returning atomic of a tile once per root; here
+// ONE workgroup takes a tile of the source for all sibling roots: entries read once, a ballot round per sibling, the siblings' slot reservations issued side by side by
+// different threads.  Same lists as k_compact_live writes (slots in source order inside a tile), cluster ranges excluded (n_parts == 1).
+constexpr uint32_t kMaxSiblings = 16;
+__global__ __launch_bounds__(kBlock) void k_compact_siblings(const CompactJob *__restrict__ jobs, const CompactGroup *__restrict__ groups) {
+    __shared__ uint32_t wave_count[kMaxSiblings][kCompactPerThread][kBlock / 64];
+    __shared__ uint32_t slot_base[kMaxSiblings];
+    const CompactGroup g = groups[blockIdx.y];
+    const CompactJob *__restrict__ J = jobs + g.first;
+    const uint32_t nc = g.n;
+    const uint32_t lane_in_wave = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t kTile = kBlock * kCompactPerThread;
+    const uint32_t *__restrict__ src = J[0].src_list;
+    const uint32_t n = src ? J[0].src_count[0] : J[0].n_lanes;
+    const bool by_pos = src && J[0].pos_rows;
+    for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {
+        uint32_t deal[kCompactPerThread];
+        unsigned long long live_bits = 0;   // bit q * kCompactPerThread + i: entry i of this thread is live below sibling q
+#pragma unroll
+        for (uint32_t i = 0; i < kCompactPerThread; ++i) {
+            const uint32_t e = base + i * kBlock + threadIdx.x;
+            deal[i] = e < n ? (src ? src[e] : e) : 0u;
+        }
+        for (uint32_t q = 0; q < nc; ++q) {
+            const float *__restrict__ reach = J[q].reach;
+#pragma unroll
+            for (uint32_t i = 0; i < kCompactPerThread; ++i) {
+                const uint32_t e = base + i * kBlock + threadIdx.x;
+                const float rv = e < n ? reach[by_pos ? (size_t)e : (size_t)deal[i]] : __builtin_nanf("");
+                const bool live = rv == rv;
+                const unsigned long long ballot = __ballot(live);
+                if (live) live_bits |= 1ull << (q * kCompactPerThread + i);
+                if (lane_in_wave == 0) wave_count[q][i][wave] = (uint32_t)__popcll(ballot);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            uint32_t total = 0;
+            for (uint32_t i = 0; i < kCompactPerThread; ++i)
+                for (int w = 0; w < kBlock / 64; ++w) total += wave_count[threadIdx.x][i][w];
+            slot_base[threadIdx.x] = total ? atomicAdd(J[threadIdx.x].count, total) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t q = 0; q < nc; ++q) {
+            const CompactJob &job = J[q];
+#pragma unroll
+            for (uint32_t i = 0; i < kCompactPerThread; ++i) {
+                const bool live = (live_bits >> (q * kCompactPerThread + i)) & 1ull;
+                const unsigned long long ballot = __ballot(live);
+                if (!live) continue;
+                uint32_t slot = slot_base[q] + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
+                for (uint32_t i2 = 0; i2 <= i; ++i2)
+                    for (uint32_t w = 0; w < (i2 < i ? (uint32_t)(kBlock / 64) : wave); ++w) slot += wave_count[q][i2][w];
+                const uint32_t e = base + i * kBlock + threadIdx.x;
+                job.list[slot] = deal[i];
+                if (job.rlist) job.rlist[slot] = job.reach[by_pos ? (size_t)e : (size_t)deal[i]];
+                if (job.plist) job.plist[slot] = by_pos ? e : deal[i];
+            }
+        }
+        __syncthreads();   // wave_count / slot_base are rewritten by the next iteration
+    }
+}
+hipError_t launch_compact_siblings(const CompactJob *d_jobs, const CompactGroup *d_groups, int n_groups, uint32_t max_lanes, hipStream_t stream) {
+    if (n_groups <= 0) return hipSuccess;
+    const size_t tile = size_t(kBlock) * kCompactPerThread;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_lanes) + tile - 1) / tile, 2048)), (unsigned)n_groups), block(kBlock);
+    hipLaunchKernelGGL(k_compact_siblings, grid, block, 0, stream, d_jobs, d_groups);
+    return hipGetLastError();
+}
 hipError_t launch_compact_live(const CompactJob *d_jobs, int n_jobs, uint32_t max_lanes, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
     const size_t tile = size_t(kBlock) * kCompactPerThread;

@@ -13,6 +13,7 @@ constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size co
 // Rows that many workgroups stream at the same offsets at the same time (delta rows, live-deal lists) must not start a power of two apart: a 4 M-deal batch puts them 16 MiB
 // apart, every stream then sits on the same memory channel at the same moment, and the row-summing pass ran 4x slower than with 4 196 416 deals (12.7 against 8.9 ms per batch)
 constexpr size_t kRowStagger = 1088;   // elements between the natural pitch and the one used (4 352 B: off every power-of-two interleave up to 4 KiB, rows stay 256-B aligned)
+constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this size compact the live deals of sibling roots in one scan of their source (rs_plan_deals.cpp)
 constexpr uint32_t kRowsMinDeals = 65536;   // deal batches beyond this size store delta rows in their list walkers (rs_solver.cpp)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER, L_ROWSUM };
@@ -22,6 +23,7 @@ struct Launch {
     int kind;
     int n_actions = 0;
     int first_job = 0, n_jobs = 0;
+    int first_group = 0, n_groups = 0;  // L_COMPACT: the launch's jobs as sibling groups (k_compact_siblings), 0 = one job per root
     uint32_t max_n_vec = 0;
     size_t max_lanes = 0;   // chance launches: largest lane count among the jobs
     double bytes = 0.0;
@@ -87,6 +89,8 @@ struct Plan {
     std::vector<CompactJob> compact_jobs;
     std::vector<size_t> count_off;      // per compact job: index of its first counter (a job has one per cluster range)
     std::vector<int> compact_round;     // per compact job: betting round of its root
+    std::vector<rs::CompactGroup> compact_groups;   // runs of sibling jobs (same source, no cluster ranges), in job order
+    rs::CompactGroup *d_compact_groups = nullptr;
     int dense_roots[RS_MAX_ROUNDS] = {0, 0, 0};   // round subtrees that walk the whole batch, per round
     uint32_t compact_max_lanes = 0;
     float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep

@@ -56,7 +56,9 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         prof_begin(t, RS_K_REACH, L.bytes);
         const size_t c_lo = plan.count_off[size_t(L.first_job)], c_hi = plan.count_off[size_t(L.first_job + L.n_jobs)];
         hipError_t ec = hipMemsetAsync(plan.d_counts + c_lo * kCountStride, 0, (c_hi - c_lo) * kCountStride * sizeof(uint32_t), t->stream);
-        if (ec == hipSuccess) ec = launch_compact_live(plan.d_compact_jobs + L.first_job, L.n_jobs, plan.compact_max_lanes, t->stream);
+        if (ec == hipSuccess)
+            ec = L.n_groups ? launch_compact_siblings(plan.d_compact_jobs, plan.d_compact_groups + L.first_group, L.n_groups, plan.compact_max_lanes, t->stream)
+                            : launch_compact_live(plan.d_compact_jobs + L.first_job, L.n_jobs, plan.compact_max_lanes, t->stream);
         prof_end(t);
         RS_HIP(ec, "k_compact_live");
         return RS_OK;
@@ -254,6 +256,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
         if (pl.d_klists) (void)hipFree(pl.d_klists);
+        if (pl.d_compact_groups) (void)hipFree(pl.d_compact_groups);
         if (pl.d_row_jobs) (void)hipFree(pl.d_row_jobs);
         if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);
         if (pl.d_frows) (void)hipFree(pl.d_frows);

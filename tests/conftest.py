@@ -54,7 +54,7 @@ FAN_LOOP_TESTS = {
     "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu", "test_config3_cluster_count_whole_table_on_few_boards",
     "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
 }
-# (test_randomised_differential draws its own form per seed: 48 cases instead of 192, every form still met a dozen times)
+# (test_randomised_differential draws its own form per seed: 40 cases instead of 192, every form still met ten times)
 
 
 def pytest_generate_tests(metafunc):
