@@ -3,7 +3,7 @@
 
     python profiles/summarize_deals_forms.py gpurun_out/r03_deals_forms profiles/r03_deals
 
-writes <prefix>.md and <prefix>.json.  form0 = LDS delta tiles (RS_JIT_ROWS=0, the round-2 path), form1 = the engine's choice (delta rows in the list walkers).
+writes <prefix>.md and <prefix>_forms.json.  form0 = LDS delta tiles and one compaction job per root (RS_JIT_ROWS=0 RS_JIT_NO_SIBLINGS=1, the round-2 path), form1 = the engine's choice (delta rows in the list walkers).
 Kernel times are per BATCH (both traversers' sweeps) from the serialised trace; `walks` = (deal, round subtree) pairs the batch's kernels of that class walked, as
 rs_solver_walk_counts reports them, so that every class has a cost per walk.
 """
@@ -35,7 +35,7 @@ def classify(name):
         if down:
             return ("turn reach-down", 1)
         return ("turn walk" if n.endswith(("_pr", "_pr_wl")) else "river walk", 1 if n.endswith(("_pr", "_pr_wl")) else 2)
-    for key, cls in (("k_compact_live", "live-deal lists (k_compact_live)"), ("k_row_sums", "row sums (k_row_sums)"), ("k_worklist", "work lists (k_worklist)"),
+    for key, cls in (("k_compact", "live-deal lists (k_compact_live / k_compact_siblings)"), ("k_row_sums", "row sums (k_row_sums)"), ("k_worklist", "work lists (k_worklist)"),
                      ("k_build_shadow", "table shadow (k_build_shadow)"), ("k_apply_delta", "apply (k_apply_delta_jobs)"), ("k_deal_clusters", "dealing: get_cluster (k_deal_clusters)"),
                      ("k_deal_sample", "dealing: generate_hand + showdown (k_deal_sample)"), ("k_deal_prune_flags", "dealing: prune flags"), ("k_pack_attr", "per-deal records (k_pack_attr)"),
                      ("fillBuffer", "memset (counters, work lists)"), ("copyBuffer", "copies")):
@@ -91,11 +91,11 @@ walks = (tm[1].get(4194304) or tm[0].get(4194304) or {}).get("walks_per_batch")
 per_class_walks = {}
 if walks:
     per_class_walks = {"flop walk": walks[0], "flop reach-down": walks[0], "turn walk": walks[1], "turn reach-down": walks[1], "river walk": walks[2],
-                       "live-deal lists (k_compact_live)": walks[1] + walks[2], "row sums (k_row_sums)": walks[1] + walks[2]}
-L = ["# deal path, three streets, 5 000-bucket files: LDS delta tiles (round 2) against delta rows (round 3)", "",
+                       "live-deal lists (k_compact_live / k_compact_siblings)": walks[1] + walks[2], "row sums (k_row_sums)": walks[1] + walks[2]}
+L = ["# deal path, three streets, 5 000-bucket files: LDS delta tiles (round 2) against delta rows + sibling compaction (round 3)", "",
      "`tools/profile_deals_forms.sh`; form 0 = `%s`, form 1 = `%s` (what the engine picks beyond 64 K deals per batch).  One MI355X." % (forms[0], forms[1]), "",
      "## batch time (hipGraph replay, the launches of a round overlapped on four streams: what `bench.py` measures)", "",
-     "| deals per batch | tiles: ms per batch | deal-iterations/s | rows: ms per batch | deal-iterations/s | ratio |", "|---|---|---|---|---|---|"]
+     "| deals per batch | round-2 forms: ms per batch | deal-iterations/s | round-3 forms: ms per batch | deal-iterations/s | ratio |", "|---|---|---|---|---|---|"]
 for n in sorted(set(tm[0]) | set(tm[1]), reverse=True):
     a, b = tm[0].get(n), tm[1].get(n)
     L.append("| %d | %s | %s | %s | %s | %s |" % (n, "%.2f" % a["ms_per_batch"] if a else "-", "%.3g" % a["deal_iterations_per_s"] if a else "-", "%.2f" % b["ms_per_batch"] if b else "-",
@@ -104,8 +104,8 @@ if walks:
     L += ["", "A 4 M-deal batch walks %s (deal, round subtree) pairs on flop / turn / river (both traversers; `rs_solver_walk_counts`): %.1f per deal." % (
         " / ".join("%.2f M" % (w / 1e6) for w in walks), sum(walks) / 4194304.0)]
 L += ["", "## kernels, 4 M deals per batch, launches serialised (`RS_JIT_NO_OVERLAP=1`, no graph): ms per batch (launches per batch)", "",
-      "| kernel class | tiles | rows | walks per batch | rows: ps per walk |", "|---|---|---|---|---|"]
-order = ["river walk", "turn walk", "flop walk", "turn reach-down", "flop reach-down", "row sums (k_row_sums)", "live-deal lists (k_compact_live)", "work lists (k_worklist)",
+      "| kernel class | round-2 forms | round-3 forms | walks per batch | round-3 forms: ps per walk |", "|---|---|---|---|---|"]
+order = ["river walk", "turn walk", "flop walk", "turn reach-down", "flop reach-down", "row sums (k_row_sums)", "live-deal lists (k_compact_live / k_compact_siblings)", "work lists (k_worklist)",
          "table shadow (k_build_shadow)", "apply (k_apply_delta_jobs)", "per-deal records (k_pack_attr)", "dealing: get_cluster (k_deal_clusters)",
          "dealing: generate_hand + showdown (k_deal_sample)", "dealing: prune flags", "memset (counters, work lists)", "copies"]
 seen = set()
@@ -146,5 +146,5 @@ if sq or tcp:
             t.get("TCP_TCC_READ_REQ_sum", 0.0) / nt, t.get("TCP_TCC_WRITE_REQ_sum", 0.0) / nt, t.get("TCP_TCP_TA_DATA_STALL_CYCLES_sum", 0.0) / nt / 256.0))
     L.append("")
 open(prefix + ".md", "w").write("\n".join(L) + "\n")
-json.dump({"forms": forms, "timing": tm, "kernels_ms_per_batch": [{k: v for k, v in s[0].items()} for s in st], "walks_per_batch_4m": walks}, open(prefix + ".json", "w"), indent=1)
+json.dump({"forms": forms, "timing": tm, "kernels_ms_per_batch": [{k: v for k, v in s[0].items()} for s in st], "walks_per_batch_4m": walks}, open(prefix + "_forms.json", "w"), indent=1)   # not <prefix>.json: bench.py reads profiles/r*_deals.json as summarize_deals.py output
 print("\n".join(L[:40]))

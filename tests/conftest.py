@@ -39,10 +39,10 @@ TWO_DEALS_PER_THREAD_TESTS = {
 TABLE_LAYOUT_TESTS = {
     "test_known_answers_update_and_strategy", "test_known_answers_discount", "test_golden_random_update_cases", "test_golden_random_discount_cases",
     "test_golden_extension_cases", "test_update_node_vs_oracle", "test_rmplus_i32_vs_oracle", "test_null_reach_means_one_and_per_board_copies",
-    "test_zero_init_and_fill_mirror", "test_iterate_river_tree_vs_oracle", "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle",
+    "test_zero_init_and_fill_mirror", "test_iterate_river_tree_vs_oracle", "test_iterate_three_street_tree_vs_oracle",
     "test_iterate_extension_dtypes_vs_oracle", "test_iterate_sampled_opponent_vs_oracle", "test_wide_nodes_through_both_plans",
     "test_action_node_without_valid_actions", "test_train_with_discount_schedule_vs_oracle", "test_leaf_util_buffers_per_traverser",
-    "test_checkpoint_roundtrip", "test_sharded_enum_sweep_equals_single_gpu", "test_allreduce_replicated_single_rank_is_identity",
+    "test_checkpoint_roundtrip", "test_allreduce_replicated_single_rank_is_identity",
     "test_calc_br_equals_oracle",
 }
 
@@ -51,10 +51,12 @@ TABLE_LAYOUT_TESTS = {
 # n_clusters % 4 == 0) or, on request, its whole deal loop (`_fan` kernels, RS_JIT_FAN=2); and the action nodes ABOVE the last round form round subtrees with a
 # reach-down and a walk-up kernel each (`_lanes_down`, `_lanes_round`) unless RS_JIT_NO_LANE_ROUNDS keeps them on the level plan: these tests run in all four forms.
 FAN_LOOP_TESTS = {
-    "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu", "test_config3_cluster_count_whole_table_on_few_boards",
+    "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu",
     "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
 }
-# (test_randomised_differential draws its own form per seed: 40 cases instead of 192, every form still met ten times)
+# (round 3, to keep the GPU suite under 450 s: the 5 000-cluster whole-table test runs the engine's own form only, the sharded and the pruned three-street tests plain rows
+# only -- tiled rows and the other fan forms meet sharding and pruning in test_iterate_three_street_tree_vs_oracle and the full-size tests)
+# (test_randomised_differential draws its own form per seed: 30 cases instead of 192, every form still met seven times)
 
 
 def pytest_generate_tests(metafunc):
