@@ -31,5 +31,5 @@ print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.in
 tr.train(2); tr.status()
 KB = int(os.environ.get("BATCHES", "5"))
 t0 = time.perf_counter(); tr.train(KB); tr.infosets.sync(); dt = (time.perf_counter() - t0) / KB
-print("three-street, %d clusters, %d deals per batch: %.2f ms per batch = %.3g deal-iterations/s" % (K, n, dt * 1e3, n / dt))
 print("walks of the last batch per round (deal, round subtree): traverser 0", tr.walk_counts(0), "traverser 1", tr.walk_counts(1))
+print("three-street, %d clusters, %d deals per batch: %.2f ms per batch = %.3g deal-iterations/s" % (K, n, dt * 1e3, n / dt))
