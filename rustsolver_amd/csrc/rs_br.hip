@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <vector>
 
 #include "rs_internal.hpp"
@@ -577,6 +578,8 @@ struct BrRun {
     BrSide side[2];
     std::vector<void *> allocs;
     std::vector<double *> q_level, v_level;   // per tree depth: [max actions][n_pad] children buffers
+    double *d_root = nullptr;                 // [n_pad_max]: the root values of the traverser's lanes
+    size_t n_pad_max = 0;
     hipError_t err = hipSuccess;
 
     template <typename T> T *dalloc(size_t n) {
@@ -691,12 +694,17 @@ size_t rs_br_runouts(const uint8_t *board0, int n_board0, uint8_t *out_cards) {
     return nb;
 }
 
-int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
-                            size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, int mode, double *out) {
-    if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
-    const bool sorted = (mode & RS_BR_SORTED) != 0;
-    mode &= ~RS_BR_SORTED;
-    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE (| RS_BR_SORTED)");
+}  // extern "C"
+
+namespace rs {
+
+// Everything of a best-response pass that depends on the GAME only (tree shape, ranges, board, cluster ids) and not on the table's contents: lane scores and masks, the lanes of
+// every info set in ascending order, the rank-order index of the showdowns, the walk's buffers.  A caller that asks again for the same game (the trainer's exploitability
+// ticks) keeps the object and pays for the walk alone.
+int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
+               size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, bool sorted, BrRun **prepared) {
+    if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !prepared) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+    *prepared = nullptr;
     if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_best_response: empty tree");
     if (n_board0 < 3 || n_board0 > 5) return fail(RS_ERR_INVALID, "rs_best_response: the initial board has 3, 4 or 5 cards (state.rs:59-64)");
     const int K = 5 - n_board0, D = 52 - n_board0;
@@ -747,10 +755,10 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
         per_prefix[r] = left;
     }
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
-    BrRun run;
+    std::unique_ptr<BrRun> owner(new BrRun);
+    BrRun &run = *owner;
     run.t = t;
     run.tree = tree;
-    run.mode = mode;
     run.sorted = sorted;
     run.NB = uint32_t(NB);
     run.d_bmask = run.upload(bmask);
@@ -844,8 +852,29 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
         run.q_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
         run.v_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
     }
-    double *d_root = run.dalloc<double>(n_pad_max);
-    std::vector<double> root(n_pad_max);
+    run.n_pad_max = n_pad_max;
+    run.d_root = run.dalloc<double>(n_pad_max);
+    if (run.err != hipSuccess) {
+        (void)hipStreamSynchronize(t->stream);   // drain the stream before ~BrRun frees what queued kernels may still touch
+        return hip_fail(run.err, "rs_best_response");
+    }
+    *prepared = owner.release();
+    return RS_OK;
+}
+
+void br_free(BrRun *run) { delete run; }
+
+// the walk: both traversers against the table as it stands
+int br_execute(BrRun *prepared, int mode, double *out) {
+    if (!prepared || !out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE (| RS_BR_SORTED)");
+    BrRun &run = *prepared;
+    rs_table *t = run.t;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    run.mode = mode;
+    run.err = hipSuccess;
+    double *d_root = run.d_root;
+    std::vector<double> root(run.n_pad_max);
     for (int p = 0; p < 2 && run.err == hipSuccess; ++p) {
         run.p = p;
         run.walk(0, run.side[1 - p].d_init_q, d_root, 0);
@@ -855,12 +884,29 @@ int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *boa
         for (uint32_t l = 0; l < run.side[p].n; ++l) total += root[l];   // ascending, like the oracle
         out[p] = total;
     }
-    // on error drain the stream before ~BrRun frees what queued kernels may still touch
+    // on error drain the stream before the caller frees what queued kernels may still touch
     if (run.err != hipSuccess) {
         (void)hipStreamSynchronize(t->stream);
         return hip_fail(run.err, "rs_best_response");
     }
     return RS_OK;
+}
+
+}  // namespace rs
+
+extern "C" {
+
+int rs_best_response_rounds(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
+                            size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, int mode, double *out) {
+    if (!out) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
+    const bool sorted = (mode & RS_BR_SORTED) != 0;
+    mode &= ~RS_BR_SORTED;
+    if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE (| RS_BR_SORTED)");
+    rs::BrRun *run = nullptr;
+    if (int rc = rs::br_prepare(t, tree, board0, n_board0, hands_p0, n_hands_p0, hands_p1, n_hands_p1, cluster, n_rounds, sorted, &run)) return rc;
+    const int rc = rs::br_execute(run, mode, out);
+    rs::br_free(run);
+    return rc;
 }
 
 // the single-round game on a full board (the configuration the reference ships): NB = 1

@@ -121,6 +121,12 @@ struct CompactJob {
     float *rlist;         // [n_parts][list_stride] or nullptr
     uint32_t *plist;      // [n_parts][list_stride] or nullptr: where the parent subtree will read this deal's utility (its list position; the deal id below an unlisted parent)
 };
+// best response over run-outs (rs_br.hip): what depends on the game only is prepared once, the walk runs against the table as it stands
+struct BrRun;
+int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1, size_t n_hands_p1,
+               const uint32_t *const *cluster, int n_rounds, bool sorted, BrRun **prepared);
+int br_execute(BrRun *prepared, int mode /* RS_BR_MAX / RS_BR_AVERAGE */, double *out /* [2] */);
+void br_free(BrRun *prepared);
 // compact jobs [first, first + n) scan one source for n sibling roots (k_compact_siblings): n <= 16, no cluster ranges
 struct CompactGroup {
     uint32_t first, n;

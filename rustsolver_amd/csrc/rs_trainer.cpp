@@ -31,6 +31,7 @@ struct rs_deal_trainer {
     std::vector<uint8_t> h_hands[2];   // host copy of the ranges (rs_deal_trainer_best_response)
     std::vector<uint32_t> br_cluster[RS_MAX_ROUNDS][2];   // cluster ids of every (board prefix, hand) of every round: they never change, computed at the first best response
     bool br_cluster_ready = false;                        // ... and valid only once every (round, player) has been filled
+    rs::BrRun *br_prepared[2] = {nullptr, nullptr};       // [pair loop, rank-order showdowns]: the game-only half of rs_best_response_rounds, kept between calls
     // train()'s prune schedule (cfr.rs:213-221): with a finite prune_threshold the solver runs in RS_UPD_PRUNE mode from the start and every
     // traverser visit honours the deal's flag byte -- all zero (= unpruned, bit for bit) until a batch reaches beyond the threshold
     uint8_t *d_prune = nullptr;        // [pitch] flags of the live batch
@@ -56,6 +57,8 @@ extern "C" {
 
 void rs_deal_trainer_destroy(rs_deal_trainer *tr) {
     if (!tr) return;
+    for (int k = 0; k < 2; ++k)
+        if (tr->br_prepared[k]) rs::br_free(tr->br_prepared[k]);
     if (tr->solver) rs_solver_destroy(tr->solver);
     if (tr->table) {
         if (tr->d_prune) rs_dfree(tr->table, tr->d_prune);
@@ -368,8 +371,12 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
     }
     for (int r = 0; r < tr->n_rounds; ++r)
         for (int p = 0; p < 2; ++p) ptrs[r * 2 + p] = tr->br_cluster[r][p].data();
-    return rs_best_response_rounds(tr->table, tr->tree, board, n_board0, tr->h_hands[0].data(), tr->n_hands[0], tr->h_hands[1].data(), tr->n_hands[1], ptrs, tr->n_rounds,
-                                   mode, out);
+    const int which = (mode & RS_BR_SORTED) ? 1 : 0;
+    if (!tr->br_prepared[which])
+        if (int rc = rs::br_prepare(tr->table, tr->tree, board, n_board0, tr->h_hands[0].data(), tr->n_hands[0], tr->h_hands[1].data(), tr->n_hands[1], ptrs, tr->n_rounds,
+                                    which == 1, &tr->br_prepared[which]))
+            return rc;
+    return rs::br_execute(tr->br_prepared[which], mode & ~RS_BR_SORTED, out);
 }
 
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {

@@ -56,7 +56,7 @@ FAN_LOOP_TESTS = {
 }
 # (round 3, to keep the GPU suite under 450 s: the 5 000-cluster whole-table test runs the engine's own form only, the sharded and the pruned three-street tests plain rows
 # only -- tiled rows and the other fan forms meet sharding and pruning in test_iterate_three_street_tree_vs_oracle and the full-size tests)
-# (test_randomised_differential draws its own form per seed: 30 cases instead of 192, every form still met seven times)
+# (test_randomised_differential draws its own form per seed: 26 cases instead of 192, every form still met six times)
 
 
 def pytest_generate_tests(metafunc):
