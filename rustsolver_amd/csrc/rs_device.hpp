@@ -230,6 +230,16 @@ __device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (
         }
     }
 }
+// an opponent node whose shadow record holds its strategy (ShadowJob.sigma): sampled from as it comes
+template <int A>
+__device__ __forceinline__ void gather_sigma(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], float (&g)[A][kVecD]) {
+    int r[A][kVecD];
+    gather_rec<A>(shadow, stride, idx, r);
+#pragma unroll
+    for (int a = 0; a < A; a++)
+#pragma unroll
+        for (int j = 0; j < kVecD; j++) g[a][j] = __int_as_float(r[a][j]);
+}
 // A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
 // from the table's own [A][pitch] rows, one 4-byte gather per (action, array).  `shadow` is a kernel argument: the branch is uniform.
 template <int A, typename V>

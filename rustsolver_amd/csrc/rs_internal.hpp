@@ -99,7 +99,8 @@ struct ShadowJob {
     const int32_t *ssum;
     int32_t *dst;             // [n_clusters][stride]: regrets (half ints), then strategy_sum (half ints) when stride == 2 * half
     uint32_t pitch, n_clusters, n_actions, half;   // half = 4 (A <= 4) or 8
-    uint32_t stride, pad_;    // half: regrets only (a node of the sweep's opponent); 2 * half: both arrays (a traverser node)
+    uint32_t stride, sigma;   // half: regrets only (a node of the sweep's opponent); 2 * half: both arrays (a traverser node).  sigma (with stride == half): the record holds
+                              // get_strategy() of the regrets (f32 bits) instead of the regrets: the sweep only reads an opponent node to sample from it
 };
 // sparse deal sweeps: live deals (reach not NaN) of one subtree root, compacted (order irrelevant: every use commutes)
 struct CompactJob {
@@ -270,6 +271,7 @@ struct Knobs {
     long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES
     long tile_min_lanes = kUnset;   // RS_TABLE_TILE_MIN_LANES
     int no_prefetch = 0;            // RS_TRAINER_NO_PREFETCH
+    int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
     int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
@@ -305,7 +307,8 @@ struct JitSubtree {
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
-                      bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false, bool rows = false);
+                      bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false, bool rows = false,
+                      const std::vector<char> *sigma = nullptr /* per tree node: its shadow record holds the strategy (opponent nodes of a deal sweep) */);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
 uint64_t jit_source_key(const std::string &source);   // what the caches are keyed by (source + compiler version + options)

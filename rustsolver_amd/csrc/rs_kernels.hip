@@ -477,6 +477,16 @@ __global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__rest
             rec[a] = a < A ? reg[(size_t)a * pitch + c] : 0;
             rec[8 + a] = (both && a < A) ? ssm[(size_t)a * pitch + c] : 0;
         }
+        if (!both && job->sigma) {   // an opponent node of this sweep: the record holds get_strategy() of the regrets (infoset.rs:83-102), by the very function the walks use
+            float sg[8];
+            switch (A) {
+#define RS_SIGMA_CASE(A_) case A_: { int rr[A_]; float ss[A_]; for (int a = 0; a < A_; ++a) rr[a] = rec[a]; regret_match<A_, int>(rr, ss); for (int a = 0; a < A_; ++a) sg[a] = ss[a]; } break;
+                RS_SIGMA_CASE(1) RS_SIGMA_CASE(2) RS_SIGMA_CASE(3) RS_SIGMA_CASE(4) RS_SIGMA_CASE(5) RS_SIGMA_CASE(6) RS_SIGMA_CASE(7) RS_SIGMA_CASE(8)
+#undef RS_SIGMA_CASE
+            default: break;
+            }
+            for (uint32_t a = 0; a < A && a < 8; ++a) rec[a] = __float_as_int(sg[a]);
+        }
         i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * job->stride);
         if (half == 2) {   // two actions: 8 bytes of regrets, or one 16-byte record {r0, r1, s0, s1}
             if (both) out[0] = i32x4{rec[0], rec[1], rec[8], rec[9]};

@@ -402,12 +402,22 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
     const bool seg = seg_root(id) && !down && t->dtype == RS_I32;
     const bool rows = s->deal_mode && rows_root(id) && !down;
     const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg && !rows && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
+    if (s->deal_mode && sigma_node.empty() && !s->shadow_off_p[p].empty() && !s->knobs.no_sigma) {
+        sigma_node.assign(n, 0);
+        for (size_t q = 0; q < n; ++q) {
+            const rs_tree_node &qn = nodes[q];
+            if (qn.kind != RS_NODE_ACTION || qn.n_children == 0 || qn.player == p) continue;
+            const bool shadowed = s->shadow_off_p[p][size_t(qn.index)] != SIZE_MAX;
+            const uint32_t half = qn.n_children <= 2 ? 2u : (qn.n_children <= 4 ? 4u : 8u);
+            sigma_node[q] = shadowed && s->shadow_stride_p[p][size_t(qn.index)] == half;
+        }
+    }
     JitSubtree js;
     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                      (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows);
+                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node);
     const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
     // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete, every distinct source at once on a pool of host threads

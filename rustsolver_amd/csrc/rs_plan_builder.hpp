@@ -115,6 +115,7 @@ struct PlanBuilder {
     std::vector<int> sparse_slot;   // per tree node: index of its compact job (the list of its live deals), -1 = it walks every lane
     int emit_deal_lists();
     int emit_round_walks();
+    std::vector<char> sigma_node;   // per tree node: this sweep's shadow record of the node holds its strategy (an opponent node with a shadow; rs_solver.cpp ShadowJob.sigma)
     int emit_row_sums();
     int emit_apply();
 

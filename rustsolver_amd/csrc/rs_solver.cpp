@@ -429,6 +429,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 j.n_actions = d.n_actions;
                 j.half = half;
                 j.stride = stride;
+                j.sigma = (stride == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
                 jobs.push_back(j);
                 ints += round_up(size_t(d.n_clusters) * stride, 64);
                 s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);

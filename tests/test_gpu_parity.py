@@ -1219,14 +1219,18 @@ def test_c_examples_run_through_the_c_abi(tmp_path):
     assert float(re.search(r"exploitability (-?[\d.]+)", r.stdout).group(1)) < 20.0, r.stdout
 
 
-@pytest.mark.parametrize("shadow", ["rule-mixed", "all"])
+@pytest.mark.parametrize("shadow", ["rule-mixed", "all", "all-regrets"])
 def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
     """sampled sweeps read a node through its AoS shadow (rebuilt per sweep) only where the batch is likely to read the record at all (rs_solver.cpp: n_deals * 8 >= clusters *
     actions * round subtrees); elsewhere the kernels gather the table's own rows (gather_node / gather_node2 with a null shadow).  3 000 deals against 30 / 300 / 140 clusters:
     every flop and turn node keeps its shadow, on the river the two-action nodes keep theirs (140 * 2 * 72 < 24 000) and the three-action nodes lose it -- both kinds inside
-    ONE generated subtree.  "all" (RS_SHADOW_ALL) shadows everything.  Same bits as the oracle either way, and the workspace figure shows the difference."""
-    if shadow == "all":
+    ONE generated subtree.  "all" (RS_SHADOW_ALL) shadows everything.  An OPPONENT node's shadow record holds its strategy (matched once per sweep by k_build_shadow, sampled
+    from as it comes); "all-regrets" (RS_JIT_NO_SIGMA) keeps regrets there and matches them in the walk, as nodes without a shadow do.  Same bits as the oracle every way, and the
+    workspace figure shows the difference."""
+    if shadow.startswith("all"):
         monkeypatch.setenv("RS_JIT_SHADOW_ALL", "1")
+    if shadow == "all-regrets":
+        monkeypatch.setenv("RS_JIT_NO_SIGMA", "1")
     n_deals = 3000
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(30, 28), (300, 280), (140, 140)], n_deals, 93)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=14)
@@ -1240,7 +1244,7 @@ def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
         ro, so = otab.get_node(nd.index)
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
     ws = test_deal_sweeps_with_and_without_table_shadows.workspace
-    if len(ws) == 2:   # rs_solver_workspace_bytes counts the shadow: shadowing every node costs the river's three-action records (16 + 32 bytes per cluster and traverser sweep)
+    if "all" in ws and "rule-mixed" in ws:   # rs_solver_workspace_bytes counts the shadow: shadowing every node costs the river's three-action records (16 + 32 bytes per cluster and traverser sweep)
         assert ws["all"] > ws["rule-mixed"]
 
 
