@@ -29,7 +29,7 @@ DEALS_PER_THREAD_TESTS = {
 # four-deal forms of their kernels are the ones test_deal_batches_vs_oracle, test_sparse_subtree_sweeps_three_streets_many_deals and the ragged-batch test force)
 # the two-deal forms are one more value of the same template parameter: the cheaper half of the list runs them too
 TWO_DEALS_PER_THREAD_TESTS = {
-    "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup", "test_sparse_subtree_sweeps_three_streets_many_deals",
+    "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup",
     "test_wide_nodes_in_deal_batches", "test_deal_trainer_reference_as_coded", "test_deal_trainer_ragged_batches",
 }
 
@@ -56,7 +56,7 @@ FAN_LOOP_TESTS = {
 }
 # (round 3, to keep the GPU suite under 450 s: the 5 000-cluster whole-table test runs the engine's own form only, the sharded and the pruned three-street tests plain rows
 # only -- tiled rows and the other fan forms meet sharding and pruning in test_iterate_three_street_tree_vs_oracle and the full-size tests)
-# (test_randomised_differential draws its own form per seed: 26 cases instead of 192, every form still met six times)
+# (test_randomised_differential draws its own form per seed: 20 cases instead of 192, every form still met five times)
 
 
 def pytest_generate_tests(metafunc):

@@ -236,7 +236,7 @@ def test_deal_trainer_reference_as_coded(fuse):
 def test_deal_trainer_prune_schedule(streets):
     """train()'s prune flag (cfr.rs:213-221) with PRUNE_THRESHOLD moved into reach: deals numbered beyond it whose q > 0.05 are traversed
     with prune = true (explored[] of cfr.rs:379-386, updates of :419-441).  The table starts with regrets on both sides of -10 000 000 so
-    that pruning bites; batch 0 carries no flag (its deals are numbered below the threshold), batch 1's tail and batches 2-4 do.  Cards, flags and
+    that pruning bites; batch 0 carries no flag (its deals are numbered below the threshold), batch 1's tail and batches 2-3 do.  Cards, flags and
     tables equal the oracle's."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
@@ -261,7 +261,7 @@ def test_deal_trainer_prune_schedule(streets):
         ctx["otab"].set_node(nd.index, R, S)
     n = ctx["n_deals"]
     seen = 0
-    for b in range(5):
+    for b in range(4):
         ctx["tr"].train(1)
         cards = oracle_batch(ctx)
         assert (ctx["tr"].cards() == cards).all()
@@ -296,13 +296,14 @@ def test_deal_trainer_three_streets_from_a_flop_with_bucket_files(parts, monkeyp
     compare_trainer_tables(ctx)
 
 
-@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (2, 3, 700), (2, 1, 1 << 21)])
+@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (2, 3, 700), (2, 3, 100_000), (2, 1, 1 << 21)])
 def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets, n):
     """`world` ranks x n deals on replicated tables, their i32 deltas summed between sweep and apply (what rs_comm_allreduce_deltas does
     over xGMI; here the test adds them on the host), equal ONE trainer with world*n deals per batch, bit for bit: cards, tables, discount
     ticks.  Ranks are emulated on one GPU, one trainer per rank.  streets = 3: a flop-start tree, i.e. round subtrees, live-deal lists and the
     rank's lane base in the sampling hash together.  n = 2 M: the property at bench.py's size (4 M deals per union batch, the whole range,
-    four deals per thread, staged dealing on the second stream)."""
+    four deals per thread, staged dealing on the second stream).  streets = 3 with 100 000 deals per rank: the list walkers store delta rows (batches beyond 64 K deals), whose
+    summing launches belong to phase 0 -- the delta tables must be complete when the ranks exchange them."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
         hands = ab.random_range(mask)[:: (3 if n < 10000 else 1)]
