@@ -162,6 +162,7 @@ struct rs_solver {
     OrderJob order_job[2];              // per traverser
     // delta rows (rs_kernel_forms.delta_rows): one buffer for both traversers' sweeps (they never overlap), [2A][batch pitch] i32 per traverser node of an eligible round
     bool rows = false;
+    int first_round = 0;                // betting round of the first action node: its subtree walks the whole batch and keeps its tiles unless RS_JIT_ROWS = 2
     int32_t *d_drows = nullptr;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
     rs_deal_batch deals{};

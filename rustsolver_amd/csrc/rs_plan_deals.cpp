@@ -15,6 +15,7 @@ namespace rs {
 
 bool rows_round_ok(const rs_solver *s, int p, int round) {
     if (!s->rows || !s->deal_mode || s->table->dtype != RS_I32) return false;
+    if (s->knobs.rows < 2 && round == s->first_round) return false;   // the dense walk of the first round: rs_plan_builder.hpp rows_root
     const rs_table *t = s->table;
     uint32_t k = 0;
     for (size_t i = 0; i < t->nodes.size(); ++i)

@@ -458,8 +458,18 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
     // 1 M 3.28 -> 2.99, 256 K 1.48 -> 1.31, 64 K 0.90 -> 0.92; lossless abstractions at 64 K 2.53 -> 2.37: the engine's choice beyond 64 K deals per batch
     {
         const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds;
+        {
+            int c = 0;
+            while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0];
+            s->first_round = tree->nodes[size_t(c)].kind == RS_NODE_ACTION ? int(tree->nodes[size_t(c)].round_idx) : 0;
+        }
         const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->deals.n_deals > kRowsMinDeals;   // only sampled sweeps have list walkers
         s->rows = can && (s->knobs.rows == kUnset ? engine : s->knobs.rows != 0);
+        if (s->rows && s->knobs.rows == kUnset) {   // the rows cost 2 x actions x 4 B per traverser node and deal (26 GB at 4 M deals on the 706-node tree): only while a quarter of the free memory holds them
+            size_t free_b = 0, total_b = 0;
+            const size_t need = std::max(drows_ints(s, 0), drows_ints(s, 1)) * sizeof(int32_t);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) s->rows = false;
+        }
     }
     // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
     // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
