@@ -554,6 +554,49 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *
     }
 }
 
+// the same with one WAVE per info set, for rounds whose info sets hold many lanes (a flop info set of the 1 176-combo game: 3 800 of the 2.8 M lanes -- one thread per info set
+// left three workgroups walking 3 800 dependent gathers each, 13 ms per node).  The lanes of the wave fetch 64 list entries at a time; the additions still run one after the
+// other in list order (every lane adds the 64 values in the same order, read from its neighbours' registers), so the sums keep the oracle's bits.
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own_wave(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
+                                                          const uint32_t *__restrict__ order, uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch,
+                                                          int mode, double *__restrict__ v) {
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * kBrBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBrBlock >> 6);
+    for (uint32_t i = start[n_clusters] + blockIdx.x * kBrBlock + threadIdx.x; i < start[n_clusters + 1]; i += gridDim.x * kBrBlock) v[order[i]] = 0.0;
+    for (uint32_t c = wave; c < n_clusters; c += n_waves) {
+        const uint32_t lo = start[c], hi = start[c + 1];
+        if (lo == hi) continue;
+        if (mode == RS_BR_MAX) {
+            double s[RS_MAX_ACTIONS];
+            for (uint32_t a = 0; a < row.n_actions; a++) {
+                const double *va = vch + (size_t)a * n_pad;
+                double acc = 0.0;
+                for (uint32_t i = lo; i < hi; i += 64) {
+                    const uint32_t cnt = min(64u, hi - i);
+                    const double t = lane < cnt ? va[order[i + lane]] : 0.0;
+                    const int t_lo = __double2loint(t), t_hi = __double2hiint(t);
+                    for (uint32_t k = 0; k < cnt; ++k)   // cnt is wave-uniform
+                        acc += __hiloint2double(__builtin_amdgcn_readlane(t_hi, (int)k), __builtin_amdgcn_readlane(t_lo, (int)k));
+                }
+                s[a] = acc;
+            }
+            uint32_t best = 0;
+            for (uint32_t a = 1; a < row.n_actions; a++)
+                if (s[best] < s[a]) best = a;
+            for (uint32_t i = lo + lane; i < hi; i += 64) v[order[i]] = vch[(size_t)best * n_pad + order[i]];
+        } else {
+            float sig[RS_MAX_ACTIONS];
+            final_sigma<DT>(ssum, row.cell_off, row.pitch, row.n_actions, c, sig);
+            for (uint32_t i = lo + lane; i < hi; i += 64) {
+                const uint32_t h = order[i];
+                double acc = 0.0;
+                for (uint32_t a = 0; a < row.n_actions; a++) acc += (double)sig[a] * vch[(size_t)a * n_pad + h];
+                v[h] = acc;
+            }
+        }
+    }
+}
+
 struct BrSide {
     uint32_t n_hands = 0;
     uint32_t n = 0, n_pad = 0;     // lanes = NB * n_hands
@@ -625,11 +668,20 @@ struct BrRun {
         if (int(n.player) == p) {
             for (int a = 0; a < n.n_children; ++a) walk(n.children[a], q, vch + size_t(a) * me.n_pad, level + 1);
             if (err != hipSuccess) return;
+            if (size_t(me.n) >= size_t(me.n_clusters[r]) * 32) {   // many lanes per info set: a wave each
+                const uint32_t blocks = uint32_t(std::min<size_t>((size_t(me.n_clusters[r]) * 64 + kBrBlock - 1) / kBrBlock, 8192));
+#define RS_OWNW(DT_)                                                                                                                                    \
+    hipLaunchKernelGGL((k_br_own_wave<DT_>), dim3(blocks), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, me.d_start[r], me.d_order[r], me.n_clusters[r], \
+                       me.n_pad, vch, mode, v_out)
+                RS_BR_DT(t->dtype, RS_OWNW);
+#undef RS_OWNW
+            } else {
 #define RS_OWN(DT_)                                                                                                                                            \
     hipLaunchKernelGGL((k_br_own<DT_>), dim3(grid1(me.n_clusters[r])), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, me.d_start[r], me.d_order[r], me.n_clusters[r], \
                        me.n_pad, vch, mode, v_out)
-            RS_BR_DT(t->dtype, RS_OWN);
+                RS_BR_DT(t->dtype, RS_OWN);
 #undef RS_OWN
+            }
         } else {
             double *qch = q_level[size_t(level)];
 #define RS_OPP(DT_) hipLaunchKernelGGL((k_br_opp_reach<DT_>), dim3(grid1(op.n)), dim3(kBrBlock), 0, t->stream, t->d_ssum, row, op.d_cid[r], op.n, op.n_pad, q, qch)
