@@ -187,7 +187,9 @@ def oracle_batch(ctx):
         oix = orc.HandIndexer([2, nb])
         arr = None if ctx["bucket_files"] is None else ctx["bucket_files"][r]
         for p in (0, 1):
-            pos = {k: i for i, k in enumerate(oix.generate_map(ctx["ranges"][p], ctx["mask"], nb, arr).tolist())}
+            if (r, p) not in ctx.setdefault("pos", {}):   # first-appearance ids of the abstraction: a function of ranges, board and bucket file, not of the batch
+                ctx["pos"][(r, p)] = {k: i for i, k in enumerate(oix.generate_map(ctx["ranges"][p], ctx["mask"], nb, arr).tolist())}
+            pos = ctx["pos"][(r, p)]
             hands = np.concatenate([cards[5 + 2 * p: 7 + 2 * p], cards[:nb]]).T.copy()
             idx = oix.get_index(hands)
             buckets = idx if arr is None else arr[idx.astype(np.int64)]
