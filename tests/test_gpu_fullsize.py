@@ -343,3 +343,31 @@ def test_config4_shape_eight_emulated_ranks_equal_the_single_gpu_table(dtype):
     for (_, tb, sv, _) in ranks:
         sv.destroy()
         tb.destroy()
+
+
+def test_three_street_trainer_kernel_forms_agree_at_size(monkeypatch):
+    """The deal path at the size bench.py times it (flop start, 706 action nodes, 5 000-bucket files, a million deals per batch) under the two families of kernel forms: LDS delta
+    tiles + one compaction job per root (round 2), and what the engine picks at this size (delta rows in the list walkers, summed per round; sibling roots compacted in one scan;
+    strategy records for the opponent's nodes).  The oracle cannot follow at this size; integer deltas commute, so every form must leave the SAME table, cell for cell: whole-table
+    checksums after three batches (dealing, indexing, showdowns, both sweeps, prune flags from the second batch on)."""
+    from rustsolver_amd import abstraction as ab
+    rng = np.random.Generator(np.random.PCG64(1))
+    mask = ab.card_mask("7h8hQc")
+    hands = ab.random_range(mask)
+    K = 5000
+    files = [rng.integers(0, K, size=1286792, dtype=np.uint32), rng.integers(0, K, size=13960050, dtype=np.uint32), rng.integers(0, K, size=123156254, dtype=np.uint32)]
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
+    sums = {}
+    for form, env in (("tiles", {"RS_JIT_ROWS": "0", "RS_JIT_NO_SIBLINGS": "1", "RS_JIT_NO_SIGMA": "1"}), ("engine", {})):
+        for k in ("RS_JIT_ROWS", "RS_JIT_NO_SIBLINGS", "RS_JIT_NO_SIGMA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, 1 << 20, seed=7, discount_interval=0, prune_threshold=1 << 20, use_graph=True)
+        tr.train(3)
+        tr.status()
+        sums[form] = tr.infosets.checksum()
+        assert sum(tr.walk_counts(0)) > 3 << 20   # every deal walked its flop subtree and a few turn / river subtrees
+        del tr
+    assert sums["tiles"] == sums["engine"], sums
