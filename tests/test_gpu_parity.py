@@ -367,7 +367,7 @@ def test_iterate_three_street_tree_vs_oracle(boards, chance, fuse, C):
     compare_tables(tree, table, otab)
 
 
-@pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([2, 2, 2], "pass")])
+@pytest.mark.parametrize("boards,chance", [([1, 2, 6], "enum"), ([1, 3, 3], "enum"), ([2, 2, 2], "pass")])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_iterate_three_street_tree_pruned_vs_oracle(boards, chance, fuse):
     """cfr() with prune = true over lanes (cfr.rs:379-386): since round 2 the generated kernels (river subtrees, round subtrees and their
@@ -657,7 +657,7 @@ def test_wide_nodes_in_deal_batches(fuse, sampled):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(32))
 def test_randomised_differential(seed, monkeypatch):
     """random game options x engine modes, GPU vs oracle, bit for bit.  The form of the subtrees below ENUM chance nodes (rs_kernel_forms.lane_fan; conftest's fan_loop
     fixture for the other lane tests) goes round with the seed."""
