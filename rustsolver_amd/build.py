@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librustsolver_amd.so")
-SOURCES = ["rs_kernels.hip", "rs_table.cpp", "rs_tree.cpp", "rs_plan.cpp", "rs_plan_deals.cpp", "rs_solver.cpp", "rs_jit_check.cpp", "rs_knobs.cpp", "rs_comm.cpp", "rs_jit.cpp", "rs_abstraction.cpp", "rs_cards.hip", "rs_trainer.cpp", "rs_kmeans.hip", "rs_br.hip"]
+SOURCES = ["rs_kernels.hip", "rs_table.cpp", "rs_tree.cpp", "rs_plan.cpp", "rs_plan_deals.cpp", "rs_solver.cpp", "rs_jit_check.cpp", "rs_knobs.cpp", "rs_comm.cpp", "rs_jit.cpp", "rs_jit_cache.cpp", "rs_abstraction.cpp", "rs_cards.hip", "rs_trainer.cpp", "rs_kmeans.hip", "rs_br.hip"]
 HEADERS = [os.path.join(CSRC, "rs_internal.hpp"), os.path.join(CSRC, "rs_plan.hpp"), os.path.join(CSRC, "rs_plan_builder.hpp"), os.path.join(CSRC, "rs_device.hpp"), os.path.join(CSRC, "rs_hand_index.hpp"), os.path.join(CSRC, "rs_eval.hpp"), os.path.join(ROOT, "include", "rustsolver_amd.h"), os.path.join(ROOT, "include", "rustsolver_amd_diag.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
