@@ -26,7 +26,7 @@ def one(pattern):
 
 def classify(name):
     """kernel -> (class, round) of the three-street sweep"""
-    n = name.split("(")[0].replace("void ", "")
+    n = re.sub(r"__[sg]\d+$", "", name.split("(")[0].replace("void ", ""))   # kernels of one form compiled together: one entry point per subtree shape
     if n.startswith("rs_tree_"):
         down = "_down" in n
         sparse = "_sparse" in n
@@ -55,7 +55,7 @@ def stats(form):
         e = out.setdefault(cls, {"ms_per_batch": 0.0, "launches_per_batch": 0.0})
         e["ms_per_batch"] += float(r["TotalDurationNs"]) / 1e6 / BATCHES
         e["launches_per_batch"] += float(r["Calls"]) / BATCHES
-        names[cls].add(r["Name"].split("(")[0].replace("void ", ""))
+        names[cls].add(re.sub(r"__[sg]\d+$", "", r["Name"].split("(")[0].replace("void ", "")))
     return out, names
 
 

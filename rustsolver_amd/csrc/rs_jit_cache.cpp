@@ -166,7 +166,7 @@ static int compile_source(const std::string &source, std::vector<char> &buf, boo
 }
 
 // Groups of sources that can share one hipRTC program: the same text in front of the prelude (the #defines that shape it), at most 24 members (a bound on the size of
-// one program), every member's own part inside its own namespace with its entry point renamed `<entry>__g<i>`.  Sources that fit no group of two are left out.
+// one program), every member's own part inside its own namespace; entry points that occur more than once in a group (one form, several subtree shapes) become `<entry>__s<i>`.  Sources that fit no group of two are left out.
 struct KernelGroup {
     std::string combined;
     std::vector<std::string> names;     // per member: its entry point inside the group
@@ -187,10 +187,12 @@ static std::vector<KernelGroup> group_sources(const std::vector<std::pair<const 
             KernelGroup G;
             G.combined = kv.first + prelude;
             bool ok = true;
+            std::map<std::string, int> total, seen_n;   // an entry point keeps its name unless the group holds several kernels of that name (same form, different subtree shapes)
+            for (size_t k = lo; k < hi; ++k) total[*items[kv.second[k]].second] += 1;
             for (size_t k = lo; k < hi && ok; ++k) {
                 const std::string &src = *items[kv.second[k]].first, &entry = *items[kv.second[k]].second;
                 std::string body = src.substr(kv.first.size() + prelude.size());
-                const std::string from = "void " + entry + "(", name = entry + "__g" + std::to_string(k - lo);
+                const std::string from = "void " + entry + "(", name = total[entry] > 1 ? entry + "__s" + std::to_string(seen_n[entry]++) : entry;
                 const size_t at = body.find(from);
                 ok = at != std::string::npos && body.find(from, at + 1) == std::string::npos;
                 if (!ok) break;
@@ -330,7 +332,7 @@ uint64_t jit_source_key(const std::string &source) { return fnv1a(source + "\n//
 
 // Many kernels at once (a solver's whole plan).  hipRTC compiles one program at a time inside a process, and a third of a kernel's 1.2 s goes into parsing the shared
 // prelude (rs_device.hpp): the sources no cache holds are therefore compiled TOGETHER, one program per group of sources with the same prelude -- every member's own part inside
-// its own namespace, its entry point renamed `<entry>__g<i>` -- and the group's code object serves all of them.
+// its own namespace -- and the group's code object serves all of them.
 int jit_get_kernels(std::vector<JitRequest> &reqs, int device, bool dump) {
     struct Todo {
         uint64_t h;
