@@ -29,7 +29,7 @@ DEALS_PER_THREAD_TESTS = {
 # four-deal forms of their kernels are the ones test_deal_batches_vs_oracle, test_sparse_subtree_sweeps_three_streets_many_deals and the ragged-batch test force)
 # the two-deal forms are one more value of the same template parameter: the cheaper half of the list runs them too
 TWO_DEALS_PER_THREAD_TESTS = {
-    "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup",
+    "test_deal_batches_vs_oracle", "test_deal_batches_many_trips_per_workgroup", "test_sparse_subtree_sweeps_three_streets_many_deals",
     "test_wide_nodes_in_deal_batches", "test_deal_trainer_reference_as_coded", "test_deal_trainer_ragged_batches",
 }
 
@@ -39,7 +39,7 @@ TWO_DEALS_PER_THREAD_TESTS = {
 TABLE_LAYOUT_TESTS = {
     "test_known_answers_update_and_strategy", "test_known_answers_discount", "test_golden_random_update_cases", "test_golden_random_discount_cases",
     "test_golden_extension_cases", "test_update_node_vs_oracle", "test_rmplus_i32_vs_oracle", "test_null_reach_means_one_and_per_board_copies",
-    "test_zero_init_and_fill_mirror", "test_iterate_river_tree_vs_oracle", "test_iterate_three_street_tree_vs_oracle",
+    "test_zero_init_and_fill_mirror", "test_iterate_river_tree_vs_oracle", "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle",
     "test_iterate_extension_dtypes_vs_oracle", "test_iterate_sampled_opponent_vs_oracle", "test_wide_nodes_through_both_plans",
     "test_action_node_without_valid_actions", "test_train_with_discount_schedule_vs_oracle", "test_leaf_util_buffers_per_traverser",
     "test_checkpoint_roundtrip", "test_sharded_enum_sweep_equals_single_gpu", "test_allreduce_replicated_single_rank_is_identity",
@@ -54,8 +54,7 @@ FAN_LOOP_TESTS = {
     "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu",
     "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
 }
-# (round 3, to keep the GPU suite under 450 s: the 5 000-cluster whole-table test runs the engine's own form only and the pruned three-street test plain rows only -- tiled rows
-# and the other fan forms meet pruning in test_iterate_three_street_tree_vs_oracle and the full-size tests)
+# (round 3, to keep the GPU suite under 450 s: the 5 000-cluster whole-table test runs the engine's own form only; the other fan forms meet 5 000 clusters in the full-size tests)
 # (test_randomised_differential draws its own form per seed: 32 cases instead of 192, every form still met eight times)
 
 

@@ -1070,8 +1070,8 @@ def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
     (seg_add) instead of LDS tiles.  "few-clusters": thousands of deals per cluster, every wave is one run; "many-clusters": a handful per cluster, most waves hold more
     runs than kSegMax and fall back to per-lane atomics, the rest mix both.  Root utilities come back by deal id.  Same bits as the oracle, which never sorts."""
     monkeypatch.setenv("RS_JIT_ORDERED", "1")
-    if (sizes == "many-clusters" and variant in ("river", "river+graph", "three-street+prune-per-deal")) or (sizes == "few-clusters" and variant in ("river+prune-per-deal", "three-street-wrap")):
-        pytest.skip("the fall-back to per-lane atomics runs on three of the six variants")
+    if sizes == "many-clusters" and variant in ("river", "river+graph"):
+        pytest.skip("the fall-back to per-lane atomics runs on four of the six variants")
     three, prune = variant.startswith("three"), "prune" in variant
     n_deals = 20011 if three else 30005
     last = (13, 17) if sizes == "few-clusters" else (3001, 2500)
