@@ -308,6 +308,244 @@ void rs::solver_release_device(rs_solver *s) {
     s->table = nullptr;
 }
 
+// deal sweeps through generated kernels: the AoS shadow of the table the sweep gathers from, rebuilt at the start of every sweep (k_build_shadow)
+static int setup_table_shadow(rs_solver *s) {
+    rs_table *table = s->table;
+    const rs_tree *tree = &s->tree;
+    const size_t n = tree->nodes.size();
+    hipError_t e = hipSuccess;
+    (void)n;
+    (void)e;
+    if (s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
+        std::vector<ShadowJob> jobs;
+        size_t ints = 0;
+        // A record is worth transposing when the sweep reads it: sampled sweeps reach a node of a later round with probability ~ 1 / (round subtrees of that round), so a
+        // node gets a shadow only while n_deals / roots * 8 >= its cells -- 64 K deals against 180 234 river clusters (lossless abstraction, 2 GB table) spent 0.9 ms per
+        // sweep transposing records nobody read.  Without one the kernels gather the table's own rows (rs_device.hpp gather_node).  RS_JIT_SHADOW_ALL keeps every shadow.
+        std::vector<size_t> round_roots(size_t(s->n_rounds) + 1, 0);
+        {
+            const int first = [&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }();
+            if (tree->nodes[size_t(first)].kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(tree->nodes[size_t(first)].round_idx, s->n_rounds))] += 1;
+            for (size_t i = 1; i < n; ++i)
+                if (tree->nodes[i].kind == RS_NODE_PUBLIC_CHANCE && tree->nodes[i].n_children > 0) {
+                    const rs_tree_node &c = tree->nodes[size_t(tree->nodes[i].children[0])];
+                    if (c.kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(c.round_idx, s->n_rounds))] += 1;
+                }
+        }
+        const bool shadow_all = s->knobs.shadow_all != 0 || s->params.opp_mode != RS_OPP_SAMPLE;
+        for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
+            s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
+            s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
+            for (size_t i = 0; i < table->nodes.size(); ++i) {
+                const rs_node_desc &d = table->nodes[i];
+                if (d.n_actions == 0) continue;
+                const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
+                if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
+                const uint32_t half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
+                const uint32_t stride = (d.player == tp || s->knobs.shadow_wide) ? 2 * half : half;
+                s->shadow_off_p[tp][i] = ints;
+                s->shadow_stride_p[tp][i] = stride;
+                ShadowJob j{};
+                j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+                j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+                j.pitch = uint32_t(table->pitch[i]);
+                j.n_clusters = d.n_clusters;
+                j.n_actions = d.n_actions;
+                j.half = half;
+                j.stride = stride;
+                j.sigma = (stride == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
+                jobs.push_back(j);
+                ints += round_up(size_t(d.n_clusters) * stride, 64);
+                s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
+            }
+        }
+        s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256);
+        e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
+        {
+            size_t k = 0;
+            for (int tp = 0; tp < 2; ++tp)
+                for (size_t i = 0; i < table->nodes.size(); ++i)
+                    if (s->shadow_off_p[tp][i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off_p[tp][i];
+        }
+        s->n_shadow_jobs = int(jobs.size() / 2);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
+        if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            return hip_fail(e, "rs_solver_create: table shadow");
+        }
+    }
+    return RS_OK;
+}
+
+// delta rows (rs_kernel_forms.delta_rows): the list walkers of a deal sweep store their deltas by list position and one streaming pass per round sums them
+// (rs_plan_deals.cpp rows_round_ok says for which rounds).  Measured on one MI355X, three streets, 5 000-bucket files (profiles/r03_deals.md): 4 M deals per batch 8.34 -> 7.47 ms,
+// 1 M 3.28 -> 2.99, 256 K 1.48 -> 1.31, 64 K 0.90 -> 0.92; lossless abstractions at 64 K 2.53 -> 2.37: the engine's choice beyond 64 K deals per batch
+static void choose_delta_rows(rs_solver *s) {
+    rs_table *table = s->table;
+    const rs_tree *tree = &s->tree;
+    {
+        const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds;
+        {
+            int c = 0;
+            while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0];
+            s->first_round = tree->nodes[size_t(c)].kind == RS_NODE_ACTION ? int(tree->nodes[size_t(c)].round_idx) : 0;
+        }
+        const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->deals.n_deals > kRowsMinDeals;   // only sampled sweeps have list walkers
+        s->rows = can && (s->knobs.rows == kUnset ? engine : s->knobs.rows != 0);
+        if (s->rows && s->knobs.rows == kUnset) {   // the rows cost 2 x actions x 4 B per traverser node and deal (26 GB at 4 M deals on the 706-node tree): only while a quarter of the free memory holds them
+            size_t free_b = 0, total_b = 0;
+            const size_t need = std::max(drows_ints(s, 0), drows_ints(s, 1)) * sizeof(int32_t);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) s->rows = false;
+        }
+    }
+}
+
+// sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
+// d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
+static int setup_deal_records(rs_solver *s) {
+    rs_table *table = s->table;
+    const rs_tree *tree = &s->tree;
+    const size_t n = tree->nodes.size();
+    hipError_t e = hipSuccess;
+    (void)n;
+    (void)e;
+    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
+        const float *leaf = nullptr;
+        bool one = true;
+        for (size_t i = 0; i < n && one; ++i) {
+            const rs_tree_node &nd = tree->nodes[i];
+            if (nd.kind != RS_NODE_TERMINAL || nd.ttype == RS_TERM_UNCONTESTED) continue;
+            for (int p = 0; p < 2; ++p) {
+                if (!leaf) leaf = s->leaves[p][i].d_buf;
+                one = one && leaf == s->leaves[p][i].d_buf;
+            }
+        }
+        // Ordered sweeps: worth it when a wave of 64 consecutive deals of the sorted batch mostly shares its last-round cluster, i.e. from about 64 deals per cluster
+        // (three streets, 5 000-bucket files, 4 M deals per batch: 838 per cluster) -- small batches against big abstractions keep the unordered forms.
+        if (one && leaf) {
+            const rs_tree_node &fr = tree->nodes[size_t([&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }())];
+            const bool round_mode = fr.kind == RS_NODE_ACTION && fr.n_children > 0 && !s->knobs.no_rounds;
+            s->order_round = s->n_rounds - 1;
+            uint32_t bins[2] = {0, 0};
+            for (size_t i = 0; i < table->nodes.size(); ++i)
+                if (table->nodes[i].round_idx == s->order_round && table->nodes[i].n_actions > 0) bins[table->nodes[i].player] = std::max(bins[table->nodes[i].player], table->nodes[i].n_clusters);
+            const bool fits = bins[0] >= 1 && bins[1] >= 1 && bins[0] <= kOrderMaxBins && bins[1] <= kOrderMaxBins && s->deals.d_cluster[s->order_round][0] &&
+                              s->deals.d_cluster[s->order_round][1] && s->deals.n_deals < (1u << 31) && table->dtype == RS_I32;
+            // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
+            // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
+            // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
+            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
+            if (s->ordered) {
+                const size_t pitch = round_up(s->deals.n_deals, kLanePad);
+                const uint32_t n = s->deals.n_deals;
+                const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus) * 2, (size_t(n) + kOrderThreads - 1) / kOrderThreads));
+                const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, kOrderThreads));
+                const uint32_t max_bins = std::max(bins[0], bins[1]);
+                s->other_bytes += pitch * 32 + size_t(2) * max_bins * sizeof(uint32_t);
+                e = hipMalloc(&s->d_arec, pitch * 32);
+                if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(2) * max_bins * sizeof(uint32_t));
+                if (e != hipSuccess) {
+                    return hip_fail(e, "rs_solver_create: ordered deal records");
+                }
+                for (int tp = 0; tp < 2; ++tp) {
+                    OrderJob &oj = s->order_job[tp];
+                    oj = OrderJob{};
+                    oj.key = s->deals.d_cluster[s->order_round][tp];
+                    for (int r = 0; r < s->n_rounds; ++r)
+                        for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = s->deals.d_cluster[r][pl];
+                    oj.leaf = leaf;
+                    oj.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                    oj.tot = s->d_order_tot;
+                    oj.cursor = s->d_order_tot + bins[tp];
+                    oj.arec = s->d_arec;
+                    oj.n = n;
+                    oj.n_bins = bins[tp];
+                    oj.n_chunks = n_chunks;
+                    oj.chunk = chunk;
+                }
+                for (int r = 0; r < s->n_rounds; ++r) s->d_attr[r] = s->d_arec;   // what the generated kernels are handed as J.attr on every round
+            }
+        }
+        if (one && !s->ordered) {
+            std::vector<PackJob> jobs;
+            const size_t pitch = round_up(s->deals.n_deals, kLanePad);
+            for (int r = 0; r < s->n_rounds && e == hipSuccess; ++r) {
+                s->other_bytes += pitch * 16;
+                e = hipMalloc(&s->d_attr[r], pitch * 16);
+                if (e == hipSuccess) e = hipMemsetAsync(s->d_attr[r], 0, pitch * 16, table->stream);
+                PackJob j{};
+                j.cid0 = s->deals.d_cluster[r][0];
+                j.cid1 = s->deals.d_cluster[r][1];
+                j.leaf = leaf;
+                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
+                j.n = s->deals.n_deals;
+                jobs.push_back(j);
+            }
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_pack_jobs, std::max<size_t>(jobs.size() * sizeof(PackJob), 256));
+            if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                return hip_fail(e, "rs_solver_create: packed deal inputs");
+            }
+            s->n_pack_jobs = int(jobs.size());
+        }
+    }
+    return RS_OK;
+}
+
+// Only the list-walking kernels read the packed records: a round whose subtrees all walk the whole batch (the first round; every round of a one-round game) needs none
+static int trim_packed_records(rs_solver *s) {
+    hipError_t e = hipSuccess;
+    if (s->n_pack_jobs) {
+        std::vector<PackJob> keep;
+        for (int r = 0; r < s->n_rounds; ++r) {
+            if (!s->d_attr[r]) continue;
+            if (s->attr_used & (1u << r)) {
+                PackJob j{};
+                j.cid0 = s->deals.d_cluster[r][0];
+                j.cid1 = s->deals.d_cluster[r][1];
+                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
+                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
+                j.n = s->deals.n_deals;
+                keep.push_back(j);
+            } else {
+                (void)hipFree(s->d_attr[r]);
+                s->d_attr[r] = nullptr;
+                s->other_bytes -= round_up(s->deals.n_deals, kLanePad) * 16;
+            }
+        }
+        if (int(keep.size()) != s->n_pack_jobs) {
+            std::vector<PackJob> all(size_t(s->n_pack_jobs));
+            e = hipMemcpy(all.data(), s->d_pack_jobs, all.size() * sizeof(PackJob), hipMemcpyDeviceToHost);
+            for (PackJob &j : keep) j.leaf = all[0].leaf;   // one leaf buffer for every round (the condition under which records are packed at all)
+            if (e == hipSuccess && !keep.empty()) e = hipMemcpy(s->d_pack_jobs, keep.data(), keep.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                return hip_fail(e, "rs_solver_create: packed deal inputs");
+            }
+            s->n_pack_jobs = int(keep.size());
+            if (keep.empty())
+                for (int p = 0; p < 2; ++p) {   // the pack launch goes too (plan.split counts launches: keep it pointing at the same one)
+                    Plan &pl = s->plan[p];
+                    std::vector<Launch> kept;
+                    size_t split = pl.split;
+                    for (size_t i = 0; i < pl.launches.size(); ++i) {
+                        if (pl.launches[i].kind == L_PACK) {
+                            if (i < pl.split) --split;
+                            continue;
+                        }
+                        kept.push_back(pl.launches[i]);
+                    }
+                    pl.launches.swap(kept);
+                    pl.split = split;
+                }
+        }
+    }
+    return RS_OK;
+}
+
+
 static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                               const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!table || !tree || !leaves_p0 || !leaves_p1 || !params || !out)
@@ -392,172 +630,14 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    if (s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32) {   // AoS shadow of every table node for the deal kernels' gathers (rs_device.hpp gather_rec)
-        std::vector<ShadowJob> jobs;
-        size_t ints = 0;
-        // A record is worth transposing when the sweep reads it: sampled sweeps reach a node of a later round with probability ~ 1 / (round subtrees of that round), so a
-        // node gets a shadow only while n_deals / roots * 8 >= its cells -- 64 K deals against 180 234 river clusters (lossless abstraction, 2 GB table) spent 0.9 ms per
-        // sweep transposing records nobody read.  Without one the kernels gather the table's own rows (rs_device.hpp gather_node).  RS_JIT_SHADOW_ALL keeps every shadow.
-        std::vector<size_t> round_roots(size_t(s->n_rounds) + 1, 0);
-        {
-            const int first = [&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }();
-            if (tree->nodes[size_t(first)].kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(tree->nodes[size_t(first)].round_idx, s->n_rounds))] += 1;
-            for (size_t i = 1; i < n; ++i)
-                if (tree->nodes[i].kind == RS_NODE_PUBLIC_CHANCE && tree->nodes[i].n_children > 0) {
-                    const rs_tree_node &c = tree->nodes[size_t(tree->nodes[i].children[0])];
-                    if (c.kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(c.round_idx, s->n_rounds))] += 1;
-                }
-        }
-        const bool shadow_all = s->knobs.shadow_all != 0 || s->params.opp_mode != RS_OPP_SAMPLE;
-        for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
-            s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
-            s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
-            for (size_t i = 0; i < table->nodes.size(); ++i) {
-                const rs_node_desc &d = table->nodes[i];
-                if (d.n_actions == 0) continue;
-                const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
-                if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
-                const uint32_t half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
-                const uint32_t stride = (d.player == tp || s->knobs.shadow_wide) ? 2 * half : half;
-                s->shadow_off_p[tp][i] = ints;
-                s->shadow_stride_p[tp][i] = stride;
-                ShadowJob j{};
-                j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
-                j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
-                j.pitch = uint32_t(table->pitch[i]);
-                j.n_clusters = d.n_clusters;
-                j.n_actions = d.n_actions;
-                j.half = half;
-                j.stride = stride;
-                j.sigma = (stride == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
-                jobs.push_back(j);
-                ints += round_up(size_t(d.n_clusters) * stride, 64);
-                s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
-            }
-        }
-        s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256);
-        e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
-        if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
-        {
-            size_t k = 0;
-            for (int tp = 0; tp < 2; ++tp)
-                for (size_t i = 0; i < table->nodes.size(); ++i)
-                    if (s->shadow_off_p[tp][i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off_p[tp][i];
-        }
-        s->n_shadow_jobs = int(jobs.size() / 2);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
-        if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            rc = hip_fail(e, "rs_solver_create: table shadow");
-            rs_solver_destroy(s);
-            return rc;
-        }
+    if (int rc2 = setup_table_shadow(s)) {
+        rs_solver_destroy(s);
+        return rc2;
     }
-    // delta rows (rs_kernel_forms.delta_rows): the list walkers of a deal sweep store their deltas by list position and one streaming pass per round sums them
-    // (rs_plan_deals.cpp rows_round_ok says for which rounds).  Measured on one MI355X, three streets, 5 000-bucket files (profiles/r03_deals.md): 4 M deals per batch 8.34 -> 7.47 ms,
-    // 1 M 3.28 -> 2.99, 256 K 1.48 -> 1.31, 64 K 0.90 -> 0.92; lossless abstractions at 64 K 2.53 -> 2.37: the engine's choice beyond 64 K deals per batch
-    {
-        const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds;
-        {
-            int c = 0;
-            while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0];
-            s->first_round = tree->nodes[size_t(c)].kind == RS_NODE_ACTION ? int(tree->nodes[size_t(c)].round_idx) : 0;
-        }
-        const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->deals.n_deals > kRowsMinDeals;   // only sampled sweeps have list walkers
-        s->rows = can && (s->knobs.rows == kUnset ? engine : s->knobs.rows != 0);
-        if (s->rows && s->knobs.rows == kUnset) {   // the rows cost 2 x actions x 4 B per traverser node and deal (26 GB at 4 M deals on the 706-node tree): only while a quarter of the free memory holds them
-            size_t free_b = 0, total_b = 0;
-            const size_t need = std::max(drows_ints(s, 0), drows_ints(s, 1)) * sizeof(int32_t);
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) s->rows = false;
-        }
-    }
-    // sparse (live-deal list) sweeps: pack the per-deal inputs of every round when ALL showdown / all-in leaves of both traversers share one buffer (the trainer's
-    // d_sign; otherwise the kernels keep their separate gathers).  RS_JIT_NO_PACK turns it off (A/B knob)
-    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
-        const float *leaf = nullptr;
-        bool one = true;
-        for (size_t i = 0; i < n && one; ++i) {
-            const rs_tree_node &nd = tree->nodes[i];
-            if (nd.kind != RS_NODE_TERMINAL || nd.ttype == RS_TERM_UNCONTESTED) continue;
-            for (int p = 0; p < 2; ++p) {
-                if (!leaf) leaf = s->leaves[p][i].d_buf;
-                one = one && leaf == s->leaves[p][i].d_buf;
-            }
-        }
-        // Ordered sweeps: worth it when a wave of 64 consecutive deals of the sorted batch mostly shares its last-round cluster, i.e. from about 64 deals per cluster
-        // (three streets, 5 000-bucket files, 4 M deals per batch: 838 per cluster) -- small batches against big abstractions keep the unordered forms.
-        if (one && leaf) {
-            const rs_tree_node &fr = tree->nodes[size_t([&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }())];
-            const bool round_mode = fr.kind == RS_NODE_ACTION && fr.n_children > 0 && !s->knobs.no_rounds;
-            s->order_round = s->n_rounds - 1;
-            uint32_t bins[2] = {0, 0};
-            for (size_t i = 0; i < table->nodes.size(); ++i)
-                if (table->nodes[i].round_idx == s->order_round && table->nodes[i].n_actions > 0) bins[table->nodes[i].player] = std::max(bins[table->nodes[i].player], table->nodes[i].n_clusters);
-            const bool fits = bins[0] >= 1 && bins[1] >= 1 && bins[0] <= kOrderMaxBins && bins[1] <= kOrderMaxBins && s->deals.d_cluster[s->order_round][0] &&
-                              s->deals.d_cluster[s->order_round][1] && s->deals.n_deals < (1u << 31) && table->dtype == RS_I32;
-            // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
-            // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
-            // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
-            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
-            if (s->ordered) {
-                const size_t pitch = round_up(s->deals.n_deals, kLanePad);
-                const uint32_t n = s->deals.n_deals;
-                const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus) * 2, (size_t(n) + kOrderThreads - 1) / kOrderThreads));
-                const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, kOrderThreads));
-                const uint32_t max_bins = std::max(bins[0], bins[1]);
-                s->other_bytes += pitch * 32 + size_t(2) * max_bins * sizeof(uint32_t);
-                e = hipMalloc(&s->d_arec, pitch * 32);
-                if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
-                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(2) * max_bins * sizeof(uint32_t));
-                if (e != hipSuccess) {
-                    rc = hip_fail(e, "rs_solver_create: ordered deal records");
-                    rs_solver_destroy(s);
-                    return rc;
-                }
-                for (int tp = 0; tp < 2; ++tp) {
-                    OrderJob &oj = s->order_job[tp];
-                    oj = OrderJob{};
-                    oj.key = s->deals.d_cluster[s->order_round][tp];
-                    for (int r = 0; r < s->n_rounds; ++r)
-                        for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = s->deals.d_cluster[r][pl];
-                    oj.leaf = leaf;
-                    oj.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
-                    oj.tot = s->d_order_tot;
-                    oj.cursor = s->d_order_tot + bins[tp];
-                    oj.arec = s->d_arec;
-                    oj.n = n;
-                    oj.n_bins = bins[tp];
-                    oj.n_chunks = n_chunks;
-                    oj.chunk = chunk;
-                }
-                for (int r = 0; r < s->n_rounds; ++r) s->d_attr[r] = s->d_arec;   // what the generated kernels are handed as J.attr on every round
-            }
-        }
-        if (one && !s->ordered) {
-            std::vector<PackJob> jobs;
-            const size_t pitch = round_up(s->deals.n_deals, kLanePad);
-            for (int r = 0; r < s->n_rounds && e == hipSuccess; ++r) {
-                s->other_bytes += pitch * 16;
-                e = hipMalloc(&s->d_attr[r], pitch * 16);
-                if (e == hipSuccess) e = hipMemsetAsync(s->d_attr[r], 0, pitch * 16, table->stream);
-                PackJob j{};
-                j.cid0 = s->deals.d_cluster[r][0];
-                j.cid1 = s->deals.d_cluster[r][1];
-                j.leaf = leaf;
-                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
-                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
-                j.n = s->deals.n_deals;
-                jobs.push_back(j);
-            }
-            if (e == hipSuccess) e = hipMalloc((void **)&s->d_pack_jobs, std::max<size_t>(jobs.size() * sizeof(PackJob), 256));
-            if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                rc = hip_fail(e, "rs_solver_create: packed deal inputs");
-                rs_solver_destroy(s);
-                return rc;
-            }
-            s->n_pack_jobs = int(jobs.size());
-        }
+    choose_delta_rows(s);
+    if (int rc2 = setup_deal_records(s)) {
+        rs_solver_destroy(s);
+        return rc2;
     }
     struct Builders {   // one plan builder per traverser; freed on every way out
         PlanBuilder *b[2] = {nullptr, nullptr};
@@ -572,52 +652,9 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         rs_solver_destroy(s);
         return rc;
     }
-    // Only the list-walking kernels read the packed records: a round whose subtrees all walk the whole batch (the first round; every round of a one-round game) needs none
-    if (s->n_pack_jobs) {
-        std::vector<PackJob> keep;
-        for (int r = 0; r < s->n_rounds; ++r) {
-            if (!s->d_attr[r]) continue;
-            if (s->attr_used & (1u << r)) {
-                PackJob j{};
-                j.cid0 = s->deals.d_cluster[r][0];
-                j.cid1 = s->deals.d_cluster[r][1];
-                j.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
-                j.out = static_cast<u32x4_host *>(s->d_attr[r]);
-                j.n = s->deals.n_deals;
-                keep.push_back(j);
-            } else {
-                (void)hipFree(s->d_attr[r]);
-                s->d_attr[r] = nullptr;
-                s->other_bytes -= round_up(s->deals.n_deals, kLanePad) * 16;
-            }
-        }
-        if (int(keep.size()) != s->n_pack_jobs) {
-            std::vector<PackJob> all(size_t(s->n_pack_jobs));
-            e = hipMemcpy(all.data(), s->d_pack_jobs, all.size() * sizeof(PackJob), hipMemcpyDeviceToHost);
-            for (PackJob &j : keep) j.leaf = all[0].leaf;   // one leaf buffer for every round (the condition under which records are packed at all)
-            if (e == hipSuccess && !keep.empty()) e = hipMemcpy(s->d_pack_jobs, keep.data(), keep.size() * sizeof(PackJob), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                rc = hip_fail(e, "rs_solver_create: packed deal inputs");
-                rs_solver_destroy(s);
-                return rc;
-            }
-            s->n_pack_jobs = int(keep.size());
-            if (keep.empty())
-                for (int p = 0; p < 2; ++p) {   // the pack launch goes too (plan.split counts launches: keep it pointing at the same one)
-                    Plan &pl = s->plan[p];
-                    std::vector<Launch> kept;
-                    size_t split = pl.split;
-                    for (size_t i = 0; i < pl.launches.size(); ++i) {
-                        if (pl.launches[i].kind == L_PACK) {
-                            if (i < pl.split) --split;
-                            continue;
-                        }
-                        kept.push_back(pl.launches[i]);
-                    }
-                    pl.launches.swap(kept);
-                    pl.split = split;
-                }
-        }
+    if (int rc2 = trim_packed_records(s)) {
+        rs_solver_destroy(s);
+        return rc2;
     }
     s->arena_bytes = std::max(s->plan[0].arena_bytes, s->plan[1].arena_bytes);
     if ((e = hipMalloc((void **)&s->d_arena, std::max<size_t>(s->arena_bytes, 256))) != hipSuccess) {
