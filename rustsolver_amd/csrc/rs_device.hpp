@@ -240,6 +240,17 @@ __device__ __forceinline__ void gather_sigma(const void *shadow, unsigned stride
 #pragma unroll
         for (int j = 0; j < kVecD; j++) g[a][j] = __int_as_float(r[a][j]);
 }
+// the strategy of the drawn action (hand-off from a reach-down kernel to the walk of the same subtree)
+template <int A>
+__device__ __forceinline__ void hand_pick(const float (&g)[A][kVecD], const int (&a)[kVecD], float (&out)[kVecD]) {
+#pragma unroll
+    for (int j = 0; j < kVecD; j++) {
+        float x = g[0][j];
+#pragma unroll
+        for (int k = 1; k < A; k++) x = (a[j] == k) ? g[k][j] : x;
+        out[j] = x;
+    }
+}
 // A node without a shadow (its table is so much larger than the batch that transposing it every sweep costs more than the extra gathers: rs_solver.cpp) is read
 // from the table's own [A][pitch] rows, one 4-byte gather per (action, array).  `shadow` is a kernel argument: the branch is uniform.
 template <int A, typename V>

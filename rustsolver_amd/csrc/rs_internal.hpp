@@ -271,6 +271,7 @@ struct Knobs {
     long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES
     long tile_min_lanes = kUnset;   // RS_TABLE_TILE_MIN_LANES
     int no_prefetch = 0;            // RS_TRAINER_NO_PREFETCH
+    int no_handoff = 0;             // RS_JIT_NO_HANDOFF: the walk of a round subtree draws the opponent's actions again instead of reading the reach-down kernel's
     int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
     int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
 };
@@ -300,6 +301,8 @@ struct JitSubtree {
     size_t off_rlist = 0;                                                                 // the reach of every entry of the live list (position-indexed rows), may be null
     size_t off_plist = 0;                                                                 // the parent-subtree position of every entry of the live list, may be null
     size_t off_klist = 0;                                                                 // delta rows: the key row of the job's list (the traverser's cluster of every entry), written by the walk
+    size_t off_hrow = 0, off_hpitch = 0;                                                  // hand-off rows of the job (reach-down kernel -> walk), pitch between them
+    int n_handed = 0;                                                                     // opponent nodes whose draw the reach-down kernel hands to the walk (+ 1 row of packed actions)
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
@@ -308,7 +311,8 @@ void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, c
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
                       bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false, bool rows = false,
-                      const std::vector<char> *sigma = nullptr /* per tree node: its shadow record holds the strategy (opponent nodes of a deal sweep) */);
+                      const std::vector<char> *sigma = nullptr /* per tree node: its shadow record holds the strategy (opponent nodes of a deal sweep) */,
+                      bool handoff = false /* deal sweeps: the reach-down kernel stores its draws by list position, the walk reads them (both kernels of a root alike) */);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
 uint64_t jit_source_key(const std::string &source);   // what the caches are keyed by (source + compiler version + options)

@@ -118,7 +118,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (sparse && opp_mode != RS_OPP_SAMPLE) continue;
                 JitSubtree js;   // opponent nodes read from strategy records (what a solver with table shadows emits); the work-list and list-position forms below keep the regrets path
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, lds, sparse, down,
-                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, knobs, 0, sparse, false, false, false, false, false, &sigma_all);   // sparse forms fetch packed per-deal records (the separate gathers remain as the
+                                 (mode & RS_UPD_PRUNE) != 0, lanes, &root, js, knobs, 0, sparse, false, false, false, false, false, &sigma_all, true);   // ... and the reach-down kernel hands its draws to the walk   // sparse forms fetch packed per-deal records (the separate gathers remain as the
                                                                                                // fallback for solvers whose leaves do not share one buffer: compiled by the GPU tests)
                 if (down && js.boundary_roots.empty()) continue;   // a last-round subtree hands no reach on
                 if (!seen.count(js.source)) {
@@ -147,7 +147,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                 if (f6 >= 4) {   // delta rows (rs_kernel_forms.delta_rows): the walk stores its deltas by position, dense and over a list
                     JitSubtree jr;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, sparse, false,
-                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jr, knobs, 0, sparse, sparse, false, false, false, true, &sigma_all);
+                                     (mode & RS_UPD_PRUNE) != 0, lanes, &root, jr, knobs, 0, sparse, sparse, false, false, false, true, &sigma_all, true);
                     if (!seen.count(jr.source)) {
                         seen[jr.source] = 1;
                     }

@@ -38,6 +38,7 @@ const Entry kEntries[] = {
     {"RS_JIT_NO_PARTS", FLAG, &Knobs::no_parts, nullptr},
     {"RS_JIT_SCAN_ALL", INT, &Knobs::scan_all, nullptr},
     {"RS_JIT_NO_POSROWS", FLAG, &Knobs::no_posrows, nullptr},
+    {"RS_JIT_NO_HANDOFF", FLAG, &Knobs::no_handoff, nullptr},
     {"RS_JIT_NO_SIGMA", FLAG, &Knobs::no_sigma, nullptr},
     {"RS_JIT_NO_SIBLINGS", INT, &Knobs::no_siblings, nullptr},
     {"RS_JIT_LDS_MAX", INT, &Knobs::lds_max, nullptr},

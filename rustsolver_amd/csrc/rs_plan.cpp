@@ -417,7 +417,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                      (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node);
+                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id));
     const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
     // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete, every distinct source at once on a pool of host threads
@@ -529,6 +529,8 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             put_ptr(js.off_plist, (pos_rows && id != first_root) ? plan.d_plists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
             put_ptr(js.off_klist, rows ? plan.d_klists + (cj.list - plan.d_lists) + size_t(part) * cj.list_stride : nullptr);
         }
+        put_ptr(js.off_hrow, handoff_root(id) ? plan.d_hrows + hrow_off[size_t(id)] : nullptr);
+        put_u32(js.off_hpitch, uint32_t(s->pitch[0] + kRowStagger));
         if (rows) {   // what k_row_sums adds up after the walks: per traverser node and array the A rows beside the job's key row (row by row where A tiles do not fit together)
             const uint32_t bp = uint32_t(s->pitch[0] + kRowStagger);   // the delta rows' own pitch (JArgs.rp of this form)
             const CompactJob *cj = sparse ? &plan.compact_jobs[size_t(sparse_slot[id])] : nullptr;

@@ -66,6 +66,7 @@ struct Plan {
     uint32_t *d_lists = nullptr;        // [n_compact][pitch]
     float *d_rlists = nullptr;          // position-indexed rows: the reach of every list entry, same shape as d_lists
     uint32_t *d_plists = nullptr;       // position-indexed rows: where the parent subtree reads every list entry's utility, same shape as d_lists
+    float *d_hrows = nullptr;           // hand-off rows of the round subtrees with a reach-down kernel: [opponent nodes handed + 1][batch pitch + stagger] floats per root
     uint32_t *d_klists = nullptr;       // delta rows: the traverser's cluster of every list entry (the key row of k_row_sums), same shape as d_lists
     std::vector<size_t> drow_off;       // delta rows: per table node the int offset of its [2A][batch pitch] rows inside the solver's d_drows (SIZE_MAX: none)
     std::vector<RowSumJob> row_jobs;

@@ -59,6 +59,9 @@ struct PlanBuilder {
         return round_mode && rows_round_ok(s, p, nodes[size_t(root)].round_idx) && (s->knobs.rows >= 2 || (want_lists && root != first_root));
     }
     Parts parts_of(int root) const;
+    // hand-off rows (rs_jit.cpp): the reach-down kernel of `root` stores its draws by list position, the walk of `root` reads them
+    std::vector<size_t> hrow_off;   // per tree node: float offset of the root's rows in plan.d_hrows, SIZE_MAX = none
+    bool handoff_root(int root) const { return !hrow_off.empty() && hrow_off[size_t(root)] != SIZE_MAX; }
 
     PlanBuilder(rs_solver *s_, int p_) : s(s_), p(p_), plan(s_->plan[p_]), nodes(s_->tree.nodes) {}
 

@@ -228,6 +228,35 @@ int PlanBuilder::emit_deal_lists() {
         for (size_t r = 0; r < roots_of_round.size(); ++r)
             for (int root : roots_of_round[r])
                 for (int b : bnd[size_t(root)]) parent_root[size_t(b)] = root;
+        // hand-off rows: every root with next-round roots below it (i.e. with a reach-down kernel), unless its lists are cut into cluster ranges
+        if (s->params.opp_mode == RS_OPP_SAMPLE && t->dtype == RS_I32 && !s->knobs.no_handoff) {
+            hrow_off.assign(n, SIZE_MAX);
+            size_t floats = 0;
+            const size_t hp = s->pitch[0] + kRowStagger;
+            for (size_t r = 0; r < roots_of_round.size(); ++r)
+                for (int root : roots_of_round[r]) {
+                    if (bnd[size_t(root)].empty() || parts_of(root).first > 1) continue;
+                    size_t opp = 0;   // opponent nodes of the round subtree: an upper bound on what the kernels hand over (at most 10 nodes + the word of drawn actions)
+                    std::vector<int> stack{root};
+                    while (!stack.empty()) {
+                        const int q = stack.back();
+                        stack.pop_back();
+                        const rs_tree_node &qn = nodes[size_t(q)];
+                        if (qn.kind == RS_NODE_ACTION && qn.player != p && qn.n_children > 0) ++opp;
+                        for (int k = 0; k < qn.n_children; ++k) {
+                            const int c = qn.children[k];
+                            if (nodes[size_t(c)].kind != RS_NODE_PRIVATE_CHANCE && nodes[size_t(c)].kind != RS_NODE_PUBLIC_CHANCE) stack.push_back(c);
+                        }
+                    }
+                    if (!opp) continue;
+                    hrow_off[size_t(root)] = floats;
+                    floats += (std::min<size_t>(opp, 10) + 1) * hp;
+                }
+            if (floats) {
+                if (hipMalloc((void **)&plan.d_hrows, floats * sizeof(float)) != hipSuccess) return fail(RS_ERR_OOM, "rs_solver_create: hand-off rows of the round subtrees");
+                plan.aux_bytes += floats * sizeof(float);
+            } else hrow_off.clear();
+        }
         nan_off.assign(size_t(n_nan) + 1, 0);
         for (size_t b = 0; b < n; ++b)
             if (nan_slot[b] >= 0) {   // rows of a listed parent hold one list-position segment per cluster range of the parent

@@ -256,6 +256,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
         if (pl.d_klists) (void)hipFree(pl.d_klists);
+        if (pl.d_hrows) (void)hipFree(pl.d_hrows);
         if (pl.d_compact_groups) (void)hipFree(pl.d_compact_groups);
         if (pl.d_row_jobs) (void)hipFree(pl.d_row_jobs);
         if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);

@@ -537,7 +537,7 @@ def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
 
 
 @pytest.mark.parametrize("blocks", [None, "2"])
-@pytest.mark.parametrize("sparse", [True, "unpacked", "ordered", "scan-parent", "scan-parent-siblings", "siblings", "rows", False, "no-rounds", "no-rounds-no-sparse"])
+@pytest.mark.parametrize("sparse", [True, "unpacked", "ordered", "scan-parent", "scan-parent-siblings", "siblings", "rows", "no-handoff", False, "no-rounds", "no-rounds-no-sparse"])
 def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypatch):
     """sampled three-street sweeps over 30 000 deals: every river subtree walks only the compacted list of its live deals (several trips per
     workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked; with RS_JIT_NO_ROUNDS the flop and
@@ -556,6 +556,8 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
             monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
     elif sparse == "siblings":    # ... the whole batch scanned once per 16 roots
         monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
+    elif sparse == "no-handoff":  # the walks draw the opponent's actions themselves instead of reading what the reach-down kernels handed over
+        monkeypatch.setenv("RS_JIT_NO_HANDOFF", "1")
     elif sparse == "rows":        # what batches beyond 512 K deals get: the list walkers store delta rows, summed per round (rs_kernel_forms.delta_rows), sibling compaction
         monkeypatch.setenv("RS_JIT_ROWS", "1")
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
