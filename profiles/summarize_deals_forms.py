@@ -93,7 +93,7 @@ if walks:
     per_class_walks = {"flop walk": walks[0], "flop reach-down": walks[0], "turn walk": walks[1], "turn reach-down": walks[1], "river walk": walks[2],
                        "live-deal lists (k_compact_live / k_compact_siblings)": walks[1] + walks[2], "row sums (k_row_sums)": walks[1] + walks[2]}
 L = ["# deal path, three streets, 5 000-bucket files: LDS delta tiles (round 2) against delta rows + sibling compaction (round 3)", "",
-     "`tools/profile_deals_forms.sh`; form 0 = `%s`, form 1 = `%s` (what the engine picks beyond 64 K deals per batch).  One MI355X." % (forms[0], forms[1]), "",
+     "`tools/profile_deals_forms.sh`; form 0 = `%s`, form 1 = `%s` (the engine's own choice: delta rows and sibling compaction beyond 512 K deals per batch, strategy records and the reach-down hand-off at every size).  One MI355X." % (forms[0], forms[1]), "",
      "## batch time (hipGraph replay, the launches of a round overlapped on four streams: what `bench.py` measures)", "",
      "| deals per batch | round-2 forms: ms per batch | deal-iterations/s | round-3 forms: ms per batch | deal-iterations/s | ratio |", "|---|---|---|---|---|---|"]
 for n in sorted(set(tm[0]) | set(tm[1]), reverse=True):

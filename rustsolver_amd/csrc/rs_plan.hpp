@@ -14,7 +14,7 @@ constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size co
 // apart, every stream then sits on the same memory channel at the same moment, and the row-summing pass ran 4x slower than with 4 196 416 deals (12.7 against 8.9 ms per batch)
 constexpr size_t kRowStagger = 1088;   // elements between the natural pitch and the one used (4 352 B: off every power-of-two interleave up to 4 KiB, rows stay 256-B aligned)
 constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this size compact the live deals of sibling roots in one scan of their source (rs_plan_deals.cpp)
-constexpr uint32_t kRowsMinDeals = 65536;   // deal batches beyond this size store delta rows in their list walkers (rs_solver.cpp)
+constexpr uint32_t kRowsMinDeals = 524288;   // deal batches beyond this size store delta rows in their list walkers (rs_solver.cpp): 4 M deals 1.13-1.19x, 1 M 1.0-1.07x, 256 K 0.95-1.1x over three cards
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER, L_ROWSUM };
 

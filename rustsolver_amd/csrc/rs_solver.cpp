@@ -381,7 +381,7 @@ static int setup_table_shadow(rs_solver *s) {
 
 // delta rows (rs_kernel_forms.delta_rows): the list walkers of a deal sweep store their deltas by list position and one streaming pass per round sums them
 // (rs_plan_deals.cpp rows_round_ok says for which rounds).  Measured on one MI355X, three streets, 5 000-bucket files (profiles/r03_deals.md): 4 M deals per batch 8.34 -> 7.47 ms,
-// 1 M 3.28 -> 2.99, 256 K 1.48 -> 1.31, 64 K 0.90 -> 0.92; lossless abstractions at 64 K 2.53 -> 2.37: the engine's choice beyond 64 K deals per batch
+// 1 M 3.28 -> 2.99; at 256 K deals the three cards it was measured on disagree (0.95-1.1x): the engine's choice beyond 512 K deals per batch
 static void choose_delta_rows(rs_solver *s) {
     rs_table *table = s->table;
     const rs_tree *tree = &s->tree;

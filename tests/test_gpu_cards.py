@@ -298,13 +298,13 @@ def test_deal_trainer_three_streets_from_a_flop_with_bucket_files(parts, monkeyp
     compare_trainer_tables(ctx)
 
 
-@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (2, 3, 700), (2, 3, 100_000), (2, 1, 1 << 21)])
+@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (2, 3, 700), (2, 3, 600_000), (2, 1, 1 << 21)])
 def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets, n):
     """`world` ranks x n deals on replicated tables, their i32 deltas summed between sweep and apply (what rs_comm_allreduce_deltas does
     over xGMI; here the test adds them on the host), equal ONE trainer with world*n deals per batch, bit for bit: cards, tables, discount
     ticks.  Ranks are emulated on one GPU, one trainer per rank.  streets = 3: a flop-start tree, i.e. round subtrees, live-deal lists and the
     rank's lane base in the sampling hash together.  n = 2 M: the property at bench.py's size (4 M deals per union batch, the whole range,
-    four deals per thread, staged dealing on the second stream).  streets = 3 with 100 000 deals per rank: the list walkers store delta rows (batches beyond 64 K deals), whose
+    four deals per thread, staged dealing on the second stream).  streets = 3 with 600 000 deals per rank: the list walkers store delta rows (batches beyond 512 K deals), whose
     summing launches belong to phase 0 -- the delta tables must be complete when the ranks exchange them."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
