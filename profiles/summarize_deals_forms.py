@@ -100,6 +100,8 @@ for n in sorted(set(tm[0]) | set(tm[1]), reverse=True):
     a, b = tm[0].get(n), tm[1].get(n)
     L.append("| %d | %s | %s | %s | %s | %s |" % (n, "%.2f" % a["ms_per_batch"] if a else "-", "%.3g" % a["deal_iterations_per_s"] if a else "-", "%.2f" % b["ms_per_batch"] if b else "-",
                                                 "%.3g" % b["deal_iterations_per_s"] if b else "-", "%.2fx" % (a["ms_per_batch"] / b["ms_per_batch"]) if a and b else "-"))
+L += ["", "At 256 K and 64 K deals per batch both columns run the same kernel forms apart from the strategy records and the reach-down hand-off (the engine keeps tiles and one "
+          "compaction job per root up to 512 K deals): their differences are the run-to-run spread of these small batches (several percent either way over the round's runs)."]
 if walks:
     L += ["", "A 4 M-deal batch walks %s (deal, round subtree) pairs on flop / turn / river (both traversers; `rs_solver_walk_counts`): %.1f per deal." % (
         " / ".join("%.2f M" % (w / 1e6) for w in walks), sum(walks) / 4194304.0)]
