@@ -877,6 +877,7 @@ hipError_t launch_prune_reach(const NodeJob *d_jobs, int n_jobs, uint32_t max_n_
 // ONE workgroup takes a tile of the source for all sibling roots: entries read once, a ballot round per sibling, the siblings' slot reservations issued side by side by
 // different threads.  Same lists as k_compact_live writes (slots in source order inside a tile), cluster ranges excluded (n_parts == 1).
 constexpr uint32_t kMaxSiblings = 16;
+static_assert(kMaxSiblings * kCompactPerThread <= 64, "k_compact_siblings keeps one liveness bit per (sibling, entry of the thread) in a 64-bit word");
 __global__ __launch_bounds__(kBlock) void k_compact_siblings(const CompactJob *__restrict__ jobs, const CompactGroup *__restrict__ groups) {
     __shared__ uint32_t wave_count[kMaxSiblings][kCompactPerThread][kBlock / 64];
     __shared__ uint32_t slot_base[kMaxSiblings];
