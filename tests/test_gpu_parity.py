@@ -1131,6 +1131,30 @@ def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("forms", ["tiles", "rows"])
+def test_handoff_with_more_opponent_nodes_than_rows(forms, monkeypatch):
+    """The reach-down kernel of a round subtree hands its draws at the opponent's nodes to the walk of the same subtree -- at most TEN nodes (3 bits of one packed word each); the
+    opponent nodes beyond that are drawn again by the walk.  A flop subtree with three bet sizes and two raise sizes has 17 opponent nodes above next-round roots: both kinds in one
+    pair of kernels, with LDS tiles and with delta rows, pruned deals included.  Same bits as the oracle."""
+    if forms == "rows":
+        monkeypatch.setenv("RS_JIT_ROWS", "1")
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    bets, raises = ((0.25, 0.5, 1.0), (1.0,), (1.0,)), ((2.0, 3.0), (3.0,), (3.0,))
+    n_deals = 6007
+    flags = (np.random.Generator(np.random.PCG64(8)).integers(0, 3, n_deals) == 0).astype(np.uint8)
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.Options((200, 200), 40, 3, bets, raises), orc.make_options((200, 200), 40, 3, bets, raises), [(9, 7), (41, 37), (53, 59)],
+                                                         n_deals, 77)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=5, prune_deal=flags)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=True, prune_deal=flags, opp_mode=orc.OPP_SAMPLE, base_seed=5)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
+
+
 def test_config1_plumbing_tree_through_rs_iterate():
     """BASELINE configs[0], "preflop-only 169-iso buckets, 2-action tree": the reference has no preflop round (state.rs:8, :59-64), so this is build-side plumbing --
     a tree adopted from plain node records (rs_tree_from_nodes) with ONE two-action node per player and 169 clusters (hand_indexer_s::init(1, [2]).size(0),
