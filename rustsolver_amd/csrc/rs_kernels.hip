@@ -1083,6 +1083,11 @@ __global__ __launch_bounds__(kRowSumBlock) void k_row_sums(const RowSumJob *__re
             for (int r = 0; r < kRowSumMaxRows; ++r)
                 if (r < (int)J.n_rows) {
                     int *t = row_tile + r * J.n_clusters;
+                    if (kc[0] == kc[3] && kc[0] == kc[1] && kc[0] == kc[2]) {   // an ordered sweep's lists come in runs of equal cluster: one add for the thread's four positions
+                        const int sum4 = (int)((unsigned)dc[r].x + (unsigned)dc[r].y + (unsigned)dc[r].z + (unsigned)dc[r].w);
+                        if (sum4) __hip_atomic_fetch_add(t + kc[0], sum4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        continue;
+                    }
                     if (dc[r].x) __hip_atomic_fetch_add(t + kc[0], dc[r].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (dc[r].y) __hip_atomic_fetch_add(t + kc[1], dc[r].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (dc[r].z) __hip_atomic_fetch_add(t + kc[2], dc[r].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
