@@ -145,6 +145,31 @@ __global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ss
     if (c >= n_clusters) return;
     const uint32_t lo = start[c], hi = start[c + 1];
     if (lo == hi) return;
+    if (mode == RS_BR_MAX && hi - lo <= 8) {   // a river info set holds a handful of lanes: its lane ids once, then every (action, lane) value in flight together -- two round
+                                               // trips instead of two per value; the additions in list order as below
+        uint32_t idx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) idx[k] = lo + k < hi ? order[lo + k] : order[lo];
+        double s[RS_MAX_ACTIONS];
+        uint32_t best = 0;
+        for (uint32_t a = 0; a < row.n_actions; a++) {
+            const double *va = vch + (size_t)a * n_pad;
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = va[idx[k]];
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (lo + k < hi) acc += t[k];
+            s[a] = acc;
+            if (a > 0 && s[best] < s[a]) best = a;
+        }
+        const double *vb = vch + (size_t)best * n_pad;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (lo + k < hi) v[idx[k]] = vb[idx[k]];
+        return;
+    }
     if (mode == RS_BR_MAX) {
         double s[RS_MAX_ACTIONS];
         for (uint32_t a = 0; a < row.n_actions; a++) {
