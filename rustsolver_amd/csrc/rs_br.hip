@@ -511,9 +511,13 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *
     double *P = (double *)br_lds;                                // [n_o]
     double *Pc = P + n_o;                                        // [52][51]
     double *O = Pc + 52 * kBrCardHolders;                        // [65] chunk offsets, O[64] = total
+    double *Q = O + 65;                                          // [n_o] the opponent's reach of this run-out: the scans below walk it in rank and card order
     const uint32_t b = blockIdx.x;
     const uint32_t nv = ix.nv[b];
-    const double *__restrict__ qb = q + (size_t)b * n_o;
+    const double *__restrict__ qg = q + (size_t)b * n_o;
+    for (uint32_t i = threadIdx.x; i < n_o; i += kBrBlock) Q[i] = qg[i];   // one coalesced pass; the dependent gathers then stay inside the LDS
+    __syncthreads();
+    const double *qb = Q;
     const uint16_t *__restrict__ ord = ix.ord + (size_t)b * n_o;
     const uint32_t len = (nv + 63u) / 64u;
     if (threadIdx.x < 64) {
@@ -674,7 +678,7 @@ struct BrRun {
             const double pot = double(float(n.value));   // tn.value as f32 (cfr.rs:316)
             const double value = unc ? (p == int(n.last_to_act) ? -pot : pot) : pot;
             if (sorted) {
-                const size_t lds = (size_t(op.n_hands) + 52 * kBrCardHolders + 65) * sizeof(double);
+                const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double);
                 hipLaunchKernelGGL(k_br_terminal_sorted, dim3(NB), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, q, op.n_hands, d_bmask, me.index,
                                    unc, value, v_out);
                 err = hipGetLastError();
