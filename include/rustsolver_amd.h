@@ -59,7 +59,8 @@ enum {
     RS_ERR_OOM = -3,         /* host or device allocation failed */
     RS_ERR_HIP = -4,         /* HIP runtime error or no usable GPU */
     RS_ERR_UNSUPPORTED = -5, /* combination not implemented (e.g. prune on float tables) */
-    RS_ERR_COMM = -6         /* RCCL error */
+    RS_ERR_COMM = -6,        /* RCCL error */
+    RS_ERR_MISMATCH = -7     /* a self-check found a disagreement (rs_hand_index_verify) */
 };
 const char *rs_last_error(void);
 int rs_abi_version(void);
@@ -403,6 +404,12 @@ int rs_hand_indexer_rounds(const rs_hand_indexer *indexer);
 int rs_hand_indexer_n_cards(const rs_hand_indexer *indexer, int round);        /* cards of rounds 0..round */
 /* .get_index(cards) for n hands (card_abstraction.rs:205); cards[n][n_cards(round)]; `round` = rounds-1 is what get_index returns */
 int rs_hand_index(const rs_hand_indexer *indexer, int round, const uint8_t *cards, size_t n, uint64_t *out);
+/* The index-ORDER self-check (card_abstraction.rs:204-209 get_cluster -> hand_indexer.get_index; :227-229 bucket files indexed by it): expect[i] = what the
+ * caller's own indexer (rust_poker's hand_indexer_s::get_index) returned for cards[i].  RS_OK when every hand agrees; RS_ERR_MISMATCH at the first that does not
+ * (*first_bad = its position, n when all agree; *got_at_first_bad = this library's index for it; either may be NULL).  Run it on ~1 000 random hands per round before
+ * loading bucket files written by the reference's gen_abstraction (rust/verify_index.rs). */
+int rs_hand_index_verify(const rs_hand_indexer *indexer, int round, const uint8_t *cards, size_t n, const uint64_t *expect, size_t *first_bad,
+                         uint64_t *got_at_first_bad);
 /* .get_hand(round, index, cards) (gen_abstraction/main.rs:117,195): one representative hand per index; cards_out[n][n_cards(round)] */
 int rs_hand_unindex(const rs_hand_indexer *indexer, int round, const uint64_t *indices, size_t n, uint8_t *cards_out);
 /* get_index on the GPU: d_cards[n_cards(round)][pitch] (u8, row i = card i, pitch = round_up(n, 64)), d_out[n]; asynchronous */

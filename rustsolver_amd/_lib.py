@@ -8,7 +8,7 @@ SO_PATH = os.environ.get("RS_LIB_PATH") or os.path.join(HERE, "librustsolver_amd
 MAX_ACTIONS, MAX_ROUNDS, MAX_SIZES, MAX_PLAYERS = 8, 3, 4, 2
 COMM_ID_BYTES = 128
 
-OK, ERR_INVALID, ERR_OOB, ERR_OOM, ERR_HIP, ERR_UNSUPPORTED, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_OOB, ERR_OOM, ERR_HIP, ERR_UNSUPPORTED, ERR_COMM, ERR_MISMATCH = 0, -1, -2, -3, -4, -5, -6, -7
 NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE, NODE_ACTION, NODE_TERMINAL = 0, 1, 2, 3
 TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED = 0, 1, 2
 ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
@@ -182,6 +182,7 @@ SYMBOLS = {
     "rs_hand_indexer_n_cards": (C.c_int, [_P, C.c_int]),
     "rs_hand_index": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P]),
     "rs_hand_unindex": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P]),
+    "rs_hand_index_verify": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, _P, _P]),
     "rs_hand_index_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_uint32, _P]),
     "rs_card_abs_create": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t, _PP]),
     "rs_card_abs_destroy": (None, [_P]),

@@ -135,6 +135,21 @@ class HandIndexer:
         L.check(rc)
         return out
 
+    def verify(self, cards, expect, round_=None):
+        """rs_hand_index_verify: `expect` = the indices ANOTHER indexer (rust_poker's) gave for `cards`; returns (first_bad, got) -- (n, None) when all agree"""
+        r = self.rounds - 1 if round_ is None else round_
+        c = np.ascontiguousarray(cards, dtype=np.uint8)
+        c = np.ascontiguousarray(c.reshape(-1, c.shape[-1])[:, : self.n_cards(r)])
+        e = np.ascontiguousarray(expect, dtype=np.uint64)
+        if len(e) != len(c):
+            raise ValueError("one expected index per hand")
+        bad, got = C.c_size_t(), C.c_uint64()
+        rc = L.load().rs_hand_index_verify(self._h, r, c.ctypes.data, len(c), e.ctypes.data, C.byref(bad), C.byref(got))
+        if rc == L.ERR_MISMATCH:
+            return int(bad.value), int(got.value)
+        L.check(rc)
+        return len(c), None
+
     def get_index_device(self, table, cards, round_=None):
         """same on the GPU: cards uint8 [n][n_cards] -> uint64 [n] (uploads SoA rows, downloads the indices)"""
         from .solver import DeviceBuffer, deal_pitch

@@ -521,6 +521,32 @@ int rs_hand_index(const rs_hand_indexer *ix, int round, const uint8_t *cards, si
     return RS_OK;
 }
 
+// The self-check an integrator runs before mixing bucket files written by the reference's gen_abstraction (indexed by rust_poker's hand_indexer_s::get_index,
+// card_abstraction.rs:204-209, :227-229) with indices computed here: `expect[i]` = what THEIR indexer returned for cards[i].  The ORDER of indices inside the
+// isomorphism partition is not pinned by any reference fixture (the crate is not vendored), so this is the place where a disagreement shows before it silently mis-buckets.
+// *first_bad = index of the first disagreeing hand, or n when all agree; *got_at_first_bad = this library's index for it.  RS_OK when all agree, RS_ERR_MISMATCH otherwise.
+int rs_hand_index_verify(const rs_hand_indexer *ix, int round, const uint8_t *cards, size_t n, const uint64_t *expect, size_t *first_bad, uint64_t *got_at_first_bad) {
+    if (!ix || (!cards && n) || (!expect && n)) return fail(RS_ERR_INVALID, "rs_hand_index_verify: NULL argument");
+    if (round < 0 || round >= ix->rounds) return fail(RS_ERR_OOB, "rs_hand_index_verify: round out of range");
+    const HandIndexView v = ix->host_view();
+    const int nc = ix->total_cards[round];
+    if (first_bad) *first_bad = n;
+    if (got_at_first_bad) *got_at_first_bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (int rc = validate_cards(ix, round, cards + i * nc, "rs_hand_index_verify")) return rc;
+        const uint64_t got = hand_index(v, round, cards + i * nc);
+        if (got != expect[i]) {
+            if (first_bad) *first_bad = i;
+            if (got_at_first_bad) *got_at_first_bad = got;
+            std::string hand;
+            for (int c = 0; c < nc; ++c) hand += (c ? " " : "") + std::to_string(int(cards[i * nc + c]));
+            return fail(RS_ERR_MISMATCH, "rs_hand_index_verify: hand " + std::to_string(i) + " (cards " + hand + "): this library indexes it " + std::to_string(got) +
+                                             ", the caller's indexer " + std::to_string(expect[i]) + " -- bucket files indexed by the other side must not be loaded");
+        }
+    }
+    return RS_OK;
+}
+
 // get_hand (hand_unindex): a representative hand of every index; cards_out[n][n_cards(round)]
 int rs_hand_unindex(const rs_hand_indexer *ix, int round, const uint64_t *indices, size_t n, uint8_t *cards_out) {
     if (!ix || (!indices && n) || (!cards_out && n)) return fail(RS_ERR_INVALID, "rs_hand_unindex: NULL argument");

@@ -284,3 +284,30 @@ def test_oracle_generate_hand_gives_up_where_the_reference_would_spin():
     mask = 0b111
     with pytest.raises(RuntimeError):
         orc.generate_hands(3, 0, mask, [(10, 11)], [(11, 12)], 1)       # the two ranges always collide
+
+
+# ---- the integrator's self-check: rs_hand_index_verify (card_abstraction.rs:204-209, :227-229) ---------------------------------------------
+def test_hand_index_verify_reports_the_first_disagreeing_hand():
+    """The order of hand indices is not pinned by any reference fixture (rust_poker is not vendored), so the library ships the check an integrator runs against
+    hand_indexer_s::get_index before loading bucket files from the other side.  Here the `other side` is the oracle's indexer (agreement expected), then a copy
+    with two entries tampered with (the first must be reported, with this library's own index for it) and malformed input (errors, not reports)."""
+    rng = np.random.Generator(np.random.PCG64(20))
+    for cpr in ([2, 3], [2, 4], [2, 5]):
+        ix, oix = ab.HandIndexer(cpr), orc.HandIndexer(cpr)
+        hands = random_hands(rng, 1000, sum(cpr))
+        theirs = np.array([oix.get_index(h) for h in hands], dtype=np.uint64)
+        assert ix.verify(hands, theirs) == (1000, None)
+        assert ix.verify(hands[:, :2], np.array([oix.get_index(h[:2], 0) for h in hands], dtype=np.uint64), round_=0) == (1000, None)
+        bad = theirs.copy()
+        bad[417] += 1
+        bad[800] ^= 5
+        first, got = ix.verify(hands, bad)
+        assert (first, got) == (417, int(theirs[417]))
+        assert "hand 417" in rs._lib.load().rs_last_error().decode()
+        assert ix.verify(hands[:0], theirs[:0]) == (0, None)                      # empty input: nothing to disagree on
+        dup = hands.copy()
+        dup[3, 1] = dup[3, 0]                                                     # a card twice: an error, not a report
+        with pytest.raises(Exception):
+            ix.verify(dup, theirs)
+        with pytest.raises(ValueError):
+            ix.verify(hands, theirs[:-1])

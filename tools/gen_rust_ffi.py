@@ -98,7 +98,8 @@ def parse(src):
             for more in line.split(",")[1:]:                     # `uint32_t world, rank;`
                 fields.append((more.strip(), field_type(first[0], [])))
         items["structs"].append((m.group(1), fields))
-    body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    body = re.sub(r"^[ \t]*#[^\n]*(?:\\\n[^\n]*)*$", " ", src, flags=re.M)   # preprocessor lines (#ifdef / #endif / #define, continuations included) are not part of any prototype
+    body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", body, flags=re.S)
     body = re.sub(r"enum\s*\{.*?\}\s*;", " ", body, flags=re.S)
     for m in re.finditer(r"([\w\s\*]+?)\b(rs_\w+)\s*\(([^()]*)\)\s*;", body):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
@@ -109,7 +110,10 @@ def parse(src):
             for a in args.split(","):
                 ctype, pname, dims = split_decl(a)
                 params.append((RESERVED.get(pname, pname), param_type(ctype, dims)))
-        items["fns"].append((name, params, None if ret == "void" else rust_type(ret)))
+        rt = None if ret == "void" else rust_type(ret)
+        if rt is not None and not re.fullmatch(r"(?:\*(?:const|mut) )*\w+", rt):   # anything else is a parse accident (rustc would reject it; there is none here to say so)
+            raise ValueError("return type of %s parsed as %r" % (name, rt))
+        items["fns"].append((name, params, rt))
     return items
 
 
