@@ -988,7 +988,7 @@ def compact_line(out):
                                           "process_group_ranks") if k in cfg}
     rf = out["roofline"]
     line["roofline"] = {k: r3(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_canned", "launches", "avg_launch_ms",
-                                               "algo_bytes_per_launch", "frac_of_copy_on_this_card") if k in rf}
+                                               "algo_bytes_per_launch", "copy_GBps", "frac_of_copy_on_this_card") if k in rf}
     line["roofline"]["kernel"] = "rs_tree_p{0,1}_lanes" if "rs_tree" in rf.get("kernel", "") else "rs::k_update"
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict) and "value" in cb:
@@ -1282,6 +1282,7 @@ def main():
             out["stream_probe"] = {"copy_GBps": g.value, "what": "nt float4 copy, 2 GiB read + 2 GiB written per launch, best of 1 024 / 4 096 / 16 384 workgroups, HIP events",
                                    "tree_kernel_over_copy": achieved / g.value if g.value > 0 else None}
             out["roofline"]["frac_of_copy_on_this_card"] = out["stream_probe"]["tree_kernel_over_copy"]
+            out["roofline"]["copy_GBps"] = g.value   # the card's own ceiling next to `frac`: boxes of this pool differ by several percent on identical code (profiles/r04_headline_ab.md)
         except Exception as e:
             out["stream_probe"] = {"error": str(e)}
 
