@@ -205,8 +205,10 @@ __device__ __forceinline__ void gather_rec_half(const RS_GLOBAL int *rec, int (&
         }
     }
 }
-// `stride` (ints between two clusters' records): 2H where the record holds regrets and strategy_sum (the sweep's traverser nodes), H where it holds regrets only (the
-// opponent's nodes: the shadow is rebuilt per sweep, so it holds what THIS traverser's sweep reads -- half the bytes and twice the records per cache line there)
+// A record holds 2H ints -- regrets and strategy_sum -- at the sweep's traverser nodes and H at the opponent's (the shadow is rebuilt per sweep, so it holds what THIS
+// traverser's sweep reads).  `stride` (ints between two clusters' records of one node) is the ROW of the node's round subtree and role: a deal addresses every traverser node
+// of a round subtree with ONE cluster id and every opponent node with another, so the records of all those nodes sit side by side, one row per cluster
+// (rs_solver.cpp setup_table_shadow) -- the 7 gathers a river walk makes at its own nodes land in two cache lines instead of seven
 template <int A>
 __device__ __forceinline__ void gather_rec(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {   // regrets only
     const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
@@ -214,19 +216,19 @@ __device__ __forceinline__ void gather_rec(const void *shadow, unsigned stride, 
     for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)idx[j] * stride, r, j);
 }
 template <int A>
-__device__ __forceinline__ void gather_rec2(const void *shadow, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
+__device__ __forceinline__ void gather_rec2(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
     constexpr int H = shadow_half<A>();
     const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
 #pragma unroll
     for (int j = 0; j < kVecD; j++) {
         if constexpr (A <= 2) {   // one 16-byte record {r0, r1, s0, s1}
-            const i32x4 w = *reinterpret_cast<const RS_GLOBAL i32x4 *>(p + (size_t)idx[j] * 4);
+            const i32x4 w = *reinterpret_cast<const RS_GLOBAL i32x4 *>(p + (size_t)idx[j] * stride);
             r[0][j] = w.x;
             s[0][j] = w.z;
             if (A > 1) { r[1 < A ? 1 : 0][j] = w.y; s[1 < A ? 1 : 0][j] = w.w; }
         } else {
-            gather_rec_half<A>(p + (size_t)idx[j] * (2 * H), r, j);
-            gather_rec_half<A>(p + (size_t)idx[j] * (2 * H) + H, s, j);
+            gather_rec_half<A>(p + (size_t)idx[j] * stride, r, j);
+            gather_rec_half<A>(p + (size_t)idx[j] * stride + H, s, j);
         }
     }
 }
@@ -267,11 +269,11 @@ __device__ __forceinline__ void gather_node(const void *shadow, unsigned stride,
     }
 }
 template <int A, typename V>
-__device__ __forceinline__ void gather_node2(const void *shadow, const void *reg, const void *ssm, unsigned tpitch, const unsigned (&idx)[kVecD], V (&r)[A][kVecD],
-                                             V (&s)[A][kVecD]) {
+__device__ __forceinline__ void gather_node2(const void *shadow, unsigned stride, const void *reg, const void *ssm, unsigned tpitch, const unsigned (&idx)[kVecD],
+                                             V (&r)[A][kVecD], V (&s)[A][kVecD]) {
     if constexpr (sizeof(V) == sizeof(int) && (V)0.5 == (V)0) {
         if (shadow) {
-            gather_rec2<A>(shadow, idx, r, s);
+            gather_rec2<A>(shadow, stride, idx, r, s);
             return;
         }
     }
@@ -282,6 +284,87 @@ __device__ __forceinline__ void gather_node2(const void *shadow, const void *reg
             gather_i32(ssm, a * tpitch, idx, s[a]);
         }
     }
+}
+// ---- staged rows (deal sweeps, list walkers with one deal per lane) -----------------------------------------------------------------------------------------
+// A gather of 64 lanes at 64 clusters costs the CU's L1 one lookup per lane whatever the lanes fetch (profiles/r04_deals.md: with every deal reading cluster 0 a river walk
+// takes a third of its time), and a walk makes one such gather per node.  Instead the WAVE copies the rows of its 64 deals into LDS with loads whose consecutive lanes read
+// consecutive 16-byte chunks of one row: load i of lane l fetches chunk (64 i + l) % CH of the deal of lane (64 i + l) / CH -- an instruction touches 64 / CH rows instead of 64,
+// and every line the wave needs crosses the L1 once.  The lanes then read their own row back (ds_read_b128 at lane * CHP chunks; CHP odd: conflict-free).
+// CH = 16-byte chunks per row in memory, CHP = per row in LDS.
+__device__ __forceinline__ void wave_lds_sync() {   // LDS operations of one wave execute in order: only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int CH, int CHP>
+__device__ __forceinline__ void stage_rows(const int *rows, unsigned idx, int *W) {
+    static_assert(kVecD == 1, "staged rows take one deal per lane");
+    static_assert(CH >= 1 && CH <= 16 && CHP == CH, "rows of at most 16 chunks, back to back in LDS");
+    // G lanes fetch one row (G = the power of two at or above CH; lanes k >= CH of a group sit out): load i covers deals 64 / G * i .. -- the lane's share of every address
+    // (its group's deal, its chunk) is the same for all i, so the whole copy costs three address registers and immediate offsets
+    constexpr int G = CH <= 2 ? 2 : (CH <= 4 ? 4 : (CH <= 8 ? 8 : 16)), PER = 64 / G;
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned k = lane & (unsigned)(G - 1), dl = lane / (unsigned)G;
+    const RS_GLOBAL i32x4 *base = as_global<i32x4>(rows) + k;
+    int *dst = W + (dl * (unsigned)CH + k) * 4u;
+    i32x4 buf[G];
+    __builtin_amdgcn_sched_barrier(0);   // the loads below start AFTER what came before (the read-back of the previous rows): their registers are the kernel's peak otherwise
+    unsigned c[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) c[i] = (unsigned)__builtin_amdgcn_ds_bpermute((int)((dl + (unsigned)(i * PER)) << 2), (int)idx);   // the cluster of the deal of lane PER i + dl;
+                                                                                                                                   // by EVERY lane: a lane that sits out reads as 0
+    if (k < (unsigned)CH) {
+#pragma unroll
+        for (int i = 0; i < G; i++) buf[i] = base[(size_t)c[i] * CH];
+    }
+    wave_lds_sync();   // whoever read the region before is done with it
+    if (k < (unsigned)CH) {
+#pragma unroll
+        for (int i = 0; i < G; i++) *reinterpret_cast<i32x4 *>(dst + i * (PER * CH * 4)) = buf[i];
+    }
+    wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+}
+// a node's record inside the lane's staged row (`rec` = W + lane * CHP * 4 + the node's offset): regrets only / strategy, or regrets and strategy sums
+template <int A>
+__device__ __forceinline__ void staged_half(const int *rec, int (&out)[A][kVecD]) {
+    if constexpr (A <= 2) {
+        const i32x2 lo = *reinterpret_cast<const i32x2 *>(rec);
+        out[0][0] = lo.x;
+        if (A > 1) out[1 < A ? 1 : 0][0] = lo.y;
+    } else {
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(rec);
+        out[0][0] = lo.x;
+        if (A > 1) out[1 < A ? 1 : 0][0] = lo.y;
+        if (A > 2) out[2 < A ? 2 : 0][0] = lo.z;
+        if (A > 3) out[3 < A ? 3 : 0][0] = lo.w;
+        if (A > 4) {
+            const i32x4 hi = *reinterpret_cast<const i32x4 *>(rec + 4);
+            out[4 < A ? 4 : 0][0] = hi.x;
+            if (A > 5) out[5 < A ? 5 : 0][0] = hi.y;
+            if (A > 6) out[6 < A ? 6 : 0][0] = hi.z;
+            if (A > 7) out[7 < A ? 7 : 0][0] = hi.w;
+        }
+    }
+}
+template <int A>
+__device__ __forceinline__ void staged_rec2(const int *rec, int (&r)[A][kVecD], int (&s)[A][kVecD]) {
+    if constexpr (A <= 2) {   // {r0, r1, s0, s1}
+        const i32x4 w = *reinterpret_cast<const i32x4 *>(rec);
+        r[0][0] = w.x;
+        s[0][0] = w.z;
+        if (A > 1) { r[1 < A ? 1 : 0][0] = w.y; s[1 < A ? 1 : 0][0] = w.w; }
+    } else {
+        staged_half<A>(rec, r);
+        staged_half<A>(rec + shadow_half<A>(), s);
+    }
+}
+template <int A>
+__device__ __forceinline__ void staged_sigma(const int *rec, float (&g)[A][kVecD]) {
+    int r[A][kVecD];
+    staged_half<A>(rec, r);
+#pragma unroll
+    for (int a = 0; a < A; a++) g[a][0] = __int_as_float(r[a][0]);
 }
 __device__ __forceinline__ void scatter_add_i32(void *base, unsigned row_off, const unsigned (&idx)[kVecD], const int (&now)[kVecD],
                                                 const int (&before)[kVecD]) {
@@ -661,39 +744,40 @@ __device__ __forceinline__ void load_arec(const void *base, const unsigned (&idx
     }
 }
 
-// Sum of x over the 64 lanes of the wave (every lane active), in a scalar register.  Inclusive prefix inside each row of 16 (row_shr with zero fill), then the rows
-// are folded with the two row broadcasts: lane 63 ends up with the total.
-__device__ __forceinline__ int wave_sum_i32(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(x, 63);
-}
-
-// In an ordered sweep the deals a wave walks in the last round share a handful of traverser clusters (mostly one): all of them add into the SAME table cells.
-// Instead of an LDS tile per traverser node (160 KB per workgroup, one workgroup per CU, zeroed and flushed around every 1 024 deals) the wave sums every delta
-// over the lanes of each DISTINCT cluster (wave_sum_i32) and issues ONE global atomic per cluster, node, action and array -- 2A lanes of one instruction.  The
-// lanes of a cluster need not be neighbours (the compaction interleaves 64-entry granules).  Integer adds commute, so the result equals the tile form's, and the
-// oracle's, bit for bit.
-constexpr int kSegMax = 6;   // more distinct clusters than this in one wave (small batches, list tails): every lane adds for itself
+// In an ordered sweep the deals a wave walks in the last round come in RUNS of equal traverser cluster (the batch is sorted by it; a list keeps the order of its source inside a
+// tile of the compaction): the lanes of a run add into the SAME table cells.  Instead of an LDS tile per traverser node, or a row of deltas per node and deal summed by a later
+// pass, the wave sums every delta along the runs inside each row of 16 lanes -- a segmented inclusive scan by DPP row shifts, four steps, the same four run masks for every
+// value of every node of the walk -- and the last lane of every (row, run) piece issues ONE global atomic per node, action and array.  Pieces of one run in different rows, waves
+// or workgroups meet in the atomics.  Integer adds commute, so the result equals the tile form's, the delta rows', and the oracle's, bit for bit.
 struct Seg {
-    unsigned n_keys;   // distinct clusters among the wave's lanes, counted up to kSegMax + 1
-    unsigned lane;
+    bool m1, m2, m4, m8;   // no run starts among this lane and the 0 / 1 / 3 / 7 lanes before it (inside its row of 16): the lane 1 / 2 / 4 / 8 back belongs to the same run
+    bool tail;             // the last lane of its piece: it holds the piece's sums after the scan
 };
 __device__ __forceinline__ Seg seg_make(unsigned key) {
     Seg sg;
-    sg.lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    sg.n_keys = 0;
-    unsigned long long todo = ~0ull;
-    while (todo && sg.n_keys <= (unsigned)kSegMax) {
-        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
-        todo &= ~__builtin_amdgcn_ballot_w64(key == ckey);
-        ++sg.n_keys;
-    }
+    const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111, 0xf, 0xf, false);   // row_shr:1; the first lane of a row keeps ~key: a run starts there
+    const unsigned next = (unsigned)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x101, 0xf, 0xf, false);   // row_shl:1; the last lane of a row keeps ~key
+    const int f1 = prev == key ? 1 : 0;
+    const int f2 = f1 & __builtin_amdgcn_update_dpp(0, f1, 0x111, 0xf, 0xf, true);
+    const int f4 = f2 & __builtin_amdgcn_update_dpp(0, f2, 0x112, 0xf, 0xf, true);
+    const int f8 = f4 & __builtin_amdgcn_update_dpp(0, f4, 0x114, 0xf, 0xf, true);
+    sg.m1 = f1 != 0;
+    sg.m2 = f2 != 0;
+    sg.m4 = f4 != 0;
+    sg.m8 = f8 != 0;
+    sg.tail = next != key;
     return sg;
+}
+__device__ __forceinline__ int seg_scan_i32(int x, const Seg &sg) {   // sum of x over the lanes of this lane's run piece up to and including this lane
+    int y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += sg.m1 ? y : 0;
+    y = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += sg.m2 ? y : 0;
+    y = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += sg.m4 ? y : 0;
+    y = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += sg.m8 ? y : 0;
+    return x;
 }
 template <int A>
 __device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch, const Seg &sg, unsigned key, const int (&r)[A][kVecD], const int (&q)[A][kVecD],
@@ -707,29 +791,13 @@ __device__ __forceinline__ void seg_add(void *dreg, void *dssm, unsigned tpitch,
         d[A + a] = (int)((unsigned)s[a][0] - (unsigned)t[a][0]);
         any = any || d[a] != 0 || d[A + a] != 0;
     }
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(any);   // lanes whose deal visited the node
-    if (todo == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;   // nobody's deal visited the node
     RS_GLOBAL int *pr = as_global<int>(dreg), *ps = as_global<int>(dssm);
-    if (sg.n_keys > (unsigned)kSegMax) {
 #pragma unroll
-        for (int a = 0; a < A; a++) {
-            if (d[a] != 0) __hip_atomic_fetch_add(pr + (size_t)a * tpitch + key, d[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d[A + a] != 0) __hip_atomic_fetch_add(ps + (size_t)a * tpitch + key, d[A + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    RS_GLOBAL int *mine_p = sg.lane < (unsigned)A ? pr + (size_t)sg.lane * tpitch : ps + (size_t)(sg.lane - (unsigned)A) * tpitch;   // lane i < 2A carries value i of a cluster
-    while (todo) {   // one trip per distinct cluster that somebody visited the node with: wave-uniform
-        const unsigned ckey = (unsigned)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
-        const bool in = key == ckey;
-        todo &= ~__builtin_amdgcn_ballot_w64(in);
-        int mine = 0;
-#pragma unroll
-        for (int i = 0; i < 2 * A; i++) {
-            const int tot = wave_sum_i32(in ? d[i] : 0);
-            mine = sg.lane == (unsigned)i ? tot : mine;
-        }
-        if (sg.lane < 2u * (unsigned)A && mine != 0) __hip_atomic_fetch_add(mine_p + ckey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int a = 0; a < A; a++) {
+        const int xr = seg_scan_i32(d[a], sg), xs = seg_scan_i32(d[A + a], sg);
+        if (sg.tail && xr != 0) __hip_atomic_fetch_add(pr + (size_t)a * tpitch + key, xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sg.tail && xs != 0) __hip_atomic_fetch_add(ps + (size_t)a * tpitch + key, xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

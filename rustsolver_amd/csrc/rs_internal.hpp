@@ -99,8 +99,9 @@ struct ShadowJob {
     const int32_t *ssum;
     int32_t *dst;             // [n_clusters][stride]: regrets (half ints), then strategy_sum (half ints) when stride == 2 * half
     uint32_t pitch, n_clusters, n_actions, half;   // half = 4 (A <= 4) or 8
-    uint32_t stride, sigma;   // half: regrets only (a node of the sweep's opponent); 2 * half: both arrays (a traverser node).  sigma (with stride == half): the record holds
-                              // get_strategy() of the regrets (f32 bits) instead of the regrets: the sweep only reads an opponent node to sample from it
+    uint32_t stride, sigma;   // ints of the RECORD: half: regrets only (a node of the sweep's opponent); 2 * half: both arrays (a traverser node).  sigma (with stride == half): the
+                              // record holds get_strategy() of the regrets (f32 bits) instead of the regrets: the sweep only reads an opponent node to sample from it
+    uint32_t row_stride, pad_;   // ints between two clusters' records: the records of all nodes of one round subtree and role sit side by side in one ROW per cluster
 };
 // sparse deal sweeps: live deals (reach not NaN) of one subtree root, compacted (order irrelevant: every use commutes)
 struct CompactJob {
@@ -274,6 +275,7 @@ struct Knobs {
     int no_handoff = 0;             // RS_JIT_NO_HANDOFF: the walk of a round subtree draws the opponent's actions again instead of reading the reach-down kernel's
     int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
     int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
+    int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
 std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), else ~/.cache/rustsolver_amd
@@ -302,17 +304,28 @@ struct JitSubtree {
     size_t off_plist = 0;                                                                 // the parent-subtree position of every entry of the live list, may be null
     size_t off_klist = 0;                                                                 // delta rows: the key row of the job's list (the traverser's cluster of every entry), written by the walk
     size_t off_hrow = 0, off_hpitch = 0;                                                  // hand-off rows of the job (reach-down kernel -> walk), pitch between them
+    size_t off_rowp = 0;                                                                  // staged rows: the shadow rows of player 0's and player 1's nodes of the subtree
+    bool staged = false;
+    size_t stage_lds_bytes = 0;                                                           // per workgroup
     int n_handed = 0;                                                                     // opponent nodes whose draw the reach-down kernel hands to the walk (+ 1 row of packed actions)
     size_t off_c0 = 0, off_rcount = 0, off_rp = 0;                                         // the cluster range a job's LDS tiles cover
     size_t off_fan = 0, off_inv = 0, off_cvec = 0;                                        // lane sweeps: deals below the ENUM chance node the kernel walks itself
     std::vector<int> boundary_roots;   // tree id of every next-round root below this subtree, in the order of butil[] / breach[]
 };
+// staged rows (rs_device.hpp stage_rows): the shadow rows of a round subtree as the generated kernel needs to know them -- structure only, no addresses
+struct JitStage {
+    int ch[2] = {0, 0};       // per PLAYER: 16-byte chunks of a row of that player's nodes in this round subtree (0: the kernel reads none)
+    int chp[2] = {0, 0};      // the same in LDS: ch rounded up to an odd number
+    std::vector<int> off;     // per tree node: ints from the start of its row to its record
+};
+constexpr int kStageMaxChunks = 16;   // rows beyond 256 bytes keep their gathers (64 deals x 17 chunks x 16 B = 17 KB of LDS per wave)
 void jit_emit_subtree(const std::vector<rs_tree_node> &nodes, int root, int p, const std::vector<char> &has_own,
                       const std::vector<int> &leaf_buf, const std::vector<int> &leaf_flags, int dtype, int arith, bool sampled,
                       bool deals, bool lds, bool sparse, bool down, bool prune, int lanes, const std::vector<char> *cut, JitSubtree &out, const Knobs &knobs, int fan = 0, bool packed = false,
                       bool posrows = false, bool worklist = false, bool ordered = false, bool seg = false, bool rows = false,
                       const std::vector<char> *sigma = nullptr /* per tree node: its shadow record holds the strategy (opponent nodes of a deal sweep) */,
-                      bool handoff = false /* deal sweeps: the reach-down kernel stores its draws by list position, the walk reads them (both kernels of a root alike) */);
+                      bool handoff = false /* deal sweeps: the reach-down kernel stores its draws by list position, the walk reads them (both kernels of a root alike) */,
+                      const JitStage *stage = nullptr /* list walkers, one deal per lane: the subtree's records come from rows the wave stages in LDS */);
 bool jit_available();
 int jit_get_kernel(const std::string &source, const std::string &entry, int device, hipFunction_t *fn, bool dump = false);
 uint64_t jit_source_key(const std::string &source);   // what the caches are keyed by (source + compiler version + options)

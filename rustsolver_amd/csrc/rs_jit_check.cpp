@@ -144,6 +144,34 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                         seen[jf.source] = 1;
                     }
                 }
+                if (lanes == 1 && sparse && !lds) {   // staged rows: the list walkers of large batches (delta-rows walk, reach-down kernel) read their records from rows staged in LDS
+                    JitStage st;
+                    st.off.assign(n, 0);
+                    for (int q = 0; q < 2; ++q) {   // the round subtree's nodes of player q, in index order: one row (rs_plan.hpp shadow_row_layout)
+                        std::vector<int> ids;
+                        std::vector<uint32_t> acts, rec, off;
+                        std::vector<int> stack{int(i)};
+                        while (!stack.empty()) {
+                            const int x = stack.back();
+                            stack.pop_back();
+                            const rs_tree_node &xn = nodes[size_t(x)];
+                            if (xn.kind != RS_NODE_ACTION || xn.n_children == 0) continue;
+                            if (xn.player == q) ids.push_back(x);
+                            for (int k = 0; k < xn.n_children; ++k)
+                                if (nodes[size_t(xn.children[k])].kind == RS_NODE_ACTION || nodes[size_t(xn.children[k])].kind == RS_NODE_TERMINAL) stack.push_back(xn.children[k]);
+                        }
+                        std::sort(ids.begin(), ids.end());
+                        for (int x : ids) acts.push_back(uint32_t(nodes[size_t(x)].n_children));
+                        if (ids.empty()) continue;
+                        st.ch[q] = int(shadow_row_layout(acts, q == p, rec, off) / 4);
+                        st.chp[q] = st.ch[q];
+                        for (size_t m = 0; m < ids.size(); ++m) st.off[size_t(ids[m])] = int(off[m]);
+                    }
+                    JitSubtree jt;
+                    jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, true, down,
+                                     (mode & RS_UPD_PRUNE) != 0, 1, &root, jt, knobs, 0, true, true, false, false, false, !down, &sigma_all, true, &st);
+                    if (!(down && jt.boundary_roots.empty()) && jt.staged && !seen.count(jt.source)) seen[jt.source] = 1;
+                }
                 if (f6 >= 4) {   // delta rows (rs_kernel_forms.delta_rows): the walk stores its deltas by position, dense and over a list
                     JitSubtree jr;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, sparse, false,

@@ -487,10 +487,10 @@ __global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__rest
             }
             for (uint32_t a = 0; a < A && a < 8; ++a) rec[a] = __float_as_int(sg[a]);
         }
-        i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * job->stride);
+        i32x4 *out = reinterpret_cast<i32x4 *>(dst + (size_t)c * job->row_stride);
         if (half == 2) {   // two actions: 8 bytes of regrets, or one 16-byte record {r0, r1, s0, s1}
             if (both) out[0] = i32x4{rec[0], rec[1], rec[8], rec[9]};
-            else *reinterpret_cast<i32x2 *>(dst + (size_t)c * job->stride) = i32x2{rec[0], rec[1]};
+            else *reinterpret_cast<i32x2 *>(dst + (size_t)c * job->row_stride) = i32x2{rec[0], rec[1]};
         } else if (half == 4) {
             out[0] = i32x4{rec[0], rec[1], rec[2], rec[3]};
             if (both) out[1] = i32x4{rec[8], rec[9], rec[10], rec[11]};

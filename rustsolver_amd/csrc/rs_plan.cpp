@@ -409,15 +409,44 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             if (qn.kind != RS_NODE_ACTION || qn.n_children == 0 || qn.player == p) continue;
             const bool shadowed = s->shadow_off_p[p][size_t(qn.index)] != SIZE_MAX;
             const uint32_t half = qn.n_children <= 2 ? 2u : (qn.n_children <= 4 ? 4u : 8u);
-            sigma_node[q] = shadowed && s->shadow_stride_p[p][size_t(qn.index)] == half;
+            sigma_node[q] = shadowed && s->shadow_rec_p[p][size_t(qn.index)] == half;
         }
+    }
+    // staged rows: when every node of the round subtree has a shadow record this sweep, the list walkers read them from rows their waves stage in LDS (rs_device.hpp stage_rows)
+    JitStage stage;
+    const int32_t *stage_rows_of[2] = {nullptr, nullptr};
+    if (s->deal_mode && sparse && !s->shadow_off_p[p].empty() && !s->knobs.no_stage) {
+        stage.off.assign(n, 0);
+        bool all = true;
+        std::vector<int> stack{id};
+        while (!stack.empty()) {
+            const int q = stack.back();
+            stack.pop_back();
+            const rs_tree_node &qn = nodes[q];
+            if (qn.kind == RS_NODE_ACTION && qn.n_children > 0) {
+                const size_t ti = size_t(qn.index);
+                if (s->shadow_off_p[p][ti] == SIZE_MAX || s->shadow_stride_p[p][ti] % 4) all = false;
+                else {
+                    stage.ch[qn.player] = int(s->shadow_stride_p[p][ti] / 4);
+                    stage.chp[qn.player] = stage.ch[qn.player];   // rows back to back in LDS: one address register for all of the wave's stores
+                    stage.off[size_t(q)] = int(s->shadow_rowoff_p[p][ti]);
+                    stage_rows_of[qn.player] = s->d_shadow + (s->shadow_off_p[p][ti] - s->shadow_rowoff_p[p][ti]);
+                }
+            }
+            for (int k = 0; k < qn.n_children; ++k) {
+                const int c = qn.children[k];
+                const bool chance = nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE;
+                if (!(round_mode && chance)) stack.push_back(c);
+            }
+        }
+        if (!all) stage.ch[0] = stage.ch[1] = 0;
     }
     JitSubtree js;
     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                      (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id));
+                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id), &stage);
     const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
     // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete, every distinct source at once on a pool of host threads
@@ -434,6 +463,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         plan.jit.back().worklist = js.worklist;
         plan.jit.back().seg = seg;
         plan.jit.back().rows = rows;
+        plan.jit.back().staged = js.stage_lds_bytes != 0;
         plan.jit.back().off_count = uint32_t(js.off_count);
         plan.jit.back().deals_per_trip = uint32_t(js.threads * js.lanes);
     }
@@ -531,6 +561,8 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         }
         put_ptr(js.off_hrow, handoff_root(id) ? plan.d_hrows + hrow_off[size_t(id)] : nullptr);
         put_u32(js.off_hpitch, uint32_t(s->pitch[0] + kRowStagger));
+        put_ptr(js.off_rowp, stage_rows_of[0]);
+        put_ptr(js.off_rowp + 8, stage_rows_of[1]);
         if (rows) {   // what k_row_sums adds up after the walks: per traverser node and array the A rows beside the job's key row (row by row where A tiles do not fit together)
             const uint32_t bp = uint32_t(s->pitch[0] + kRowStagger);   // the delta rows' own pitch (JArgs.rp of this form)
             const CompactJob *cj = sparse ? &plan.compact_jobs[size_t(sparse_slot[id])] : nullptr;
@@ -605,6 +637,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             if (n_res) JL.persistent = true;
         }
         if (use_lds) JL.lds_bytes = std::max(JL.lds_bytes, lds_total);
+        if (js.stage_lds_bytes) JL.lds_bytes = std::max(JL.lds_bytes, js.stage_lds_bytes);
     }
     JL.n_jobs += 1;
     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);

@@ -14,7 +14,9 @@ constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size co
 // apart, every stream then sits on the same memory channel at the same moment, and the row-summing pass ran 4x slower than with 4 196 416 deals (12.7 against 8.9 ms per batch)
 constexpr size_t kRowStagger = 1088;   // elements between the natural pitch and the one used (4 352 B: off every power-of-two interleave up to 4 KiB, rows stay 256-B aligned)
 constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this size compact the live deals of sibling roots in one scan of their source (rs_plan_deals.cpp)
-constexpr uint32_t kRowsMinDeals = 524288;   // deal batches beyond this size store delta rows in their list walkers (rs_solver.cpp): 4 M deals 1.13-1.19x, 1 M 1.0-1.07x, 256 K 0.95-1.1x over three cards
+constexpr uint32_t kRowsMinDeals = 49152;   // deal batches beyond this size store delta rows in their list walkers and walk the batch in the order of the traverser's last-round cluster (rs_solver.cpp).
+                                            // Round 3 (gathering walks): 4 M deals 1.13-1.19x, 256 K a wash -> 512 K.  Round 4 (staged rows, runs summed by DPP): 4 M 1.16x, 1 M 1.18x, 512 K 1.16x,
+                                            // 256 K 1.10x, 128 K 1.11x, 64 K 1.24x over the tile kernels on one card (profiles/r04_deals.md)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
 enum LaunchKind { L_REACH, L_PRUNE_REACH, L_EXPAND, L_UPDATE, L_NODE_UTIL, L_REDUCE, L_TREE, L_SEED, L_APPLY, L_SHADOW, L_COMPACT, L_NANFILL, L_PACK, L_ORDER, L_ROWSUM };
 
@@ -50,6 +52,7 @@ struct JitLaunch {
     bool persistent = false;            // resident LDS tiles: one long-lived workgroup per CU, flushes once
     bool seg = false;                   // ordered sweeps, last round: no LDS, 256-thread workgroups, many per CU
     bool rows = false;                  // delta rows: no LDS, no barrier, 256-thread workgroups, many per CU
+    bool staged = false;                // staged rows: lds_bytes is the waves' staging area, not delta tiles (grid as for the forms without LDS)
     bool worklist = false;              // list-walking kernels with LDS tiles: a 1-D grid of resident workgroups pulls (job, trip) items; k_worklist runs right before
     uint32_t *d_wl = nullptr;           // [2 + n_jobs + 1]
     uint32_t off_count = 0, deals_per_trip = 0;
@@ -146,8 +149,10 @@ struct rs_solver {
     int32_t *d_shadow = nullptr;
     ShadowJob *d_shadow_jobs = nullptr;   // the jobs of traverser 0's sweep, then those of traverser 1's (the same nodes, different record widths)
     int n_shadow_jobs = 0;                // per traverser
-    std::vector<size_t> shadow_off_p[2];  // per traverser and table node, in ints (SIZE_MAX: no shadow)
-    std::vector<uint32_t> shadow_stride_p[2];
+    std::vector<size_t> shadow_off_p[2];  // per traverser and table node, in ints (SIZE_MAX: no shadow): where cluster 0's record of the node starts
+    std::vector<uint32_t> shadow_stride_p[2];   // ints between two clusters' records of the node: the ROW of its round subtree and role (rs_solver.cpp setup_table_shadow)
+    std::vector<uint32_t> shadow_rec_p[2];      // ints of the node's own record: 2 * half at the sweep's traverser nodes, half at the opponent's
+    std::vector<uint32_t> shadow_rowoff_p[2];   // ints from the start of the row to the node's record
     uint32_t shadow_max_clusters = 0;
     // sparse deal sweeps fetch the per-deal inputs of a round (both cluster ids, leaf value, prune flag) as ONE packed 16-byte record per live deal
     void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
@@ -181,6 +186,10 @@ namespace rs {
 
 // rs_plan.cpp: shapes and sharding derived from table + tree (validation included), then one PlanBuilder per traverser: layout() decides which buffers exist
 // (offsets into the arena the caller then allocates), emit() writes the jobs and launches
+// rs_plan_deals.cpp: one ROW of the sweep's table shadow = the records of the nodes of one player in one round subtree (action counts `n_actions`, in ActionNode.index order),
+// `wide`: records hold regrets and strategy sums (the sweep's traverser), else regrets / strategy only.  Returns the row's ints (a multiple of 4: rows start 16-byte aligned);
+// rec[k] = ints of node k's record, off[k] = where it starts in the row (16-byte records first, the 8-byte ones of two-action opponent nodes behind them)
+uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, std::vector<uint32_t> &rec, std::vector<uint32_t> &off);
 int derive_geometry(rs_solver *s);
 bool rows_round_ok(const rs_solver *s, int p, int round);   // rs_plan_deals.cpp: do traverser p's nodes of this round take the delta-rows form?
 size_t drows_ints(const rs_solver *s, int p);               // ints of delta rows traverser p's sweep needs

@@ -13,9 +13,27 @@ using namespace rs;
 
 namespace rs {
 
+uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, std::vector<uint32_t> &rec, std::vector<uint32_t> &off) {
+    const size_t k = n_actions.size();
+    rec.assign(k, 0);
+    off.assign(k, 0);
+    uint32_t at = 0;
+    for (int pass = 0; pass < 2; ++pass)   // 16-byte loads want 16-byte aligned records: those of 4 ints and more first, the 8-byte ones at the end of the row
+        for (size_t i = 0; i < k; ++i) {
+            const uint32_t half = n_actions[i] <= 2 ? 2 : (n_actions[i] <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
+            const uint32_t r = wide ? 2 * half : half;
+            if ((r >= 4) != (pass == 0)) continue;
+            rec[i] = r;
+            off[i] = at;
+            at += r;
+        }
+    return uint32_t(round_up(size_t(at), 4));
+}
+
 bool rows_round_ok(const rs_solver *s, int p, int round) {
     if (!s->rows || !s->deal_mode || s->table->dtype != RS_I32) return false;
     if (s->knobs.rows < 2 && round == s->first_round) return false;   // the dense walk of the first round: rs_plan_builder.hpp rows_root
+    if (s->ordered && round == s->order_round) return false;   // ordered sweeps: the last round's lists come in runs of equal traverser cluster, summed by wave segments (seg_add)
     const rs_table *t = s->table;
     uint32_t k = 0;
     for (size_t i = 0; i < t->nodes.size(); ++i)

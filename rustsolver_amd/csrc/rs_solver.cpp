@@ -108,7 +108,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     case L_TREE: {
         const JitLaunch &JL = plan.jit[L.first_job];
         size_t blocks = (size_t(JL.max_n_vec) + JL.threads - 1) / JL.threads;   // interleaved A/B: block size and grid cap are irrelevant for the lane kernels
-        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), JL.lds_bytes ? 256 * 4 : 256 * 16);   // LDS form: fewer, longer-lived workgroups
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), (JL.lds_bytes && !JL.staged) ? 256 * 4 : 256 * 16);   // LDS tiles: fewer, longer-lived workgroups
         if (JL.persistent) blocks = std::min<size_t>(blocks, size_t(s->n_cus));   // 224 VGPRs: one workgroup per CU is all that fits; more would only flush more
         if ((JL.seg || JL.rows) && JL.n_jobs > 1) blocks = std::min<size_t>(blocks, std::max<size_t>(64, size_t(s->n_cus) * 32 / size_t(JL.n_jobs) * 4));   // list walkers: a list holds a share of the batch
         if (s->knobs.max_blocks != kUnset)   // tests: force several trips per workgroup
@@ -334,42 +334,73 @@ static int setup_table_shadow(rs_solver *s) {
                 }
         }
         const bool shadow_all = s->knobs.shadow_all != 0 || s->params.opp_mode != RS_OPP_SAMPLE;
+        // Rows.  A deal addresses every node of one player inside a round subtree with the SAME cluster id (get_cluster depends on round and player only, cfr.rs:361-365), so the
+        // records of those nodes sit side by side: one ROW per cluster, per (round subtree, player).  A walk's gathers at its own nodes then land in the row's two or three cache
+        // lines instead of one line per node (a river subtree: 7 own nodes, 192 bytes; 7 opponent nodes, 96 bytes).  comp_root: the topmost action node reached from a node
+        // without crossing a chance node.
+        std::vector<int> comp_root(n, -1), tree_of(table->nodes.size(), -1);
+        for (size_t id = 0; id < n; ++id) {
+            const rs_tree_node &nd = tree->nodes[id];
+            if (nd.kind != RS_NODE_ACTION || nd.n_children <= 0 || nd.index < 0) continue;
+            int q = int(id);
+            while (tree->nodes[size_t(q)].parent >= 0 && tree->nodes[size_t(tree->nodes[size_t(q)].parent)].kind == RS_NODE_ACTION) q = tree->nodes[size_t(q)].parent;
+            comp_root[id] = q;
+            if (size_t(nd.index) < tree_of.size()) tree_of[size_t(nd.index)] = int(id);
+        }
         for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
             s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
             s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
+            s->shadow_rec_p[tp].assign(table->nodes.size(), 0);
+            s->shadow_rowoff_p[tp].assign(table->nodes.size(), 0);
+            std::map<std::pair<int, int>, std::vector<size_t>> groups;   // (component root, player) -> its table nodes, in ActionNode.index order
             for (size_t i = 0; i < table->nodes.size(); ++i) {
                 const rs_node_desc &d = table->nodes[i];
                 if (d.n_actions == 0) continue;
                 const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
                 if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
-                const uint32_t half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
-                const uint32_t stride = (d.player == tp || s->knobs.shadow_wide) ? 2 * half : half;
-                s->shadow_off_p[tp][i] = ints;
-                s->shadow_stride_p[tp][i] = stride;
-                ShadowJob j{};
-                j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
-                j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
-                j.pitch = uint32_t(table->pitch[i]);
-                j.n_clusters = d.n_clusters;
-                j.n_actions = d.n_actions;
-                j.half = half;
-                j.stride = stride;
-                j.sigma = (stride == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
-                jobs.push_back(j);
-                ints += round_up(size_t(d.n_clusters) * stride, 64);
-                s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
+                groups[{tree_of[i] >= 0 ? comp_root[size_t(tree_of[i])] : -1 - int(i), int(d.player)}].push_back(i);
             }
+            for (auto &kv : groups) {
+                std::vector<size_t> &mem = kv.second;
+                std::vector<uint32_t> acts, recs, offs;
+                uint32_t n_cl = 0;
+                for (size_t i : mem) {
+                    acts.push_back(table->nodes[i].n_actions);
+                    n_cl = std::max(n_cl, table->nodes[i].n_clusters);
+                }
+                const bool wide = kv.first.second == tp || s->knobs.shadow_wide;
+                const uint32_t row = shadow_row_layout(acts, wide, recs, offs);
+                for (size_t m = 0; m < mem.size(); ++m) {
+                    const size_t i = mem[m];
+                    const rs_node_desc &d = table->nodes[i];
+                    const uint32_t half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);
+                    s->shadow_off_p[tp][i] = ints + offs[m];
+                    s->shadow_stride_p[tp][i] = row;
+                    s->shadow_rec_p[tp][i] = recs[m];
+                    s->shadow_rowoff_p[tp][i] = offs[m];
+                    ShadowJob j{};
+                    j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+                    j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+                    j.pitch = uint32_t(table->pitch[i]);
+                    j.n_clusters = d.n_clusters;
+                    j.n_actions = d.n_actions;
+                    j.half = half;
+                    j.stride = recs[m];
+                    j.row_stride = row;
+                    j.sigma = (recs[m] == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
+                    j.dst = reinterpret_cast<int32_t *>(ints + offs[m]);   // an offset for now: the buffer does not exist yet
+                    jobs.push_back(j);
+                    s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
+                }
+                ints += round_up(size_t(n_cl) * row, 64);
+            }
+            if (tp == 0) s->n_shadow_jobs = int(jobs.size());
         }
         s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256);
         e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
         if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
-        {
-            size_t k = 0;
-            for (int tp = 0; tp < 2; ++tp)
-                for (size_t i = 0; i < table->nodes.size(); ++i)
-                    if (s->shadow_off_p[tp][i] != SIZE_MAX) jobs[k++].dst = s->d_shadow + s->shadow_off_p[tp][i];
-        }
-        s->n_shadow_jobs = int(jobs.size() / 2);
+        for (ShadowJob &j : jobs) j.dst = s->d_shadow + reinterpret_cast<size_t>(j.dst);
+        if (jobs.size() != size_t(2) * size_t(s->n_shadow_jobs)) return fail(RS_ERR_INVALID, "rs_solver_create: the two sweeps' shadows hold different node sets");
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
         if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -436,7 +467,10 @@ static int setup_deal_records(rs_solver *s) {
             // Measured (round 3, one MI355X, profiles/r03_deals_ab.md): the segment-summing river kernels are 1.3-1.4x faster than the tile kernels (three streets, 5 000-bucket files,
             // 4 M deals per batch: 20.7 + 16.1 ms against 29.6 + 19.7 ms over seven batches), but the sort and the records cost 0.15 ms per sweep: 8.36 against 8.56 ms per batch there,
             // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
-            s->ordered = round_mode && fits && s->knobs.ordered != kUnset && s->knobs.ordered != 0;
+            // Round 4 (profiles/r04_deals.md): with the list walkers staging their deals' rows in LDS the runs of an ordered sweep share the traverser's row, the last round sums
+            // its deltas along the runs (no delta rows, no summing pass for it), and the form wins on three streets beyond half a million deals per batch: 6.5 -> 6.0 ms at 4 M
+            const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->n_rounds > 1 && s->deals.n_deals > kRowsMinDeals;
+            s->ordered = round_mode && fits && (s->knobs.ordered == kUnset ? engine : s->knobs.ordered != 0);
             if (s->ordered) {
                 const size_t pitch = round_up(s->deals.n_deals, kLanePad);
                 const uint32_t n = s->deals.n_deals;
