@@ -40,10 +40,12 @@ Rccl *rccl() {
     static bool tried = false;
     if (tried) return r.handle ? &r : nullptr;
     tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
-    }
+    if (const char *over = rccl_library_override()) r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);   // tests only; no fallback to the real library: a wrong path must fail loudly
+    else
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
     if (!r.handle) return nullptr;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");

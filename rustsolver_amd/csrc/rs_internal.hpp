@@ -278,6 +278,7 @@ struct Knobs {
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
+const char *rccl_library_override();   // $RS_RCCL_LIB (tests: tests/stub_rccl.c), or nullptr
 std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), else ~/.cache/rustsolver_amd
 
 // ---- tree-specialised kernels (rs_jit.cpp) ---------------------------------------------------------

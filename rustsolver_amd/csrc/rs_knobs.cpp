@@ -83,6 +83,13 @@ Knobs knobs_resolve(const rs_kernel_forms *forms) {
     return k;
 }
 
+// Test-only: the collective library rs_comm.cpp loads instead of librccl.so.  tests/stub_rccl.c implements the same five entry points over shared memory for several
+// PROCESSES ON ONE GPU (RCCL refuses two ranks on one device), so that the multi-rank paths run with more than one rank on a one-card box.
+const char *rccl_library_override() {
+    const char *e = getenv("RS_RCCL_LIB");
+    return (e && *e) ? e : nullptr;
+}
+
 std::string jit_cache_dir() {
     if (const char *e = getenv("RS_JIT_CACHE")) return *e ? std::string(e) : std::string();
     const char *home = getenv("HOME");
