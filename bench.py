@@ -760,6 +760,39 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     return out
 
 
+def jit_leg(device):
+    """Cold start of the deal path's generated kernels: creating the three-street deal trainer (the 706-node tree's round subtrees: several dozen
+    hipRTC kernels) in a FRESH process with an EMPTY kernel cache and comgr's own cache switched off, then once more with the cache the first run left."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    prog = ("import sys, time; sys.path.insert(0, %r)\nimport numpy as np\nimport rustsolver_amd as rs\nfrom rustsolver_amd import abstraction as ab\n"
+            "rng = np.random.Generator(np.random.PCG64(1)); mask = ab.card_mask('7h8hQc'); hands = ab.random_range(mask)\n"
+            "files = [rng.integers(0, 5000, size=s, dtype=np.uint32) for s in (1286792, 13960050, 123156254)]\n"
+            "n_actions, tree = rs.build_game_tree(rs.three_street_options())\n"
+            "card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]\n"
+            "t0 = time.perf_counter(); tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, 1 << 22, seed=7, discount_interval=0, use_graph=True, device=%d)\n"
+            "print('CREATE_S', time.perf_counter() - t0)\n") % (root, device)
+    cache = tempfile.mkdtemp(prefix="rs_jit_bench_")
+    out = {"what": "seconds rs.DealTrainer(...) takes on the three-street tree (5 000-bucket files, 4 M deals per batch) in a fresh process: empty kernel cache "
+                   "(and AMD_COMGR_CACHE=0), then with the cache that run left"}
+    try:
+        for key in ("cold_s", "warm_s"):
+            env = dict(os.environ, RS_JIT_CACHE=cache, AMD_COMGR_CACHE="0")
+            r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("CREATE_S")]
+            if r.returncode != 0 or not line:
+                out["error"] = (r.stderr or r.stdout)[-300:]
+                break
+            out[key] = float(line[0].split()[1])
+            if key == "cold_s":
+                out["kernels"] = len([f for f in os.listdir(cache) if f.endswith(".hsaco")])
+    finally:
+        shutil.rmtree(cache, ignore_errors=True)
+    return out
+
+
 def make_comm(table, dist, rank, n_gpus):
     """an RCCL communicator over the ranks of the torch process group (its unique id travels through one broadcast)"""
     import ctypes as C2
@@ -1017,6 +1050,7 @@ def compact_line(out):
         "solve_3s_full_s": g(out, "solve_three_street", "full_ranges", "seconds_training"),
         "kmeans_predict_ms": (g(out, "kmeans_predict", "seconds_per_sweep") or 0) * 1e3 or None, "kmeans_fit_regular_s": g(out, "kmeans_predict", "fit_regular", "seconds"),
         "dp_deals_Mps": (g(out, "dp_deals", "value") or 0) / 1e6 or None,
+        "jit_cold_s": g(out, "jit", "cold_s"), "jit_warm_s": g(out, "jit", "warm_s"), "jit_kernels": g(out, "jit", "kernels"),
     }
     for key in ("config3", "config4"):
         c = out.get(key)
@@ -1393,6 +1427,11 @@ def main():
         out["deal_trainer"] = deal_trainer_leg(rs, device, 1 << 22, not a.no_cpu, min(a.cpu_seconds, 6.0))
     except Exception as e:
         out["deal_trainer"] = {"error": str(e)}
+
+    try:   # before the legs that would leave these kernels in comgr's cache
+        out["jit"] = jit_leg(device)
+    except Exception as e:
+        out["jit"] = {"error": str(e)}
 
     try:
         out["deal_trainer_three_street"] = three_street_leg(rs, device, not a.no_cpu, min(a.cpu_seconds, 5.0))

@@ -53,6 +53,12 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+    jitc_src, jitc = os.path.join(CSRC, "rs_jitc.cpp"), os.path.join(HERE, "rs_jitc")   # the compile helper rs_jit_cache.cpp starts (plain C++: hipRTC is loaded with dlopen)
+    if force or _stale(jitc, [jitc_src]):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", jitc_src, "-o", jitc, "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     if force or _stale(SO, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
         if verbose:

@@ -275,6 +275,7 @@ struct Knobs {
     int no_handoff = 0;             // RS_JIT_NO_HANDOFF: the walk of a round subtree draws the opponent's actions again instead of reading the reach-down kernel's
     int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
     int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
+    int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
@@ -337,7 +338,7 @@ struct JitRequest {
 // the same for many kernels: the ones no cache holds are compiled concurrently on host threads, then loaded one after the other
 int jit_get_kernels(std::vector<JitRequest> &reqs, int device, bool dump = false);
 int jit_compile_only(const std::string &source, bool dump = false);
-int jit_compile_many(const std::map<std::string, int> &sources, bool dump = false);   // the keys, concurrently (hipRTC programs are independent objects)
+int jit_compile_many(const std::map<std::string, int> &sources, bool dump = false);   // the keys, by helper processes side by side (compile-only check of the CPU suite)
 const char *jit_device_source();
 
 // ---- host-side objects ----------------------------------------------------------------------------

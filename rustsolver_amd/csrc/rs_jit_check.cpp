@@ -71,7 +71,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             }
         }
     }
-    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, on a pool of host threads
+    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, by helper processes side by side (rs_jit_cache.cpp)
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }
@@ -199,7 +199,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
             }
         }
     }
-    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, on a pool of host threads
+    if (int rc = jit_compile_many(seen, knobs.dump != 0)) return rc;   // every distinct source, by helper processes side by side (rs_jit_cache.cpp)
     if (n_kernels) *n_kernels = int(seen.size());
     return RS_OK;
 }

@@ -449,8 +449,8 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                      int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id), &stage);
     const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
-    // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete, every distinct source at once on a pool of host threads
-    // (rs_solver.cpp, jit_get_kernels): a three-street deal solver needs several dozen kernels of a second or two of hipRTC each
+    // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete: every distinct source no cache holds goes to a helper process
+    // (rs_solver.cpp, jit_get_kernels: hipRTC serialises compiles inside a process; a three-street deal solver needs several dozen kernels of a second of hipRTC each)
     const uint64_t fn = jit_source_key(js.source);
     auto bi = by_fn.find(fn);
     if (bi == by_fn.end()) {
