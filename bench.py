@@ -898,22 +898,23 @@ def dp_deals_leg(rs, dist, rank, n_gpus, device, steps, warmup, n=1 << 22):
             "replicas_identical": bool(cmin.item() == cmax.item())}
 
 
-def three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, steps):
+def three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, steps, dtype="i32"):
     """BASELINE configs[2] (N = 1: `config3`) and configs[3] (N > 1: `config4`): the 706-action-node flop+turn+river tree, 5 000 clusters on every
     round, boards 1 / 49 / 2 352, i32 tables (135 GB in all), full-width cfr() with ENUM chance nodes (cfr.rs:502-522).  N > 1: turn and river
     boards sharded over the ranks, flop replicated, ONE RCCL all-gather of the turn-root utility rows per traverser sweep between phase 0
     (> 99 % of the bytes) and phase 1: STRONG scaling, bit-identical to the single-GPU sweep for any rank count."""
     from rustsolver_amd import _lib as L
     from rustsolver_amd.dist import shard_boards
-    C_, G = 5000, [1, 49, 2352]
+    C_, G = 5000, ([1, 49, 2352] if dtype != "f16" else [1, 98, 4704])   # BASELINE configs[4]: binary16 tables hold twice the boards in the same 135 GB
+    cfg_no = (3 if n_gpus == 1 else 4) if dtype != "f16" else 5
     boards3, shard = list(G), None
     if n_gpus > 1:
         tlo, thi = shard_boards(G[1], rank, n_gpus)
         shard = (n_gpus, rank, 1, G[1])
         boards3 = [G[0], thi - tlo, (thi - tlo) * (G[2] // G[1])]
     t0 = time.perf_counter()
-    tr = _agree(dist if n_gpus > 1 else None, lambda: make_trainer(rs, boards3, C_, a.mode, 0, device, 1234 + 2 + rank, a.fuse, "three-street", "i32", "full", shard),
-                "config%d tables and launch plan" % (3 if n_gpus == 1 else 4))
+    tr = _agree(dist if n_gpus > 1 else None, lambda: make_trainer(rs, boards3, C_, a.mode, 0, device, 1234 + 2 + rank, a.fuse, "three-street", dtype, "full", shard),
+                "config%d tables and launch plan" % cfg_no)
     create_s = time.perf_counter() - t0
     table = tr.infosets
     comm = None
@@ -939,10 +940,12 @@ def three_street_sweep_leg(rs, dist, rank, n_gpus, device, a, steps):
     barrier()
     elapsed = _max_over_ranks(dist, time.perf_counter() - t0)
     step_ms = table.profile_marks()
-    out = {"workload": "config%d flop+turn+river: 706-action-node tree, %d clusters per round, boards %s%s, i32 tables, %s, "
+    out = {"workload": "config%d flop+turn+river: 706-action-node tree, %d clusters per round, boards %s%s, %s tables, %s, "
                        "full-width opponents, ENUM chance; 1 step = 1 CFR iteration (both traversers, all lanes)"
-                       % (3 if n_gpus == 1 else 4, C_, "/".join(str(b) for b in G), "" if n_gpus == 1 else " (global; turn and river boards sharded x%d)" % n_gpus,
-                          "cfr.rs:413-464 clamp update scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap update scale 10000"),
+                       % (cfg_no, C_, "/".join(str(b) for b in G), "" if n_gpus == 1 else " (global; turn and river boards sharded x%d)" % n_gpus,
+                          {"i32": "i32", "f32": "f32", "f16": "binary16 (f32 arithmetic in registers)"}[dtype],
+                          ("cfr.rs:413-464 clamp update scale 100" if a.mode == "clamp" else "cfr.rs:612-621 wrap update scale 10000") if dtype == "i32" else
+                          "r += (scale * reach) * (u - util), scale 2^-12"),
            "n_gpus": n_gpus, "scaling": "strong", "steps": steps, "ms_per_iteration": elapsed / steps * 1e3, "step_ms_hip_events_rank0": _step_stats(step_ms),
            "value": G[2] * steps / elapsed, "unit": "river-board-iterations/s (global)",
            "table_bytes_per_gpu": table.nbytes, "workspace_bytes_per_gpu": tr.workspace_bytes, "launches_per_iteration": tr.n_launches(0) + tr.n_launches(1),
@@ -1052,7 +1055,7 @@ def compact_line(out):
         "dp_deals_Mps": (g(out, "dp_deals", "value") or 0) / 1e6 or None,
         "jit_cold_s": g(out, "jit", "cold_s"), "jit_warm_s": g(out, "jit", "warm_s"), "jit_kernels": g(out, "jit", "kernels"),
     }
-    for key in ("config3", "config4"):
+    for key in ("config3", "config4", "config5"):
         c = out.get(key)
         if not isinstance(c, dict):
             continue
@@ -1402,6 +1405,13 @@ def main():
                 out["config3"]["gpu_over_cpu_soa"] = g / c3["cpu_soa"]["value"]
             except Exception as e:
                 out["config3"]["cpu_baseline"] = {"error": str(e)}
+
+    # ---- BASELINE configs[4] on one GPU: binary16 tables, twice the boards, the same 135 GB -----------------------------------------------------------
+    if a.config3_steps > 0 and "config5" not in a.skip.split(","):
+        try:
+            out["config5"] = three_street_sweep_leg(rs, None, 0, 1, device, a, a.config3_steps, dtype="f16")
+        except Exception as e:
+            out["config5"] = {"error": str(e)}
 
     # ---- single-board latency (the reference-as-coded shape: n_boards = 1), hipGraph replay ------------------
     try:

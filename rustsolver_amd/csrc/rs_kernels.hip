@@ -312,41 +312,68 @@ __global__ __launch_bounds__(kBlock) void k_chance_reduce(const ChanceJob *__res
     const ChanceJob job = jobs[blockIdx.y];
     const uint32_t C = job.n_clusters, fan = job.fan;
     const uint32_t n_par = job.n_parent_lanes / VEC;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_par; i += gridDim.x * kBlock) {
-        const uint32_t l = i * VEC;
+    // row of deal d: contiguous [boards][C], or, when the child round is sharded, inside the owning rank's slot
+    auto row = [&](uint32_t l, uint32_t d) -> const float * {
         const uint32_t b = l / C, c = l - b * C;
-        // row of deal d: contiguous [boards][C], or, when the child round is sharded, inside the owning rank's slot
-        auto row = [&](uint32_t d) -> const float * {
-            const uint32_t gb = b * fan + d;
-            if (job.shard_world == 0) return job.src + (size_t)gb * C + c;
-            uint32_t g = 0;
-            while (g + 1 < job.shard_world && gb >= job.shard_lo[g + 1]) ++g;
-            return job.src + (size_t)g * job.rank_stride + (size_t)(gb - job.shard_lo[g]) * C + c;
-        };
-        if constexpr (VEC == 4) {
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            constexpr uint32_t G = 8;   // deals whose rows are in flight together; the sum itself stays in deal order (cfr.rs:519)
+        const uint32_t gb = b * fan + d;
+        if (job.shard_world == 0) return job.src + (size_t)gb * C + c;
+        uint32_t g = 0;
+        while (g + 1 < job.shard_world && gb >= job.shard_lo[g + 1]) ++g;
+        return job.src + (size_t)g * job.rank_stride + (size_t)(gb - job.shard_lo[g]) * C + c;
+    };
+    if constexpr (VEC == 4) {
+        // A board's row of C floats starts wherever C puts it (5 000 floats: 32 bytes off a cache line), so the 1 KB window a wave reads per load touches nine lines, the first and
+        // the last shared with the neighbouring windows.  A thread therefore owns kWin vectors a wave apart -- the wave's kWin windows are one contiguous stretch, the shared lines
+        // are re-read by the SAME wave in its next instruction -- and the loads are the plain kind (a non-temporal load lets go of the line and the neighbour fetches it from memory
+        // again).  PMC read bytes over algorithmic: 1.08 (one window per thread, streaming loads) -> 1.04 (plain loads) -> see profiles/r04_config3.md.
+        constexpr uint32_t kWin = 4, G = 4;   // G deals' rows in flight together; the sum itself stays in deal order (cfr.rs:519)
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        for (uint32_t w0 = (blockIdx.x * (kBlock / 64) + wave) * (64 * kWin); w0 < n_par; w0 += gridDim.x * (kBlock / 64) * (64 * kWin)) {
+            float acc[kWin][4];
+            uint32_t li[kWin];
+            bool ok[kWin];
+#pragma unroll
+            for (uint32_t k = 0; k < kWin; k++) {
+                const uint32_t i = w0 + k * 64 + lane;
+                ok[k] = i < n_par;
+                li[k] = (ok[k] ? i : n_par - 1) * 4;
+                acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0f;
+            }
             uint32_t d = 0;
             for (; d + G <= fan; d += G) {
-                float u[G][4];
+                f32x4 u[G][kWin];
 #pragma unroll
-                for (uint32_t k = 0; k < G; k++) load_f32_row(row(d + k), 0, u[k]);
+                for (uint32_t g = 0; g < G; g++)
 #pragma unroll
-                for (uint32_t k = 0; k < G; k++)
+                    for (uint32_t k = 0; k < kWin; k++) u[g][k] = *(as_global<f32x4>(row(li[k], d + g)));
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] = acc[j] + u[k][j];
+                for (uint32_t g = 0; g < G; g++)
+#pragma unroll
+                    for (uint32_t k = 0; k < kWin; k++) {
+                        acc[k][0] = acc[k][0] + u[g][k].x;
+                        acc[k][1] = acc[k][1] + u[g][k].y;
+                        acc[k][2] = acc[k][2] + u[g][k].z;
+                        acc[k][3] = acc[k][3] + u[g][k].w;
+                    }
             }
-            for (; d < fan; d++) {
-                float u[4];
-                load_f32_row(row(d), 0, u);
+            for (; d < fan; d++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] = acc[j] + u[j];
-            }
-            store_f32_row(job.dst + l, 0, acc);
-        } else {
+                for (uint32_t k = 0; k < kWin; k++) {
+                    const f32x4 x = *(as_global<f32x4>(row(li[k], d)));
+                    acc[k][0] = acc[k][0] + x.x;
+                    acc[k][1] = acc[k][1] + x.y;
+                    acc[k][2] = acc[k][2] + x.z;
+                    acc[k][3] = acc[k][3] + x.w;
+                }
+#pragma unroll
+            for (uint32_t k = 0; k < kWin; k++)
+                if (ok[k]) *(as_global<f32x4>(job.dst + li[k])) = f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]};   // read by the parent round's kernel next: a plain store keeps it in L2
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_par; i += gridDim.x * kBlock) {
             float acc = 0.0f;
-            for (uint32_t d = 0; d < fan; d++) acc = acc + *row(d);
-            job.dst[l] = acc;
+            for (uint32_t d = 0; d < fan; d++) acc = acc + *row(i, d);
+            job.dst[i] = acc;
         }
     }
 }
@@ -1168,7 +1195,7 @@ hipError_t launch_chance_expand(const ChanceJob *d_jobs, int n_jobs, size_t max_
     return hipGetLastError();
 }
 hipError_t launch_chance_reduce(const ChanceJob *d_jobs, int n_jobs, size_t max_parent_lanes, bool vec4, hipStream_t stream) {
-    dim3 grid(grid_for(max_parent_lanes / (vec4 ? 4 : 1)), (uint32_t)n_jobs), block(kBlock);
+    dim3 grid(grid_for(vec4 ? (max_parent_lanes / 4 + 3) / 4 : max_parent_lanes), (uint32_t)n_jobs), block(kBlock);   // vec4: a thread owns four vectors, a wave apart
     if (vec4) hipLaunchKernelGGL((k_chance_reduce<4>), grid, block, 0, stream, d_jobs);
     else hipLaunchKernelGGL((k_chance_reduce<1>), grid, block, 0, stream, d_jobs);
     return hipGetLastError();
