@@ -500,6 +500,12 @@ int rs_deal_trainer_set_tick_br(rs_deal_trainer *trainer, int enable);
 int rs_deal_trainer_last_br(const rs_deal_trainer *trainer, float *out /*[2]*/, uint64_t *iterations);
 int rs_deal_trainer_calc_br(rs_deal_trainer *trainer, float *out /*[2]*/);
 int rs_deal_trainer_best_response(rs_deal_trainer *trainer, int mode, double *out /*[2]*/);
+/* The best-response objects a trainer keeps between calls (one per showdown mode: the game-only index, and the walk's workspace -- a buffer per tree edge while that stays
+ * below 16 GB, two per tree depth otherwise): the device bytes they hold, a call that gives the workspaces back (the next best response allocates them again), and the kernel
+ * launches the last call made (-1: the depth-first walk ran, one or two launches per tree node). */
+size_t rs_deal_trainer_br_bytes(const rs_deal_trainer *trainer);
+int rs_deal_trainer_br_release(rs_deal_trainer *trainer);
+int rs_deal_trainer_br_launches(const rs_deal_trainer *trainer, int sorted);
 const uint8_t *rs_deal_trainer_cards(const rs_deal_trainer *trainer);  /* device: the current batch's d_cards[9][pitch] */
 const float *rs_deal_trainer_signs(const rs_deal_trainer *trainer);    /* device: its showdown signs [pitch] */
 const uint8_t *rs_deal_trainer_prune_flags(const rs_deal_trainer *trainer);   /* device: its per-deal prune flags [pitch] (all 0 before the threshold) */

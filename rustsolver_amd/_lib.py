@@ -207,6 +207,9 @@ SYMBOLS = {
     "rs_deal_trainer_last_br": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "rs_deal_trainer_calc_br": (C.c_int, [_P, _P]),
     "rs_deal_trainer_best_response": (C.c_int, [_P, C.c_int, _P]),
+    "rs_deal_trainer_br_bytes": (C.c_size_t, [_P]),
+    "rs_deal_trainer_br_release": (C.c_int, [_P]),
+    "rs_deal_trainer_br_launches": (C.c_int, [_P, C.c_int]),
     "rs_deal_trainer_cards": (C.c_void_p, [_P]),
     "rs_deal_trainer_signs": (C.c_void_p, [_P]),
     "rs_deal_trainer_prune_flags": (C.c_void_p, [_P]),

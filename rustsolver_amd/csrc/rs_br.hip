@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBrBlock) void k_hand_scores(const uint8_t *__restr
 
 // opponent node: q_a[h] = q[h] * sigma_bar(cluster(h), a) for every action (cfr.rs:585's reach product, over the whole range at once)
 template <int DT>
-__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n,
+__device__ __forceinline__ void br_opp_reach_body(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n,
                                                            uint32_t n_pad, const double *__restrict__ q, double *__restrict__ q_out /*[A][n_pad]*/) {
     const uint32_t h = blockIdx.x * kBrBlock + threadIdx.x;
     if (h >= n) return;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal(const uint64_t *__rest
 }
 
 // opponent node, on the way up: v[h] = v_0[h] + v_1[h] + ... in action order
-__global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ vch /*[A][n_pad]*/, uint32_t n_actions, uint32_t n, uint32_t n_pad,
+__device__ __forceinline__ void br_sum_body(const double *__restrict__ vch /*[A][n_pad]*/, uint32_t n_actions, uint32_t n, uint32_t n_pad,
                                                      double *__restrict__ v) {
     const uint32_t h = blockIdx.x * kBrBlock + threadIdx.x;
     if (h >= n) return;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ 
 // own node: one thread per info set (cluster).  RS_BR_MAX: the action with the largest value summed over the cluster's hands
 // (ascending hand order; first maximum, strict < as cfr.rs:684-690) is played by every hand of the cluster; RS_BR_AVERAGE: sigma_bar.
 template <int DT>
-__global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
+__device__ __forceinline__ void br_own_body(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
                                                      const uint32_t *__restrict__ order, uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch,
                                                      int mode, double *__restrict__ v) {
     // lanes that are no deal at all (the hand uses a card of the run-out) are listed after the last cluster: worth 0, summed nowhere (x + 0.0 == x)
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_weights(const uint64_t *__restr
 
 // terminal: v[b, hp] = pw[b, hp] * sum over the opponent's hands ho of the SAME run-out that share no card with hp or the run-out, ascending, of q[b, ho] * u;
 // u as the trainer's leaves (cfr.rs:314-348).  One workgroup = up to 256 hands of one run-out; the opponent's side of that run-out is staged in LDS.
-__global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
+__device__ __forceinline__ void br_terminal_boards_body(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
                                                                  uint32_t n_p, const uint64_t *__restrict__ mask_o, const uint32_t *__restrict__ score_o,
                                                                  const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, int uncontested,
                                                                  double value, double *__restrict__ v) {
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_index(const uint8_t *__restrict
     }
 }
 // one workgroup per run-out: wave 0 builds P (chunked, see above) and the per-card prefixes in LDS, then all threads evaluate the traverser's hands
-__global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
+__device__ __forceinline__ void br_terminal_sorted_body(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
                                                                  uint32_t n_p, const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
                                                                  int uncontested, double value, double *__restrict__ v) {
     extern __shared__ unsigned char br_lds[];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *
 // left three workgroups walking 3 800 dependent gathers each, 13 ms per node).  The lanes of the wave fetch 64 list entries at a time; the additions still run one after the
 // other in list order (every lane adds the 64 values in the same order, read from its neighbours' registers), so the sums keep the oracle's bits.
 template <int DT>
-__global__ __launch_bounds__(kBrBlock) void k_br_own_wave(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
+__device__ __forceinline__ void br_own_wave_body(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start /*[n_clusters + 2]*/,
                                                           const uint32_t *__restrict__ order, uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch,
                                                           int mode, double *__restrict__ v) {
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * kBrBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBrBlock >> 6);
@@ -626,6 +626,83 @@ __global__ __launch_bounds__(kBrBlock) void k_br_own_wave(const void *__restrict
     }
 }
 
+
+// ---- the kernels: one node per launch (the depth-first walk), or one JOB per node and grid row (the level plan: all nodes of one tree depth and kind in one launch) -------------
+struct BrJob {
+    BrNodeRow row;                 // action nodes: the node's strategy_sum block
+    const uint32_t *cid;           // opponent node: the opponent's lane -> cluster of the node's round
+    const uint32_t *start, *order; // own node: the lanes of every info set of the node's round
+    const double *q;               // opponent node: the reach that comes in; terminal: the opponent's reach
+    double *q_out;                 // opponent node: [A][n_pad] reach of its children
+    const double *vch;             // action node: [A][n_pad] values of its children
+    double *v;                     // where the node's own value goes (a slot of its parent's vch, or the root vector)
+    uint32_t n_clusters, n_children;
+    int uncontested, pad_;
+    double value;
+};
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n, uint32_t n_pad,
+                                                           const double *__restrict__ q, double *__restrict__ q_out) {
+    br_opp_reach_body<DT>(ssum, row, cid, n, n_pad, q, q_out);
+}
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n, uint32_t n_pad) {
+    const BrJob j = jobs[blockIdx.y];
+    br_opp_reach_body<DT>(ssum, j.row, j.cid, n, n_pad, j.q, j.q_out);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ vch, uint32_t n_actions, uint32_t n, uint32_t n_pad, double *__restrict__ v) {
+    br_sum_body(vch, n_actions, n, n_pad, v);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_sum_jobs(const BrJob *__restrict__ jobs, uint32_t n, uint32_t n_pad) {
+    const BrJob j = jobs[blockIdx.y];
+    br_sum_body(j.vch, j.n_children, n, n_pad, j.v);
+}
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
+                                                     uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch, int mode, double *__restrict__ v) {
+    br_own_body<DT>(ssum, row, start, order, n_clusters, n_pad, vch, mode, v);
+}
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n_pad, int mode) {
+    const BrJob j = jobs[blockIdx.y];
+    br_own_body<DT>(ssum, j.row, j.start, j.order, j.n_clusters, n_pad, j.vch, mode, j.v);
+}
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own_wave(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
+                                                          uint32_t n_clusters, uint32_t n_pad, const double *__restrict__ vch, int mode, double *__restrict__ v) {
+    br_own_wave_body<DT>(ssum, row, start, order, n_clusters, n_pad, vch, mode, v);
+}
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own_wave_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n_pad, int mode) {
+    const BrJob j = jobs[blockIdx.y];
+    br_own_wave_body<DT>(ssum, j.row, j.start, j.order, j.n_clusters, n_pad, j.vch, mode, j.v);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
+                                                                 uint32_t n_p, const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
+                                                                 int uncontested, double value, double *__restrict__ v) {
+    br_terminal_sorted_body(hands_p, mask_p, pw, n_p, q, n_o, bmask, ix, uncontested, value, v);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_jobs(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
+                                                                      uint32_t n_p, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
+                                                                      const BrJob *__restrict__ jobs) {
+    const BrJob j = jobs[blockIdx.y];
+    br_terminal_sorted_body(hands_p, mask_p, pw, n_p, j.q, n_o, bmask, ix, j.uncontested, j.value, j.v);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
+                                                                 uint32_t n_p, const uint64_t *__restrict__ mask_o, const uint32_t *__restrict__ score_o,
+                                                                 const double *__restrict__ q, uint32_t n_o, const uint64_t *__restrict__ bmask, int uncontested,
+                                                                 double value, double *__restrict__ v) {
+    br_terminal_boards_body(mask_p, score_p, pw, n_p, mask_o, score_o, q, n_o, bmask, uncontested, value, v);
+}
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards_jobs(const uint64_t *__restrict__ mask_p, const uint32_t *__restrict__ score_p, const double *__restrict__ pw,
+                                                                      uint32_t n_p, const uint64_t *__restrict__ mask_o, const uint32_t *__restrict__ score_o, uint32_t n_o,
+                                                                      const uint64_t *__restrict__ bmask, const BrJob *__restrict__ jobs) {
+    const BrJob j = jobs[blockIdx.z];
+    br_terminal_boards_body(mask_p, score_p, pw, n_p, mask_o, score_o, j.q, n_o, bmask, j.uncontested, j.value, j.v);
+}
+
+constexpr size_t kBrLevelPlanBytes = size_t(16) << 30;   // the level plan's workspace is kept with the object: not beyond 16 GB
+
 struct BrSide {
     uint32_t n_hands = 0;
     uint32_t n = 0, n_pad = 0;     // lanes = NB * n_hands
@@ -650,14 +727,33 @@ struct BrRun {
     BrSide side[2];
     std::vector<void *> allocs;
     std::vector<double *> q_level, v_level;   // per tree depth: [max actions][n_pad] children buffers
-    double *d_root = nullptr;                 // [n_pad_max]: the root values of the traverser's lanes
+    double *d_root = nullptr;                 // [n_pad_max]: the root values of the traverser's lanes (depth-first walk)
+    bool last_level_plan = false;             // what the last br_execute ran, and its launches (level plan)
+    int last_launches = 0;
+    double *ws = nullptr;                     // the walk's workspace, allocated by the first br_execute and kept (a 60 GB hipMalloc takes seconds): level plan or depth-first
+    size_t ws_bytes = 0, game_bytes = 0;      // game_bytes: what dalloc handed out (the game-only half)
+    bool ws_levels = false;
+    void release_workspace() {
+        if (ws) {
+            (void)hipStreamSynchronize(t->stream);
+            (void)hipFree(ws);
+        }
+        ws = nullptr;
+        ws_bytes = 0;
+        q_level.clear();
+        v_level.clear();
+        d_root = nullptr;
+    }
     size_t n_pad_max = 0;
     hipError_t err = hipSuccess;
 
     template <typename T> T *dalloc(size_t n) {
         void *ptr = nullptr;
         if (err == hipSuccess) err = hipMalloc(&ptr, (n ? n : 1) * sizeof(T));
-        if (err == hipSuccess) allocs.push_back(ptr);
+        if (err == hipSuccess) {
+            allocs.push_back(ptr);
+            game_bytes += (n ? n : 1) * sizeof(T);
+        }
         return static_cast<T *>(ptr);
     }
     template <typename T> T *upload(const std::vector<T> &h) {
@@ -666,8 +762,166 @@ struct BrRun {
         return d;
     }
     ~BrRun() {
+        if (ws) (void)hipFree(ws);
         for (void *ptr : allocs) (void)hipFree(ptr);
     }
+
+    // ---- the level plan: every node gets buffers of its own (an action node: [A][n_pad] for its children's values, an opponent's node the same for their reach), so the
+    // nodes of one tree depth no longer wait for each other and ONE launch takes all of a depth's nodes of one kind (grid row = node): reach down level by level, every
+    // leaf in one launch, values up level by level -- about sixty launches per traverser instead of one or two per tree node (1 864 nodes: 4 300 launches per call).
+    // The arithmetic of a node is the depth-first walk's (same kernels' bodies), so are its bits.  Costs memory: see level_plan_bytes.
+    int max_depth = 0;
+    std::vector<int> depth_of;    // per tree node: action-node ancestors
+    void fill_depths() {
+        depth_of.assign(tree->nodes.size(), 0);
+        max_depth = 0;
+        for (size_t id = 0; id < tree->nodes.size(); ++id) {   // parents come before children
+            const rs_tree_node &n = tree->nodes[id];
+            for (int a = 0; a < n.n_children; ++a) depth_of[size_t(n.children[a])] = depth_of[id] + (n.kind == RS_NODE_ACTION ? 1 : 0);
+            if (n.kind == RS_NODE_ACTION) max_depth = std::max(max_depth, depth_of[id] + 1);
+        }
+    }
+    size_t level_plan_bytes(int pl) const {   // workspace of traverser pl's pass
+        const BrSide &me = side[pl], &op = side[1 - pl];
+        size_t doubles = me.n_pad;   // the root vector
+        for (const rs_tree_node &n : tree->nodes)
+            if (n.kind == RS_NODE_ACTION && n.n_children > 0) doubles += size_t(n.n_children) * (size_t(me.n_pad) + (int(n.player) != pl ? size_t(op.n_pad) : 0));
+        return doubles * sizeof(double);
+    }
+    int run_levels(double *ws, double **root_out) {
+        const BrSide &me = side[p], &op = side[1 - p];
+        const size_t N = tree->nodes.size();
+        if (depth_of.size() != N) fill_depths();
+        std::vector<const double *> q_in(N, nullptr);
+        std::vector<double *> v_out(N, nullptr), vch(N, nullptr), qch(N, nullptr);
+        double *at = ws;
+        *root_out = at;
+        at += me.n_pad;
+        v_out[0] = *root_out;
+        q_in[0] = op.d_init_q;
+        std::vector<std::vector<BrJob>> down(size_t(max_depth) + 1), up_own(size_t(max_depth) + 1), up_wave(size_t(max_depth) + 1), up_sum(size_t(max_depth) + 1);
+        std::vector<BrJob> leaves;
+        for (size_t id = 0; id < N; ++id) {   // parents before children: a node's q and v slot are known when it comes up
+            const rs_tree_node &n = tree->nodes[id];
+            if (n.kind == RS_NODE_TERMINAL) {
+                const int unc = n.ttype == RS_TERM_UNCONTESTED;
+                const double pot = double(float(n.value));   // tn.value as f32 (cfr.rs:316)
+                BrJob j{};
+                j.q = q_in[id];
+                j.v = v_out[id];
+                j.uncontested = unc;
+                j.value = unc ? (p == int(n.last_to_act) ? -pot : pot) : pot;
+                leaves.push_back(j);
+                continue;
+            }
+            if (n.kind != RS_NODE_ACTION) {   // chance nodes pass through (cfr.rs:306-313)
+                if (n.n_children > 0) {
+                    q_in[size_t(n.children[0])] = q_in[id];
+                    v_out[size_t(n.children[0])] = v_out[id];
+                }
+                continue;
+            }
+            if (n.n_children == 0) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: an action node without actions");
+            const int r = n.round_idx, d = depth_of[id];
+            vch[id] = at;
+            at += size_t(n.n_children) * me.n_pad;
+            BrJob j{};
+            j.row = row_of(t, n.index);
+            j.vch = vch[id];
+            j.v = v_out[id];
+            j.n_children = uint32_t(n.n_children);
+            if (int(n.player) == p) {
+                j.start = me.d_start[r];
+                j.order = me.d_order[r];
+                j.n_clusters = me.n_clusters[r];
+                (size_t(me.n) >= size_t(me.n_clusters[r]) * 32 ? up_wave : up_own)[size_t(d)].push_back(j);   // many lanes per info set: a wave each
+                for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = q_in[id];
+            } else {
+                qch[id] = at;
+                at += size_t(n.n_children) * op.n_pad;
+                j.cid = op.d_cid[r];
+                j.q = q_in[id];
+                j.q_out = qch[id];
+                down[size_t(d)].push_back(j);
+                up_sum[size_t(d)].push_back(j);
+                for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = qch[id] + size_t(a) * op.n_pad;
+            }
+            for (int a = 0; a < n.n_children; ++a) v_out[size_t(n.children[a])] = vch[id] + size_t(a) * me.n_pad;
+        }
+        // all jobs in one upload
+        std::vector<BrJob> all;
+        auto put = [&](const std::vector<BrJob> &v) {
+            const size_t at_ = all.size();
+            all.insert(all.end(), v.begin(), v.end());
+            return at_;
+        };
+        std::vector<size_t> o_down, o_own, o_wave, o_sum;
+        for (int d = 0; d <= max_depth; ++d) {
+            o_down.push_back(put(down[size_t(d)]));
+            o_own.push_back(put(up_own[size_t(d)]));
+            o_wave.push_back(put(up_wave[size_t(d)]));
+            o_sum.push_back(put(up_sum[size_t(d)]));
+        }
+        const size_t o_leaves = put(leaves);
+        BrJob *d_jobs = nullptr;
+        err = hipMalloc((void **)&d_jobs, std::max<size_t>(all.size(), 1) * sizeof(BrJob));
+        if (err == hipSuccess) err = hipMemcpyAsync(d_jobs, all.data(), all.size() * sizeof(BrJob), hipMemcpyHostToDevice, t->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(t->stream);   // `all` is a local
+        n_launches = 0;
+        for (int d = 0; d <= max_depth && err == hipSuccess; ++d) {   // reach, level by level
+            const uint32_t nj = uint32_t(down[size_t(d)].size());
+            if (!nj) continue;
+#define RS_OPPJ(DT_) hipLaunchKernelGGL((k_br_opp_reach_jobs<DT_>), dim3(grid1(op.n), nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_down[size_t(d)], op.n, op.n_pad)
+            RS_BR_DT(t->dtype, RS_OPPJ);
+#undef RS_OPPJ
+            err = hipGetLastError();
+            ++n_launches;
+        }
+        for (size_t lo = 0; lo < leaves.size() && err == hipSuccess; lo += 16384) {   // every leaf
+            const uint32_t nj = uint32_t(std::min<size_t>(16384, leaves.size() - lo));
+            if (sorted) {
+                const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double);
+                hipLaunchKernelGGL(k_br_terminal_sorted_jobs, dim3(NB, nj), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
+                                   d_jobs + o_leaves + lo);
+            } else {
+                const size_t lds = size_t(op.n_hands) * (sizeof(double) + sizeof(uint64_t) + sizeof(uint32_t));
+                hipLaunchKernelGGL(k_br_terminal_boards_jobs, dim3(grid1(me.n_hands), NB, nj), dim3(kBrBlock), lds, t->stream, me.d_mask, me.d_score, me.d_pw, me.n_hands, op.d_mask,
+                                   op.d_score, op.n_hands, d_bmask, d_jobs + o_leaves + lo);
+            }
+            err = hipGetLastError();
+            ++n_launches;
+        }
+        for (int d = max_depth; d >= 0 && err == hipSuccess; --d) {   // values, deepest level first
+            if (const uint32_t nj = uint32_t(up_wave[size_t(d)].size())) {
+                uint32_t ncl = 0;
+                for (const BrJob &j : up_wave[size_t(d)]) ncl = std::max(ncl, j.n_clusters);
+                const uint32_t blocks = uint32_t(std::min<size_t>((size_t(ncl) * 64 + kBrBlock - 1) / kBrBlock, 8192));
+#define RS_OWNWJ(DT_) hipLaunchKernelGGL((k_br_own_wave_jobs<DT_>), dim3(blocks, nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_wave[size_t(d)], me.n_pad, mode)
+                RS_BR_DT(t->dtype, RS_OWNWJ);
+#undef RS_OWNWJ
+                err = hipGetLastError();
+                ++n_launches;
+            }
+            if (const uint32_t nj = uint32_t(up_own[size_t(d)].size())) {
+                uint32_t ncl = 0;
+                for (const BrJob &j : up_own[size_t(d)]) ncl = std::max(ncl, j.n_clusters);
+#define RS_OWNJ(DT_) hipLaunchKernelGGL((k_br_own_jobs<DT_>), dim3(grid1(ncl), nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_own[size_t(d)], me.n_pad, mode)
+                RS_BR_DT(t->dtype, RS_OWNJ);
+#undef RS_OWNJ
+                if (err == hipSuccess) err = hipGetLastError();
+                ++n_launches;
+            }
+            if (const uint32_t nj = uint32_t(up_sum[size_t(d)].size())) {
+                hipLaunchKernelGGL(k_br_sum_jobs, dim3(grid1(me.n), nj), dim3(kBrBlock), 0, t->stream, d_jobs + o_sum[size_t(d)], me.n, me.n_pad);
+                if (err == hipSuccess) err = hipGetLastError();
+                ++n_launches;
+            }
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(t->stream);   // d_jobs is freed below
+        if (d_jobs) (void)hipFree(d_jobs);
+        return err == hipSuccess ? RS_OK : hip_fail(err, "rs_best_response (level plan)");
+    }
+    int n_launches = 0;
 
     void walk(int id, const double *q, double *v_out, int level) {
         if (err != hipSuccess) return;
@@ -820,6 +1074,13 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
             if (mask[p][h] & board_mask) return fail(RS_ERR_INVALID, "rs_best_response: a range combo uses a board card");
         }
     }
+    if (sorted)   // the rank-order index lists the opponent's hands by card (at most kBrCardHolders per card) and knows ONE opponent hand per card pair (`same`)
+        for (int p = 0; p < 2; ++p) {
+            std::vector<uint64_t> m(mask[p]);
+            std::sort(m.begin(), m.end());
+            if (std::adjacent_find(m.begin(), m.end()) != m.end())
+                return fail(RS_ERR_INVALID, "rs_best_response: RS_BR_SORTED takes ranges of distinct combos (a combo occurs twice in player " + std::to_string(p) + "'s range)");
+        }
     std::vector<uint8_t> cards;
     const size_t NB = enumerate_runouts(board0, n_board0, &cards);
     if (NB * std::max(n_hands[0], n_hands[1]) >= (size_t(1) << 31)) return fail(RS_ERR_UNSUPPORTED, "rs_best_response: too many lanes");
@@ -925,16 +1186,9 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
     double *d_ones = run.upload(ones);
     run.side[0].d_init_q = run.side[0].d_pw = d_w0;
     run.side[1].d_init_q = run.side[1].d_pw = d_ones;
-    int max_a = 1;
-    for (const rs_tree_node &n : tree->nodes) max_a = std::max(max_a, n.n_children);
-    const int depth = tree_depth(tree->nodes, 0);
-    const size_t n_pad_max = std::max(run.side[0].n_pad, run.side[1].n_pad);
-    for (int l = 0; l < depth; ++l) {
-        run.q_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
-        run.v_level.push_back(run.dalloc<double>(size_t(max_a) * n_pad_max));
-    }
-    run.n_pad_max = n_pad_max;
-    run.d_root = run.dalloc<double>(n_pad_max);
+    // the walk's buffers are allocated by every call (br_execute) and freed when it returns: a kept object holds what depends on the game only
+    run.n_pad_max = std::max(run.side[0].n_pad, run.side[1].n_pad);
+    run.fill_depths();
     if (run.err != hipSuccess) {
         (void)hipStreamSynchronize(t->stream);   // drain the stream before ~BrRun frees what queued kernels may still touch
         return hip_fail(run.err, "rs_best_response");
@@ -944,6 +1198,11 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
 }
 
 void br_free(BrRun *run) { delete run; }
+size_t br_held_bytes(const BrRun *run) { return run ? run->game_bytes + run->ws_bytes : 0; }
+void br_release_workspace(BrRun *run) {
+    if (run) run->release_workspace();
+}
+int br_last_launches(const BrRun *run) { return run && run->last_level_plan ? run->last_launches : -1; }
 
 // the walk: both traversers against the table as it stands
 int br_execute(BrRun *prepared, int mode, double *out) {
@@ -954,22 +1213,59 @@ int br_execute(BrRun *prepared, int mode, double *out) {
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     run.mode = mode;
     run.err = hipSuccess;
-    double *d_root = run.d_root;
+    // The level plan wants a buffer per tree edge (full 1 176-combo ranges from a flop on the 706-node tree: 59 GB, and a hipMalloc of that size takes seconds; 200 combos: 10 GB)
+    // and buys launches, not kernel time (4 300 -> 66 per call; at full ranges both orders spend 0.24-0.27 s in their kernels): it is taken while it fits kBrLevelPlanBytes and half
+    // of the free memory, else the depth-first walk runs with its two buffers per tree depth.  The workspace is allocated by the first call and KEPT with the object
+    // (br_workspace_bytes / br_release_workspace: a trainer holds one object per showdown mode).
+    if (!run.ws) {
+        const size_t need = std::max(run.level_plan_bytes(0), run.level_plan_bytes(1));
+        size_t free_b = 0, total_b = 0;
+        const bool levels = !knobs_resolve(nullptr).br_depth_first && need <= kBrLevelPlanBytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2;
+        (void)hipGetLastError();
+        if (levels && hipMalloc((void **)&run.ws, need) == hipSuccess) {
+            run.ws_bytes = need;
+            run.ws_levels = true;
+        } else {
+            (void)hipGetLastError();
+            int max_a = 1;
+            for (const rs_tree_node &n : run.tree->nodes) max_a = std::max(max_a, n.n_children);
+            const int depth = tree_depth(run.tree->nodes, 0);
+            const size_t per = size_t(max_a) * run.n_pad_max;
+            run.ws_bytes = (size_t(2) * size_t(depth) * per + run.n_pad_max) * sizeof(double);
+            if (hipMalloc((void **)&run.ws, run.ws_bytes) != hipSuccess) {
+                run.ws = nullptr;
+                run.ws_bytes = 0;
+                return fail(RS_ERR_OOM, "rs_best_response: the walk's buffers");
+            }
+            run.ws_levels = false;
+            for (int l = 0; l < depth; ++l) {
+                run.q_level.push_back(run.ws + size_t(2 * l) * per);
+                run.v_level.push_back(run.ws + size_t(2 * l + 1) * per);
+            }
+            run.d_root = run.ws + size_t(2) * size_t(depth) * per;
+        }
+    }
+    const bool levels = run.ws_levels;
+    double *ws = run.ws;
+    int rc = RS_OK;
+    run.last_level_plan = levels;
+    run.last_launches = 0;
     std::vector<double> root(run.n_pad_max);
-    for (int p = 0; p < 2 && run.err == hipSuccess; ++p) {
+    for (int p = 0; p < 2 && run.err == hipSuccess && rc == RS_OK; ++p) {
         run.p = p;
-        run.walk(0, run.side[1 - p].d_init_q, d_root, 0);
-        if (run.err == hipSuccess) run.err = hipMemcpyAsync(root.data(), d_root, run.side[p].n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
-        if (run.err == hipSuccess) run.err = hipStreamSynchronize(t->stream);
+        double *d_root = run.d_root;
+        if (levels) rc = run.run_levels(ws, &d_root);
+        else run.walk(0, run.side[1 - p].d_init_q, d_root, 0);
+        run.last_launches += levels ? run.n_launches : 0;
+        if (rc == RS_OK && run.err == hipSuccess) run.err = hipMemcpyAsync(root.data(), d_root, run.side[p].n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
+        if (rc == RS_OK && run.err == hipSuccess) run.err = hipStreamSynchronize(t->stream);
         double total = 0.0;
         for (uint32_t l = 0; l < run.side[p].n; ++l) total += root[l];   // ascending, like the oracle
         out[p] = total;
     }
-    // on error drain the stream before the caller frees what queued kernels may still touch
-    if (run.err != hipSuccess) {
-        (void)hipStreamSynchronize(t->stream);
-        return hip_fail(run.err, "rs_best_response");
-    }
+    if (rc != RS_OK || run.err != hipSuccess) (void)hipStreamSynchronize(t->stream);   // on error drain the stream before the caller frees what queued kernels may still touch
+    if (rc != RS_OK) return rc;
+    if (run.err != hipSuccess) return hip_fail(run.err, "rs_best_response");
     return RS_OK;
 }
 

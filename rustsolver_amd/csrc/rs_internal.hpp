@@ -129,6 +129,9 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
                const uint32_t *const *cluster, int n_rounds, bool sorted, BrRun **prepared);
 int br_execute(BrRun *prepared, int mode /* RS_BR_MAX / RS_BR_AVERAGE */, double *out /* [2] */);
 void br_free(BrRun *prepared);
+size_t br_held_bytes(const BrRun *prepared);        // device bytes the object holds: the game-only half + the walk's workspace (kept from the first br_execute on)
+void br_release_workspace(BrRun *prepared);         // gives the workspace back; the next br_execute allocates it again
+int br_last_launches(const BrRun *prepared);        // launches of the last br_execute when it ran the level plan, else -1
 // compact jobs [first, first + n) scan one source for n sibling roots (k_compact_siblings): n <= 16, no cluster ranges
 struct CompactGroup {
     uint32_t first, n;
@@ -276,6 +279,8 @@ struct Knobs {
     int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
     int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
     int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
+    int br_depth_first = 0;         // RS_BR_DEPTH_FIRST: the best response walks the tree depth first (one launch per node) instead of level by level (what happens anyway when
+                                    // the level plan's buffers do not fit)
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);

@@ -42,6 +42,7 @@ const Entry kEntries[] = {
     {"RS_JIT_NO_SIGMA", FLAG, &Knobs::no_sigma, nullptr},
     {"RS_JIT_NO_SIBLINGS", INT, &Knobs::no_siblings, nullptr},
     {"RS_JIT_NO_STAGE", FLAG, &Knobs::no_stage, nullptr},
+    {"RS_BR_DEPTH_FIRST", FLAG, &Knobs::br_depth_first, nullptr},
     {"RS_JIT_NO_PROCS", FLAG, &Knobs::jit_no_procs, nullptr},
     {"RS_JIT_LDS_MAX", INT, &Knobs::lds_max, nullptr},
     {"RS_JIT_NO_LANE_ROUNDS", FLAG, &Knobs::no_lane_rounds, nullptr},

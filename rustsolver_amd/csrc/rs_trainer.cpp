@@ -379,6 +379,23 @@ int rs_deal_trainer_best_response(rs_deal_trainer *tr, int mode, double *out) {
     return rs::br_execute(tr->br_prepared[which], mode & ~RS_BR_SORTED, out);
 }
 
+// what the best-response objects a trainer keeps between calls hold on the device (the game-only index of both showdown modes + the walks' workspaces), and a way to give
+// the workspaces back (the next call allocates them again)
+size_t rs_deal_trainer_br_bytes(const rs_deal_trainer *tr) {
+    size_t b = 0;
+    if (tr)
+        for (int k = 0; k < 2; ++k) b += rs::br_held_bytes(tr->br_prepared[k]);
+    return b;
+}
+int rs_deal_trainer_br_release(rs_deal_trainer *tr) {
+    if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_br_release: trainer is NULL");
+    for (int k = 0; k < 2; ++k) rs::br_release_workspace(tr->br_prepared[k]);
+    return RS_OK;
+}
+int rs_deal_trainer_br_launches(const rs_deal_trainer *tr, int sorted) {   // launches of the last best-response call (level plan), -1: depth-first walk or no call yet
+    return tr ? rs::br_last_launches(tr->br_prepared[sorted ? 1 : 0]) : -1;
+}
+
 int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_attach_comm: trainer is NULL");
     return rs_solver_attach_comm(tr->solver, comm);

@@ -734,6 +734,16 @@ class DealTrainer:
         L.check(L.load().rs_deal_trainer_best_response(self._h, mode, _vp(out)))
         return out
 
+    def br_bytes(self):
+        """device bytes held by the best-response objects the trainer keeps between calls"""
+        return int(L.load().rs_deal_trainer_br_bytes(self._h))
+
+    def br_release(self):
+        L.check(L.load().rs_deal_trainer_br_release(self._h))
+
+    def br_launches(self, sorted_showdowns=True):
+        return int(L.load().rs_deal_trainer_br_launches(self._h, int(sorted_showdowns)))
+
     def exploitability(self, sorted_showdowns=True):
         """(BR value of player 0 + BR value of player 1) / 2 against the current average strategies, per deal, in pot units of the leaves.  sorted_showdowns: the leaves by
         rank order (RS_BR_SORTED: O(n log n) per run-out, equal to the pair loop of cfr.rs:323-347 within f64 rounding)"""
