@@ -286,7 +286,11 @@ typedef struct rs_kernel_forms {
     int32_t delta_rows;         /* RS_FORM_*: i32 deal sweeps keep no delta tiles and issue no atomics inside the walk: a visit stores its deltas at the deal's LIST POSITION
                                    ([2A][batch pitch] i32 rows per traverser node, coalesced), and one streaming pass per sweep sums every row by cluster (LDS histogram of
                                    one row at a time) into the delta tables.  Applies to the round subtrees whose traverser nodes have at most 16 384 clusters */
-    int32_t reserved[2];        /* zero */
+    int32_t direct_rows;        /* RS_FORM_*: round subtrees whose traverser nodes have MORE than 16 384 clusters (lossless abstractions: 180 234 on the river) store delta rows too, and
+                                   one pass per round adds them straight into the TABLE once the round's walks are done (atomic adds at the key row's clusters) -- no delta-table
+                                   entries, no share of the apply pass for those nodes.  Default: on; data-parallel deal batches exchange the delta TABLES between sweep and apply
+                                   and must switch it off (rs_solver_attach_comm refuses a solver that has it on; rs_deal_trainer does so for world > 1) */
+    int32_t reserved[1];        /* zero */
 } rs_kernel_forms;
 
 typedef struct rs_solver_params {

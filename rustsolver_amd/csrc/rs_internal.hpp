@@ -201,8 +201,9 @@ struct RowSumJob {
     const uint32_t *key;       // [n]
     const uint32_t *count;     // device count of list entries, or null: n_const
     int32_t *dst;              // [n_rows][tpitch] inside the delta table
-    uint32_t n_rows, pitch, tpitch, n_clusters, n_const, pad_;
+    uint32_t n_rows, pitch, tpitch, n_clusters, n_const, direct;   // direct: dst is the TABLE's own rows of the node (k_row_apply: no LDS tile, any cluster count)
 };
+hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream);
 hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream);
 constexpr uint32_t kRowSumMaxCells = 16384;   // ints of one job's LDS tile (64 KiB: two workgroups per CU)
 constexpr uint32_t kRowSumChunk = 262144;     // list positions per workgroup
@@ -281,6 +282,7 @@ struct Knobs {
     int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
     int br_depth_first = 0;         // RS_BR_DEPTH_FIRST: the best response walks the tree depth first (one launch per node) instead of level by level (what happens anyway when
                                     // the level plan's buffers do not fit)
+    int direct_rows = kUnset;       // RS_JIT_DIRECT_ROWS / rs_kernel_forms.direct_rows: 1 on / 0 off
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);

@@ -1144,6 +1144,29 @@ __global__ __launch_bounds__(kRowSumBlock) void k_row_sums(const RowSumJob *__re
         __hip_atomic_fetch_add(J.dst + (size_t)r * J.tpitch + c, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// delta rows of nodes with more clusters than an LDS tile holds (a lossless river abstraction: 180 234): every non-zero delta goes straight into the TABLE's cell of its
+// position's cluster.  Runs once the round's walks -- the only readers of these nodes in the sweep -- are done; integer adds commute, so the table ends up as with delta tables
+// and an apply pass, without either.
+__global__ __launch_bounds__(kBlock) void k_row_apply(const RowSumJob *__restrict__ jobs) {
+    const RowSumJob J = jobs[blockIdx.y];
+    const uint32_t n = J.count ? *J.count : J.n_const;
+    const __attribute__((address_space(1))) uint32_t *key = (const __attribute__((address_space(1))) uint32_t *)J.key;
+    const __attribute__((address_space(1))) int *rows = (const __attribute__((address_space(1))) int *)J.rows;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t k = key[i];
+        for (uint32_t r = 0; r < J.n_rows; ++r) {
+            const int d = rows[(size_t)r * J.pitch + i];
+            if (d) __hip_atomic_fetch_add(J.dst + (size_t)r * J.tpitch + k, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((size_t(max_entries) + kBlock - 1) / kBlock, 1), 1024);
+    hipLaunchKernelGGL(k_row_apply, dim3(blocks, (unsigned)n_jobs), dim3(kBlock), 0, stream, d_jobs);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream) {
     if (n_jobs <= 0 || max_entries == 0) return hipSuccess;
     chunk = std::max<uint32_t>(std::max<uint32_t>(4, chunk / 4 * 4), (max_entries / 65535 + 4) / 4 * 4);   // grid.y <= 65535

@@ -42,6 +42,7 @@ const Entry kEntries[] = {
     {"RS_JIT_NO_SIGMA", FLAG, &Knobs::no_sigma, nullptr},
     {"RS_JIT_NO_SIBLINGS", INT, &Knobs::no_siblings, nullptr},
     {"RS_JIT_NO_STAGE", FLAG, &Knobs::no_stage, nullptr},
+    {"RS_JIT_DIRECT_ROWS", INT, &Knobs::direct_rows, nullptr},
     {"RS_BR_DEPTH_FIRST", FLAG, &Knobs::br_depth_first, nullptr},
     {"RS_JIT_NO_PROCS", FLAG, &Knobs::jit_no_procs, nullptr},
     {"RS_JIT_LDS_MAX", INT, &Knobs::lds_max, nullptr},
@@ -71,6 +72,8 @@ Knobs knobs_resolve(const rs_kernel_forms *forms) {
         else if (forms->deal_order == RS_FORM_OFF) k.ordered = 0;
         if (forms->delta_rows == RS_FORM_ON) k.rows = 1;
         else if (forms->delta_rows == RS_FORM_OFF) k.rows = 0;
+        if (forms->direct_rows == RS_FORM_ON) k.direct_rows = 1;
+        else if (forms->direct_rows == RS_FORM_OFF) k.direct_rows = 0;
     }
     for (const Entry &e : kEntries) {   // then the test-only overrides
         const char *v = getenv(e.name);

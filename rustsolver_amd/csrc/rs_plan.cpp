@@ -580,7 +580,13 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                     rj.n_clusters = ncl;
                     const int32_t *src = s->d_drows + plan.drow_off[size_t(an.index)] + size_t(arr) * A * bp;
                     int32_t *dst = static_cast<int32_t *>(arr == 0 ? t->d_dregrets : t->d_dssum) + t->cell_off[an.index];
-                    if (A * ncl <= kRowSumMaxCells) {
+                    if (ncl > kRowSumMaxCells) {   // no LDS tile holds a row: its deltas go straight into the table (k_row_apply)
+                        rj.rows = src;
+                        rj.dst = static_cast<int32_t *>(arr == 0 ? t->regrets_ptr(an.index) : t->ssum_ptr(an.index));
+                        rj.n_rows = A;
+                        rj.direct = 1;
+                        plan.row_jobs.push_back(rj);
+                    } else if (A * ncl <= kRowSumMaxCells) {
                         rj.rows = src;
                         rj.dst = dst;
                         rj.n_rows = A;

@@ -168,6 +168,7 @@ struct rs_solver {
     OrderJob order_job[2];              // per traverser
     // delta rows (rs_kernel_forms.delta_rows): one buffer for both traversers' sweeps (they never overlap), [2A][batch pitch] i32 per traverser node of an eligible round
     bool rows = false;
+    bool direct_rows = false;           // rounds whose traverser nodes outgrow the summing pass's LDS tile store delta rows too, added straight into the table (k_row_apply)
     int first_round = 0;                // betting round of the first action node: its subtree walks the whole batch and keeps its tiles unless RS_JIT_ROWS = 2
     int32_t *d_drows = nullptr;
     bool deal_mode = false;             // lanes are deals (rs_solver_create_deals)
@@ -191,6 +192,7 @@ namespace rs {
 // rec[k] = ints of node k's record, off[k] = where it starts in the row (16-byte records first, the 8-byte ones of two-action opponent nodes behind them)
 uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, std::vector<uint32_t> &rec, std::vector<uint32_t> &off);
 int derive_geometry(rs_solver *s);
+bool rows_round_direct(const rs_solver *s, int p, int round);   // ... and are its rows added straight into the table (more clusters than the summing pass's LDS tile holds)?
 bool rows_round_ok(const rs_solver *s, int p, int round);   // rs_plan_deals.cpp: do traverser p's nodes of this round take the delta-rows form?
 size_t drows_ints(const rs_solver *s, int p);               // ints of delta rows traverser p's sweep needs
 struct PlanBuilder;

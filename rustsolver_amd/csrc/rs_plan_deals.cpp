@@ -36,9 +36,22 @@ bool rows_round_ok(const rs_solver *s, int p, int round) {
     if (s->ordered && round == s->order_round) return false;   // ordered sweeps: the last round's lists come in runs of equal traverser cluster, summed by wave segments (seg_add)
     const rs_table *t = s->table;
     uint32_t k = 0;
+    bool tiled = false;
+    for (size_t i = 0; i < t->nodes.size(); ++i)
+        if (t->nodes[i].round_idx == round && t->nodes[i].player == p && t->nodes[i].n_actions > 0) {
+            k = std::max(k, t->nodes[i].n_clusters);
+            tiled = tiled || t->tiled(int(i));
+        }
+    return k > 0 && (k <= kRowSumMaxCells || (s->direct_rows && !tiled));   // one row's LDS tile must fit -- or the rows go straight into the table's (plain) rows
+}
+
+bool rows_round_direct(const rs_solver *s, int p, int round) {
+    if (!s->direct_rows || !rows_round_ok(s, p, round)) return false;
+    const rs_table *t = s->table;
+    uint32_t k = 0;
     for (size_t i = 0; i < t->nodes.size(); ++i)
         if (t->nodes[i].round_idx == round && t->nodes[i].player == p && t->nodes[i].n_actions > 0) k = std::max(k, t->nodes[i].n_clusters);
-    return k > 0 && k <= kRowSumMaxCells;   // one row's LDS tile must fit
+    return k > kRowSumMaxCells;
 }
 
 size_t drows_ints(const rs_solver *s, int p) {
@@ -352,11 +365,12 @@ int PlanBuilder::emit_round_walks() {   // ---- round subtrees, bottom-up: last 
         L.group = group;
         L.first_job = int(first);
         L.n_jobs = int(end - first);
+        L.n_actions = plan.row_jobs[first].direct ? 1 : 0;   // a round's jobs are all of one kind (a player's nodes of a round share their cluster count)
         double entries = 0.0;
         for (size_t k = first; k < end; ++k) {
             const RowSumJob &j = plan.row_jobs[k];
             entries += double(j.n_rows + 1) * (j.count ? double(s->deals.n_deals) / 8.0 : double(j.n_const));   // a list holds a share of the batch (an estimate for the profiling hooks)
-            plan.row_max_cells = std::max(plan.row_max_cells, j.n_rows * j.n_clusters);
+            if (!j.direct) plan.row_max_cells = std::max(plan.row_max_cells, j.n_rows * j.n_clusters);
         }
         L.bytes = entries * 4.0;
         plan.launches.push_back(L);
@@ -449,6 +463,7 @@ int PlanBuilder::emit_apply() {
         for (size_t i = 0; i < t->nodes.size(); ++i) {
             const rs_node_desc &d = t->nodes[i];
             if (d.n_actions == 0 || d.player != p) continue;
+            if (rows_round_direct(s, p, d.round_idx) && s->rows) continue;   // its deltas never touch the delta tables
             const size_t nc = size_t(d.n_actions) * t->pitch[i];
             if ((t->cell_off[i] % kVec) || (nc % kVec)) { aj.clear(); break; }   // never with 64-lane padded pitches; the whole-table form is the fallback
             aj.push_back(ApplyJob{t->cell_off[i] / kVec, nc / kVec});

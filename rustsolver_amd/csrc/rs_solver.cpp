@@ -73,7 +73,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     if (L.kind == L_ROWSUM) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         const uint32_t chunk = s->knobs.rows_chunk != kUnset && s->knobs.rows_chunk > 0 ? uint32_t(s->knobs.rows_chunk) : kRowSumChunk;
-        hipError_t er = launch_row_sums(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, chunk, plan.row_max_cells, tree_stream);
+        hipError_t er = L.n_actions ? launch_row_apply(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, tree_stream)
+                                    : launch_row_sums(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, chunk, plan.row_max_cells, tree_stream);
         prof_end(t);
         RS_HIP(er, "k_row_sums");
         return RS_OK;
@@ -423,6 +424,7 @@ static void choose_delta_rows(rs_solver *s) {
             while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0];
             s->first_round = tree->nodes[size_t(c)].kind == RS_NODE_ACTION ? int(tree->nodes[size_t(c)].round_idx) : 0;
         }
+        s->direct_rows = can && (s->knobs.direct_rows == kUnset ? true : s->knobs.direct_rows != 0);
         const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->deals.n_deals > kRowsMinDeals;   // only sampled sweeps have list walkers
         s->rows = can && (s->knobs.rows == kUnset ? engine : s->knobs.rows != 0);
         if (s->rows && s->knobs.rows == kUnset) {   // the rows cost 2 x actions x 4 B per traverser node and deal (26 GB at 4 M deals on the 706-node tree): only while a quarter of the free memory holds them
@@ -833,6 +835,12 @@ int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util)
 
 int rs_solver_attach_comm(rs_solver *s, rs_comm *comm) {
     if (!s) return fail(RS_ERR_INVALID, "rs_solver_attach_comm: solver is NULL");
+    if (comm && s->deal_mode && s->rows && s->direct_rows)
+        for (int p = 0; p < 2; ++p)
+            for (int r = 0; r < s->n_rounds; ++r)
+                if (rows_round_direct(s, p, r))
+                    return fail(RS_ERR_UNSUPPORTED, "rs_solver_attach_comm: this solver adds the delta rows of its large rounds straight into the table; data-parallel deal batches "
+                                                    "exchange the delta tables: create it with rs_kernel_forms.direct_rows = RS_FORM_OFF");
     s->comm = comm;
     return RS_OK;
 }

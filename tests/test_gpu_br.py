@@ -289,4 +289,4 @@ def test_three_street_trainer_is_solving_the_game():
     assert held > 0
     tr.br_release()
     assert 0 < tr.br_bytes() < held
-    assert tr.exploitability() == e2 and tr.br_bytes() == held
+    assert tr.exploitability() == e2 and tr.br_bytes() <= held   # the object of the showdown mode just asked for has its workspace again; the other mode's stays released

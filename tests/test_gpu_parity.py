@@ -1097,15 +1097,19 @@ def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["river", "river-full-width", "river+graph+prune-per-deal", "three-street", "three-street+prune-per-deal", "three-street-wrap",
-                                     "three-street-full-width", "three-street-big-river", "three-street-scan-parent-lists-only", "three-street+prune-per-deal-lists-only"])
+                                     "three-street-full-width", "three-street-big-river", "three-street-big-river-tiles", "three-street-big-river+prune-per-deal-lists-only",
+                                     "three-street-scan-parent-lists-only", "three-street+prune-per-deal-lists-only"])
 def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
     """rs_kernel_forms.delta_rows (forced through its test override): no delta tiles, no atomics inside the walk -- a visit stores its two delta vectors at the deal's
     list position ([2A][batch pitch] rows per traverser node), and k_row_sums adds every row up per cluster after the walks (a few hundred positions per workgroup here, so
     that rows are cut into many chunks).  Dense walks (the first round; every round with a full-width opponent) index the rows by deal id.  "big-river": the river's
-    20 000 clusters exceed the summing pass's tile, so that round keeps its tiles while flop and turn store rows.  "lists-only": what rs_kernel_forms.delta_rows = RS_FORM_ON
+    20 000 clusters exceed the summing pass's tile: its rows are added straight into the table once the river's walks are done (k_row_apply, rs_kernel_forms.direct_rows: what the
+    lossless abstractions of solve_three_street get) -- "-tiles": direct rows off, that round keeps its tiles while flop and turn store rows.  "lists-only": what rs_kernel_forms.delta_rows = RS_FORM_ON
     gives -- the list walkers store rows, the first round's dense walk keeps its LDS tiles.  Same bits as the oracle."""
     monkeypatch.setenv("RS_JIT_ROWS", "1" if "lists-only" in variant else "2")
     monkeypatch.setenv("RS_JIT_ROWS_CHUNK", "1000")
+    if variant.endswith("-tiles"):
+        monkeypatch.setenv("RS_JIT_DIRECT_ROWS", "0")
     three, prune, full = variant.startswith("three"), "prune" in variant, "full-width" in variant
     if "scan-parent" in variant:
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
