@@ -270,19 +270,18 @@ typedef struct rs_leaf_desc {
 enum { RS_FORM_DEFAULT = 0, RS_FORM_ON = 1, RS_FORM_OFF = 2 };
 enum { RS_FAN_DEFAULT = 0,   /* = RS_FAN_EXPAND */
        RS_FAN_NONE = 1,      /* lane sweeps, subtree directly below an ENUM chance node (cfr.rs:502-522): separate expand / reduce launches */
-       RS_FAN_EXPAND = 2,    /* the subtree's kernel scales the chance node's own reach row by 1/len itself: no expand launch, no per-deal reach rows */
-       RS_FAN_LOOP = 3 };    /* it also walks the node's deals and sums them in order: no reduce launch, 25x less workspace, 6-10 % slower at config-3 size */
+       RS_FAN_EXPAND = 2 };  /* the subtree's kernel scales the chance node's own reach row by 1/len itself: no expand launch, no per-deal reach rows */
 enum { RS_SHADOW_DEFAULT = 0,   /* = RS_SHADOW_RULE */
        RS_SHADOW_RULE = 1,      /* deal sweeps: a node keeps an AoS shadow only while the batch is likely to read it (n_deals * 8 >= its cells * round subtrees) */
-       RS_SHADOW_ALL = 2,       /* a shadow for every node */
-       RS_SHADOW_WIDE = 3 };    /* every node, 32-byte records (regrets + strategy sums) at the opponent's nodes too */
+       RS_SHADOW_ALL = 2 };     /* a shadow for every node */
 typedef struct rs_kernel_forms {
     int32_t lane_fan;           /* RS_FAN_* */
     int32_t deals_per_thread;   /* deal sweeps: 1, 2 or 4 deals per thread of the generated kernels */
-    int32_t worklist;           /* RS_FORM_*: list-walking deal kernels with LDS tiles pull (job, trip) items from a device-built work list */
+    int32_t reserved0;          /* zero (ABI 4: `worklist`; the list-walking kernels with LDS tiles always pull their trips from a device-built work list) */
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
-                                   sum their deltas by wave segments instead of LDS tiles (default: off -- measured slower at every batch size tried) */
+                                   sum their deltas along the runs of equal cluster (DPP segmented scan) instead of LDS tiles or delta rows (default: on for multi-round
+                                   trees beyond 48 K deals per batch, profiles/r04_deals.md) */
     int32_t delta_rows;         /* RS_FORM_*: i32 deal sweeps keep no delta tiles and issue no atomics inside the walk: a visit stores its deltas at the deal's LIST POSITION
                                    ([2A][batch pitch] i32 rows per traverser node, coalesced), and one streaming pass per sweep sums every row by cluster (LDS histogram of
                                    one row at a time) into the delta tables.  Applies to the round subtrees whose traverser nodes have at most 16 384 clusters */

@@ -13,7 +13,7 @@ from . import _lib  # noqa: E402
 from ._lib import (ACT_BET, ACT_CALL, ACT_CHECK, ACT_FOLD, ACT_RAISE, CHANCE_ENUM, CHANCE_PASS, F16, F32, I32,
                    LEAF_SIGN, LEAF_UNCONTESTED, LEAF_UTIL, OPP_FULL, OPP_SAMPLE, NODE_ACTION, NODE_PRIVATE_CHANCE, NODE_PUBLIC_CHANCE,
                    NODE_TERMINAL, TERM_ALLIN, TERM_SHOWDOWN, TERM_UNCONTESTED, UPD_CLAMP_I64, UPD_PRUNE, UPD_RMPLUS,
-                   UPD_WRAP_I32, RsError)
+                   UPD_WRAP_I32, RsError, FORM_DEFAULT, FORM_ON, FORM_OFF, FAN_DEFAULT, FAN_NONE, FAN_EXPAND, SHADOW_RULE, SHADOW_ALL)
 
 if not _BUILDING:
     _lib.load()  # ImportError if librustsolver_amd.so is missing

@@ -15,6 +15,9 @@ ACT_BET, ACT_RAISE, ACT_CHECK, ACT_CALL, ACT_FOLD = 0, 1, 2, 3, 4
 I32, F32, F16 = 0, 1, 2
 UPD_CLAMP_I64, UPD_WRAP_I32, UPD_RMPLUS, UPD_PRUNE = 0, 1, 0x100, 0x200
 LEAF_UNCONTESTED, LEAF_SIGN, LEAF_UTIL = 0, 1, 2
+FORM_DEFAULT, FORM_ON, FORM_OFF = 0, 1, 2            # rs_kernel_forms values (RS_FORM_*)
+FAN_DEFAULT, FAN_NONE, FAN_EXPAND = 0, 1, 2          # .lane_fan (RS_FAN_*)
+SHADOW_RULE, SHADOW_ALL = 1, 2                       # .shadow (RS_SHADOW_*)
 CHANCE_PASS, CHANCE_ENUM = 0, 1
 OPP_FULL, OPP_SAMPLE = 0, 1
 BR_MAX, BR_AVERAGE = 0, 1   # rs_best_response modes
@@ -56,7 +59,7 @@ class DealBatch(C.Structure):
 
 
 class KernelForms(C.Structure):   # rs_kernel_forms: every field 0 = the engine's own choice
-    _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("worklist", C.c_int32), ("shadow", C.c_int32),
+    _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("reserved0", C.c_int32), ("shadow", C.c_int32),
                 ("deal_order", C.c_int32), ("delta_rows", C.c_int32), ("direct_rows", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 

@@ -33,13 +33,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // order).  All of them are hipMalloc'ed global memory: say so, and get global_load_dwordx4 / global_store_dwordx4.
 #define RS_GLOBAL __attribute__((address_space(1)))
 // streaming accesses: every table row is read once and written once per sweep, so keep it out of the caches' way
-#ifdef RS_PLAIN_ACCESS
-#define RS_LOADG(p) (*(p))
-#define RS_STOREG(v, p) (*(p) = (v))
-#else
 #define RS_LOADG(p) __builtin_nontemporal_load(p)
 #define RS_STOREG(v, p) __builtin_nontemporal_store(v, p)
-#endif
 template <typename T> __device__ __forceinline__ const RS_GLOBAL T *as_global(const void *p) {
     return (const RS_GLOBAL T *)(unsigned long long)p;
 }
@@ -462,9 +457,6 @@ __device__ __forceinline__ void mask_tail_lanes(float (&reach)[kVecD], unsigned 
 // (rs_selftest_division compares the two on the device).  Regret matching on i32 tables divides a positive regret by the sum of the positive regrets: both are
 // integers in [1, 2^34] as floats, the quotient lies in [2^-34, 1].  Explicit fma calls are not contractions: -ffp-contract=off does not touch them.
 __device__ __forceinline__ float div_exact_pos(float a, float b) {
-#ifdef RS_NO_FAST_DIV
-    return a / b;
-#else
     const float r0 = __builtin_amdgcn_rcpf(b);
     const float e0 = __builtin_fmaf(-b, r0, 1.0f);
     const float r1 = __builtin_fmaf(e0, r0, r0);
@@ -473,7 +465,6 @@ __device__ __forceinline__ float div_exact_pos(float a, float b) {
     const float q1 = __builtin_fmaf(e1, r1, q0);
     const float e2 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(e2, r1, q1);
-#endif
 }
 
 // ---- regret matching: Infoset::get_strategy (infoset.rs:83-102) -----------------------------------
@@ -523,9 +514,6 @@ __device__ __forceinline__ float visit_i32(int (&r)[A], int (&s)[A], const float
             small = small && (!ex[a] || (__builtin_fabsf(dr[a]) < 2147483648.0f && __builtin_fabsf(ds[a]) < 2147483648.0f));   // false for NaN
         }
         small = small || !active;
-#ifdef RS_NO_FAST_CLAMP   // A/B knob (RS_JIT_NO_FAST_CLAMP): the exact path for everybody
-        small = false;
-#endif
         if (__builtin_amdgcn_ballot_w64(small) == __builtin_amdgcn_ballot_w64(true)) {
 #pragma unroll
             for (int a = 0; a < A; a++) {

@@ -242,48 +242,26 @@ hipError_t launch_delta_swap(void *x, void *snap, size_t n, int dtype, hipStream
 // a knob from the environment.  kUnset = nobody said anything: the code's own rule decides.
 constexpr int kUnset = -2147483647 - 1;
 struct Knobs {
-    // API-backed (rs_kernel_forms); the environment overrides them for tests
-    int fan = kUnset;               // RS_JIT_FAN: 0 / 1 / 2
-    int lanes = kUnset;             // RS_JIT_LANES: deals per thread 1 / 2 / 4
-    int no_worklist = 0;            // RS_JIT_NO_WORKLIST
-    int shadow_all = 0;             // RS_JIT_SHADOW_ALL
-    int shadow_wide = 0;            // RS_JIT_SHADOW_WIDE
-    int ordered = kUnset;           // RS_JIT_ORDERED: 1 on / 0 off
-    int rows = kUnset;              // RS_JIT_ROWS: 1 on / 0 off (delta rows by list position + one summing pass per sweep)
-    int rows_chunk = kUnset;        // RS_JIT_ROWS_CHUNK: list entries one workgroup of the summing pass takes (tests: small values force several chunks per row)
-    // generator switches (test-only)
-    int distance = kUnset;          // RS_JIT_DISTANCE
-    int threads = kUnset;           // RS_JIT_THREADS
-    int waves = 0;                  // RS_JIT_WAVES
-    int plain = 0;                  // RS_JIT_PLAIN
-    int no_fast_clamp = 0;          // RS_JIT_NO_FAST_CLAMP
-    int no_fast_div = 0;            // RS_JIT_NO_FAST_DIV
-    int dump = 0;                   // RS_JIT_DUMP
-    int no_rounds = 0;              // RS_JIT_NO_ROUNDS
-    int no_sparse = 0;              // RS_JIT_NO_SPARSE
-    int no_parts = 0;               // RS_JIT_NO_PARTS
-    int scan_all = kUnset;          // RS_JIT_SCAN_ALL
-    int no_posrows = 0;             // RS_JIT_NO_POSROWS
-    int lds_max = kUnset;           // RS_JIT_LDS_MAX
-    int no_lane_rounds = 0;         // RS_JIT_NO_LANE_ROUNDS
-    int no_lds = 0;                 // RS_JIT_NO_LDS
-    int no_resident = 0;            // RS_JIT_NO_RESIDENT
-    int apply_whole_table = 0;      // RS_APPLY_WHOLE_TABLE
-    int max_blocks = kUnset;        // RS_JIT_MAX_BLOCKS
-    int no_overlap = 0;             // RS_JIT_NO_OVERLAP
-    int lane_overlap = 0;           // RS_LANE_OVERLAP
-    int no_pack = 0;                // RS_JIT_NO_PACK
-    long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES
-    long tile_min_lanes = kUnset;   // RS_TABLE_TILE_MIN_LANES
-    int no_prefetch = 0;            // RS_TRAINER_NO_PREFETCH
-    int no_handoff = 0;             // RS_JIT_NO_HANDOFF: the walk of a round subtree draws the opponent's actions again instead of reading the reach-down kernel's
-    int no_sigma = 0;               // RS_JIT_NO_SIGMA: opponent nodes' shadow records hold regrets (matched in the walk) instead of strategies
-    int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings)
-    int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
-    int br_depth_first = 0;         // RS_BR_DEPTH_FIRST: the best response walks the tree depth first (one launch per node) instead of level by level (what happens anyway when
-                                    // the level plan's buffers do not fit)
-    int direct_rows = kUnset;       // RS_JIT_DIRECT_ROWS / rs_kernel_forms.direct_rows: 1 on / 0 off
+    // API-backed (rs_kernel_forms); the environment overrides three of them for tests
+    int fan = kUnset;               // rs_kernel_forms.lane_fan: 0 none / 1 the expand step inside the subtree kernel
+    int lanes = kUnset;             // RS_JIT_LANES / deals_per_thread: 1 / 2 / 4
+    int shadow_all = 0;             // rs_kernel_forms.shadow = RS_SHADOW_ALL
+    int ordered = kUnset;           // RS_JIT_ORDERED / deal_order: 1 on / 0 off
+    int rows = kUnset;              // RS_JIT_ROWS / delta_rows: 1 on / 0 off (delta rows by list position + one summing pass per round)
+    int direct_rows = kUnset;       // RS_JIT_DIRECT_ROWS / direct_rows: 1 on / 0 off
+    // test-only: forms the engine picks by size, forced onto small inputs
+    int rows_chunk = kUnset;        // RS_JIT_ROWS_CHUNK: list entries one workgroup of the summing pass takes (small values: several chunks per row)
+    int scan_all = kUnset;          // RS_JIT_SCAN_ALL: 0 = a root's live deals are compacted from its parent's lists (what batches beyond 64 K deals get), 1 = from the whole batch
+    int lds_max = kUnset;           // RS_JIT_LDS_MAX: bytes of LDS a workgroup may take (small values: cluster ranges on every round)
+    int max_blocks = kUnset;        // RS_JIT_MAX_BLOCKS: grid cap of the generated kernels (small values: several trips per workgroup)
+    int no_siblings = kUnset;       // RS_JIT_NO_SIBLINGS: 1 = one compaction job per root (k_compact_live), 0 = one per parent (k_compact_siblings: batches beyond 512 K deals)
+    long tile_lanes = kUnset;       // RS_TABLE_TILE_LANES: lanes per tile of a tiled node block; every node wider than that is tiled (0: never tile)
+    // test-only: facilities with a fallback
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
+    int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
+    int br_depth_first = 0;         // RS_BR_DEPTH_FIRST: the best response walks the tree depth first (what happens anyway when the level plan's buffers do not fit)
+    int no_overlap = 0;             // RS_JIT_NO_OVERLAP: the launches of a round run one after the other on the table's stream (profiling: overlapped kernels stretch each other's durations)
+    int dump = 0;                   // RS_JIT_DUMP: every generated source is written to /tmp/rs_tree_kernel_<hash>.hip
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
 const char *rccl_library_override();   // $RS_RCCL_LIB (tests: tests/stub_rccl.c), or nullptr

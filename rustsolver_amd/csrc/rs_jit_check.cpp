@@ -61,7 +61,7 @@ int rs_jit_check_tree(const rs_tree *tree, int dtype, int mode, int opp_mode, in
             const rs_tree_node &nd = nodes[i];
             if (nd.kind != RS_NODE_ACTION || !closed[i] || nd.n_children == 0) continue;
             if (nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_ACTION && closed[nd.parent]) continue;   // not topmost
-            for (int fan = 0; fan < 3; ++fan) {   // below a public chance node also the forms that take over the node's expand (1) and its deal loop (2)
+            for (int fan = 0; fan < 2; ++fan) {   // below a public chance node also the form that takes over the node's expand step
                 if (fan && !(nd.parent >= 0 && nodes[nd.parent].kind == RS_NODE_PUBLIC_CHANCE)) continue;
                 JitSubtree js;
                 jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, dtype, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, false, false, false, false,
@@ -172,7 +172,7 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                                      (mode & RS_UPD_PRUNE) != 0, 1, &root, jt, knobs, 0, true, true, false, false, false, !down, &sigma_all, true, &st);
                     if (!(down && jt.boundary_roots.empty()) && jt.staged && !seen.count(jt.source)) seen[jt.source] = 1;
                 }
-                if (f6 >= 4) {   // delta rows (rs_kernel_forms.delta_rows): the walk stores its deltas by position, dense and over a list
+                if (f6 == 5) {   // delta rows (rs_kernel_forms.delta_rows): the list walk stores its deltas by position
                     JitSubtree jr;
                     jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_I32, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, sparse, false,
                                      (mode & RS_UPD_PRUNE) != 0, lanes, &root, jr, knobs, 0, sparse, sparse, false, false, false, true, &sigma_all, true);

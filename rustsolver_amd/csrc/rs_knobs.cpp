@@ -1,8 +1,10 @@
 // rs_knobs.cpp -- the ONE place where the library reads switches from the environment.
 //
-// A caller chooses kernel forms through the API (rs_kernel_forms in rs_solver_params, rs_table_params, rs_deal_trainer_params.prefetch).  The variables below
-// exist for the test-suite and the A/B tools, which force every generated form against the oracle; they are resolved once per solver / table / trainer, at its
-// creation (round 1 cached them per process, which let tests that toggled them silently run the default path).  DESIGN.md section 7a lists what each one does.
+// A caller chooses kernel forms through the API (rs_kernel_forms in rs_solver_params, rs_table_params, rs_deal_trainer_params.prefetch).  The fifteen variables below
+// exist for the test-suite and the profiling tools: each forces a form that the engine otherwise picks by batch or table size (so that small test inputs meet the forms big
+// inputs get), or switches a facility off that has a fallback (staged rows, helper processes, launch overlap); they are resolved once per solver / table / trainer, at its
+// creation.  Round 4 removed twenty-four more: forms measured as losers went with their code (the whole-deal-loop lane kernels, dense walks on delta rows, wide opponent
+// records, the grouped compiles), tuning constants became constants, optimisation layers that have no regime left where they are off lost their switch.  DESIGN.md section 9.
 #include <cstdlib>
 
 #include "rs_internal.hpp"
@@ -18,56 +20,30 @@ struct Entry {
     long Knobs::*lfield;
 };
 const Entry kEntries[] = {
-    {"RS_JIT_FAN", INT, &Knobs::fan, nullptr},
     {"RS_JIT_LANES", INT, &Knobs::lanes, nullptr},
-    {"RS_JIT_NO_WORKLIST", FLAG, &Knobs::no_worklist, nullptr},
-    {"RS_JIT_SHADOW_ALL", FLAG, &Knobs::shadow_all, nullptr},
-    {"RS_JIT_SHADOW_WIDE", FLAG, &Knobs::shadow_wide, nullptr},
     {"RS_JIT_ORDERED", INT, &Knobs::ordered, nullptr},
     {"RS_JIT_ROWS", INT, &Knobs::rows, nullptr},
     {"RS_JIT_ROWS_CHUNK", INT, &Knobs::rows_chunk, nullptr},
-    {"RS_JIT_DISTANCE", INT, &Knobs::distance, nullptr},
-    {"RS_JIT_THREADS", INT, &Knobs::threads, nullptr},
-    {"RS_JIT_WAVES", INT, &Knobs::waves, nullptr},
-    {"RS_JIT_PLAIN", BOOL, &Knobs::plain, nullptr},
-    {"RS_JIT_NO_FAST_CLAMP", BOOL, &Knobs::no_fast_clamp, nullptr},
-    {"RS_JIT_NO_FAST_DIV", BOOL, &Knobs::no_fast_div, nullptr},
     {"RS_JIT_DUMP", FLAG, &Knobs::dump, nullptr},
-    {"RS_JIT_NO_ROUNDS", FLAG, &Knobs::no_rounds, nullptr},
-    {"RS_JIT_NO_SPARSE", FLAG, &Knobs::no_sparse, nullptr},
-    {"RS_JIT_NO_PARTS", FLAG, &Knobs::no_parts, nullptr},
     {"RS_JIT_SCAN_ALL", INT, &Knobs::scan_all, nullptr},
-    {"RS_JIT_NO_POSROWS", FLAG, &Knobs::no_posrows, nullptr},
-    {"RS_JIT_NO_HANDOFF", FLAG, &Knobs::no_handoff, nullptr},
-    {"RS_JIT_NO_SIGMA", FLAG, &Knobs::no_sigma, nullptr},
     {"RS_JIT_NO_SIBLINGS", INT, &Knobs::no_siblings, nullptr},
     {"RS_JIT_NO_STAGE", FLAG, &Knobs::no_stage, nullptr},
     {"RS_JIT_DIRECT_ROWS", INT, &Knobs::direct_rows, nullptr},
     {"RS_BR_DEPTH_FIRST", FLAG, &Knobs::br_depth_first, nullptr},
     {"RS_JIT_NO_PROCS", FLAG, &Knobs::jit_no_procs, nullptr},
     {"RS_JIT_LDS_MAX", INT, &Knobs::lds_max, nullptr},
-    {"RS_JIT_NO_LANE_ROUNDS", FLAG, &Knobs::no_lane_rounds, nullptr},
-    {"RS_JIT_NO_LDS", FLAG, &Knobs::no_lds, nullptr},
-    {"RS_JIT_NO_RESIDENT", FLAG, &Knobs::no_resident, nullptr},
-    {"RS_APPLY_WHOLE_TABLE", FLAG, &Knobs::apply_whole_table, nullptr},
     {"RS_JIT_MAX_BLOCKS", INT, &Knobs::max_blocks, nullptr},
     {"RS_JIT_NO_OVERLAP", FLAG, &Knobs::no_overlap, nullptr},
-    {"RS_LANE_OVERLAP", BOOL, &Knobs::lane_overlap, nullptr},
-    {"RS_JIT_NO_PACK", FLAG, &Knobs::no_pack, nullptr},
     {"RS_TABLE_TILE_LANES", LONG, nullptr, &Knobs::tile_lanes},
-    {"RS_TABLE_TILE_MIN_LANES", LONG, nullptr, &Knobs::tile_min_lanes},
-    {"RS_TRAINER_NO_PREFETCH", FLAG, &Knobs::no_prefetch, nullptr},
 };
 }  // namespace
 
 Knobs knobs_resolve(const rs_kernel_forms *forms) {
     Knobs k;
     if (forms) {   // the caller's API first
-        if (forms->lane_fan >= RS_FAN_NONE && forms->lane_fan <= RS_FAN_LOOP) k.fan = forms->lane_fan - 1;
+        if (forms->lane_fan == RS_FAN_NONE || forms->lane_fan == RS_FAN_EXPAND) k.fan = forms->lane_fan - 1;
         if (forms->deals_per_thread == 1 || forms->deals_per_thread == 2 || forms->deals_per_thread == 4) k.lanes = forms->deals_per_thread;
-        if (forms->worklist == RS_FORM_OFF) k.no_worklist = 1;
-        if (forms->shadow == RS_SHADOW_ALL || forms->shadow == RS_SHADOW_WIDE) k.shadow_all = 1;
-        if (forms->shadow == RS_SHADOW_WIDE) k.shadow_wide = 1;
+        if (forms->shadow == RS_SHADOW_ALL) k.shadow_all = 1;
         if (forms->deal_order == RS_FORM_ON) k.ordered = 1;
         else if (forms->deal_order == RS_FORM_OFF) k.ordered = 0;
         if (forms->delta_rows == RS_FORM_ON) k.rows = 1;

@@ -142,9 +142,7 @@ void PlanBuilder::mark_inside(int id) {
 void PlanBuilder::fan_mode(int id) {   // may the kernel of root `id` take over work of the ENUM chance node above it?
     const int par = nodes[id].parent;
     if (par >= 0 && chance_enum(nodes[par]) && !boundary(par) && s->n_clusters % 4 == 0 && !s->deal_mode) {
-        const int mode = s->knobs.fan != kUnset ? s->knobs.fan : 1;
-        if (mode == 1 || (mode == 2 && closed[id])) fan_root[id] = char(mode);
-        else if (mode == 2) fan_root[id] = 1;   // a round subtree with chance nodes below cannot walk its own deals (its rows are per deal of the round above): expand step only
+        if (s->knobs.fan == kUnset || s->knobs.fan == 1) fan_root[id] = 1;
     }
 }
 
@@ -290,7 +288,6 @@ int PlanBuilder::build() {
     nan_slot.assign(n, -1);
     {
         const Knobs &kn = s->knobs;
-        const bool round_off = kn.no_rounds != 0;
         first_root = resolve(0);
         // Small deal batches leave most SIMDs without a wave, and a generated kernel is a long dependent instruction stream: one deal per
         // thread puts four times as many waves on the chip, each walking a quarter of the code (RS_JIT_LANES = 1 / 4 overrides)
@@ -304,19 +301,18 @@ int PlanBuilder::build() {
         jit_lanes = (s->deal_mode && s->deals.n_deals <= kSmallDealBatch) ? 1 : 4;
         jit_lanes_below = s->deal_mode ? 1 : 4;
         if (kn.lanes != kUnset) jit_lanes = jit_lanes_below = (kn.lanes == 1 || kn.lanes == 2) ? kn.lanes : 4;
-        round_mode = s->deal_mode && s->params.fuse_subtrees && !round_off && nodes[first_root].kind == RS_NODE_ACTION &&
+        round_mode = s->deal_mode && s->params.fuse_subtrees && nodes[first_root].kind == RS_NODE_ACTION &&
                      nodes[first_root].n_children > 0;
-        const bool sparse_off = kn.no_sparse != 0, parts_off = kn.no_parts != 0;
         if (s->deal_mode && s->table->dtype == RS_F32 && !round_mode)
             return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables run through the generated round subtrees only (the first node below the root must be an action node)");
-        want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && !sparse_off && s->table->dtype == RS_I32;   // f32 deal sweeps walk every deal (their delta rows are per deal)
-        want_parts = round_mode && want_lists && !parts_off;
+        want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && s->table->dtype == RS_I32;   // f32 deal sweeps walk every deal (their delta rows are per deal)
+        want_parts = round_mode && want_lists;
         // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
         // so only batches beyond the small-batch switch (RS_JIT_SCAN_ALL = 1 / 0 forces either)
         scan_parent = round_mode && want_lists && s->deals.n_deals > kScanParentMin;   // with list-position rows it pays from 128 K deals per batch on (1.21 -> 1.07 ms; 64 K: 1.00 -> 1.02,
                                                                                        // lossless abstractions at 64 K 2.5 -> 2.9: gpurun_out/r04d/ab_scan_small.log)
         if (kn.scan_all != kUnset) scan_parent = round_mode && want_lists && kn.scan_all == 0;
-        pos_rows = scan_parent && !kn.no_posrows;
+        pos_rows = scan_parent;
         lds_limit = s->lds_limit;
         if (kn.lds_max != kUnset) lds_limit = std::min(lds_limit, kn.lds_max);
         lds_limit -= int(kWorklistLdsBytes);   // the work-list kernels keep their ticket in front of the tiles
@@ -326,8 +322,7 @@ int PlanBuilder::build() {
         layout_round(first_root);
     } else {
         // lane sweeps: round subtrees above the last round (full-width cfr() with ENUM chance nodes; prune keeps the level plan's NaN bookkeeping)
-        lane_rounds = !s->deal_mode && s->params.fuse_subtrees && s->params.chance_mode == RS_CHANCE_ENUM && s->params.opp_mode == RS_OPP_FULL &&
-                      !s->knobs.no_lane_rounds;
+        lane_rounds = !s->deal_mode && s->params.fuse_subtrees && s->params.chance_mode == RS_CHANCE_ENUM && s->params.opp_mode == RS_OPP_FULL;
         for (size_t id = 0; id < n; ++id)
             if (nodes[id].kind == RS_NODE_PUBLIC_CHANCE) {
                 const int c = nodes[id].children[0];
@@ -395,14 +390,13 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             }
         }
     }
-    const bool lds_off = s->knobs.no_lds != 0;
     const bool sparse = sparse_slot[id] >= 0;
     const Parts parts = sparse ? parts_of(id) : Parts{1u, 0u, 0u, 0u};
     if (parts.first > 1) lds_need = lds_need / std::max<size_t>(1, parts.pitch) * parts.second;   // tiles cover one range
     const bool seg = seg_root(id) && !down && t->dtype == RS_I32;
     const bool rows = s->deal_mode && rows_root(id) && !down;
-    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !lds_off && !down && !seg && !rows && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
-    if (s->deal_mode && sigma_node.empty() && !s->shadow_off_p[p].empty() && !s->knobs.no_sigma) {
+    const bool use_lds = s->deal_mode && lds_need > 0 && lds_need <= size_t(lds_limit) && !down && !seg && !rows && t->dtype == RS_I32;   // f32 deal sweeps add nothing anywhere: no tiles
+    if (s->deal_mode && sigma_node.empty() && !s->shadow_off_p[p].empty()) {
         sigma_node.assign(n, 0);
         for (size_t q = 0; q < n; ++q) {
             const rs_tree_node &qn = nodes[q];
@@ -446,8 +440,8 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
                      (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
-                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, !s->knobs.no_worklist, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id), &stage);
-    const bool fan = fan_root[id] == 2, xfan = fan_root[id] == 1;
+                     int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, true, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id), &stage);
+    const bool xfan = fan_root[id] == 1;
     const int fan_par = fan_root[id] ? nodes[id].parent : -1;   // the ENUM chance node whose work this kernel takes over
     // the kernel itself is compiled (or fetched from the caches) after BOTH traversers' plans are complete: every distinct source no cache holds goes to a helper process
     // (rs_solver.cpp, jit_get_kernels: hipRTC serialises compiles inside a process; a three-street deal solver needs several dozen kernels of a second of hipRTC each)
@@ -490,13 +484,12 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         put_f32(js.off_cval + 4 * k, tn.ttype == RS_TERM_UNCONTESTED ? ((p == tn.last_to_act) ? -1.0f * pot : 1.0f * pot) : pot);
     }
     put_ptr(js.off_reach, reach[id].ptr);
-    put_ptr(js.off_out, fan ? uptr(fan_par) : uptr(id));
+    put_ptr(js.off_out, uptr(id));
     put_ptr(js.off_seed, s->d_seed());
     put_f32(js.off_reach_const, reach[id].cst);
     put_f32(js.off_scale, s->params.scale);
-    // fan: one thread per 4 clusters of a PARENT board (n_clusters % 4 == 0: exactly lanes / 4 vectors, no padding lanes)
-    const uint32_t n_vec = fan ? uint32_t(size_t(s->n_boards[lane_round[fan_par]]) * s->n_clusters / 4)
-                           : (xfan ? uint32_t(size_t(s->n_boards[lane_round[id]]) * s->n_clusters / 4) : uint32_t(s->pitch[lane_round[id]] / size_t(js.lanes)));
+    // xfan: n_clusters % 4 == 0, exactly lanes / 4 vectors, no padding lanes
+    const uint32_t n_vec = xfan ? uint32_t(size_t(s->n_boards[lane_round[id]]) * s->n_clusters / 4) : uint32_t(s->pitch[lane_round[id]] / size_t(js.lanes));
     put_u32(js.off_n_vec, n_vec);
     if (!s->deal_mode) {
         const uint32_t f = fan_par >= 0 ? fan_of(fan_par) : 1u;
@@ -617,7 +610,6 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         put_ptr(js.off_attr, (sparse || s->ordered) ? s->d_attr[nodes[id].round_idx] : nullptr);
         if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
         if (use_lds) {
-            const bool resident_off = s->knobs.no_resident != 0;
             std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)
             for (size_t k = 0; k < js.node_ids.size(); ++k) {
                 const rs_tree_node &an = nodes[js.node_ids[k]];
@@ -626,7 +618,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             std::sort(tiles.begin(), tiles.end());
             const size_t limit = size_t(lds_limit) / 4;
             size_t resident = 0, n_res = 0;
-            while (!resident_off && n_res < tiles.size()) {
+            while (n_res < tiles.size()) {
                 const size_t rest = n_res + 1 < tiles.size() ? tiles.back().first : 0;   // largest tile that would stay transient
                 if (resident + tiles[n_res].first + rest > limit) break;
                 resident += tiles[n_res].first;
@@ -647,8 +639,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
     }
     JL.n_jobs += 1;
     JL.max_n_vec = std::max(JL.max_n_vec, n_vec);
-    if (fan) JL.bytes += bytes + lanes(id) * 4.0 * js.leaf_terms.size() + lanes(fan_par) * ((reach[id].ptr ? 4.0 : 0.0) + 4.0);
-    else if (xfan) JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + 4.0) + lanes(fan_par) * (reach[id].ptr ? 4.0 : 0.0);
+    if (xfan) JL.bytes += bytes + lanes(id) * (4.0 * js.leaf_terms.size() + 4.0) + lanes(fan_par) * (reach[id].ptr ? 4.0 : 0.0);
     else JL.bytes += (bytes + lanes(id) * (4.0 * js.leaf_terms.size() + (reach[id].ptr ? 4.0 : 0.0) + 4.0)) / parts.first;
     }   // parts
     return RS_OK;
@@ -857,7 +848,6 @@ int PlanBuilder::emit() {
             if (nd.kind == RS_NODE_ACTION) (nd.player == p ? upd_groups : util_groups)[nd.n_children].push_back(id);
             else if (chance_enum(nd)) {
                 const int c = nd.children[0];
-                if (fan_root[c] == 2) continue;   // the child's kernel sums its deals in order and writes this node's row itself (cfr.rs:519)
                 const ChildSrc src = child_source(c);
                 if (src.kind != CH_BUF) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create: chance node above a terminal");
                 ChanceJob cj{};

@@ -54,10 +54,8 @@ struct PlanBuilder {
     };
     bool seg_root(int root) const { return s->ordered && nodes[size_t(root)].round_idx == s->order_round && !rows_root(root); }   // its deltas are summed by wave segments: no LDS tiles
     // delta rows (rs_kernel_forms.delta_rows): the walk of this root stores its deltas by list position, k_row_sums adds them up per cluster: no tiles, no cluster ranges
-    // (the engine's choice, 1: the list walkers only -- the first round's dense walk keeps its tiles, four deals per thread; 2, tests: every round subtree)
-    bool rows_root(int root) const {
-        return round_mode && rows_round_ok(s, p, nodes[size_t(root)].round_idx) && (s->knobs.rows >= 2 || (want_lists && root != first_root));
-    }
+    // (the list walkers only: the first round's dense walk keeps its tiles)
+    bool rows_root(int root) const { return round_mode && rows_round_ok(s, p, nodes[size_t(root)].round_idx) && want_lists && root != first_root; }
     Parts parts_of(int root) const;
     // hand-off rows (rs_jit.cpp): the reach-down kernel of `root` stores its draws by list position, the walk of `root` reads them
     std::vector<size_t> hrow_off;   // per tree node: float offset of the root's rows in plan.d_hrows, SIZE_MAX = none

@@ -32,7 +32,7 @@ uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, st
 
 bool rows_round_ok(const rs_solver *s, int p, int round) {
     if (!s->rows || !s->deal_mode || s->table->dtype != RS_I32) return false;
-    if (s->knobs.rows < 2 && round == s->first_round) return false;   // the dense walk of the first round: rs_plan_builder.hpp rows_root
+    if (round == s->first_round) return false;   // the dense walk of the first round keeps its resident tiles (river game 0.66 against 1.69 ms per batch with rows): rows are for the list walkers
     if (s->ordered && round == s->order_round) return false;   // ordered sweeps: the last round's lists come in runs of equal traverser cluster, summed by wave segments (seg_add)
     const rs_table *t = s->table;
     uint32_t k = 0;
@@ -260,7 +260,7 @@ int PlanBuilder::emit_deal_lists() {
             for (int root : roots_of_round[r])
                 for (int b : bnd[size_t(root)]) parent_root[size_t(b)] = root;
         // hand-off rows: every root with next-round roots below it (i.e. with a reach-down kernel), unless its lists are cut into cluster ranges
-        if (s->params.opp_mode == RS_OPP_SAMPLE && t->dtype == RS_I32 && !s->knobs.no_handoff) {
+        if (s->params.opp_mode == RS_OPP_SAMPLE && t->dtype == RS_I32) {
             hrow_off.assign(n, SIZE_MAX);
             size_t floats = 0;
             const size_t hp = s->pitch[0] + kRowStagger;
@@ -470,7 +470,7 @@ int PlanBuilder::emit_apply() {
             plan.apply_max_vec = std::max(plan.apply_max_vec, nc / kVec);
             cells += double(nc);
         }
-        if (!aj.empty() && !s->knobs.apply_whole_table) {
+        if (!aj.empty()) {
             hipError_t ea = hipMalloc((void **)&plan.d_apply_jobs, aj.size() * sizeof(ApplyJob));
             if (ea == hipSuccess) ea = hipMemcpy(plan.d_apply_jobs, aj.data(), aj.size() * sizeof(ApplyJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");

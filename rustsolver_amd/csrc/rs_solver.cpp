@@ -369,7 +369,7 @@ static int setup_table_shadow(rs_solver *s) {
                     acts.push_back(table->nodes[i].n_actions);
                     n_cl = std::max(n_cl, table->nodes[i].n_clusters);
                 }
-                const bool wide = kv.first.second == tp || s->knobs.shadow_wide;
+                const bool wide = kv.first.second == tp;
                 const uint32_t row = shadow_row_layout(acts, wide, recs, offs);
                 for (size_t m = 0; m < mem.size(); ++m) {
                     const size_t i = mem[m];
@@ -388,7 +388,7 @@ static int setup_table_shadow(rs_solver *s) {
                     j.half = half;
                     j.stride = recs[m];
                     j.row_stride = row;
-                    j.sigma = (recs[m] == half && d.player != tp && !s->knobs.no_sigma) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
+                    j.sigma = (recs[m] == half && d.player != tp) ? 1u : 0u;   // PlanBuilder::sigma_node says the same to the emitter
                     j.dst = reinterpret_cast<int32_t *>(ints + offs[m]);   // an offset for now: the buffer does not exist yet
                     jobs.push_back(j);
                     s->shadow_max_clusters = std::max(s->shadow_max_clusters, d.n_clusters);
@@ -418,7 +418,7 @@ static void choose_delta_rows(rs_solver *s) {
     rs_table *table = s->table;
     const rs_tree *tree = &s->tree;
     {
-        const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32 && !s->knobs.no_rounds;
+        const bool can = s->deal_mode && s->params.fuse_subtrees && table->dtype == RS_I32;
         {
             int c = 0;
             while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0];
@@ -444,7 +444,7 @@ static int setup_deal_records(rs_solver *s) {
     hipError_t e = hipSuccess;
     (void)n;
     (void)e;
-    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_sparse && !s->knobs.no_pack && table->dtype == RS_I32) {
+    if (s->deal_mode && s->params.fuse_subtrees && s->params.opp_mode == RS_OPP_SAMPLE && table->dtype == RS_I32) {
         const float *leaf = nullptr;
         bool one = true;
         for (size_t i = 0; i < n && one; ++i) {
@@ -459,7 +459,7 @@ static int setup_deal_records(rs_solver *s) {
         // (three streets, 5 000-bucket files, 4 M deals per batch: 838 per cluster) -- small batches against big abstractions keep the unordered forms.
         if (one && leaf) {
             const rs_tree_node &fr = tree->nodes[size_t([&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }())];
-            const bool round_mode = fr.kind == RS_NODE_ACTION && fr.n_children > 0 && !s->knobs.no_rounds;
+            const bool round_mode = fr.kind == RS_NODE_ACTION && fr.n_children > 0;
             s->order_round = s->n_rounds - 1;
             uint32_t bins[2] = {0, 0};
             for (size_t i = 0; i < table->nodes.size(); ++i)
@@ -652,10 +652,10 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    // streams for independent round subtrees (deal sweeps) and, on request (RS_LANE_OVERLAP=1), for the independent subtree launches of one tree depth in lane sweeps
+    // streams for the independent round subtrees of a deal sweep
     if (hipDeviceGetAttribute(&s->lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, table->device) != hipSuccess || s->lds_limit < 1024) s->lds_limit = 64 * 1024;
     if (hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, table->device) != hipSuccess || s->n_cus < 1) s->n_cus = 256;
-    if (((s->deal_mode && !s->knobs.no_overlap) || (!s->deal_mode && s->knobs.lane_overlap)) && s->params.fuse_subtrees) {
+    if (s->deal_mode && !s->knobs.no_overlap && s->params.fuse_subtrees) {
         e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
         for (int k = 0; e == hipSuccess && k < rs_solver::kAux; ++k) {
             e = hipStreamCreateWithFlags(&s->aux[k], hipStreamNonBlocking);

@@ -198,11 +198,11 @@ int rs_table_create_with(const rs_node_desc *nodes, int n_nodes, int dtype, int 
     if (params && params->tile_lanes) tile_lanes = (params->tile_lanes >= uint32_t(kLanePad) && (params->tile_lanes & (params->tile_lanes - 1)) == 0) ? size_t(params->tile_lanes) : 0;
     if (params && params->tile_min_lanes) tile_min = params->tile_min_lanes;
     const Knobs knobs = knobs_resolve(nullptr);   // tests force small tiles on small tables
-    if (knobs.tile_lanes != kUnset) {
+    if (knobs.tile_lanes != kUnset) {   // RS_TABLE_TILE_LANES = T: every node wider than T lanes is tiled in T-lane tiles
         const long v = knobs.tile_lanes;
         tile_lanes = (v >= long(kLanePad) && (v & (v - 1)) == 0) ? size_t(v) : 0;   // anything else: never tile
+        tile_min = tile_lanes + 1;
     }
-    if (knobs.tile_min_lanes != kUnset) tile_min = size_t(std::max(0L, knobs.tile_min_lanes));
     t->tile.resize(size_t(n_nodes));
     size_t off = 0;
     for (int i = 0; i < n_nodes; ++i) {

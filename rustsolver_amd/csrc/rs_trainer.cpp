@@ -158,7 +158,7 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->d_err, 0, 256);
     // staging for the batch dealt ahead; small batches are bound by the NUMBER of launches on the table's stream (about 5 us each), and swapping a
     // staged batch in costs more of them (four copies + the flags) than dealing in place (two kernels): no staging up to 256 K deals
-    const bool prefetch = params->prefetch == RS_FORM_ON || (params->prefetch != RS_FORM_OFF && !knobs_resolve(nullptr).no_prefetch && params->deals_per_batch > (1u << 18));
+    const bool prefetch = params->prefetch == RS_FORM_ON || (params->prefetch != RS_FORM_OFF && params->deals_per_batch > (1u << 18));
     if (rc == RS_OK && prefetch) {
         rc = rs_dmalloc(tr->table, 9 * pitch, reinterpret_cast<void **>(&tr->s_cards));
         if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_cards, 0, 9 * pitch);

@@ -499,6 +499,9 @@ def create_infosets(n_actions, tree, card_abs, n_boards=(1, 1, 1), dtype=L.I32, 
     return InfosetTable(h)
 
 
+DEFAULT_FORMS = {}   # rs_kernel_forms fields every MCCFRTrainer of this process starts from (the test-suite's fixtures set it; a caller passes forms=)
+
+
 class MCCFRTrainer:
     """cfr.rs:146-297 for the batched lane model."""
 
@@ -506,7 +509,7 @@ class MCCFRTrainer:
     DISCOUNT_CAP = 20_000_000     # cfr.rs:194
 
     def __init__(self, tree, infosets, leaves, scale=10000.0, mode=L.UPD_WRAP_I32, chance_mode=L.CHANCE_ENUM,
-                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None, shard=None, prune_deal=None):
+                 use_graph=False, leaves_p1=None, fuse_subtrees=None, opp_mode=L.OPP_FULL, sample_seed=0, deals=None, shard=None, prune_deal=None, forms=None):
         """leaves: dict tree-node-id -> (LEAF_* kind, DeviceBuffer) for every showdown / all-in terminal.
         deals: None (lane model) or dict (round_idx, player) -> uint32 array of dense cluster ids, one per deal
         (what get_cluster() returned, cfr.rs:361-365): batch-synchronous deal sweeps on the reference-shaped table."""
@@ -544,6 +547,8 @@ class MCCFRTrainer:
             arrs.append(arr)
         sw, sr, srd, sg = shard if shard else (0, 0, 0, 0)   # (world, rank, round, global boards of that round)
         p = L.SolverParams(scale, mode, chance_mode, int(use_graph), int(fuse_subtrees), opp_mode, sample_seed, sw, sr, srd, sg)
+        for k, v in dict(DEFAULT_FORMS, **(forms or {})).items():   # rs_kernel_forms by field name: lane_fan, deals_per_thread, shadow, deal_order, delta_rows, direct_rows (0 = the engine's choice)
+            setattr(p.forms, k, int(v))
         h = C.c_void_p()
         if batch is None:
             L.check(L.load().rs_solver_create(infosets._h, tree._h, arrs[0], arrs[1], C.byref(p), C.byref(h)))

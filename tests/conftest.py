@@ -48,8 +48,8 @@ TABLE_LAYOUT_TESTS = {
 
 
 # Lane sweeps with ENUM chance nodes: a fused subtree directly below a chance node takes over the node's expand step (rs_jit.cpp `_xr` kernels, the default when
-# n_clusters % 4 == 0) or, on request, its whole deal loop (`_fan` kernels, RS_JIT_FAN=2); and the action nodes ABOVE the last round form round subtrees with a
-# reach-down and a walk-up kernel each (`_lanes_down`, `_lanes_round`) unless RS_JIT_NO_LANE_ROUNDS keeps them on the level plan: these tests run in all four forms.
+# n_clusters % 4 == 0) or leaves it to an expand launch (rs_kernel_forms.lane_fan = RS_FAN_NONE: what cluster counts that are no multiple of four get anyway): these tests run
+# in both forms (the fixture sets the wrapper's default rs_kernel_forms for the test).
 FAN_LOOP_TESTS = {
     "test_iterate_three_street_tree_vs_oracle", "test_iterate_three_street_tree_pruned_vs_oracle", "test_sharded_enum_sweep_equals_single_gpu",
     "test_wide_nodes_through_both_plans", "test_action_node_without_valid_actions",
@@ -62,7 +62,7 @@ def pytest_generate_tests(metafunc):
     if metafunc.function.__name__ in FAN_LOOP_TESTS:
         if "fan_loop" not in metafunc.fixturenames:
             metafunc.fixturenames.append("fan_loop")
-        metafunc.parametrize("fan_loop", ["xr", "fan", "off", "levels"], indirect=True)
+        metafunc.parametrize("fan_loop", ["xr", "off"], indirect=True)
     if metafunc.function.__name__ in TABLE_LAYOUT_TESTS:
         if "table_layout" not in metafunc.fixturenames:
             metafunc.fixturenames.append("table_layout")
@@ -82,15 +82,13 @@ def deals_per_thread(request, monkeypatch):
 
 @pytest.fixture
 def fan_loop(request, monkeypatch):
-    monkeypatch.setenv("RS_JIT_FAN", {"xr": "1", "fan": "2", "off": "0", "levels": "1"}[request.param])
-    if request.param == "levels":
-        monkeypatch.setenv("RS_JIT_NO_LANE_ROUNDS", "1")
+    from rustsolver_amd import solver
+    monkeypatch.setattr(solver, "DEFAULT_FORMS", {"lane_fan": 2 if request.param == "xr" else 1})   # RS_FAN_EXPAND / RS_FAN_NONE
     return request.param
 
 
 @pytest.fixture
 def table_layout(request, monkeypatch):
     if request.param == "tiled64":
-        monkeypatch.setenv("RS_TABLE_TILE_LANES", "64")
-        monkeypatch.setenv("RS_TABLE_TILE_MIN_LANES", "65")
+        monkeypatch.setenv("RS_TABLE_TILE_LANES", "64")   # every node wider than 64 lanes is tiled in 64-lane tiles
     return request.param

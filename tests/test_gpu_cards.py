@@ -280,8 +280,11 @@ def test_deal_trainer_prune_schedule(streets):
 def test_deal_trainer_three_streets_from_a_flop_with_bucket_files(parts, monkeypatch):
     """flop start (3 board cards), three rounds: EMD-style bucket files on flop and turn, ISOMORPHIC river; narrow ranges so that many
     deals share an info set; all five batches in one train() call"""
-    if not parts:   # the ISOMORPHIC river abstraction has ~40-55 K clusters: partitioned into ~40-54 cluster ranges by default, direct atomics without
-        monkeypatch.setenv("RS_JIT_NO_PARTS", "1")
+    if not parts:   # the ISOMORPHIC river abstraction has ~40-55 K clusters: LDS tiles over ~40-54 cluster ranges with the rows off; with them (the engine's choice for any
+                    # batch that has list walkers) its delta rows go straight into the table
+        monkeypatch.setenv("RS_JIT_ROWS", "1")
+    else:
+        monkeypatch.setenv("RS_JIT_ROWS", "0")
     rng = np.random.Generator(np.random.PCG64(77))
     mask = ab.card_mask("7h8hQc")
     allh = ab.random_range(mask)

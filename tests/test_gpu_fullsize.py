@@ -179,13 +179,12 @@ def test_batched_get_infosets_equals_single_gets():
     for dtype in (rs.I32, rs.F16):
         for tile in (None, "64"):
             if tile:
-                os.environ["RS_TABLE_TILE_LANES"], os.environ["RS_TABLE_TILE_MIN_LANES"] = tile, "65"
+                os.environ["RS_TABLE_TILE_LANES"] = tile
             try:
                 n, tree = rs.build_game_tree(rs.default_flop())
                 table = rs.create_infosets(n, tree, [50], [3], dtype)
             finally:
                 os.environ.pop("RS_TABLE_TILE_LANES", None)
-                os.environ.pop("RS_TABLE_TILE_MIN_LANES", None)
             rng = np.random.Generator(np.random.PCG64(3))
             nd = tree.action_nodes()[1]
             lanes = table.lanes(nd.index)
@@ -359,8 +358,8 @@ def test_three_street_trainer_kernel_forms_agree_at_size(monkeypatch):
     n_actions, tree = rs.build_game_tree(rs.three_street_options())
     card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
     sums = {}
-    for form, env in (("tiles", {"RS_JIT_ROWS": "0", "RS_JIT_NO_SIBLINGS": "1", "RS_JIT_NO_SIGMA": "1"}), ("engine", {})):
-        for k in ("RS_JIT_ROWS", "RS_JIT_NO_SIBLINGS", "RS_JIT_NO_SIGMA"):
+    for form, env in (("tiles", {"RS_JIT_ROWS": "0", "RS_JIT_ORDERED": "0", "RS_JIT_NO_SIBLINGS": "1", "RS_JIT_NO_STAGE": "1"}), ("engine", {})):
+        for k in ("RS_JIT_ROWS", "RS_JIT_ORDERED", "RS_JIT_NO_SIBLINGS", "RS_JIT_NO_STAGE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -516,13 +516,11 @@ def test_deal_batches_large_cluster_counts(sizes, lds_max, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("blocks,resident", [("1", True), ("2", True), ("1", False)])
-def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
+@pytest.mark.parametrize("blocks", ["1", "2"])
+def test_deal_batches_many_trips_per_workgroup(blocks, monkeypatch):
     """resident LDS tiles hold the sums of ALL trips of a workgroup and are flushed once at the end: force 1-2 workgroups over 7 000
-    deals (4+ trips of 2 048 deals, the last one partial) and compare with the oracle; also with resident tiles switched off"""
+    deals (4+ trips of 2 048 deals, the last one partial) and compare with the oracle"""
     monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
-    if not resident:
-        monkeypatch.setenv("RS_JIT_NO_RESIDENT", "1")
     n_deals = 7000
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.default_flop(), orc.options_default_river(), [(1081, 700)], n_deals, 78)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=3)
@@ -537,35 +535,36 @@ def test_deal_batches_many_trips_per_workgroup(blocks, resident, monkeypatch):
 
 
 @pytest.mark.parametrize("blocks", [None, "2"])
-@pytest.mark.parametrize("sparse", [True, "unpacked", "ordered", "scan-parent", "scan-parent-siblings", "siblings", "rows", "no-handoff", False, "no-rounds", "no-rounds-no-sparse"])
+@pytest.mark.parametrize("sparse", [True, "ordered", "scan-parent", "scan-parent-siblings", "siblings", "rows", "gathers", "rows+ordered"])
 def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypatch):
     """sampled three-street sweeps over 30 000 deals: every river subtree walks only the compacted list of its live deals (several trips per
     workgroup when the grid is capped); with the lists switched off (RS_JIT_NO_SPARSE) every lane is walked and masked; with RS_JIT_NO_ROUNDS the flop and
     turn rounds run as level kernels again.  The knobs are read when a solver is created.  Same bits, and equal to the oracle."""
-    if blocks and sparse not in (True, "ordered", "rows", False):
-        pytest.skip("several trips per workgroup: run on the list walkers, the ordered / rows / sibling forms and the dense form")
+    if blocks and sparse not in (True, "ordered", "rows", "rows+ordered"):
+        pytest.skip("several trips per workgroup: run on the list walkers with tiles, rows and runs")
     if blocks:
         monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
-    if sparse is False or sparse == "no-rounds-no-sparse":
-        monkeypatch.setenv("RS_JIT_NO_SPARSE", "1")
-    if sparse == "unpacked":      # the per-deal inputs through four separate gathers instead of the packed 16-byte record (the form solvers with several leaf buffers get)
-        monkeypatch.setenv("RS_JIT_NO_PACK", "1")
-    elif sparse in ("scan-parent", "scan-parent-siblings"):   # the compaction of a root's live deals walks its parent's lists (what batches beyond 64 K deals get) instead of the whole batch
+    if sparse in ("scan-parent", "scan-parent-siblings"):   # the compaction of a root's live deals walks its parent's lists (what batches beyond 64 K deals get) instead of the whole batch
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
         if "siblings" in sparse:   # what batches beyond 512 K deals get: one compaction job per parent (k_compact_siblings) instead of one per root (k_compact_live)
             monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
     elif sparse == "siblings":    # ... the whole batch scanned once per 16 roots
         monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
-    elif sparse == "no-handoff":  # the walks draw the opponent's actions themselves instead of reading what the reach-down kernels handed over
-        monkeypatch.setenv("RS_JIT_NO_HANDOFF", "1")
     elif sparse == "rows":        # what batches beyond 512 K deals get: the list walkers store delta rows, summed per round (rs_kernel_forms.delta_rows), sibling compaction
         monkeypatch.setenv("RS_JIT_ROWS", "1")
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
         monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
-    elif sparse == "ordered":     # the batch walked in the order of the traverser's river cluster, river deltas summed by wave segments (what big batches get: rs_kernel_forms.deal_order)
+    elif sparse == "ordered":     # the batch walked in the order of the traverser's river cluster, river deltas summed along the runs (rs_kernel_forms.deal_order), tiles on flop / turn
         monkeypatch.setenv("RS_JIT_ORDERED", "1")
-    elif isinstance(sparse, str):   # the level plan for flop / turn and chance-free river subtrees, as before the round subtrees
-        monkeypatch.setenv("RS_JIT_NO_ROUNDS", "1")
+    elif sparse == "rows+ordered":   # what batches beyond 48 K deals get: delta rows on flop / turn lists, runs on the river, staged rows, parent-list compaction
+        monkeypatch.setenv("RS_JIT_ROWS", "1")
+        monkeypatch.setenv("RS_JIT_ORDERED", "1")
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    elif sparse == "gathers":     # the same with the list walkers gathering a record per node instead of staging their deals' rows in LDS (the fallback for rows beyond 256 bytes)
+        monkeypatch.setenv("RS_JIT_ROWS", "1")
+        monkeypatch.setenv("RS_JIT_ORDERED", "1")
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+        monkeypatch.setenv("RS_JIT_NO_STAGE", "1")
     n_deals = 30000
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (11, 8), (13, 17)], n_deals, 91)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=12)
@@ -579,7 +578,7 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("rows", ["list-position", "deal-id", "whole-batch-scan", "many-ranges"])
+@pytest.mark.parametrize("rows", ["list-position", "whole-batch-scan", "many-ranges"])
 def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
     """What batches beyond 256 K deals get, forced onto a small one: LDS capped so that EVERY round subtree (the first included) is cut into cluster ranges,
     the compaction of a root's live deals scans its parent's per-range lists, and -- "list-position" -- the parent's reach-down kernel writes the reach rows
@@ -590,8 +589,6 @@ def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
     monkeypatch.setenv("RS_JIT_LDS_MAX", "8256" if rows == "many-ranges" else "16384")
     if rows != "whole-batch-scan":
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
-    if rows == "deal-id":
-        monkeypatch.setenv("RS_JIT_NO_POSROWS", "1")
     n_deals = 30011
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(300, 280), (500, 450), (700, 650)], n_deals, 92)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=13)
@@ -661,12 +658,9 @@ def test_wide_nodes_in_deal_batches(fuse, sampled):
 
 @pytest.mark.parametrize("seed", range(32))
 def test_randomised_differential(seed, monkeypatch):
-    """random game options x engine modes, GPU vs oracle, bit for bit.  The form of the subtrees below ENUM chance nodes (rs_kernel_forms.lane_fan; conftest's fan_loop
-    fixture for the other lane tests) goes round with the seed."""
-    form = ["xr", "fan", "off", "levels"][seed % 4]
-    monkeypatch.setenv("RS_JIT_FAN", {"xr": "1", "fan": "2", "off": "0", "levels": "1"}[form])
-    if form == "levels":
-        monkeypatch.setenv("RS_JIT_NO_LANE_ROUNDS", "1")
+    """random game options x engine modes, GPU vs oracle, bit for bit.  The form of the subtrees below ENUM chance nodes (rs_kernel_forms.lane_fan: the expand step inside
+    the subtree kernel, or expand / reduce launches of their own; conftest's fan_loop fixture for the other lane tests) alternates with the seed."""
+    lane_fan = [rs.FAN_EXPAND, rs.FAN_NONE][seed % 2]
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     nb = int(rng.choice([5, 5, 4, 3]))
     rounds = 6 - nb
@@ -690,7 +684,7 @@ def test_randomised_differential(seed, monkeypatch):
         sizes = [(int(rng.integers(3, 40)), int(rng.integers(3, 40))) for _ in range(rounds)]
         n_deals = int(rng.integers(70, 600))
         tree, table, otree, otab, lg, lo, cidx = setup_deals(og, oo, sizes, n_deals, 5000 + seed)
-        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, fuse_subtrees=fuse, deals=cidx, use_graph=graph,
+        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, fuse_subtrees=fuse, deals=cidx, use_graph=graph, forms={"lane_fan": lane_fan},
                              opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
         osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=scale, mode=mo, prune=prune,
                                     opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=seed)
@@ -705,7 +699,7 @@ def test_randomised_differential(seed, monkeypatch):
                 boards.append(boards[-1] * int(rng.integers(1, 4)))
             cm_g, cm_o = rs.CHANCE_ENUM, orc.CHANCE_ENUM
         tree, table, otree, otab, lg, lo = setup_pair(og, oo, boards, C, 6000 + seed)
-        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, chance_mode=cm_g, fuse_subtrees=fuse, use_graph=graph,
+        tr = rs.MCCFRTrainer(tree, table, lg, scale=scale, mode=mgf, chance_mode=cm_g, fuse_subtrees=fuse, use_graph=graph, forms={"lane_fan": lane_fan},
                              opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=seed)
         osol = orc.OracleSolver(otree, otab, lo, scale=scale, mode=mo, prune=prune, chance_mode=cm_o,
                                 opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=seed)
@@ -909,7 +903,6 @@ def test_checkpoint_roundtrip(tmp_path, table_layout, monkeypatch):
                 m.setenv("RS_TABLE_TILE_LANES", "0")
             else:
                 m.setenv("RS_TABLE_TILE_LANES", "64")
-                m.setenv("RS_TABLE_TILE_MIN_LANES", "65")
             loads.append(rs.InfosetTable.load(path))
             other_tiled = sum(loads[1].tile_lanes(nd.index) != loads[1].pitch(nd.index) for nd in tree.action_nodes() if nd.n_children)
             assert (other_tiled > 0) == (table_layout != "tiled64")
@@ -1096,21 +1089,19 @@ def test_ordered_deal_sweeps_vs_oracle(variant, sizes, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("variant", ["river", "river-full-width", "river+graph+prune-per-deal", "three-street", "three-street+prune-per-deal", "three-street-wrap",
-                                     "three-street-full-width", "three-street-big-river", "three-street-big-river-tiles", "three-street-big-river+prune-per-deal-lists-only",
-                                     "three-street-scan-parent-lists-only", "three-street+prune-per-deal-lists-only"])
+@pytest.mark.parametrize("variant", ["three-street", "three-street+graph+prune-per-deal", "three-street-wrap", "three-street-big-river", "three-street-big-river-tiles",
+                                     "three-street-big-river+prune-per-deal", "three-street-scan-parent"])
 def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
-    """rs_kernel_forms.delta_rows (forced through its test override): no delta tiles, no atomics inside the walk -- a visit stores its two delta vectors at the deal's
-    list position ([2A][batch pitch] rows per traverser node), and k_row_sums adds every row up per cluster after the walks (a few hundred positions per workgroup here, so
-    that rows are cut into many chunks).  Dense walks (the first round; every round with a full-width opponent) index the rows by deal id.  "big-river": the river's
+    """rs_kernel_forms.delta_rows (forced through its test override onto a small batch): no delta tiles, no atomics inside the list walkers -- a visit stores its two delta
+    vectors at the deal's list position ([2A][batch pitch] rows per traverser node), and k_row_sums adds every row up per cluster after the walks (a few hundred positions per
+    workgroup here, so that rows are cut into many chunks); the first round's dense walk keeps its LDS tiles.  "big-river": the river's
     20 000 clusters exceed the summing pass's tile: its rows are added straight into the table once the river's walks are done (k_row_apply, rs_kernel_forms.direct_rows: what the
-    lossless abstractions of solve_three_street get) -- "-tiles": direct rows off, that round keeps its tiles while flop and turn store rows.  "lists-only": what rs_kernel_forms.delta_rows = RS_FORM_ON
-    gives -- the list walkers store rows, the first round's dense walk keeps its LDS tiles.  Same bits as the oracle."""
-    monkeypatch.setenv("RS_JIT_ROWS", "1" if "lists-only" in variant else "2")
+    lossless abstractions of solve_three_street get) -- "-tiles": direct rows off, that round keeps its tiles while the turn stores rows.  Same bits as the oracle."""
+    monkeypatch.setenv("RS_JIT_ROWS", "1")
     monkeypatch.setenv("RS_JIT_ROWS_CHUNK", "1000")
     if variant.endswith("-tiles"):
         monkeypatch.setenv("RS_JIT_DIRECT_ROWS", "0")
-    three, prune, full = variant.startswith("three"), "prune" in variant, "full-width" in variant
+    three, prune, full = True, "prune" in variant, False
     if "scan-parent" in variant:
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
     n_deals = (3001 if full else 20011) if three else 30005
@@ -1249,21 +1240,18 @@ def test_c_examples_run_through_the_c_abi(tmp_path):
     assert float(re.search(r"exploitability (-?[\d.]+)", r.stdout).group(1)) < 20.0, r.stdout
 
 
-@pytest.mark.parametrize("shadow", ["rule-mixed", "all", "all-regrets"])
+@pytest.mark.parametrize("shadow", ["rule-mixed", "all"])
 def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
     """sampled sweeps read a node through its AoS shadow (rebuilt per sweep) only where the batch is likely to read the record at all (rs_solver.cpp: n_deals * 8 >= clusters *
     actions * round subtrees); elsewhere the kernels gather the table's own rows (gather_node / gather_node2 with a null shadow).  3 000 deals against 30 / 300 / 140 clusters:
     every flop and turn node keeps its shadow, on the river the two-action nodes keep theirs (140 * 2 * 72 < 24 000) and the three-action nodes lose it -- both kinds inside
-    ONE generated subtree.  "all" (RS_SHADOW_ALL) shadows everything.  An OPPONENT node's shadow record holds its strategy (matched once per sweep by k_build_shadow, sampled
-    from as it comes); "all-regrets" (RS_JIT_NO_SIGMA) keeps regrets there and matches them in the walk, as nodes without a shadow do.  Same bits as the oracle every way, and the
-    workspace figure shows the difference."""
-    if shadow.startswith("all"):
-        monkeypatch.setenv("RS_JIT_SHADOW_ALL", "1")
-    if shadow == "all-regrets":
-        monkeypatch.setenv("RS_JIT_NO_SIGMA", "1")
+    ONE generated subtree.  "all" (rs_kernel_forms.shadow = RS_SHADOW_ALL) shadows everything.  An OPPONENT node's shadow record holds its strategy (matched once per sweep by
+    k_build_shadow, sampled from as it comes); a node without a shadow has its regrets matched in the walk.  Same bits as the oracle every way, and the workspace figure shows the
+    difference."""
     n_deals = 3000
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(30, 28), (300, 280), (140, 140)], n_deals, 93)
-    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=14)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=14,
+                         forms={"shadow": rs.SHADOW_ALL} if shadow == "all" else None)
     osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=True, opp_mode=orc.OPP_SAMPLE, base_seed=14)
     test_deal_sweeps_with_and_without_table_shadows.workspace[shadow] = tr.workspace_bytes
     for it in range(2):

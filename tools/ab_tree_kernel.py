@@ -3,7 +3,7 @@
 from interleaved rounds in ONE process).  Variants are selected through the RS_JIT_* environment variables that
 rs_jit.cpp reads at solver creation; all trainers share one table, so every variant streams the same bytes.
 
-    python tools/ab_tree_kernel.py "RS_JIT_DISTANCE=0" "RS_JIT_DISTANCE=5" "RS_JIT_DISTANCE=8" --rounds 7
+    python tools/ab_tree_kernel.py "" "RS_TABLE_TILE_LANES=0" "FUSE=0" --rounds 7
 """
 import argparse
 import os

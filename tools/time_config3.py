@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Times BASELINE configs[2] (706-node flop+turn+river tree, 5 000 clusters, boards 1/49/2 352, i32, ENUM chance) under the knobs of the environment --
-one setting per process: RS_JIT_FAN (0 / 1 / 2), RS_LANE_OVERLAP (0 / 1), RS_TABLE_TILE_LANES ...
+one setting per process: RS_TABLE_TILE_LANES, DTYPE, BOARDS ...
 
-    TAG=fan1 RS_JIT_FAN=1 python tools/time_config3.py
+    TAG=untiled RS_TABLE_TILE_LANES=0 python tools/time_config3.py
 BOARDS=1,24,1152 emulates the per-rank share of a 2-GPU run (49 turn boards over 2 ranks).
 """
 import importlib.util

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the device trainer on the reference's as-coded game (options::default_flop(): board 4d5dAs3cKs, random ranges, ISOMORPHIC river).
-Knobs are read once per process (RS_JIT_DISTANCE, RS_JIT_THREADS, RS_JIT_NO_RESIDENT, ...): run one setting per process.
+Knobs are read when a solver is created (RS_JIT_LANES, RS_JIT_MAX_BLOCKS, ...): run one setting per process.
 
     TAG=default python tools/time_deal_trainer.py
 """

@@ -3,7 +3,7 @@
 "real" configuration (options.rs:68-77 commented vectors), sampled mccfr.  DESIGN.md section 8 quotes its output.
 
     python tools/time_three_street.py            # K=5000 N=1048576 by default (environment variables K, N)
-    RS_JIT_NO_ROUNDS=1 / RS_JIT_NO_SPARSE=1 python tools/time_three_street.py   # the earlier forms, for comparison (one setting per process)
+    RS_JIT_ROWS=0 RS_JIT_ORDERED=0 / RS_JIT_NO_STAGE=1 python tools/time_three_street.py   # the earlier forms, for comparison (one setting per process)
 """
 import os
 import sys
