@@ -204,11 +204,12 @@ __device__ __forceinline__ void gather_rec_half(const RS_GLOBAL int *rec, int (&
 // traverser's sweep reads).  `stride` (ints between two clusters' records of one node) is the ROW of the node's round subtree and role: a deal addresses every traverser node
 // of a round subtree with ONE cluster id and every opponent node with another, so the records of all those nodes sit side by side, one row per cluster
 // (rs_solver.cpp setup_table_shadow) -- the 7 gathers a river walk makes at its own nodes land in two cache lines instead of seven
+// (idx * stride in 32 bits: setup_table_shadow keeps no shadow of 2^32 ints)
 template <int A>
 __device__ __forceinline__ void gather_rec(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], int (&r)[A][kVecD]) {   // regrets only
     const RS_GLOBAL int *p = as_global<int>((const int *)shadow);
 #pragma unroll
-    for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)idx[j] * stride, r, j);
+    for (int j = 0; j < kVecD; j++) gather_rec_half<A>(p + (size_t)(idx[j] * stride), r, j);
 }
 template <int A>
 __device__ __forceinline__ void gather_rec2(const void *shadow, unsigned stride, const unsigned (&idx)[kVecD], int (&r)[A][kVecD], int (&s)[A][kVecD]) {
@@ -217,13 +218,13 @@ __device__ __forceinline__ void gather_rec2(const void *shadow, unsigned stride,
 #pragma unroll
     for (int j = 0; j < kVecD; j++) {
         if constexpr (A <= 2) {   // one 16-byte record {r0, r1, s0, s1}
-            const i32x4 w = *reinterpret_cast<const RS_GLOBAL i32x4 *>(p + (size_t)idx[j] * stride);
+            const i32x4 w = *reinterpret_cast<const RS_GLOBAL i32x4 *>(p + (size_t)(idx[j] * stride));
             r[0][j] = w.x;
             s[0][j] = w.z;
             if (A > 1) { r[1 < A ? 1 : 0][j] = w.y; s[1 < A ? 1 : 0][j] = w.w; }
         } else {
-            gather_rec_half<A>(p + (size_t)idx[j] * stride, r, j);
-            gather_rec_half<A>(p + (size_t)idx[j] * stride + H, s, j);
+            gather_rec_half<A>(p + (size_t)(idx[j] * stride), r, j);
+            gather_rec_half<A>(p + (size_t)(idx[j] * stride) + H, s, j);
         }
     }
 }

@@ -419,7 +419,8 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             const rs_tree_node &qn = nodes[q];
             if (qn.kind == RS_NODE_ACTION && qn.n_children > 0) {
                 const size_t ti = size_t(qn.index);
-                if (s->shadow_off_p[p][ti] == SIZE_MAX || s->shadow_stride_p[p][ti] % 4) all = false;
+                const int32_t *base = s->shadow_off_p[p][ti] == SIZE_MAX ? nullptr : s->d_shadow + (s->shadow_off_p[p][ti] - s->shadow_rowoff_p[p][ti]);
+                if (!base || s->shadow_stride_p[p][ti] % 4 || (stage_rows_of[qn.player] && stage_rows_of[qn.player] != base)) all = false;   // one row per player, or none
                 else {
                     stage.ch[qn.player] = int(s->shadow_stride_p[p][ti] / 4);
                     stage.chp[qn.player] = stage.ch[qn.player];   // rows back to back in LDS: one address register for all of the wave's stores

@@ -27,7 +27,7 @@ uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, st
             off[i] = at;
             at += r;
         }
-    return uint32_t(round_up(size_t(at), 4));
+    return k == 1 ? at : uint32_t(round_up(size_t(at), 4));   // a node on its own (dense walks, rs_solver.cpp setup_table_shadow): records back to back
 }
 
 bool rows_round_ok(const rs_solver *s, int p, int round) {

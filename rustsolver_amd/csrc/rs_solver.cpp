@@ -325,8 +325,10 @@ static int setup_table_shadow(rs_solver *s) {
         // node gets a shadow only while n_deals / roots * 8 >= its cells -- 64 K deals against 180 234 river clusters (lossless abstraction, 2 GB table) spent 0.9 ms per
         // sweep transposing records nobody read.  Without one the kernels gather the table's own rows (rs_device.hpp gather_node).  RS_JIT_SHADOW_ALL keeps every shadow.
         std::vector<size_t> round_roots(size_t(s->n_rounds) + 1, 0);
+        int first_round = -1;
         {
             const int first = [&] { int c = 0; while (tree->nodes[size_t(c)].kind == RS_NODE_PRIVATE_CHANCE || tree->nodes[size_t(c)].kind == RS_NODE_PUBLIC_CHANCE) c = tree->nodes[size_t(c)].children[0]; return c; }();
+            if (tree->nodes[size_t(first)].kind == RS_NODE_ACTION) first_round = int(tree->nodes[size_t(first)].round_idx);
             if (tree->nodes[size_t(first)].kind == RS_NODE_ACTION) round_roots[size_t(std::min<int>(tree->nodes[size_t(first)].round_idx, s->n_rounds))] += 1;
             for (size_t i = 1; i < n; ++i)
                 if (tree->nodes[i].kind == RS_NODE_PUBLIC_CHANCE && tree->nodes[i].n_children > 0) {
@@ -338,7 +340,10 @@ static int setup_table_shadow(rs_solver *s) {
         // Rows.  A deal addresses every node of one player inside a round subtree with the SAME cluster id (get_cluster depends on round and player only, cfr.rs:361-365), so the
         // records of those nodes sit side by side: one ROW per cluster, per (round subtree, player).  A walk's gathers at its own nodes then land in the row's two or three cache
         // lines instead of one line per node (a river subtree: 7 own nodes, 192 bytes; 7 opponent nodes, 96 bytes).  comp_root: the topmost action node reached from a node
-        // without crossing a chance node.
+        // without crossing a chance node.  Only where the rows get STAGED (the list walkers of a sampled sweep's later rounds): a dense walk -- the first round, every deal
+        // at every node at about the same time -- is better off with one array per node, whose few KB stay in L1 while all the CU's waves are at that node (the as-coded river
+        // game, 4 M deals per batch: 0.64 ms with node arrays, 0.77 ms with rows).
+        const bool staged_rows = s->params.opp_mode == RS_OPP_SAMPLE && !s->knobs.no_stage;
         std::vector<int> comp_root(n, -1), tree_of(table->nodes.size(), -1);
         for (size_t id = 0; id < n; ++id) {
             const rs_tree_node &nd = tree->nodes[id];
@@ -359,7 +364,7 @@ static int setup_table_shadow(rs_solver *s) {
                 if (d.n_actions == 0) continue;
                 const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
                 if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
-                groups[{tree_of[i] >= 0 ? comp_root[size_t(tree_of[i])] : -1 - int(i), int(d.player)}].push_back(i);
+                groups[{tree_of[i] >= 0 && staged_rows && int(d.round_idx) != first_round ? comp_root[size_t(tree_of[i])] : -1 - int(i), int(d.player)}].push_back(i);
             }
             for (auto &kv : groups) {
                 std::vector<size_t> &mem = kv.second;
@@ -370,6 +375,7 @@ static int setup_table_shadow(rs_solver *s) {
                     n_cl = std::max(n_cl, table->nodes[i].n_clusters);
                 }
                 const bool wide = kv.first.second == tp;
+                if (size_t(n_cl) * shadow_row_layout(acts, true, recs, offs) >= (size_t(1) << 32)) continue;   // the kernels address a record with 32-bit arithmetic: no shadow (either sweep)
                 const uint32_t row = shadow_row_layout(acts, wide, recs, offs);
                 for (size_t m = 0; m < mem.size(); ++m) {
                     const size_t i = mem[m];
