@@ -18,11 +18,13 @@ uint32_t shadow_row_layout(const std::vector<uint32_t> &n_actions, bool wide, st
     rec.assign(k, 0);
     off.assign(k, 0);
     uint32_t at = 0;
-    for (int pass = 0; pass < 2; ++pass)   // 16-byte loads want 16-byte aligned records: those of 4 ints and more first, the 8-byte ones at the end of the row
+    // records by size, the largest first (sizes are powers of two: 2 .. 16 ints): every record starts at a multiple of its size -- 16-byte loads find 16-byte aligned records,
+    // and a row can be cut into parts at any multiple of 16 ints that is not inside a record of 16 (rs_jit.cpp, the staged rows of the traverser go through LDS in parts)
+    for (uint32_t size = 16; size >= 2; size /= 2)
         for (size_t i = 0; i < k; ++i) {
             const uint32_t half = n_actions[i] <= 2 ? 2 : (n_actions[i] <= 4 ? 4 : 8);   // rs_device.hpp shadow_half<A>()
             const uint32_t r = wide ? 2 * half : half;
-            if ((r >= 4) != (pass == 0)) continue;
+            if (r != size) continue;
             rec[i] = r;
             off[i] = at;
             at += r;
