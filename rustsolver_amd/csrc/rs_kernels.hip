@@ -309,17 +309,20 @@ __global__ __launch_bounds__(kBlock) void k_chance_expand(const ChanceJob *__res
 // bottom-up: util = 0 + u_0 + u_1 + ... in deal order (util.store(util.load() + u), cfr.rs:519)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_chance_reduce(const ChanceJob *__restrict__ jobs) {
-    const ChanceJob job = jobs[blockIdx.y];
-    const uint32_t C = job.n_clusters, fan = job.fan;
-    const uint32_t n_par = job.n_parent_lanes / VEC;
+    // the scalar fields by value; shard_lo[] stays where it is (a uniform address: scalar loads) -- a by-value copy of the whole descriptor put the array, which `row` indexes
+    // with a loop variable, in scratch: 100 bytes of scratch stores per thread in front of the 64 bytes it is there to write (PMC write bytes 2.4x the algorithmic ones)
+    struct { const float *src; float *dst; uint32_t shard_world, rank_stride; } job = {jobs[blockIdx.y].src, jobs[blockIdx.y].dst, jobs[blockIdx.y].shard_world, jobs[blockIdx.y].rank_stride};
+    const uint32_t *__restrict__ shard_lo = jobs[blockIdx.y].shard_lo;
+    const uint32_t C = jobs[blockIdx.y].n_clusters, fan = jobs[blockIdx.y].fan;
+    const uint32_t n_par = jobs[blockIdx.y].n_parent_lanes / VEC;
     // row of deal d: contiguous [boards][C], or, when the child round is sharded, inside the owning rank's slot
     auto row = [&](uint32_t l, uint32_t d) -> const float * {
         const uint32_t b = l / C, c = l - b * C;
         const uint32_t gb = b * fan + d;
         if (job.shard_world == 0) return job.src + (size_t)gb * C + c;
         uint32_t g = 0;
-        while (g + 1 < job.shard_world && gb >= job.shard_lo[g + 1]) ++g;
-        return job.src + (size_t)g * job.rank_stride + (size_t)(gb - job.shard_lo[g]) * C + c;
+        while (g + 1 < job.shard_world && gb >= shard_lo[g + 1]) ++g;
+        return job.src + (size_t)g * job.rank_stride + (size_t)(gb - shard_lo[g]) * C + c;
     };
     if constexpr (VEC == 4) {
         // A board's row of C floats starts wherever C puts it (5 000 floats: 32 bytes off a cache line), so the 1 KB window a wave reads per load touches nine lines, the first and
