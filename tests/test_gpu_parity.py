@@ -578,6 +578,47 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_staged_rows_random_trees(seed, monkeypatch):
+    """The forms big batches get (delta rows, ordered sweeps with runs, staged shadow rows) on RANDOM two- and three-round trees: node records of 8 / 16 / 32 / 64 bytes in one
+    row, rows that go through LDS in one part and in two (rs_device.hpp stage_rows / stage_rows_two, cut where the emitter finds a record boundary), rows beyond 16 chunks (no
+    staging: gathers), pruned deals.  Same bits as the oracle."""
+    monkeypatch.setenv("RS_JIT_ROWS", "1")
+    monkeypatch.setenv("RS_JIT_ORDERED", "1")
+    monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    nb = int(rng.choice([4, 3]))
+    rounds = 6 - nb
+    pool = [0.33, 0.5, 0.75, 1.0, 2.0]
+    bets = [sorted(rng.choice(pool, size=int(rng.integers(1, 4 if r else 3)), replace=False).tolist()) for r in range(rounds)]
+    raises = [sorted(rng.choice([2.0, 3.0], size=int(rng.integers(1, 3)), replace=False).tolist()) for _ in range(rounds)]
+    stacks, pot = (int(rng.integers(150, 900)), int(rng.integers(150, 900))), int(rng.integers(10, 80))
+    if seed == 0:     # five-action nodes on the second round: 8-int and 16-int records beside the 4-int ones
+        nb, rounds, bets, raises, stacks, pot = 4, 2, [[1.0], [0.33, 0.5, 1.0, 2.0]], [[3.0], [2.0, 3.0]], (400, 400), 40
+    elif seed == 1:   # six-action nodes (32 / 64-byte records)
+        nb, rounds, bets, raises, stacks, pot = 4, 2, [[0.5], [0.25, 0.5, 1.0, 2.0]], [[3.0], [2.0, 2.5, 3.0, 4.0]], (2000, 2000), 20
+    og, oo = rs.Options(stacks, pot, nb, bets, raises), orc.make_options(stacks, pot, nb, bets, raises)
+    _, probe = rs.build_game_tree(og)
+    if any(nd.n_children == 0 for nd in probe.action_nodes()):
+        pytest.skip("a node without valid actions makes mccfr panic (WeightedIndex::new(&[]).unwrap())")
+    sizes = [(int(rng.integers(5, 60)), int(rng.integers(5, 60))) for _ in range(rounds)]
+    n_deals = int(rng.integers(3000, 9000))
+    prune = bool(seed % 2)
+    flags = (rng.integers(0, 3, n_deals) == 0).astype(np.uint8) if prune else None
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(og, oo, sizes, n_deals, 7100 + seed)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | (rs.UPD_PRUNE if prune else 0), fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=seed,
+                         prune_deal=flags)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, prune=prune, prune_deal=flags, opp_mode=orc.OPP_SAMPLE, base_seed=seed)
+    tag = dict(nb=nb, bets=bets, raises=raises, stacks=stacks, pot=pot, sizes=sizes, n_deals=n_deals, prune=prune)
+    for it in range(2):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d %r" % (it, player, tag))
+    for nd in tree.action_nodes():
+        r, s = table.download_node(nd.index)
+        ro, so = otab.get_node(nd.index)
+        assert (r == ro).all() and (s == so).all(), "table differs at node %d: %r" % (nd.index, tag)
+
+
 @pytest.mark.parametrize("rows", ["list-position", "whole-batch-scan", "many-ranges"])
 def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
     """What batches beyond 256 K deals get, forced onto a small one: LDS capped so that EVERY round subtree (the first included) is cut into cluster ranges,
