@@ -59,7 +59,7 @@ class DealBatch(C.Structure):
 
 
 class KernelForms(C.Structure):   # rs_kernel_forms: every field 0 = the engine's own choice
-    _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("reserved0", C.c_int32), ("shadow", C.c_int32),
+    _fields_ = [("lane_fan", C.c_int32), ("deals_per_thread", C.c_int32), ("kept_records", C.c_int32), ("shadow", C.c_int32),
                 ("deal_order", C.c_int32), ("delta_rows", C.c_int32), ("direct_rows", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 

@@ -200,6 +200,7 @@ int rs_allreduce_replicated(rs_table *t, rs_comm *c, uint32_t round_mask) {
     if (!t || !c) return fail(RS_ERR_INVALID, "rs_allreduce_replicated: NULL argument");
     if (t->rep_mask != round_mask || t->rep_nodes.empty())
         return fail(RS_ERR_INVALID, "rs_allreduce_replicated: call rs_replicated_begin with the same round_mask first");
+    ++t->epoch;
     Rccl *r = rccl();
     if (!r) return fail(RS_ERR_COMM, "rs_allreduce_replicated: librccl.so could not be loaded");
     hipError_t e = hipSetDevice(t->device);

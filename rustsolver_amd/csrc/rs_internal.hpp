@@ -202,7 +202,16 @@ struct RowSumJob {
     const uint32_t *count;     // device count of list entries, or null: n_const
     int32_t *dst;              // [n_rows][tpitch] inside the delta table
     uint32_t n_rows, pitch, tpitch, n_clusters, n_const, direct;   // direct: dst is the TABLE's own rows of the node (k_row_apply: no LDS tile, any cluster count)
+    int32_t *mirror;           // direct: the node's KEPT shadow records (this array's half of them), which take the same additions as the table -- or null
+    const uint32_t *primary;   // ... and ONLY they while *primary != 0 (the working copy of a training loop: rs_solver.cpp solver_kept_primary)
+    uint32_t mstride, pad_;    // ints between two clusters' records there
 };
+struct DiscountJob {
+    void *regrets, *ssum;
+    size_t n_vec;
+};
+hipError_t launch_discount_jobs(const DiscountJob *d_jobs, int n_jobs, size_t max_vec, float d, int dtype, hipStream_t stream);
+hipError_t launch_unbuild_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
 hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream);
 hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream);
 constexpr uint32_t kRowSumMaxCells = 16384;   // ints of one job's LDS tile (64 KiB: two workgroups per CU)
@@ -246,6 +255,7 @@ struct Knobs {
     int fan = kUnset;               // rs_kernel_forms.lane_fan: 0 none / 1 the expand step inside the subtree kernel
     int lanes = kUnset;             // RS_JIT_LANES / deals_per_thread: 1 / 2 / 4
     int shadow_all = 0;             // rs_kernel_forms.shadow = RS_SHADOW_ALL
+    int no_kept = 0;                // rs_kernel_forms.kept_records = RS_FORM_OFF
     int ordered = kUnset;           // RS_JIT_ORDERED / deal_order: 1 on / 0 off
     int rows = kUnset;              // RS_JIT_ROWS / delta_rows: 1 on / 0 off (delta rows by list position + one summing pass per round)
     int direct_rows = kUnset;       // RS_JIT_DIRECT_ROWS / direct_rows: 1 on / 0 off
@@ -373,6 +383,8 @@ struct rs_table {
     void *d_dregrets = nullptr;       // deal batches: delta tables (same layout as the table), zero between sweeps
     void *d_dssum = nullptr;
     std::vector<struct rs_solver *> solvers;   // live solvers built on this table: released before the table goes away
+    uint64_t epoch = 0;                        // counts the calls that wrote regrets / strategy sums (uploads, fills, sweeps, discounts, ...): a deal solver's KEPT shadow
+                                               // records (rs_solver.cpp setup_table_shadow) are rebuilt when the table moved on without them
     void *d_query = nullptr;          // scratch of the single-info-set strategy queries (rs_get_strategy)
     uint32_t *d_err_sink = nullptr;   // error word for card kernels whose caller passed none (rs_deals_sample)
     void *d_km_scratch = nullptr;     // staged k-means centers (rs_kmeans_predict), grow-only
@@ -407,6 +419,12 @@ int deals_sample_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t fir
 int deal_prune_flags_on(rs_table *t, hipStream_t stream, uint64_t seed, uint64_t first_deal, uint64_t prune_threshold, uint32_t n_deals, uint8_t *d_flags);
 int table_copy_node_raw(rs_table *t, int node, int which /* 0 regrets, 1 strategy_sum */, void *host /* [A][lanes], table element type */, int dir /* 0 up, 1 down */);
 void solver_release_device(struct rs_solver *s);   // frees a solver's device state and detaches it from its table
+void solver_table_discounted(struct rs_solver *s, float d, uint64_t epoch_before);   // rs_discount ran on the solver's table: the same sweep over its kept shadow records
+// Training loops (rs_train, rs_deal_trainer_train) make the kept records the WORKING COPY for their duration: on = 1 at the start (records rebuilt if out of step), 0 before
+// returning (the table's rows written back from the records).  While on, nothing but the solver's sweeps and solver_discount_primary may touch the table.
+int solver_kept_primary(struct rs_solver *s, bool on);
+bool solver_is_primary(const struct rs_solver *s);
+int solver_discount_primary(struct rs_solver *s, float d);   // rs_discount while on: the kept records and the table WITHOUT their nodes
 // profiling hooks used around launches
 void prof_begin(rs_table *t, int kind, double bytes);
 void prof_end(rs_table *t);

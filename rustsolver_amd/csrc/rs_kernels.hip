@@ -383,8 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_chance_reduce(const ChanceJob *__res
 
 // ---- discount sweep (cfr.rs:250-261): 16 bytes per cell (2 arrays, read + write) ------------------------------
 template <int DT>
-__global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets, void *__restrict__ ssum, size_t n_vec,
-                                                     float d) {
+__device__ __forceinline__ void discount_body(void *__restrict__ regrets, void *__restrict__ ssum, size_t n_vec, float d) {
     using R = Row<DT>;
     using V = typename R::val;
     constexpr size_t esize = (DT == RS_F16) ? 2 : 4;
@@ -422,6 +421,16 @@ __global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets,
             }
         }
     }
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_discount(void *__restrict__ regrets, void *__restrict__ ssum, size_t n_vec, float d) {
+    discount_body<DT>(regrets, ssum, n_vec, d);
+}
+// the same over a list of stretches (blockIdx.y): the table WITHOUT the nodes whose kept shadow records are the working copy (rs_solver.cpp solver_kept_primary)
+template <int DT>
+__global__ __launch_bounds__(kBlock) void k_discount_jobs(const DiscountJob *__restrict__ jobs, float d) {
+    const DiscountJob j = jobs[blockIdx.y];
+    discount_body<DT>(j.regrets, j.ssum, j.n_vec, d);
 }
 
 // ---- sparse deal sweeps: the deals whose reach into a subtree is not NaN, as an index list.  A workgroup counts the live lanes of its 256
@@ -1027,6 +1036,26 @@ hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max
     hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs, d_seed_state);
     return hipGetLastError();
 }
+// the way back for KEPT wide records ({regrets, strategy sums}, ShadowJob.stride == 2 * half): the table's rows from the records that were the working copy of a training loop
+__global__ __launch_bounds__(kBlock) void k_unbuild_shadow(const ShadowJob *__restrict__ jobs) {
+    const ShadowJob *job = jobs + blockIdx.y;
+    const uint32_t n = job->n_clusters, pitch = job->pitch, A = job->n_actions, half = job->half;
+    int32_t *__restrict__ reg = const_cast<int32_t *>(job->regrets), *__restrict__ ssm = const_cast<int32_t *>(job->ssum);
+    const int32_t *__restrict__ src = job->dst;
+    for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < n; c += gridDim.x * kBlock) {
+        const int32_t *rec = src + (size_t)c * job->row_stride;
+        for (uint32_t a = 0; a < A; ++a) {
+            reg[(size_t)a * pitch + c] = rec[a];
+            ssm[(size_t)a * pitch + c] = rec[half + a];
+        }
+    }
+}
+hipError_t launch_unbuild_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_unbuild_shadow, grid, block, 0, stream, d_jobs);
+    return hipGetLastError();
+}
 hipError_t launch_pack_attr(const PackJob *d_jobs, int n_jobs, uint32_t max_n, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
     dim3 grid(grid_for(max_n), (unsigned)n_jobs), block(kBlock);
@@ -1155,11 +1184,15 @@ __global__ __launch_bounds__(kBlock) void k_row_apply(const RowSumJob *__restric
     const uint32_t n = J.count ? *J.count : J.n_const;
     const __attribute__((address_space(1))) uint32_t *key = (const __attribute__((address_space(1))) uint32_t *)J.key;
     const __attribute__((address_space(1))) int *rows = (const __attribute__((address_space(1))) int *)J.rows;
+    const bool only_records = J.mirror && J.primary && *J.primary != 0;   // inside a training loop the kept records are the working copy: the table's rows follow at its end
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const uint32_t k = key[i];
         for (uint32_t r = 0; r < J.n_rows; ++r) {
             const int d = rows[(size_t)r * J.pitch + i];
-            if (d) __hip_atomic_fetch_add(J.dst + (size_t)r * J.tpitch + k, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d) {
+                if (!only_records) __hip_atomic_fetch_add(J.dst + (size_t)r * J.tpitch + k, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (J.mirror) __hip_atomic_fetch_add(J.mirror + (size_t)(k * J.mstride) + r, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the node's kept shadow record
+            }
         }
     }
 }
@@ -1233,6 +1266,15 @@ hipError_t launch_discount(void *regrets, void *ssum, size_t n_cells, float d, i
     if (dtype == RS_I32) hipLaunchKernelGGL((k_discount<RS_I32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
     else if (dtype == RS_F32) hipLaunchKernelGGL((k_discount<RS_F32>), grid, block, 0, stream, regrets, ssum, n_vec, d);
     else hipLaunchKernelGGL((k_discount<RS_F16>), grid, block, 0, stream, regrets, ssum, n_vec, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_discount_jobs(const DiscountJob *d_jobs, int n_jobs, size_t max_vec, float d, int dtype, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid(grid_for((max_vec + 3) / 4), (unsigned)n_jobs), block(kBlock);
+    if (dtype == RS_I32) hipLaunchKernelGGL((k_discount_jobs<RS_I32>), grid, block, 0, stream, d_jobs, d);
+    else if (dtype == RS_F32) hipLaunchKernelGGL((k_discount_jobs<RS_F32>), grid, block, 0, stream, d_jobs, d);
+    else hipLaunchKernelGGL((k_discount_jobs<RS_F16>), grid, block, 0, stream, d_jobs, d);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ Knobs knobs_resolve(const rs_kernel_forms *forms) {
         else if (forms->delta_rows == RS_FORM_OFF) k.rows = 0;
         if (forms->direct_rows == RS_FORM_ON) k.direct_rows = 1;
         else if (forms->direct_rows == RS_FORM_OFF) k.direct_rows = 0;
+        if (forms->kept_records == RS_FORM_OFF) k.no_kept = 1;
     }
     for (const Entry &e : kEntries) {   // then the test-only overrides
         const char *v = getenv(e.name);

@@ -579,6 +579,12 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                         rj.dst = static_cast<int32_t *>(arr == 0 ? t->regrets_ptr(an.index) : t->ssum_ptr(an.index));
                         rj.n_rows = A;
                         rj.direct = 1;
+                        if (!s->kept_node.empty() && s->kept_node[size_t(an.index)]) {   // the node's kept records take the same additions (rs_solver.cpp setup_table_shadow)
+                            const uint32_t half = A <= 2 ? 2u : (A <= 4 ? 4u : 8u);
+                            rj.mirror = s->d_shadow + s->shadow_off_p[p][size_t(an.index)] + (arr ? half : 0u);
+                            rj.mstride = s->shadow_stride_p[p][size_t(an.index)];
+                            rj.primary = s->d_kept_primary;
+                        }
                         plan.row_jobs.push_back(rj);
                     } else if (A * ncl <= kRowSumMaxCells) {
                         rj.rows = src;

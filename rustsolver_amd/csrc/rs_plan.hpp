@@ -154,6 +154,20 @@ struct rs_solver {
     std::vector<uint32_t> shadow_rec_p[2];      // ints of the node's own record: 2 * half at the sweep's traverser nodes, half at the opponent's
     std::vector<uint32_t> shadow_rowoff_p[2];   // ints from the start of the row to the node's record
     uint32_t shadow_max_clusters = 0;
+    // KEPT records (setup_table_shadow): the nodes of the rounds whose delta rows go straight into the table keep their records between sweeps -- wide records ({regrets,
+    // strategy sums}, no strategies) at the front of d_shadow, shared by both traversers' sweeps, built when the table has moved on without them (rs_table.epoch), and taking
+    // every addition k_row_apply makes to the table and every discount sweep (solver_table_discounted)
+    size_t kept_ints = 0;                 // d_shadow[0 .. kept_ints)
+    ShadowJob *d_kept_jobs = nullptr;
+    int n_kept_jobs = 0;
+    uint32_t kept_max_clusters = 0;
+    uint64_t kept_epoch = ~uint64_t(0);   // the table epoch the kept records are in step with
+    std::vector<char> kept_node;          // per table node
+    uint32_t *d_kept_primary = nullptr;   // device flag k_row_apply reads: the kept records alone take the additions (solver_kept_primary)
+    bool primary = false;
+    rs::DiscountJob *d_disc_jobs = nullptr;   // the table without the kept nodes, as stretches of consecutive nodes
+    int n_disc_jobs = 0;
+    size_t disc_max_vec = 0;
     // sparse deal sweeps fetch the per-deal inputs of a round (both cluster ids, leaf value, prune flag) as ONE packed 16-byte record per live deal
     void *d_attr[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
     PackJob *d_pack_jobs = nullptr;

@@ -182,7 +182,20 @@ int run_range(rs_solver *s, Plan &plan, size_t lo, size_t hi) {
 }
 
 // phase -1: the whole plan; 0: launches before the exchange; 1: after it (sharded sweeps only)
+static int run_plan_inner(rs_solver *s, int p, int phase);
 int run_plan(rs_solver *s, int p, int phase = -1) {
+    rs_table *t = s->table;
+    if (s->n_kept_jobs && s->kept_epoch != t->epoch) {   // the table was written by somebody else since the kept records were last in step with it: transpose them again
+        RS_HIP(launch_build_shadow(s->d_kept_jobs, s->n_kept_jobs, s->kept_max_clusters, t->stream, nullptr), "k_build_shadow (kept records)");
+        s->kept_epoch = t->epoch;
+    }
+    const int rc = run_plan_inner(s, p, phase);
+    const bool in_step = s->n_kept_jobs && s->kept_epoch == t->epoch && rc == RS_OK;
+    ++t->epoch;                                           // a sweep writes the table; its own kept records took the same additions
+    if (in_step) s->kept_epoch = t->epoch;
+    return rc;
+}
+static int run_plan_inner(rs_solver *s, int p, int phase) {
     Plan &plan = s->plan[p];
     rs_table *t = s->table;
     if (phase < 0 && s->params.use_graph && !t->prof.on && !s->sharded && !s->comm) {
@@ -241,6 +254,48 @@ int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_b
 
 }  // extern "C"
 
+void rs::solver_table_discounted(rs_solver *s, float d, uint64_t epoch_before) {
+    if (!s || !s->table || !s->n_kept_jobs || s->kept_epoch != epoch_before) return;   // nothing kept, or already out of step (rebuilt at the next sweep)
+    rs_table *t = s->table;
+    // the kept region is whole groups of 64 ints, padding zero: its two halves as the two arrays of one discount sweep
+    if (launch_discount(s->d_shadow, s->d_shadow + s->kept_ints / 2, s->kept_ints / 2, d, RS_I32, t->stream) == hipSuccess) s->kept_epoch = t->epoch;
+}
+
+bool rs::solver_is_primary(const rs_solver *s) { return s && s->table && s->primary; }
+
+int rs::solver_kept_primary(rs_solver *s, bool on) {
+    if (!s || !s->table || !s->n_kept_jobs || s->primary == on) return RS_OK;
+    rs_table *t = s->table;
+    RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    if (on) {
+        for (rs_solver *o : t->solvers)
+            if (o != s && o->primary) return RS_OK;   // somebody else's records are the working copy: this loop runs with the table's rows (both written)
+        if (s->kept_epoch != t->epoch) {
+            RS_HIP(launch_build_shadow(s->d_kept_jobs, s->n_kept_jobs, s->kept_max_clusters, t->stream, nullptr), "k_build_shadow (kept records)");
+            s->kept_epoch = t->epoch;
+        }
+        const uint32_t one = 1;
+        RS_HIP(hipMemcpyAsync(s->d_kept_primary, &one, sizeof(one), hipMemcpyHostToDevice, t->stream), "kept records: working copy on");
+        RS_HIP(hipStreamSynchronize(t->stream), "kept records: working copy on");   // `one` is a stack variable
+        s->primary = true;
+        return RS_OK;
+    }
+    // off: the table's rows of the kept nodes from the records, which stay in step with them
+    RS_HIP(launch_unbuild_shadow(s->d_kept_jobs, s->n_kept_jobs, s->kept_max_clusters, t->stream), "k_unbuild_shadow");
+    RS_HIP(hipMemsetAsync(s->d_kept_primary, 0, sizeof(uint32_t), t->stream), "kept records: working copy off");
+    s->primary = false;
+    s->kept_epoch = ++t->epoch;
+    return RS_OK;
+}
+
+int rs::solver_discount_primary(rs_solver *s, float d) {
+    rs_table *t = s->table;
+    RS_HIP(launch_discount_jobs(s->d_disc_jobs, s->n_disc_jobs, s->disc_max_vec, d, t->dtype, t->stream), "k_discount_jobs");
+    RS_HIP(launch_discount(s->d_shadow, s->d_shadow + s->kept_ints / 2, s->kept_ints / 2, d, RS_I32, t->stream), "k_discount (kept records)");
+    s->kept_epoch = ++t->epoch;
+    return RS_OK;
+}
+
 void rs::solver_release_device(rs_solver *s) {
     if (!s || !s->table) return;   // already detached (its table was destroyed first)
     rs_table *t = s->table;
@@ -287,6 +342,14 @@ void rs::solver_release_device(rs_solver *s) {
     s->ev_fork = nullptr;
     if (s->d_shadow) (void)hipFree(s->d_shadow);
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
+    if (s->primary) (void)solver_kept_primary(s, false);   // the table's rows back from the records before they go
+    if (s->d_kept_jobs) (void)hipFree(s->d_kept_jobs);
+    if (s->d_kept_primary) (void)hipFree(s->d_kept_primary);
+    if (s->d_disc_jobs) (void)hipFree(s->d_disc_jobs);
+    s->d_kept_jobs = nullptr;
+    s->d_kept_primary = nullptr;
+    s->d_disc_jobs = nullptr;
+    s->n_kept_jobs = 0;
     for (int r = 0; r < RS_MAX_ROUNDS; ++r) {
         if (s->d_attr[r] && s->d_attr[r] != s->d_arec) (void)hipFree(s->d_attr[r]);
         s->d_attr[r] = nullptr;
@@ -353,15 +416,74 @@ static int setup_table_shadow(rs_solver *s) {
             comp_root[id] = q;
             if (size_t(nd.index) < tree_of.size()) tree_of[size_t(nd.index)] = int(id);
         }
+        // Kept records.  Where a round's delta rows go straight into the table (rows_round_direct: more clusters than a summing tile holds -- the lossless abstractions of
+        // solve_three_street, 180 234 river clusters, 2 GB of table), transposing the table once per sweep costs more than the whole sweep, and without a shadow the walks
+        // gather the table's own rows: ~105 four-byte gathers per walked deal and subtree, a sector each (1.2 of 1.7 ms per 64 K-deal batch).  Those nodes KEEP their records
+        // between sweeps instead: k_row_apply adds every delta to the record as well as to the table row (integer additions: the two stay equal), rs_discount sweeps the
+        // records too, and any other write to the table (rs_table.epoch) has them rebuilt at the start of the next sweep.  One set of WIDE records serves both traversers'
+        // sweeps (the opponent's role reads the regrets half and matches them itself: a kept record cannot hold a strategy).
+        s->kept_node.assign(table->nodes.size(), 0);
+        std::vector<ShadowJob> kept_jobs;
+        for (size_t i = 0; i < table->nodes.size(); ++i) {
+            const rs_node_desc &d = table->nodes[i];
+            s->kept_node[i] = !s->knobs.no_kept && d.n_actions > 0 && !shadow_all && !table->tiled(int(i)) && s->rows && tree_of[i] >= 0 && rows_round_direct(s, int(d.player), int(d.round_idx));
+        }
         for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
             s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
             s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
             s->shadow_rec_p[tp].assign(table->nodes.size(), 0);
             s->shadow_rowoff_p[tp].assign(table->nodes.size(), 0);
+        }
+        {
+            std::map<std::pair<int, int>, std::vector<size_t>> groups;
+            for (size_t i = 0; i < table->nodes.size(); ++i)
+                if (s->kept_node[i]) groups[{staged_rows ? comp_root[size_t(tree_of[i])] : -1 - int(i), int(table->nodes[i].player)}].push_back(i);
+            for (auto &kv : groups) {
+                std::vector<size_t> &mem = kv.second;
+                std::vector<uint32_t> acts, recs, offs;
+                uint32_t n_cl = 0;
+                for (size_t i : mem) {
+                    acts.push_back(table->nodes[i].n_actions);
+                    n_cl = std::max(n_cl, table->nodes[i].n_clusters);
+                }
+                const uint32_t row = shadow_row_layout(acts, true, recs, offs);
+                if (size_t(n_cl) * row >= (size_t(1) << 32)) {   // 32-bit record addressing: these stay without a shadow
+                    for (size_t i : mem) s->kept_node[i] = 0;
+                    continue;
+                }
+                for (size_t m = 0; m < mem.size(); ++m) {
+                    const size_t i = mem[m];
+                    const rs_node_desc &d = table->nodes[i];
+                    for (int tp = 0; tp < 2; ++tp) {
+                        s->shadow_off_p[tp][i] = ints + offs[m];
+                        s->shadow_stride_p[tp][i] = row;
+                        s->shadow_rec_p[tp][i] = recs[m];
+                        s->shadow_rowoff_p[tp][i] = offs[m];
+                    }
+                    ShadowJob j{};
+                    j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+                    j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+                    j.pitch = uint32_t(table->pitch[i]);
+                    j.n_clusters = d.n_clusters;
+                    j.n_actions = d.n_actions;
+                    j.half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);
+                    j.stride = recs[m];
+                    j.row_stride = row;
+                    j.sigma = 0;
+                    j.dst = reinterpret_cast<int32_t *>(ints + offs[m]);   // an offset for now
+                    kept_jobs.push_back(j);
+                    s->kept_max_clusters = std::max(s->kept_max_clusters, d.n_clusters);
+                }
+                ints += round_up(size_t(n_cl) * row, 64);
+            }
+            s->kept_ints = ints;
+            s->n_kept_jobs = int(kept_jobs.size());
+        }
+        for (int tp = 0; tp < 2; ++tp) {
             std::map<std::pair<int, int>, std::vector<size_t>> groups;   // (component root, player) -> its table nodes, in ActionNode.index order
             for (size_t i = 0; i < table->nodes.size(); ++i) {
                 const rs_node_desc &d = table->nodes[i];
-                if (d.n_actions == 0) continue;
+                if (d.n_actions == 0 || s->kept_node[i]) continue;
                 const size_t roots = std::max<size_t>(1, round_roots[size_t(std::min<int>(d.round_idx, s->n_rounds))]);
                 if (!shadow_all && !table->tiled(int(i)) && size_t(s->deals.n_deals) * 8 < size_t(d.n_clusters) * d.n_actions * roots) continue;   // no shadow: J.shd = nullptr
                 groups[{tree_of[i] >= 0 && staged_rows && int(d.round_idx) != first_round ? comp_root[size_t(tree_of[i])] : -1 - int(i), int(d.player)}].push_back(i);
@@ -403,10 +525,37 @@ static int setup_table_shadow(rs_solver *s) {
             }
             if (tp == 0) s->n_shadow_jobs = int(jobs.size());
         }
-        s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256);
+        s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256) + kept_jobs.size() * sizeof(ShadowJob);
         e = hipMalloc((void **)&s->d_shadow, std::max<size_t>(ints * 4, 256));
         if (e == hipSuccess) e = hipMemsetAsync(s->d_shadow, 0, std::max<size_t>(ints * 4, 256), table->stream);
         for (ShadowJob &j : jobs) j.dst = s->d_shadow + reinterpret_cast<size_t>(j.dst);
+        for (ShadowJob &j : kept_jobs) j.dst = s->d_shadow + reinterpret_cast<size_t>(j.dst);
+        if (e == hipSuccess && !kept_jobs.empty()) e = hipMalloc((void **)&s->d_kept_jobs, kept_jobs.size() * sizeof(ShadowJob));
+        if (e == hipSuccess && !kept_jobs.empty()) e = hipMemcpy(s->d_kept_jobs, kept_jobs.data(), kept_jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
+        s->kept_epoch = ~uint64_t(0);
+        if (e == hipSuccess && !kept_jobs.empty()) {   // the flag k_row_apply reads, and the table without the kept nodes as stretches of consecutive nodes (solver_discount_primary)
+            e = hipMalloc((void **)&s->d_kept_primary, 256);
+            if (e == hipSuccess) e = hipMemsetAsync(s->d_kept_primary, 0, 256, table->stream);
+            std::vector<DiscountJob> runs;
+            const size_t es = 4;   // kept records exist on RS_I32 tables only
+            for (size_t i = 0; i < table->nodes.size();) {
+                if (s->kept_node[i] || table->nodes[i].n_actions == 0) {
+                    ++i;
+                    continue;
+                }
+                size_t j = i, cells = 0;
+                while (j < table->nodes.size() && !s->kept_node[j]) {
+                    cells += size_t(table->nodes[j].n_actions) * table->pitch[j];
+                    ++j;
+                }
+                runs.push_back(DiscountJob{static_cast<char *>(table->d_regrets) + table->cell_off[i] * es, static_cast<char *>(table->d_ssum) + table->cell_off[i] * es, cells / kVec});
+                s->disc_max_vec = std::max(s->disc_max_vec, cells / kVec);
+                i = j;
+            }
+            s->n_disc_jobs = int(runs.size());
+            if (e == hipSuccess && !runs.empty()) e = hipMalloc((void **)&s->d_disc_jobs, runs.size() * sizeof(DiscountJob));
+            if (e == hipSuccess && !runs.empty()) e = hipMemcpy(s->d_disc_jobs, runs.data(), runs.size() * sizeof(DiscountJob), hipMemcpyHostToDevice);
+        }
         if (jobs.size() != size_t(2) * size_t(s->n_shadow_jobs)) return fail(RS_ERR_INVALID, "rs_solver_create: the two sweeps' shadows hold different node sets");
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_shadow_jobs, std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256));
         if (e == hipSuccess && !jobs.empty()) e = hipMemcpy(s->d_shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice);
@@ -673,12 +822,12 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
             return rc;
         }
     }
-    if (int rc2 = setup_table_shadow(s)) {
+    choose_delta_rows(s);
+    if (int rc2 = setup_deal_records(s)) {
         rs_solver_destroy(s);
         return rc2;
     }
-    choose_delta_rows(s);
-    if (int rc2 = setup_deal_records(s)) {
+    if (int rc2 = setup_table_shadow(s)) {   // after the two above: which nodes KEEP their records depends on where the delta rows go
         rs_solver_destroy(s);
         return rc2;
     }
@@ -864,17 +1013,21 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
     if (!s->table) return fail(RS_ERR_INVALID, "rs_train: the solver's table has been destroyed");
     if (discount_interval == 0) return fail(RS_ERR_INVALID, "rs_train: discount_interval must be > 0");
     uint64_t t = 0, threshold = discount_interval;
-    while (t < iterations) {                       // cfr.rs:207
-        for (int player = 0; player < 2; ++player)  // cfr.rs:216-224
-            if (int rc = rs_iterate(s, player, nullptr)) return rc;
+    if (int rc = solver_kept_primary(s, true)) return rc;   // kept shadow records (if any) are the working copy until the loop is over
+    int rc = RS_OK;
+    while (t < iterations && rc == RS_OK) {        // cfr.rs:207
+        for (int player = 0; player < 2 && rc == RS_OK; ++player)  // cfr.rs:216-224
+            rc = rs_iterate(s, player, nullptr);
+        if (rc != RS_OK) break;
         t += 1;                                     // cfr.rs:226
         if (t > discount_cap) continue;             // cfr.rs:240-242
         if (t > threshold) {                        // cfr.rs:243
-            if (int rc = rs_discount(s->table, rs_discount_factor(t, discount_interval))) return rc;  // cfr.rs:248-261
+            rc = rs_discount(s->table, rs_discount_factor(t, discount_interval));  // cfr.rs:248-261
             threshold = t + discount_interval;      // cfr.rs:262
         }
     }
-    return RS_OK;
+    const int rc_off = solver_kept_primary(s, false);
+    return rc != RS_OK ? rc : rc_off;
 }
 
 size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes + s->other_bytes : 0; }

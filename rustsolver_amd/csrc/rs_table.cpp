@@ -308,6 +308,7 @@ static int board_copy(rs_table *t, int node, int board, void *regrets, void *ssu
     return RS_OK;
 }
 int rs_table_upload(rs_table *t, int node, int board, const void *regrets, const void *ssum) {
+    if (t) ++t->epoch;
     return board_copy(t, node, board, (void *)regrets, (void *)ssum, 0, "rs_table_upload");
 }
 int rs_table_download(rs_table *t, int node, int board, void *regrets, void *ssum) {
@@ -325,6 +326,7 @@ static int node_copy(rs_table *t, int node, void *regrets, void *ssum, int dir, 
     return RS_OK;
 }
 int rs_table_upload_node(rs_table *t, int node, const void *regrets, const void *ssum) {
+    if (t) ++t->epoch;
     return node_copy(t, node, (void *)regrets, (void *)ssum, 0, "rs_table_upload_node");
 }
 int rs_table_download_node(rs_table *t, int node, void *regrets, void *ssum) {
@@ -350,6 +352,7 @@ int rs_get_infoset(rs_table *t, int node, int board, int cluster, void *regrets,
     return infoset_copy(t, node, board, cluster, regrets, ssum, 1, "rs_get_infoset");
 }
 int rs_set_infoset(rs_table *t, int node, int board, int cluster, const void *regrets, const void *ssum) {
+    if (t) ++t->epoch;
     return infoset_copy(t, node, board, cluster, (void *)regrets, (void *)ssum, 0, "rs_set_infoset");
 }
 
@@ -471,6 +474,7 @@ int rs_get_final_strategy(rs_table *t, int node, int board, int cluster, float *
 int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi) {
     if (!t) return fail(RS_ERR_INVALID, "rs_table_fill_random: table is NULL");
     if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random: empty range");
+    ++t->epoch;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     RS_HIP(launch_fill_random(t->d_regrets, t->n_cells, seed, rlo, rhi, t->dtype, t->stream), "fill_random(regrets)");
     RS_HIP(launch_fill_random(t->d_ssum, t->n_cells, seed ^ 0x5353554Dull /* "SSUM" */, slo, shi, t->dtype, t->stream),
@@ -480,6 +484,7 @@ int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, i
 int rs_table_plant_saturating(rs_table *t, uint64_t seed, uint32_t one_in) {
     if (!t || one_in == 0) return fail(RS_ERR_INVALID, "rs_table_plant_saturating: bad argument");
     if (t->dtype != RS_I32) return fail(RS_ERR_UNSUPPORTED, "rs_table_plant_saturating: i32 tables (the saturating range is the i32 range)");
+    ++t->epoch;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     RS_HIP(launch_plant_saturating(t->d_regrets, t->n_cells, seed, one_in, t->stream), "plant_saturating");
     return RS_OK;
@@ -525,6 +530,7 @@ static int logical_sweep(rs_table *t, const uint64_t *lane_off, int op, uint64_t
 }
 int rs_table_fill_random_logical(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, const uint64_t *lane_off) {
     if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random_logical: empty range");
+    if (t) ++t->epoch;
     return logical_sweep(t, lane_off, 0, seed, rlo, rhi, slo, shi, nullptr, "rs_table_fill_random_logical");
 }
 int rs_table_checksum_logical(rs_table *t, const uint64_t *lane_off, uint64_t *out) {
@@ -653,6 +659,7 @@ int rs_update_node(rs_table *t, int node, const float *d_action_utils, const flo
                    float *d_node_util) {
     if (int rc = check_node(t, node, "rs_update_node")) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
+    ++t->epoch;
     if (!d_action_utils) return fail(RS_ERR_INVALID, "rs_update_node: d_action_utils is NULL");
     if (int rc = check_mode(t, mode, "rs_update_node")) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -715,10 +722,19 @@ float rs_discount_factor(uint64_t tc, uint64_t interval) {  // cfr.rs:248-249
 int rs_discount(rs_table *t, float d) {
     if (!t) return fail(RS_ERR_INVALID, "rs_discount: table is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+    for (rs_solver *s : t->solvers)
+        if (solver_is_primary(s)) {   // inside a training loop whose kept shadow records are the working copy: they and the table without their nodes
+            prof_begin(t, RS_K_DISCOUNT, double(t->n_cells) * 4.0 * elem_size(t->dtype));
+            const int rc = solver_discount_primary(s, d);
+            prof_end(t);
+            return rc;
+        }
     prof_begin(t, RS_K_DISCOUNT, double(t->n_cells) * 4.0 * elem_size(t->dtype));
     hipError_t e = launch_discount(t->d_regrets, t->d_ssum, t->n_cells, d, t->dtype, t->stream);
     prof_end(t);
     RS_HIP(e, "k_discount");
+    const uint64_t before = t->epoch++;
+    for (rs_solver *s : t->solvers) solver_table_discounted(s, d, before);   // kept shadow records take the same sweep (every int on its own: (x as f32 * d) as i32)
     return RS_OK;
 }
 

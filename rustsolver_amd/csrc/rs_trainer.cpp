@@ -291,7 +291,12 @@ int rs_deal_trainer_finish_batch(rs_deal_trainer *tr) {
     if (tr->params.discount_interval == 0 || tr->t > tr->params.discount_cap) return RS_OK;   // cfr.rs:240-242
     if (tr->t > tr->threshold) {                                  // cfr.rs:243
         if (tr->tick_br) {                                        // cfr.rs:244-246: calc_br on the table as it is before the sweep
+            const bool was_primary = solver_is_primary(tr->solver);   // calc_br reads the table's rows: bring them up to date first
+            if (was_primary)
+                if (int rc = solver_kept_primary(tr->solver, false)) return rc;
             if (int rc = rs_calc_br(tr->table, tr->tree, tr->last_br)) return rc;
+            if (was_primary)
+                if (int rc = solver_kept_primary(tr->solver, true)) return rc;
             tr->last_br_t = tr->t;
             tr->have_br = true;
         }
@@ -405,15 +410,17 @@ int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
 // train(): every batch is deals_per_batch iterations of cfr.rs:207-226 on this rank (world times as many over all ranks)
 int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_train: trainer is NULL");
-    for (uint64_t b = 0; b < n_batches; ++b) {
-        if (int rc = rs_deal_trainer_deal(tr)) return rc;
-        if (b + 1 < n_batches)   // deal the next batch beside this one's sweeps (never beyond what was asked for)
-            if (int rc = prefetch(tr)) return rc;
-        for (int player = 0; player < 2; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
-            if (int rc = rs_iterate(tr->solver, player, nullptr)) return rc;
-        if (int rc = rs_deal_trainer_finish_batch(tr)) return rc;
+    if (int rc = solver_kept_primary(tr->solver, true)) return rc;   // kept shadow records (rs_solver.cpp setup_table_shadow) are the working copy until the loop is over
+    int rc = RS_OK;
+    for (uint64_t b = 0; b < n_batches && rc == RS_OK; ++b) {
+        rc = rs_deal_trainer_deal(tr);
+        if (rc == RS_OK && b + 1 < n_batches) rc = prefetch(tr);   // deal the next batch beside this one's sweeps (never beyond what was asked for)
+        for (int player = 0; player < 2 && rc == RS_OK; ++player)   // cfr.rs:216-224; with a communicator: sweep, all-reduce the deltas, apply
+            rc = rs_iterate(tr->solver, player, nullptr);
+        if (rc == RS_OK) rc = rs_deal_trainer_finish_batch(tr);
     }
-    return RS_OK;
+    const int rc_off = solver_kept_primary(tr->solver, false);   // the table's rows back from the records
+    return rc != RS_OK ? rc : rc_off;
 }
 
 // synchronises; fails if any deal since the last call could not be sampled or addressed (the reference would spin or panic)

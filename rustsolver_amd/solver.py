@@ -654,8 +654,8 @@ class DealTrainer:
 
     def __init__(self, tree, card_abs, hand_ranges, board_mask, deals_per_batch, seed=0, scale=100.0, mode=L.UPD_CLAMP_I64,
                  opp_mode=L.OPP_SAMPLE, discount_interval=MCCFRTrainer.DISCOUNT_INTERVAL, discount_cap=MCCFRTrainer.DISCOUNT_CAP,
-                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0, prune_threshold=10_000_000):
-        """prune_threshold: cfr.rs:190 PRUNE_THRESHOLD (None = never prune).  world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
+                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0, prune_threshold=10_000_000, forms=None):
+        """prune_threshold: cfr.rs:190 PRUNE_THRESHOLD (None = never prune).  forms: rs_kernel_forms fields by name, as for MCCFRTrainer.  world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
         batch; attach_comm() makes every rank apply the deltas of the union batch."""
         if fuse_subtrees is None:
             fuse_subtrees = bool(L.load().rs_jit_available())
@@ -668,6 +668,8 @@ class DealTrainer:
         p.solver.scale, p.solver.mode, p.solver.chance_mode = scale, mode, L.CHANCE_PASS
         p.solver.use_graph, p.solver.fuse_subtrees = int(use_graph), int(bool(fuse_subtrees))
         p.solver.opp_mode, p.solver.sample_seed = opp_mode, seed
+        for k, v in dict(DEFAULT_FORMS, **(forms or {})).items():
+            setattr(p.solver.forms, k, int(v))
         h0 = np.ascontiguousarray(hand_ranges[0], dtype=np.uint8).reshape(-1, 2)
         h1 = np.ascontiguousarray(hand_ranges[1], dtype=np.uint8).reshape(-1, 2)
         abs_arr = (C.c_void_p * len(self.card_abs))(*[a._h for a in self.card_abs])

@@ -1167,6 +1167,75 @@ def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
+@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "two-solvers"])
+def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
+    """A round whose delta rows go straight into the table (20 000 / 17 000 river clusters: rs_kernel_forms.direct_rows) keeps its shadow records between sweeps: k_row_apply adds
+    every delta to the record as well as to the table row, rs_discount sweeps the records too, and any other write to the table has them rebuilt before the next sweep
+    (rs_solver.cpp setup_table_shadow).  "steps": sweeps with a discount, an upload and a single-infoset write between them; "train-loop": rs_train, inside which the records ARE
+    the working copy (the table's river rows are written back when the loop ends) -- discount ticks every iteration; "two-solvers": two solvers on one table taking turns;
+    "-off": rs_kernel_forms.kept_records = RS_FORM_OFF (those nodes have no shadow then: the walks gather the table's own rows).  Same bits as the oracle after every step."""
+    monkeypatch.setenv("RS_JIT_ROWS", "1")
+    monkeypatch.setenv("RS_JIT_ROWS_CHUNK", "1000")
+    n_deals = 9001
+    tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(7, 9), (211, 190), (20000, 17000)], n_deals, 41)
+    def solver(seed):
+        return (rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=seed, use_graph="graph" in variant,
+                                forms={"kept_records": rs.FORM_OFF} if variant.endswith("-off") else None),
+                orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed))
+    def same_tables(what):
+        for nd in tree.action_nodes():
+            r, s_ = table.download_node(nd.index)
+            ro, so = otab.get_node(nd.index)
+            assert (r == ro).all() and (s_ == so).all(), "table differs at node %d after %s" % (nd.index, what)
+    tr, osol = solver(99)
+    assert tr.delta_rows
+    river = [nd for nd in tree.action_nodes() if nd.round_idx == 2][:3]
+    if variant.startswith("train-loop"):
+        its, interval = 5, 2
+        tr.train(its, discount_interval=interval, discount_cap=10**9)      # rs_train: cfr.rs:207-262 with t counted per loop trip
+        t, threshold = 0, interval
+        while t < its:
+            for player in (0, 1):
+                osol.iterate(player)
+            t += 1
+            if t > threshold:
+                otab.discount(orc.discount_factor(t, interval))
+                threshold = t + interval
+        same_tables("rs_train")
+        for player in (0, 1):   # and the records are still good for a plain sweep afterwards
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util after the loop p=%d" % player)
+        same_tables("a sweep after rs_train")
+        return
+    if variant == "two-solvers":
+        tr2, osol2 = solver(7)
+        for it in range(2):
+            for (a, b) in ((tr, osol), (tr2, osol2)):
+                for player in (0, 1):
+                    assert_bits(a.iterate(player, want_root_util=True), b.iterate(player), "root util it=%d p=%d" % (it, player))
+        same_tables("two solvers taking turns")
+        return
+    rng = np.random.Generator(np.random.PCG64(5))
+    for step in range(4):
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util step=%d p=%d" % (step, player))
+        if step == 0:     # rs_discount: the records take the same sweep
+            table.discount(0.75)
+            otab.discount(np.float32(0.75))
+        elif step == 1:   # rs_table_upload_node: the records are rebuilt before the next sweep
+            for nd in river:
+                r, s_ = table.download_node(nd.index)
+                r = (r + rng.integers(-50000, 50000, size=r.shape)).astype(np.int32)
+                table.upload_node(nd.index, r, s_)
+                otab.set_node(nd.index, r, s_)
+        elif step == 2:   # rs_set_infoset
+            nd = river[0]
+            r, s_ = table.download_node(nd.index)
+            r[:, 123] += 777
+            table[nd.index][123].set(r[:, 123], s_[:, 123])
+            otab.set_node(nd.index, r, s_)
+    same_tables("sweeps, a discount, uploads")
+
+
 @pytest.mark.parametrize("forms", ["tiles", "rows"])
 def test_handoff_with_more_opponent_nodes_than_rows(forms, monkeypatch):
     """The reach-down kernel of a round subtree hands its draws at the opponent's nodes to the walk of the same subtree -- at most TEN nodes (3 bits of one packed word each); the
