@@ -428,6 +428,12 @@ static int setup_table_shadow(rs_solver *s) {
             const rs_node_desc &d = table->nodes[i];
             s->kept_node[i] = !s->knobs.no_kept && d.n_actions > 0 && !shadow_all && !table->tiled(int(i)) && s->rows && tree_of[i] >= 0 && rows_round_direct(s, int(d.player), int(d.round_idx));
         }
+        {   // the records are a second copy of those nodes (1.3x their table rows): only while a quarter of the free memory holds them
+            size_t need = 0, free_b = 0, total_b = 0;
+            for (size_t i = 0; i < table->nodes.size(); ++i)
+                if (s->kept_node[i]) need += size_t(table->nodes[i].n_clusters) * 2 * (table->nodes[i].n_actions <= 2 ? 2 : (table->nodes[i].n_actions <= 4 ? 4 : 8)) * sizeof(int32_t);
+            if (need && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4)) s->kept_node.assign(table->nodes.size(), 0);
+        }
         for (int tp = 0; tp < 2; ++tp) {   // traverser tp's sweep: 2 * half ints per record at its own nodes, half at the opponent's
             s->shadow_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
             s->shadow_stride_p[tp].assign(table->nodes.size(), 0);
