@@ -423,6 +423,7 @@ void solver_table_discounted(struct rs_solver *s, float d, uint64_t epoch_before
 // Training loops (rs_train, rs_deal_trainer_train) make the kept records the WORKING COPY for their duration: on = 1 at the start (records rebuilt if out of step), 0 before
 // returning (the table's rows written back from the records).  While on, nothing but the solver's sweeps and solver_discount_primary may touch the table.
 int solver_kept_primary(struct rs_solver *s, bool on);
+constexpr uint64_t kKeptPrimaryMinTrips = 16;   // training loops shorter than this leave the table's rows the working copy (the write-back at the end would cost more than it saves)
 bool solver_is_primary(const struct rs_solver *s);
 int solver_discount_primary(struct rs_solver *s, float d);   // rs_discount while on: the kept records and the table WITHOUT their nodes
 // profiling hooks used around launches

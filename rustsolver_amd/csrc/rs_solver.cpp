@@ -1019,7 +1019,8 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
     if (!s->table) return fail(RS_ERR_INVALID, "rs_train: the solver's table has been destroyed");
     if (discount_interval == 0) return fail(RS_ERR_INVALID, "rs_train: discount_interval must be > 0");
     uint64_t t = 0, threshold = discount_interval;
-    if (int rc = solver_kept_primary(s, true)) return rc;   // kept shadow records (if any) are the working copy until the loop is over
+    if (iterations >= kKeptPrimaryMinTrips)
+        if (int rc = solver_kept_primary(s, true)) return rc;   // kept shadow records (if any) are the working copy until the loop is over
     int rc = RS_OK;
     while (t < iterations && rc == RS_OK) {        // cfr.rs:207
         for (int player = 0; player < 2 && rc == RS_OK; ++player)  // cfr.rs:216-224

@@ -410,7 +410,10 @@ int rs_deal_trainer_attach_comm(rs_deal_trainer *tr, rs_comm *comm) {
 // train(): every batch is deals_per_batch iterations of cfr.rs:207-226 on this rank (world times as many over all ranks)
 int rs_deal_trainer_train(rs_deal_trainer *tr, uint64_t n_batches) {
     if (!tr) return fail(RS_ERR_INVALID, "rs_deal_trainer_train: trainer is NULL");
-    if (int rc = solver_kept_primary(tr->solver, true)) return rc;   // kept shadow records (rs_solver.cpp setup_table_shadow) are the working copy until the loop is over
+    // kept shadow records (rs_solver.cpp setup_table_shadow) are the working copy until the loop is over -- when the loop is long enough to pay for writing the table's rows back
+    // at its end (a pass over those nodes: 2 ms for the 2 GB of solve_three_street); a caller that trains a batch at a time keeps table and records both up to date
+    if (n_batches >= kKeptPrimaryMinTrips)
+        if (int rc = solver_kept_primary(tr->solver, true)) return rc;
     int rc = RS_OK;
     for (uint64_t b = 0; b < n_batches && rc == RS_OK; ++b) {
         rc = rs_deal_trainer_deal(tr);

@@ -1191,7 +1191,7 @@ def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
     assert tr.delta_rows
     river = [nd for nd in tree.action_nodes() if nd.round_idx == 2][:3]
     if variant.startswith("train-loop"):
-        its, interval = 5, 2
+        its, interval = 18, 4   # 16 trips or more: the records become the working copy (kKeptPrimaryMinTrips)
         tr.train(its, discount_interval=interval, discount_cap=10**9)      # rs_train: cfr.rs:207-262 with t counted per loop trip
         t, threshold = 0, interval
         while t < its:
