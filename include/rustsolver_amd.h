@@ -39,8 +39,10 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 4   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h;
-                              4: rs_kernel_forms inside rs_solver_params, rs_table_params + rs_table_create_with, rs_deal_trainer_params.prefetch, f32 deal batches */
+#define RS_ABI_VERSION 5   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h;
+                              4: rs_kernel_forms inside rs_solver_params, rs_table_params + rs_table_create_with, rs_deal_trainer_params.prefetch, f32 deal batches;
+                              5: rs_kernel_forms without `worklist` and RS_FAN_LOOP / RS_SHADOW_WIDE, with direct_rows and kept_records (same size: a zeroed struct means what it meant);
+                                 rs_hand_index_verify, rs_deal_trainer_br_bytes / _br_release / _br_launches, RS_ERR_MISMATCH */
 #define RS_MAX_ACTIONS 8
 #define RS_MAX_ROUNDS 3
 #define RS_MAX_SIZES 4
@@ -282,7 +284,7 @@ typedef struct rs_kernel_forms {
                                    write to the table has them rebuilt before the next sweep; inside rs_train / rs_deal_trainer_train they are the working copy and the table's
                                    rows of those nodes are written back when the loop returns.  The walks then read staged rows instead of gathering a table that is too large
                                    to transpose per sweep (solve_three_street, 64 K deals against 2 GB: 1.60 -> 1.23 ms per batch, 1.28 -> 0.81 without discount ticks).
-                                   Costs the records' memory (1.3x the nodes' table rows).  Default: on.  (ABI 4 had `worklist` here, ABI 5 a reserved zero.) */
+                                   Costs the records' memory (1.3x the nodes' table rows).  Default: on.  (ABI 4 had `worklist` in this slot.) */
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
                                    sum their deltas along the runs of equal cluster (DPP segmented scan) instead of LDS tiles or delta rows (default: on for multi-round
