@@ -411,3 +411,30 @@ def test_deal_trainer_rejects_bad_inputs():
     tr.train(1)
     with pytest.raises(rs.RsError):
         tr.status()
+
+
+def test_kept_records_at_size_equal_the_table_only_training():
+    """solve_three_street's game at its own size (flop start, lossless abstractions: 180 234 river clusters with 200-combo ranges, 2 GB of table, 65 536 deals per batch): forty
+    batches with the reference's discount ticks (one every 1.5 batches) by two trainers, one with kept shadow records (the working copy inside rs_deal_trainer_train; written
+    back to the table when the call returns), one without (rs_kernel_forms.kept_records = RS_FORM_OFF: the walks gather the table's rows).  Same table checksums after
+    every call -- also after a short call (fewer than 16 batches: table and records both written) and after a discount from outside."""
+    mask = ab.card_mask("7h8hQc")
+    rng = np.random.Generator(np.random.PCG64(2))
+    hands = ab.random_range(mask)
+    hands = hands[np.sort(rng.choice(len(hands), 200, replace=False))]
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, None) for r in range(3)]
+    n = 1 << 16
+    kept = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=1, use_graph=True)
+    plain = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=1, use_graph=True, forms={"kept_records": rs.FORM_OFF})
+    for step, batches in enumerate((24, 3, 16)):
+        for tr in (kept, plain):
+            tr.train(batches)
+            tr.status()
+        assert kept.infosets.checksum() == plain.infosets.checksum(), "after call %d (%d batches)" % (step, batches)
+        if step == 1:   # a write from outside the loop: the records follow (rs_discount) or are rebuilt (anything else)
+            for tr in (kept, plain):
+                tr.infosets.discount(0.9)
+    assert kept.infosets.checksum() == plain.infosets.checksum()
+    kept.destroy()
+    plain.destroy()
