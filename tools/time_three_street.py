@@ -27,7 +27,8 @@ print("abstractions: %.1f s, sizes" % (time.perf_counter() - t0), [a.get_size(0)
 n = int(os.environ.get("N", str(1 << 20)))
 t0 = time.perf_counter()
 tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE, use_graph=bool(int(os.environ.get("GRAPH", "0"))),
-                    forms={"shadow": rs.SHADOW_ALL} if os.environ.get("SHADOW_ALL") else None)   # SHADOW_ALL=1: rs_kernel_forms.shadow = RS_SHADOW_ALL instead of the rule
+                    forms={"shadow": rs.SHADOW_ALL} if os.environ.get("SHADOW_ALL") else ({"kept_records": rs.FORM_OFF} if os.environ.get("NO_KEPT") else None))
+# SHADOW_ALL=1: rs_kernel_forms.shadow = RS_SHADOW_ALL instead of the rule; NO_KEPT=1: rs_kernel_forms.kept_records = RS_FORM_OFF
 print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.infosets.nbytes / 1e6 if not callable(tr.infosets.nbytes) else tr.infosets.nbytes() / 1e6))
 tr.train(2); tr.status()
 KB = int(os.environ.get("BATCHES", "5"))
