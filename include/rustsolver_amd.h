@@ -284,7 +284,9 @@ typedef struct rs_kernel_forms {
                                    write to the table has them rebuilt before the next sweep; inside rs_train / rs_deal_trainer_train they are the working copy and the table's
                                    rows of those nodes are written back when the loop returns.  The walks then read staged rows instead of gathering a table that is too large
                                    to transpose per sweep (solve_three_street, 64 K deals against 2 GB: 1.60 -> 1.23 ms per batch, 1.28 -> 0.81 without discount ticks).
-                                   Costs the records' memory (1.3x the nodes' table rows).  Default: on.  (ABI 4 had `worklist` in this slot.) */
+                                   Costs the records' memory (1.3x the nodes' table rows) -- and, for a host that drives rs_iterate and rs_discount ITSELF, a discount
+                                   sweep over table and records both (1.6 -> 1.9 ms per batch while a tick comes every 1.5 batches, 1.3 -> 0.95 after the discount
+                                   phase): such a loop should call rs_train / rs_deal_trainer_train for its batches, or switch this off for short runs.  Default: on.  (ABI 4 had `worklist` in this slot.) */
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
                                    sum their deltas along the runs of equal cluster (DPP segmented scan) instead of LDS tiles or delta rows (default: on for multi-round
