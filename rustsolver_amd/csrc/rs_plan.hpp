@@ -142,7 +142,10 @@ struct rs_solver {
     rs_comm *comm = nullptr;
     int n_cus = 256;                    // multiprocessors of the device (grid of the persistent deal kernels)
     // round subtrees of one round are independent: their launches are spread over a few auxiliary streams (fork / join with events)
-    static constexpr int kAux = 4;   // (8: three streets 4 M deals per batch 6.95 -> 7.24 ms, 64 K 0.91 -> 1.10)
+    // Three: with the table's own stream that makes four, one per hardware queue of the device (GPU_MAX_HW_QUEUES defaults to 4) -- a fifth stream shares a queue with another
+    // and which two collide differs from process to process: with four auxiliary streams a 64 K-deal batch took 0.81 or 0.97 ms depending on the run, with three 0.76-0.77 in
+    // every run (16 K deals 0.95 -> 0.82, 256 K 1.40 -> 1.30, the 2 GB lossless table 1.43 -> 1.36; 1 M and 4 M deals unchanged).  (8: 4 M deals 6.95 -> 7.24 ms, 64 K 0.91 -> 1.10)
+    static constexpr int kAux = 3;
     hipStream_t aux[kAux] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
     // deal sweeps through tree-specialised kernels read the table from an AoS shadow rebuilt at the start of every sweep
