@@ -176,7 +176,7 @@ struct WorklistBatch {
 };
 hipError_t launch_worklist(const WorklistBatch &batch, int n, hipStream_t stream);
 // d_seed_state != nullptr: the same launch advances the sweep seed (k_next_seed's work), one launch less per sampled deal sweep
-hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state = nullptr);
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state, uint32_t *d_zero = nullptr, uint32_t n_zero = 0);   // d_zero: words zeroed by the same launch (the sweep's list counters)
 hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *dssum, size_t n_cells, hipStream_t stream);
 // the same over the cell ranges of some nodes only (a traverser's sweep writes deltas at ITS nodes; the other half of the delta arrays is zero and need not be read)
 struct ApplyJob {

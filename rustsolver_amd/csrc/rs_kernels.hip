@@ -499,11 +499,13 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
 
 // ---- deal batches: SoA table rows -> AoS records for the sweep's gathers (rs_device.hpp gather_rec); reads coalesce over clusters,
 // every thread writes its record with 16-byte stores (a wave covers 2-4 KB contiguous)
-__global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__restrict__ jobs, uint64_t *__restrict__ seed_state) {
+__global__ __launch_bounds__(kBlock) void k_build_shadow(const ShadowJob *__restrict__ jobs, uint64_t *__restrict__ seed_state, uint32_t *__restrict__ zero, uint32_t n_zero) {
     if (seed_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // k_next_seed folded in: the tree kernels read state[2] after this launch
         seed_state[2] = sweep_seed(seed_state[0], seed_state[1]);
         seed_state[1] += 1;
     }
+    if (zero && blockIdx.y == 0)   // the sweep's list counters, which every compaction of this sweep adds to: zeroed here instead of by a memset in front of each compaction
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_zero; i += gridDim.x * kBlock) zero[i] = 0u;
     const ShadowJob *job = jobs + blockIdx.y;
     const uint32_t n = job->n_clusters, pitch = job->pitch, A = job->n_actions, half = job->half;
     const int32_t *__restrict__ reg = job->regrets, *__restrict__ ssm = job->ssum;
@@ -1030,10 +1032,16 @@ hipError_t launch_worklist(const WorklistBatch &batch, int n, hipStream_t stream
     hipLaunchKernelGGL(k_worklist, dim3((unsigned)n), dim3(kBlock), 0, stream, batch);
     return hipGetLastError();
 }
-hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state) {
-    if (n_jobs <= 0) return d_seed_state ? launch_next_seed(d_seed_state, stream) : hipSuccess;
+hipError_t launch_build_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream, uint64_t *d_seed_state, uint32_t *d_zero, uint32_t n_zero) {
+    if (n_jobs <= 0) {
+        if (d_zero && n_zero) {
+            const hipError_t e = hipMemsetAsync(d_zero, 0, size_t(n_zero) * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+        }
+        return d_seed_state ? launch_next_seed(d_seed_state, stream) : hipSuccess;
+    }
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
-    hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs, d_seed_state);
+    hipLaunchKernelGGL(k_build_shadow, grid, block, 0, stream, d_jobs, d_seed_state, d_zero, n_zero);
     return hipGetLastError();
 }
 // the way back for KEPT wide records ({regrets, strategy sums}, ShadowJob.stride == 2 * half): the table's rows from the records that were the working copy of a training loop

@@ -88,6 +88,7 @@ struct Plan {
     size_t apply_max_vec = 0;
     size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees
     size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
+    bool counts_zeroed_by_shadow = false;   // the sweep opens with a k_build_shadow launch, which zeroes d_counts too (else: a memset in front of every compaction)
     uint32_t *d_counts = nullptr;       // [n_compact]
     CompactJob *d_compact_jobs = nullptr;
     std::vector<CompactJob> compact_jobs;

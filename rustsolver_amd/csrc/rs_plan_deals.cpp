@@ -160,6 +160,8 @@ int PlanBuilder::emit_deal_lists() {
         plan.n_count_words = n_counts * kCountStride;
         if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_counts, n_counts * kCountStride * sizeof(uint32_t));
         if (ea == hipSuccess) ea = hipMemsetAsync(plan.d_counts, 0, n_counts * kCountStride * sizeof(uint32_t), t->stream);
+        for (const Launch &L0 : plan.launches) plan.counts_zeroed_by_shadow = plan.counts_zeroed_by_shadow || L0.kind == L_SHADOW;   // pushed before any compaction (rs_plan.cpp)
+        plan.counts_zeroed_by_shadow = plan.counts_zeroed_by_shadow && plan.n_count_words < (size_t(1) << 32);
         if (ea == hipSuccess) ea = hipMalloc((void **)&plan.d_compact_jobs, n_sparse * sizeof(CompactJob));
         if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
         plan.compact_jobs.resize(n_sparse);

@@ -55,7 +55,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     if (L.kind == L_COMPACT) {   // jobs [first_job, first_job + n_jobs)
         prof_begin(t, RS_K_REACH, L.bytes);
         const size_t c_lo = plan.count_off[size_t(L.first_job)], c_hi = plan.count_off[size_t(L.first_job + L.n_jobs)];
-        hipError_t ec = hipMemsetAsync(plan.d_counts + c_lo * kCountStride, 0, (c_hi - c_lo) * kCountStride * sizeof(uint32_t), t->stream);
+        // the counters were zeroed by the launch that opened the sweep (L_SHADOW below) when there is one
+        hipError_t ec = plan.counts_zeroed_by_shadow ? hipSuccess : hipMemsetAsync(plan.d_counts + c_lo * kCountStride, 0, (c_hi - c_lo) * kCountStride * sizeof(uint32_t), t->stream);
         if (ec == hipSuccess)
             ec = L.n_groups ? launch_compact_siblings(plan.d_compact_jobs, plan.d_compact_groups + L.first_group, L.n_groups, plan.compact_max_lanes, t->stream)
                             : launch_compact_live(plan.d_compact_jobs + L.first_job, L.n_jobs, plan.compact_max_lanes, t->stream);
@@ -86,7 +87,8 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     if (L.kind == L_SHADOW) {
         prof_begin(t, RS_K_STRATEGY, L.bytes);
         const int which = &plan == &s->plan[1] ? 1 : 0;   // the shadow holds what THIS traverser's sweep reads: regrets everywhere, strategy sums at its own nodes
-        hipError_t es = launch_build_shadow(s->d_shadow_jobs + size_t(which) * s->n_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr);
+        hipError_t es = launch_build_shadow(s->d_shadow_jobs + size_t(which) * s->n_shadow_jobs, s->n_shadow_jobs, s->shadow_max_clusters, t->stream, L.n_jobs ? s->d_seed_state : nullptr,
+                                            plan.counts_zeroed_by_shadow ? plan.d_counts : nullptr, uint32_t(plan.n_count_words));
         prof_end(t);
         RS_HIP(es, "k_build_shadow");
         return RS_OK;
