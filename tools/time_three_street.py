@@ -26,7 +26,7 @@ card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in 
 print("abstractions: %.1f s, sizes" % (time.perf_counter() - t0), [a.get_size(0) for a in card_abs], "action nodes", n_actions)
 n = int(os.environ.get("N", str(1 << 20)))
 t0 = time.perf_counter()
-tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE, use_graph=bool(int(os.environ.get("GRAPH", "0"))),
+tr = rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, seed=7, discount_interval=0, prune_threshold=PRUNE, use_graph=bool(int(os.environ.get("GRAPH", "0"))), prefetch=(None if os.environ.get("PREFETCH") is None else bool(int(os.environ["PREFETCH"]))),
                     forms={"shadow": rs.SHADOW_ALL} if os.environ.get("SHADOW_ALL") else ({"kept_records": rs.FORM_OFF} if os.environ.get("NO_KEPT") else None))
 # SHADOW_ALL=1: rs_kernel_forms.shadow = RS_SHADOW_ALL instead of the rule; NO_KEPT=1: rs_kernel_forms.kept_records = RS_FORM_OFF
 print("trainer create: %.1f s, table %.1f MB" % (time.perf_counter() - t0, tr.infosets.nbytes / 1e6 if not callable(tr.infosets.nbytes) else tr.infosets.nbytes() / 1e6))
