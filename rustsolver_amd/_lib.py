@@ -90,6 +90,7 @@ _PP = C.POINTER(C.c_void_p)
 SYMBOLS = {
     "rs_last_error": (C.c_char_p, []),
     "rs_abi_version": (C.c_int, []),
+    "rs_solver_training_loop": (C.c_int, [C.c_void_p, C.c_int]),
     "rs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rs_options_default": (C.c_int, [C.POINTER(OptionsC)]),
     "rs_tree_build": (C.c_int, [C.POINTER(OptionsC), _PP]),

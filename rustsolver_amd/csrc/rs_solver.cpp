@@ -1016,6 +1016,12 @@ int rs_solver_exchange_info(rs_solver *s, int traverser, void **d_buf, size_t *b
     return RS_OK;
 }
 
+int rs_solver_training_loop(rs_solver *s, int on) {
+    if (!s) return fail(RS_ERR_INVALID, "rs_solver_training_loop: solver is NULL");
+    if (!s->table) return fail(RS_ERR_INVALID, "rs_solver_training_loop: the solver's table has been destroyed");
+    return solver_kept_primary(s, on != 0);
+}
+
 int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap) {
     if (!s) return fail(RS_ERR_INVALID, "rs_train: solver is NULL");
     if (!s->table) return fail(RS_ERR_INVALID, "rs_train: the solver's table has been destroyed");

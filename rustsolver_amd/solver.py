@@ -623,6 +623,10 @@ class MCCFRTrainer:
     def attach_comm(self, comm_handle):
         L.check(L.load().rs_solver_attach_comm(self._h, comm_handle))
 
+    def training_loop(self, on):
+        """rs_solver_training_loop: bracket a hand-written loop of iterate() / table.discount() calls (nothing else may touch the table in between)"""
+        L.check(L.load().rs_solver_training_loop(self._h, int(bool(on))))
+
     def train(self, iterations, discount_interval=None, discount_cap=None):
         """cfr.rs:188"""
         L.check(L.load().rs_train(self._h, iterations, discount_interval or self.DISCOUNT_INTERVAL,

@@ -1167,7 +1167,7 @@ def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "two-solvers"])
+@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "host-loop", "two-solvers"])
 def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
     """A round whose delta rows go straight into the table (20 000 / 17 000 river clusters: rs_kernel_forms.direct_rows) keeps its shadow records between sweeps: k_row_apply adds
     every delta to the record as well as to the table row, rs_discount sweeps the records too, and any other write to the table has them rebuilt before the next sweep
@@ -1205,6 +1205,21 @@ def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
         for player in (0, 1):   # and the records are still good for a plain sweep afterwards
             assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util after the loop p=%d" % player)
         same_tables("a sweep after rs_train")
+        return
+    if variant == "host-loop":   # rs_solver_training_loop around a loop the HOST writes: sweeps and discounts only in between, the table read after it
+        tr.training_loop(True)
+        for it in range(4):
+            for player in (0, 1):
+                tr.iterate(player)
+                osol.iterate(player)
+            if it % 2:
+                table.discount(0.5 + 0.1 * it)
+                otab.discount(np.float32(0.5 + 0.1 * it))
+        tr.training_loop(False)
+        same_tables("a host-written loop inside rs_solver_training_loop")
+        for player in (0, 1):
+            assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util after the loop p=%d" % player)
+        same_tables("a sweep after the loop")
         return
     if variant == "two-solvers":
         tr2, osol2 = solver(7)
