@@ -290,7 +290,7 @@ typedef struct rs_kernel_forms {
     int32_t shadow;             /* RS_SHADOW_* */
     int32_t deal_order;         /* RS_FORM_*: sampled deal sweeps walk the batch in the order of the traverser's last-round cluster id, and the last round's subtrees
                                    sum their deltas along the runs of equal cluster (DPP segmented scan) instead of LDS tiles or delta rows (default: on for multi-round
-                                   trees beyond 48 K deals per batch, profiles/r04_deals.md) */
+                                   trees beyond 24 K deals per batch, profiles/r04_deals.md) */
     int32_t delta_rows;         /* RS_FORM_*: i32 deal sweeps keep no delta tiles and issue no atomics inside the walk: a visit stores its deltas at the deal's LIST POSITION
                                    ([2A][batch pitch] i32 rows per traverser node, coalesced), and one streaming pass per sweep sums every row by cluster (LDS histogram of
                                    one row at a time) into the delta tables.  Applies to the round subtrees whose traverser nodes have at most 16 384 clusters */

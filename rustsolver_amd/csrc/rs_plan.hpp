@@ -9,12 +9,17 @@
 namespace rs {
 
 constexpr size_t kCountStride = 64;   // u32 elements between two live-deal counters (256 B)
-constexpr uint32_t kScanParentMin = 65536;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent)
+constexpr uint32_t kScanParentMin = 2048;   // deal batches beyond this size compact a round subtree's live deals from its parent's lists (rs_solver.cpp scan_parent); 65 536 until the end of
+                                            // round 4: re-measured with three auxiliary streams 4 K / 16 K / 64 K deals 0.48-0.54 / 0.63-0.69 / 0.75-0.76 against 0.51-0.58 / 0.66-0.71 / 0.82-0.84 ms
 // Rows that many workgroups stream at the same offsets at the same time (delta rows, live-deal lists) must not start a power of two apart: a 4 M-deal batch puts them 16 MiB
 // apart, every stream then sits on the same memory channel at the same moment, and the row-summing pass ran 4x slower than with 4 196 416 deals (12.7 against 8.9 ms per batch)
 constexpr size_t kRowStagger = 1088;   // elements between the natural pitch and the one used (4 352 B: off every power-of-two interleave up to 4 KiB, rows stay 256-B aligned)
 constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this size compact the live deals of sibling roots in one scan of their source (rs_plan_deals.cpp)
-constexpr uint32_t kRowsMinDeals = 49152;   // deal batches beyond this size store delta rows in their list walkers and walk the batch in the order of the traverser's last-round cluster (rs_solver.cpp).
+// Deal batches beyond kRowsMinDeals store delta rows in their list walkers, beyond kOrderMinDeals they also walk the batch in the order of the traverser's last-round cluster
+// (rs_solver.cpp).  Three streets, 5 000-bucket files, ms per batch with LDS tiles / rows / rows + order (profiles/r04_deals.md): 1 K deals 0.55 / 0.46 / 0.48, 4 K 0.60 / 0.52 /
+// 0.53, 16 K 0.70-0.81 / 0.65 / 0.72, 32 K 0.80 / 0.77 / 0.60-0.70, 64 K - / 0.83-0.91 / 0.74-0.84 (until the end of round 4 both forms started at 48 K deals).
+constexpr uint32_t kRowsMinDeals = 1024;
+constexpr uint32_t kOrderMinDeals = 24576;
                                             // Round 3 (gathering walks): 4 M deals 1.13-1.19x, 256 K a wash -> 512 K.  Round 4 (staged rows, runs summed by DPP): 4 M 1.16x, 1 M 1.18x, 512 K 1.16x,
                                             // 256 K 1.10x, 128 K 1.11x, 64 K 1.24x over the tile kernels on one card (profiles/r04_deals.md)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)

@@ -634,7 +634,7 @@ static int setup_deal_records(rs_solver *s) {
             // 3.57 against 3.40 at 1 M deals, and on the river game 0.84 against 0.69 -- a wash at best, so the form is opt-in (rs_kernel_forms.deal_order = RS_FORM_ON)
             // Round 4 (profiles/r04_deals.md): with the list walkers staging their deals' rows in LDS the runs of an ordered sweep share the traverser's row, the last round sums
             // its deltas along the runs (no delta rows, no summing pass for it), and the form wins on three streets beyond half a million deals per batch: 6.5 -> 6.0 ms at 4 M
-            const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->n_rounds > 1 && s->deals.n_deals > kRowsMinDeals;
+            const bool engine = s->params.opp_mode == RS_OPP_SAMPLE && s->n_rounds > 1 && s->deals.n_deals > kOrderMinDeals;
             s->ordered = round_mode && fits && (s->knobs.ordered == kUnset ? engine : s->knobs.ordered != 0);
             if (s->ordered) {
                 const size_t pitch = round_up(s->deals.n_deals, kLanePad);

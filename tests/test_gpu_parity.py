@@ -544,7 +544,13 @@ def test_sparse_subtree_sweeps_three_streets_many_deals(blocks, sparse, monkeypa
         pytest.skip("several trips per workgroup: run on the list walkers with tiles, rows and runs")
     if blocks:
         monkeypatch.setenv("RS_JIT_MAX_BLOCKS", blocks)
-    if sparse in ("scan-parent", "scan-parent-siblings"):   # the compaction of a root's live deals walks its parent's lists (what batches beyond 64 K deals get) instead of the whole batch
+    if sparse not in ("rows", "rows+ordered", "gathers"):   # the list walkers with LDS tiles and work lists: what the engine itself only picks below 1 024 deals per batch
+        monkeypatch.setenv("RS_JIT_ROWS", "0")
+    if sparse not in ("ordered", "rows+ordered", "gathers"):
+        monkeypatch.setenv("RS_JIT_ORDERED", "0")
+    if sparse in (True, "ordered", "siblings"):   # the compaction scans the whole batch per root: the engine's choice up to 2 K deals per batch
+        monkeypatch.setenv("RS_JIT_SCAN_ALL", "1")
+    if sparse in ("scan-parent", "scan-parent-siblings"):   # the compaction of a root's live deals walks its parent's lists (what batches beyond 2 K deals get) instead of the whole batch
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
         if "siblings" in sparse:   # what batches beyond 512 K deals get: one compaction job per parent (k_compact_siblings) instead of one per root (k_compact_live)
             monkeypatch.setenv("RS_JIT_NO_SIBLINGS", "0")
@@ -628,8 +634,9 @@ def test_sparse_three_streets_cluster_ranges_on_every_round(rows, monkeypatch):
     # "many-ranges": half of the LDS again (64-cluster ranges on the river), so that the launches of the river round carry several hundred (subtree, range) jobs each -- more than one
     # chunk of k_worklist's prefix scan -- most of them with a handful of deals or none
     monkeypatch.setenv("RS_JIT_LDS_MAX", "8256" if rows == "many-ranges" else "16384")
-    if rows != "whole-batch-scan":
-        monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    monkeypatch.setenv("RS_JIT_ROWS", "0")      # cluster ranges belong to the list walkers with LDS tiles
+    monkeypatch.setenv("RS_JIT_ORDERED", "0")
+    monkeypatch.setenv("RS_JIT_SCAN_ALL", "1" if rows == "whole-batch-scan" else "0")
     n_deals = 30011
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(300, 280), (500, 450), (700, 650)], n_deals, 92)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=13)
@@ -1259,6 +1266,8 @@ def test_handoff_with_more_opponent_nodes_than_rows(forms, monkeypatch):
     if forms == "rows":
         monkeypatch.setenv("RS_JIT_ROWS", "1")
         monkeypatch.setenv("RS_JIT_SCAN_ALL", "0")
+    else:
+        monkeypatch.setenv("RS_JIT_ROWS", "0")
     bets, raises = ((0.25, 0.5, 1.0), (1.0,), (1.0,)), ((2.0, 3.0), (3.0,), (3.0,))
     n_deals = 6007
     flags = (np.random.Generator(np.random.PCG64(8)).integers(0, 3, n_deals) == 0).astype(np.uint8)
@@ -1374,6 +1383,7 @@ def test_deal_sweeps_with_and_without_table_shadows(shadow, monkeypatch):
     k_build_shadow, sampled from as it comes); a node without a shadow has its regrets matched in the walk.  Same bits as the oracle every way, and the workspace figure shows the
     difference."""
     n_deals = 3000
+    monkeypatch.setenv("RS_JIT_ROWS", "0")   # shadowed and unshadowed nodes side by side inside the tile kernels (with delta rows the walkers stage rows or gather all of a subtree)
     tree, table, otree, otab, lg, lo, cidx = setup_deals(rs.three_street_options(), orc.options_three_street(), [(30, 28), (300, 280), (140, 140)], n_deals, 93)
     tr = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=14,
                          forms={"shadow": rs.SHADOW_ALL} if shadow == "all" else None)
