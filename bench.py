@@ -723,15 +723,23 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     create_s = time.perf_counter() - t0
     tr.train(2)
     tr.status()
-    reps = 20   # one call: its first batch is dealt in front of its sweeps, the others beside the previous batch's (0.9 ms of dealing: 0.18 ms per batch over 5, 0.05 over 20)
+    reps = 5    # batches 3-7 of a fresh trainer, as in every round so far (the work per batch FALLS as training proceeds -- fewer live subtrees per deal -- so the window is part of the number)
     t0 = time.perf_counter()
     tr.train(reps)
     tr.infosets.sync()
     dt = (time.perf_counter() - t0) / reps
+    tr.train(40)                                # ... and batches 48-67, one call of 20
+    tr.infosets.sync()
+    t0 = time.perf_counter()
+    tr.train(20)
+    tr.infosets.sync()
+    dt_later = (time.perf_counter() - t0) / 20
+    walks_later = [tr.walk_counts(0), tr.walk_counts(1)]
     out = {"what": "MCCFRTrainer::train on a flop-start three-street tree (%d action nodes), %d-bucket files on flop / turn / river, %d deals per batch, sampled "
                    "opponents: deal sampling, hand indexing through the bucket files, showdowns and the sweep on the device" % (n_actions, k, n),
            "value": n / dt, "unit": "deal-iterations/s", "ms_per_batch": dt * 1e3, "n_deals": n, "clusters": [a_.get_size(0) for a_ in card_abs],
-           "table_bytes": int(tr.infosets.nbytes if not callable(tr.infosets.nbytes) else tr.infosets.nbytes()), "trainer_create_s": create_s}
+           "table_bytes": int(tr.infosets.nbytes if not callable(tr.infosets.nbytes) else tr.infosets.nbytes()), "trainer_create_s": create_s,
+           "ms_per_batch_batches_48_67": dt_later * 1e3, "walks_per_round_batch_67": walks_later}
     out["roofline_deals"] = roofline_deals("three_street_4m", out["ms_per_batch"])
     sizes = [(a_.get_size(0), a_.get_size(1)) for a_ in card_abs]
     tr.destroy()
@@ -1043,7 +1051,7 @@ def compact_line(out):
         "deal_batch_Mps": (g(out, "deal_batch", "value") or 0) / 1e6 or None, "deal_batch_ms": g(out, "deal_batch", "ms_per_batch"),
         "deal_trainer_Mps": (g(out, "deal_trainer", "value") or 0) / 1e6 or None, "deal_trainer_ms": g(out, "deal_trainer", "ms_per_batch"),
         "deal_trainer_valu_frac": g(out, "deal_trainer", "roofline_deals", "frac"),
-        "deal_trainer_3s_Mps": (g(out, "deal_trainer_three_street", "value") or 0) / 1e6 or None, "deal_trainer_3s_ms": g(out, "deal_trainer_three_street", "ms_per_batch"),
+        "deal_trainer_3s_Mps": (g(out, "deal_trainer_three_street", "value") or 0) / 1e6 or None, "deal_trainer_3s_ms": g(out, "deal_trainer_three_street", "ms_per_batch"), "deal_trainer_3s_ms_later": g(out, "deal_trainer_three_street", "ms_per_batch_batches_48_67"),
         "deal_trainer_3s_valu_frac": g(out, "deal_trainer_three_street", "roofline_deals", "frac"),
         "solve_expl": [g(out, "solve", "exploitability_before"), g(out, "solve", "exploitability_after")], "solve_s": g(out, "solve", "seconds_training"),
         "solve_3s_expl": [x[1] for x in (g(out, "solve_three_street", "exploitability_curve") or [])] or None, "solve_3s_s": g(out, "solve_three_street", "seconds_training"),
