@@ -303,6 +303,10 @@ void rs::solver_release_device(rs_solver *s) {
     rs_table *t = s->table;
     (void)hipSetDevice(t->device);
     (void)hipStreamSynchronize(t->stream);
+    if (s->primary) {   // the table's rows back from the records BEFORE anything they live in is freed (k_unbuild_shadow reads d_shadow through d_kept_jobs)
+        (void)solver_kept_primary(s, false);
+        (void)hipStreamSynchronize(t->stream);
+    }
     for (int p = 0; p < 2; ++p) {
         Plan &pl = s->plan[p];
         if (pl.graph_exec) (void)hipGraphExecDestroy(pl.graph_exec);
@@ -344,7 +348,6 @@ void rs::solver_release_device(rs_solver *s) {
     s->ev_fork = nullptr;
     if (s->d_shadow) (void)hipFree(s->d_shadow);
     if (s->d_shadow_jobs) (void)hipFree(s->d_shadow_jobs);
-    if (s->primary) (void)solver_kept_primary(s, false);   // the table's rows back from the records before they go
     if (s->d_kept_jobs) (void)hipFree(s->d_kept_jobs);
     if (s->d_kept_primary) (void)hipFree(s->d_kept_primary);
     if (s->d_disc_jobs) (void)hipFree(s->d_disc_jobs);
@@ -991,6 +994,11 @@ int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util)
     if (!s || !s->table) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad solver");
     if ((traverser != 0 && traverser != 1) || (phase != 0 && phase != 1)) return fail(RS_ERR_INVALID, "rs_iterate_phase: bad traverser / phase");
     if (!s->sharded && !s->deal_mode) return fail(RS_ERR_INVALID, "rs_iterate_phase: the solver is neither sharded nor a deal-batch solver");
+    if (!s->sharded && s->deal_mode && s->rows && s->direct_rows)   // phase 0 must leave the table untouched (the host sums the delta tables between the phases)
+        for (int r = 0; r < s->n_rounds; ++r)
+            if (rows_round_direct(s, traverser, r))
+                return fail(RS_ERR_UNSUPPORTED, "rs_iterate_phase: this solver adds the delta rows of its large rounds straight into the table during the walks, so the delta tables "
+                                                "a host would exchange between the phases are incomplete: create it with rs_kernel_forms.direct_rows = RS_FORM_OFF");
     RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
     if (int rc = run_plan(s, traverser, phase)) return rc;
     return phase == 1 ? copy_root(s, traverser, d_root_util) : RS_OK;

@@ -1,6 +1,6 @@
 """One rank of tests/test_gpu_multiproc.py: a fresh process that shares GPU 0 with its peers and talks to them through tests/libstub_rccl.so (RS_RCCL_LIB).
     python tests/_multiproc_worker.py <case> <workdir> <world> <rank> <id-hex>
-Reads <workdir>/inputs.npz (written by the test), runs the library's OWN multi-rank path -- rs_solver_attach_comm + rs_iterate, or rs_deal_trainer_attach_comm + train --
+Reads <workdir>/inputs.npz (written by the test), runs the library's OWN multi-rank path -- rs_solver_attach_comm + rs_iterate, rs_deal_trainer_attach_comm + train, or rs_replicated_begin + rs_iterate + rs_allreduce_replicated --
 and writes what it ended up with to <workdir>/rank<rank>.npz."""
 import ctypes as C
 import os
@@ -78,10 +78,37 @@ elif case == "dp-deals":
     tr.status()
     tr.attach_comm(None)
     lib.rs_comm_destroy(comm)
-elif case == "replicated":
-    # rs_replicated_begin / rs_allreduce_replicated: every rank sweeps its OWN boards of the sharded rounds without exchanging anything (PASS chance nodes), then the
-    # replicated flop round is reconciled: x = snapshot + sum over ranks of (x - snapshot)
-    raise SystemExit("not used")
+elif case.startswith("replicated"):
+    # rs_replicated_begin / rs_allreduce_replicated (the collective north_star names: "RCCL all-reduce ... for the average-strategy accumulator"): every rank sweeps its OWN
+    # boards of the turn and the river without exchanging anything (PASS chance nodes: a lane keeps its board through the rounds), then the replicated flop round is
+    # reconciled: x = snapshot + sum over ranks of (x - snapshot), regrets and strategy sums alike
+    dtype = {"i32": rs.I32, "f32": rs.F32}[case.split("-")[1]]
+    Cn, B, trips = int(inp["Cn"]), int(inp["B"]), int(inp["trips"])
+    scale, mode = float(inp["scale"]), int(inp["mode"])
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    tb = rs.create_infosets(n_actions, tree, [Cn], [B, B, B], dtype)
+    for nd in tree.action_nodes():
+        who = "" if nd.round_idx == 0 else "_%d" % rank          # the flop's rows are the same on every rank, the later rounds' are the rank's own
+        tb.upload_node(nd.index, inp["R%d%s" % (nd.index, who)], inp["S%d%s" % (nd.index, who)])
+    leaves, bufs = {}, {}
+    for i, nd in enumerate(tree.nodes):
+        if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+            parent = tree.nodes[nd.parent]
+            r = parent.round_idx
+            if r not in bufs:
+                bufs[r] = tb.lane_buffer(parent.index, 1, inp["sign%d_%d" % (r, rank)])
+            leaves[i] = (rs.LEAF_SIGN, bufs[r])
+    sv = rs.MCCFRTrainer(tree, tb, leaves, scale=scale, mode=mode, chance_mode=rs.CHANCE_PASS, fuse_subtrees=int(inp["fuse"]))
+    comm = C.c_void_p()
+    L.check(lib.rs_comm_create(tb._h, ident, rank, world, C.byref(comm)))
+    for trip in range(trips):
+        L.check(lib.rs_replicated_begin(tb._h, 0b001))
+        sv.iterate(0), sv.iterate(1)
+        L.check(lib.rs_allreduce_replicated(tb._h, comm, 0b001))
+    for nd in tree.action_nodes():
+        r, s2 = tb.download_node(nd.index)
+        out["R%d" % nd.index], out["S%d" % nd.index] = r, s2
+    lib.rs_comm_destroy(comm)
 else:
     raise SystemExit("unknown case " + case)
 np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)

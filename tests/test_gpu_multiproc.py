@@ -30,9 +30,9 @@ def build_stub():
     return STUB_SO
 
 
-def run_ranks(case, workdir, world, timeout=300):
+def run_ranks(case, workdir, world, timeout=300, extra_env=None):
     """start `world` fresh worker processes (they share GPU 0), wait, return their result files"""
-    env = dict(os.environ, RS_RCCL_LIB=build_stub(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, RS_RCCL_LIB=build_stub(), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     ident = ("/rs_stub_test_%d_%s" % (os.getpid(), os.urandom(6).hex())).encode().hex()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multiproc_worker.py"), case, str(workdir), str(world), str(r), ident], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -117,3 +117,81 @@ def test_data_parallel_trainer_in_real_processes_equals_one_gpu_with_the_union_b
             want = single.infosets.download_node(nd.index)
             assert (got["R%d" % nd.index] == want[0]).all() and (got["S%d" % nd.index] == want[1]).all(), "node %d on rank %d" % (nd.index, g)
     single.status()
+
+
+@pytest.mark.parametrize("world,dtype,layout,fuse", [(2, "i32", "plain", 1), (3, "i32", "tiled64", 1), (5, "i32", "plain", 0), (2, "f32", "plain", 1), (3, "f32", "tiled64", 1)])
+def test_allreduce_replicated_in_real_processes(world, dtype, layout, fuse, tmp_path):
+    """rs_replicated_begin -> rs_iterate x 2 -> rs_allreduce_replicated(round_mask = flop) with `world` PROCESSES: every rank owns B boards of the turn and the river (PASS chance
+    nodes, its own leaves), the flop's rows start out the same everywhere and must END the same everywhere: snapshot + the sum of every rank's (row - snapshot), the
+    reference's eight threads adding into one table (cfr.rs:195-229) made deterministic.  The parent works the expected table out with the ORACLE, rank by rank:
+    i32 sums wrap and commute -> bit for bit; f32: within 1e-5 relative (the order of an RCCL sum is the library's; the stub's is rank order).  Two trips, so that the second
+    snapshot is taken of the reconciled rows.  "tiled64": the ranks keep their rows in 64-lane tiles (RS_TABLE_TILE_LANES) -- the collective works on the node's cells as
+    they lie, and every rank lays them out alike."""
+    Cn, B, trips = 40, 3, 2
+    dt_o = {"i32": orc.T_I32, "f32": orc.T_F32}[dtype]
+    scale, mode, mode_o = (10000.0, rs.UPD_WRAP_I32, orc.UPD_WRAP_I32) if dtype == "i32" else (2.0 ** -6, rs.UPD_CLAMP_I64, orc.UPD_CLAMP_I64)
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    otree = orc.OracleTree(orc.options_three_street())
+    rng = np.random.Generator(np.random.PCG64(1000 + world))
+    lanes = B * Cn
+
+    def rows(a):
+        if dtype == "i32":
+            return rng.integers(-10**6, 10**6, size=(a, lanes)).astype(np.int32), rng.integers(0, 10**6, size=(a, lanes)).astype(np.int32)
+        return rng.uniform(-1000, 1000, size=(a, lanes)).astype(np.float32), rng.uniform(0, 1000, size=(a, lanes)).astype(np.float32)
+
+    inputs = dict(Cn=Cn, B=B, trips=trips, scale=scale, mode=mode, fuse=fuse)
+    flop = [nd for nd in tree.action_nodes() if nd.round_idx == 0]
+    for nd in flop:
+        inputs["R%d" % nd.index], inputs["S%d" % nd.index] = rows(nd.n_children)
+    for g in range(world):
+        for nd in tree.action_nodes():
+            if nd.round_idx != 0:
+                inputs["R%d_%d" % (nd.index, g)], inputs["S%d_%d" % (nd.index, g)] = rows(nd.n_children)
+        for r in range(3):
+            inputs["sign%d_%d" % (r, g)] = rng.integers(-1, 2, size=lanes).astype(np.float32)
+    np.savez(os.path.join(tmp_path, "inputs.npz"), **inputs)
+    # the oracle, one table per rank
+    otabs, osols = [], []
+    for g in range(world):
+        otab = orc.OracleTable(otree, [B, B, B], Cn, dt_o)
+        for nd in tree.action_nodes():
+            who = "" if nd.round_idx == 0 else "_%d" % g
+            otab.set_node(nd.index, inputs["R%d%s" % (nd.index, who)], inputs["S%d%s" % (nd.index, who)])
+        lo = {}
+        for i, nd in enumerate(tree.nodes):
+            if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED:
+                lo[i] = (orc.LEAF_SIGN, inputs["sign%d_%d" % (tree.nodes[nd.parent].round_idx, g)])
+        otabs.append(otab)
+        osols.append(orc.OracleSolver(otree, otab, lo, scale=scale, mode=mode_o, chance_mode=orc.CHANCE_PASS))
+    from rustsolver_amd.dist import replicated_allreduce
+    for trip in range(trips):
+        snap = {nd.index: otabs[0].get_node(nd.index) for nd in flop}
+        for g in range(world):
+            osols[g].iterate(0), osols[g].iterate(1)
+        for nd in flop:
+            new = []
+            for k in range(2):
+                xs = [np.ascontiguousarray(otabs[g].get_node(nd.index)[k]) for g in range(world)]
+
+                def total(neg_delta_of_rank0, xs=xs, k=k, nd=nd):   # rank order, like the stub
+                    acc = neg_delta_of_rank0.copy()
+                    for x in xs[1:]:
+                        d = (snap[nd.index][k].view(np.uint32) - x.view(np.uint32)).view(np.int32) if dtype == "i32" else (snap[nd.index][k] - x).astype(np.float32)
+                        acc = (acc.view(np.uint32) + d.view(np.uint32)).view(np.int32) if dtype == "i32" else (acc + d).astype(np.float32)
+                    return acc
+                new.append(replicated_allreduce(xs[0], np.ascontiguousarray(snap[nd.index][k]), total))
+            for g in range(world):
+                otabs[g].set_node(nd.index, new[0], new[1])
+    ranks = run_ranks("replicated-" + dtype, tmp_path, world, extra_env={"RS_TABLE_TILE_LANES": "64"} if layout == "tiled64" else None)
+    for g, got in enumerate(ranks):
+        for nd in tree.action_nodes():
+            ro, so = otabs[g].get_node(nd.index)
+            if dtype == "i32":
+                assert (got["R%d" % nd.index] == ro).all() and (got["S%d" % nd.index] == so).all(), "node %d (round %d) on rank %d" % (nd.index, nd.round_idx, g)
+            else:
+                np.testing.assert_allclose(got["R%d" % nd.index], ro, rtol=1e-5, atol=1e-3, err_msg="regrets of node %d on rank %d" % (nd.index, g))
+                np.testing.assert_allclose(got["S%d" % nd.index], so, rtol=1e-5, atol=1e-3, err_msg="strategy sums of node %d on rank %d" % (nd.index, g))
+        if g:   # the replicated round is the SAME on every rank, to the last bit, float tables included (every rank adds the same total to the same snapshot)
+            for nd in flop:
+                assert got["R%d" % nd.index].tobytes() == ranks[0]["R%d" % nd.index].tobytes() and got["S%d" % nd.index].tobytes() == ranks[0]["S%d" % nd.index].tobytes()

@@ -1174,7 +1174,7 @@ def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "host-loop", "two-solvers"])
+@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "host-loop", "host-loop-destroyed", "host-phases-refused", "two-solvers"])
 def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
     """A round whose delta rows go straight into the table (20 000 / 17 000 river clusters: rs_kernel_forms.direct_rows) keeps its shadow records between sweeps: k_row_apply adds
     every delta to the record as well as to the table row, rs_discount sweeps the records too, and any other write to the table has them rebuilt before the next sweep
@@ -1212,6 +1212,33 @@ def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
         for player in (0, 1):   # and the records are still good for a plain sweep afterwards
             assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util after the loop p=%d" % player)
         same_tables("a sweep after rs_train")
+        return
+    if variant == "host-loop-destroyed":   # a solver destroyed INSIDE its training loop (an exception in the host's loop, say): the records' rows go back to the table first
+        tr.training_loop(True)
+        for it in range(3):
+            for player in (0, 1):
+                tr.iterate(player)
+                osol.iterate(player)
+        tr.destroy()
+        same_tables("a solver destroyed while its kept records were the working copy")
+        tr2, osol2 = solver(7)   # and the table is good for the next solver
+        for player in (0, 1):
+            assert_bits(tr2.iterate(player, want_root_util=True), osol2.iterate(player), "root util of the next solver p=%d" % player)
+        same_tables("the next solver's sweep")
+        return
+    if variant == "host-phases-refused":   # rs_iterate_phase promises "phase 0 leaves the table untouched": a solver whose river rows go straight into the table cannot keep it
+        with pytest.raises(rs.RsError, match="direct_rows"):
+            tr.iterate_phase(0, 0)
+        tr_off = rs.MCCFRTrainer(tree, table, lg, scale=100.0, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE, sample_seed=99,
+                                 forms={"direct_rows": rs.FORM_OFF})
+        before = {nd.index: table.download_node(nd.index) for nd in tree.action_nodes()}
+        tr_off.iterate_phase(0, 0)
+        for nd in tree.action_nodes():
+            r, s_ = table.download_node(nd.index)
+            assert (r == before[nd.index][0]).all() and (s_ == before[nd.index][1]).all(), "phase 0 wrote node %d" % nd.index
+        tr_off.iterate_phase(0, 1)
+        osol.iterate(0)
+        same_tables("phases driven by hand, direct rows off")
         return
     if variant == "host-loop":   # rs_solver_training_loop around a loop the HOST writes: sweeps and discounts only in between, the table read after it
         tr.training_loop(True)
