@@ -207,7 +207,16 @@ struct ClusterJob {
     uint64_t mask;
     uint32_t *out;                 // [pitch] dense cluster ids
     const uint32_t *lut;           // [52 * 52] get_cluster by hole cards when the abstraction's whole board is the initial board, else nullptr
+    // One or two board cards beyond the initial board (a flop-start game's turn and river): get_cluster is a function of the hole cards and those cards -- tabulated too
+    // (k_cluster_xlut, once per device): xlut[pair id of the hole cards * xw + (the one card | pair id of the two cards)], pair ids from pid[52 * 52] (0xffff: a card of the
+    // initial board, or twice the same card).  A deal whose first n_fixed board cards are NOT the initial board takes the index path below.  nullptr: no such table.
+    const uint32_t *xlut;
+    const uint16_t *pid;
+    uint64_t fixed_mask;
+    uint32_t xw;
+    int32_t n_fixed, cards_left;
 };
+constexpr uint32_t kDenseBeyond = kDenseMissing - 1u;   // table entries: the canonical index lies beyond the bucket file
 
 __global__ __launch_bounds__(kBlock) void k_hand_index(HandIndexView v, int upto, CardRows rows, const uint8_t *__restrict__ cards, uint32_t n,
                                                        uint32_t pitch, uint64_t *__restrict__ out) {
@@ -281,10 +290,35 @@ __global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJobs jobs
         }
         return;
     }
+    const uint32_t *__restrict__ xlut = job->xlut;
+    const uint16_t *__restrict__ pid = job->pid;
+    const int n_fixed = job->n_fixed, cards_left = job->cards_left;
+    const uint64_t fixed_mask = job->fixed_mask;
+    const uint32_t xw = job->xw;
     for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < n; l += gridDim.x * kBlock) {
         uint8_t c[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) c[i] = i < n_cards ? cards[(size_t)job->rows.row[i] * pitch + l] : (uint8_t)0;
+        if (xlut) {   // the deal's board starts with the abstraction's initial board (any order): one table read instead of the index, the bucket file and the hash probe
+            uint64_t seen = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < n_fixed) seen |= 1ull << (c[2 + i] & 63u);
+            if (seen == fixed_mask && c[0] < 52u && c[1] < 52u) {
+                const uint32_t hp = pid[(uint32_t)c[0] * 52u + c[1]];
+                const uint32_t f0 = c[2 + n_fixed], f1 = cards_left == 2 ? c[3 + n_fixed] : 0u;
+                uint32_t col = 0xffffu;
+                if (cards_left == 1) col = f0 < 52u ? f0 : 0xffffu;
+                else if (f0 < 52u && f1 < 52u) col = pid[f0 * 52u + f1];
+                uint32_t dense = (hp != 0xffffu && col != 0xffffu) ? xlut[(size_t)hp * xw + col] : kDenseMissing;
+                if (dense >= kDenseBeyond) {
+                    atomicOr(err, dense == kDenseBeyond ? 2u : 1u);
+                    dense = 0;
+                }
+                dst[l] = dense;
+                continue;
+            }
+        }
         uint64_t bucket = hand_index(job->view, job->upto, c);
         if (arr) {
             if (bucket < arr_len) bucket = arr[bucket];
@@ -299,6 +333,46 @@ __global__ __launch_bounds__(kBlock) void k_deal_clusters(const ClusterJobs jobs
             dense = 0;   // stays inside the table; the error word makes the host refuse the batch
         }
         dst[l] = dense;
+    }
+}
+
+// The table behind ClusterJob::xlut, filled once per device: entry (hole pair, free card(s)) = what the index path gives for that hand on the initial board.
+// pair_cards[id] = (x << 8) | y, x > y: the cards of pair `id` (cards of the initial board have no pairs).  Hands that share a card: kDenseMissing.
+__global__ __launch_bounds__(kBlock) void k_cluster_xlut(ClusterJob job, const uint16_t *__restrict__ pair_cards, uint32_t n_pairs, uint32_t *__restrict__ out) {
+    const uint64_t total = (uint64_t)n_pairs * job.xw;
+    for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t hp = (uint32_t)(e / job.xw), col = (uint32_t)(e % job.xw);
+        uint8_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+        c[0] = (uint8_t)(pair_cards[hp] >> 8);
+        c[1] = (uint8_t)(pair_cards[hp] & 0xffu);
+        int at = 2;
+        for (uint64_t m = job.fixed_mask; m; m &= m - 1) c[at++] = (uint8_t)__builtin_ctzll(m);
+        bool ok = true;
+        if (job.cards_left == 1) {
+            ok = col < 52u && !((job.fixed_mask >> col) & 1ull);
+            c[at++] = (uint8_t)col;
+        } else {
+            ok = col < n_pairs;
+            const uint16_t bc = ok ? pair_cards[col] : (uint16_t)0;
+            c[at++] = (uint8_t)(bc >> 8);
+            c[at++] = (uint8_t)(bc & 0xffu);
+        }
+        uint64_t used = 0;
+        for (int i = 0; i < at && ok; ++i) {
+            ok = !((used >> c[i]) & 1ull);
+            used |= 1ull << c[i];
+        }
+        uint32_t dense = kDenseMissing;
+        if (ok) {
+            uint64_t bucket = hand_index(job.view, job.upto, c);
+            bool beyond = false;
+            if (job.cluster_arr) {
+                if (bucket < job.arr_len) bucket = job.cluster_arr[bucket];
+                else beyond = true;
+            }
+            dense = beyond ? kDenseBeyond : dense_lookup(job.slots, job.mask, bucket);
+        }
+        out[e] = dense;
     }
 }
 
@@ -402,17 +476,26 @@ struct rs_card_abs {
     std::vector<DenseSlot> slots[2];            // cluster_map[player]
     std::vector<uint64_t> keys[2];              // dense id -> bucket
     std::vector<uint32_t> lut[2];               // [52 * 52] get_cluster by hole cards, when the round's board IS the initial board (else empty)
+    uint64_t initial_mask = 0;                  // the board the abstraction was generated from (card_abstraction.rs:94-98)
+    int n_fixed = 0, cards_left = 0;            // its cards, and the round's board cards beyond it (0, 1 or 2)
+    std::vector<uint16_t> pid, pair_cards;      // cards_left > 0: pair id by two cards [52 * 52] (0xffff: none) and back (ClusterJob::xlut)
     struct Dev {                                // mirror on one GPU, created on first use
         int device;
         uint32_t *cluster_arr;
         DenseSlot *slots[2];
         uint32_t *lut[2];
         uint32_t *err;
+        uint32_t *xlut[2];                      // cards_left > 0: get_cluster by (hole pair, free board cards), filled on the device at first use
+        uint16_t *pid;
+        uint32_t xw;
     };
     std::vector<Dev> devs;
     std::mutex mu;
 };
 
+namespace rs {
+hipError_t build_xlut(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *d);   // below the kernels
+}
 namespace {
 int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
     std::lock_guard<std::mutex> lock(a->mu);
@@ -439,6 +522,7 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d.err), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d.err, 0, sizeof(uint32_t), t->stream);
+    if (e == hipSuccess && a->cards_left > 0 && !a->pair_cards.empty()) e = build_xlut(a, t, &d);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     if (e != hipSuccess) {
         (void)hipFree(d.cluster_arr);
@@ -446,6 +530,9 @@ int abs_device(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *out) {
         (void)hipFree(d.slots[1]);
         (void)hipFree(d.lut[0]);
         (void)hipFree(d.lut[1]);
+        (void)hipFree(d.xlut[0]);
+        (void)hipFree(d.xlut[1]);
+        (void)hipFree(d.pid);
         (void)hipFree(d.err);
         return hip_fail(e, "rs_card_abs: device mirror");
     }
@@ -658,6 +745,9 @@ void rs_card_abs_destroy(rs_card_abs *a) {
             (void)hipFree(d.slots[1]);
             (void)hipFree(d.lut[0]);
             (void)hipFree(d.lut[1]);
+            (void)hipFree(d.xlut[0]);
+            (void)hipFree(d.xlut[1]);
+            (void)hipFree(d.pid);
             (void)hipFree(d.err);
         }
     rs_hand_indexer_destroy(a->ix);
@@ -675,6 +765,18 @@ int rs_card_abs_create(int betting_round, const uint8_t *hands_p0, size_t n_hand
     rs_card_abs *a = new (std::nothrow) rs_card_abs();
     if (!a) return fail(RS_ERR_OOM, "rs_card_abs_create: out of memory");
     a->round = betting_round;
+    a->initial_mask = initial_board_mask;
+    a->n_fixed = n_board;
+    a->cards_left = cards_left;
+    if (cards_left > 0) {   // pair ids over the cards that are not on the initial board: id(x, y) = id(y, x), x > y in pair_cards
+        a->pid.assign(52 * 52, uint16_t(0xffff));
+        for (int x = 0; x < 52; ++x)
+            for (int y = 0; y < x; ++y) {
+                if ((1ull << x | 1ull << y) & initial_board_mask) continue;
+                a->pid[size_t(x) * 52 + y] = a->pid[size_t(y) * 52 + x] = uint16_t(a->pair_cards.size());
+                a->pair_cards.push_back(uint16_t(x << 8 | y));
+            }
+    }
     const uint8_t cpr[2] = {2, uint8_t(3 + betting_round)};
     int rc = rs_hand_indexer_create(2, cpr, &a->ix);
     if (rc == RS_OK && cluster_arr) {
@@ -792,6 +894,42 @@ int rs_card_abs_clusters_device(rs_card_abs *a, rs_table *t, const uint8_t *d_ca
 }  // extern "C" (interrupted: the stream-taking forms below are internal)
 
 namespace rs {
+// get_cluster tabulated over (hole pair, the one or two board cards beyond the initial board): 1 176 x 52 entries for a flop-start game's turn, 1 176 x 1 176 (5.5 MB) for its
+// river, per player.  The index path (hand index: ~1 000 vector instructions of 64-bit arithmetic, a 4-byte read from a bucket file of up to 492 MB, a hash probe) then runs
+// once per table entry instead of once per deal and sweep: 4 M deals, flop start, river: 219 -> ~20 us per call.
+hipError_t build_xlut(rs_card_abs *a, rs_table *t, rs_card_abs::Dev *d) {
+    HandIndexView v;
+    if (device_view(a->ix, t->device, t->stream, &v) != RS_OK) return hipErrorUnknown;
+    const uint32_t n_pairs = uint32_t(a->pair_cards.size());
+    d->xw = a->cards_left == 1 ? 52u : n_pairs;
+    uint16_t *d_pairs = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d->pid), a->pid.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d->pid, a->pid.data(), a->pid.size() * sizeof(uint16_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_pairs), n_pairs * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, a->pair_cards.data(), n_pairs * sizeof(uint16_t), hipMemcpyHostToDevice, t->stream);
+    const size_t entries = size_t(n_pairs) * d->xw;
+    for (int p = 0; e == hipSuccess && p < 2; ++p) {
+        e = hipMalloc(reinterpret_cast<void **>(&d->xlut[p]), entries * sizeof(uint32_t));
+        if (e != hipSuccess) break;
+        ClusterJob j;
+        std::memset(&j, 0, sizeof(j));
+        j.view = v;
+        j.upto = 1;
+        j.cluster_arr = d->cluster_arr;
+        j.arr_len = a->cluster_arr.size();
+        j.slots = d->slots[p];
+        j.mask = a->slots[p].size() - 1;
+        j.fixed_mask = a->initial_mask;
+        j.xw = d->xw;
+        j.n_fixed = a->n_fixed;
+        j.cards_left = a->cards_left;
+        hipLaunchKernelGGL(k_cluster_xlut, dim3(uint32_t(std::min<size_t>((entries + kBlock - 1) / kBlock, 8192))), dim3(kBlock), 0, t->stream, j, d_pairs, n_pairs, d->xlut[p]);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);   // d_pairs is freed below
+    (void)hipFree(d_pairs);
+    return e;
+}
 // the same on a stream of the caller's choice (the trainer deals the NEXT batch beside the sweeps of the current one)
 int card_abs_clusters_on(rs_card_abs *a, rs_table *t, hipStream_t stream, const uint8_t *d_cards, uint32_t n_deals, uint32_t *d_cluster_p0,
                          uint32_t *d_cluster_p1) {
@@ -821,6 +959,12 @@ int card_abs_clusters_on(rs_card_abs *a, rs_table *t, hipStream_t stream, const 
         j.lut = dev.lut[p];
         j.mask = a->slots[p].size() - 1;
         j.out = dst;
+        j.xlut = dev.xlut[p];
+        j.pid = dev.pid;
+        j.fixed_mask = a->initial_mask;
+        j.xw = dev.xw;
+        j.n_fixed = a->n_fixed;
+        j.cards_left = a->cards_left;
     }
     if (n_deals == 0) return RS_OK;
     hipLaunchKernelGGL(k_deal_clusters, lane_grid(n_deals, uint32_t(n_jobs)), dim3(kBlock), 0, stream, jobs, d_cards, n_deals,

@@ -92,7 +92,7 @@ def deals_from(rng, n, mask, h0, h1):
 
 
 @pytest.mark.parametrize("round_,n_board,bucketed", [(ab.RIVER, 5, False), (ab.TURN, 3, False), (ab.RIVER, 3, False), (ab.FLOP, 3, True),
-                                                    (ab.TURN, 3, True)])
+                                                    (ab.TURN, 3, True), (ab.RIVER, 3, True), (ab.RIVER, 4, False), (ab.TURN, 4, True)])
 def test_device_get_cluster_equals_host(table, round_, n_board, bucketed):
     rng = np.random.Generator(np.random.PCG64(round_ * 10 + n_board + 50 * bucketed))
     mask = sum(1 << int(c) for c in rng.permutation(52)[:n_board])
@@ -119,6 +119,27 @@ def test_device_get_cluster_equals_host(table, round_, n_board, bucketed):
         b = oix.get_index(hand0[i])
         b = int(arr[b]) if arr is not None else b
         assert pos[b] == c0[i]
+
+
+def test_device_get_cluster_on_boards_the_tables_do_not_cover(table):
+    """One or two board cards beyond the initial board: the device reads get_cluster from a table over (hole pair, those cards), filled once through the index path
+    (k_cluster_xlut).  A deal whose board does NOT start with the initial board (any order) is none of the table's: it takes the index path itself.  Bucket files with few
+    buckets, so that every bucket has a cluster id whatever the board: both kinds of deals in one batch must equal the host's get_cluster."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for round_ in (ab.TURN, ab.RIVER):
+        mask = ab.card_mask("2c9dKh")
+        other = ab.card_mask("2c9dQs")
+        allh = [h for h in ab.random_range(mask).tolist() if not ((1 << h[0] | 1 << h[1]) & other)]
+        hands = np.array(allh, dtype=np.uint8)[rng.permutation(len(allh))[:80]]
+        arr = rng.integers(0, 19, size=ab.HandIndexer([2, 3 + round_]).size(1), dtype=np.uint32)
+        card_abs = ab.CardAbstraction.init([hands, hands], mask, round_, arr)
+        home, away = deals_from(rng, 1500, mask, hands, hands), deals_from(rng, 1500, other, hands, hands)
+        home[:3] = home[:3][rng.permutation(3)]              # the initial board in another order is still the initial board
+        deals = np.concatenate([home, away], axis=1)[:, rng.permutation(3000)]
+        c0, c1 = card_abs.get_clusters_device(table, deals)
+        nb = 3 + round_
+        assert (c0 == card_abs.get_cluster(np.concatenate([deals[5:7], deals[:nb]]).T, 0)).all()
+        assert (c1 == card_abs.get_cluster(np.concatenate([deals[7:9], deals[:nb]]).T, 1)).all()
 
 
 def test_device_get_cluster_reports_hands_outside_the_map(table):
