@@ -425,6 +425,9 @@ void solver_table_discounted(struct rs_solver *s, float d, uint64_t epoch_before
 int solver_kept_primary(struct rs_solver *s, bool on);
 constexpr uint64_t kKeptPrimaryMinTrips = 16;   // training loops shorter than this leave the table's rows the working copy (the write-back at the end would cost more than it saves)
 bool solver_is_primary(const struct rs_solver *s);
+// ordered deal sweeps: the caller sorts the per-deal records of every batch itself, ahead of the sweep (true: accepted -- an ordered solver on one GPU that has not swept yet)
+bool solver_order_ahead(struct rs_solver *s, bool on, int (*before_sweep)(void *ctx, int traverser), void *ctx);
+int solver_order_on(struct rs_solver *s, int traverser, hipStream_t stream, const uint32_t *const cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], const float *leaf, const uint8_t *prune);
 int solver_discount_primary(struct rs_solver *s, float d);   // rs_discount while on: the kept records and the table WITHOUT their nodes
 // profiling hooks used around launches
 void prof_begin(rs_table *t, int kind, double bytes);

@@ -614,7 +614,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         put_u32(js.off_rcount, parts.first > 1 ? std::min(parts.second, n_cl > c0 ? n_cl - c0 : 0u) : own_pitch);
         put_u32(js.off_rp, rows ? uint32_t(s->pitch[0] + kRowStagger) : rp);
         put_ptr(js.off_prune, (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr);
-        put_ptr(js.off_attr, (sparse || s->ordered) ? s->d_attr[nodes[id].round_idx] : nullptr);
+        put_ptr(js.off_attr, s->ordered ? s->d_arec_p[p] : (sparse ? s->d_attr[nodes[id].round_idx] : nullptr));
         if (sparse && s->d_attr[nodes[id].round_idx]) s->attr_used |= 1u << nodes[id].round_idx;
         if (use_lds) {
             std::vector<std::pair<size_t, size_t>> tiles;   // (ints, k)

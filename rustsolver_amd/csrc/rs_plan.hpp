@@ -186,9 +186,15 @@ struct rs_solver {
     // records in that order (rebuilt at the start of every sweep by k_order_*), d_attr[r] all point at it
     bool ordered = false;
     int order_round = 0;                // the last betting round of the tree
-    void *d_arec = nullptr;
-    uint32_t *d_order_tot = nullptr;    // [2][n_bins]: counts and cursors of the counting sort
+    void *d_arec = nullptr;             // == d_arec_p[0]
+    void *d_arec_p[2] = {nullptr, nullptr};   // one set of records per traverser (round 5): traverser 1's can be sorted while traverser 0's sweep still reads its own
+    uint32_t *d_order_tot = nullptr;    // [2 traversers][2][n_bins]: counts and cursors of the counting sorts
     OrderJob order_job[2];              // per traverser
+    // The records depend on the deals alone, not on the table: a caller that knows the next batch early (rs_deal_trainer deals ahead on a second stream) sorts them itself,
+    // beside the sweeps (solver_order_on), and the plans' own L_ORDER launches do nothing.  Set before the first sweep (a captured graph keeps what it was captured with).
+    bool order_ahead = false;
+    int (*before_sweep)(void *ctx, int traverser) = nullptr;   // ... and is asked in front of every sweep whether the records are the live batch's (rs_iterate, rs_iterate_phase 0)
+    void *before_sweep_ctx = nullptr;
     // delta rows (rs_kernel_forms.delta_rows): one buffer for both traversers' sweeps (they never overlap), [2A][batch pitch] i32 per traverser node of an eligible round
     bool rows = false;
     bool direct_rows = false;           // rounds whose traverser nodes outgrow the summing pass's LDS tile store delta rows too, added straight into the table (k_row_apply)

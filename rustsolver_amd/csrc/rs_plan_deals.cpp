@@ -184,7 +184,7 @@ int PlanBuilder::emit_deal_lists() {
             cj.key = n_parts[k] > 1 ? s->deals.d_cluster[nodes[id].round_idx][p] : nullptr;   // the traverser's cluster on this round
             cj.key_stride = 1;
             if (cj.key && s->ordered) {   // list entries are ranks: the key sits in the rank's record
-                cj.key = static_cast<const uint32_t *>(s->d_arec) + 2 * nodes[id].round_idx + p;
+                cj.key = static_cast<const uint32_t *>(s->d_arec_p[p]) + 2 * nodes[id].round_idx + p;
                 cj.key_stride = 8;
             }
             plan.count_off[k] = cat;

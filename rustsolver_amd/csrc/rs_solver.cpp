@@ -65,6 +65,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         return RS_OK;
     }
     if (L.kind == L_ORDER) {
+        if (s->order_ahead) return RS_OK;   // the caller sorted this batch's records itself (solver_order_on)
         prof_begin(t, RS_K_REACH, L.bytes);
         hipError_t eo = launch_order(s->order_job[&plan == &s->plan[1] ? 1 : 0], t->stream);
         prof_end(t);
@@ -265,6 +266,28 @@ void rs::solver_table_discounted(rs_solver *s, float d, uint64_t epoch_before) {
 
 bool rs::solver_is_primary(const rs_solver *s) { return s && s->table && s->primary; }
 
+// ---- ordered sweeps whose records are sorted AHEAD of the sweep, by the caller, on a stream of its choice (rs_trainer.cpp) -------------------------------------------------
+bool rs::solver_order_ahead(rs_solver *s, bool on, int (*before_sweep)(void *ctx, int traverser), void *ctx) {
+    if (!s || !s->ordered || s->comm || s->sharded || s->plan[0].graph_exec || s->plan[1].graph_exec) return false;
+    s->order_ahead = on;
+    s->before_sweep = on ? before_sweep : nullptr;
+    s->before_sweep_ctx = on ? ctx : nullptr;
+    return true;
+}
+// traverser p's records from the given per-deal arrays (the layout of rs_deal_batch: cluster[round][player], one leaf row, prune flags or null), on `stream`
+int rs::solver_order_on(rs_solver *s, int p, hipStream_t stream, const uint32_t *const cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], const float *leaf, const uint8_t *prune) {
+    if (!s || !s->table || !s->ordered || p < 0 || p > 1) return fail(RS_ERR_INVALID, "solver_order_on: not an ordered deal solver");
+    OrderJob oj = s->order_job[p];
+    oj.key = cluster[s->order_round][p];
+    for (int r = 0; r < s->n_rounds; ++r)
+        for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = cluster[r][pl];
+    oj.leaf = leaf;
+    oj.prune = (s->params.mode & RS_UPD_PRUNE) ? prune : nullptr;
+    RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+    RS_HIP(launch_order(oj, stream), "k_order (ahead of the sweep)");
+    return RS_OK;
+}
+
 int rs::solver_kept_primary(rs_solver *s, bool on) {
     if (!s || !s->table || !s->n_kept_jobs || s->primary == on) return RS_OK;
     rs_table *t = s->table;
@@ -359,7 +382,10 @@ void rs::solver_release_device(rs_solver *s) {
         if (s->d_attr[r] && s->d_attr[r] != s->d_arec) (void)hipFree(s->d_attr[r]);
         s->d_attr[r] = nullptr;
     }
-    if (s->d_arec) (void)hipFree(s->d_arec);
+    for (int tp = 0; tp < 2; ++tp) {
+        if (s->d_arec_p[tp]) (void)hipFree(s->d_arec_p[tp]);
+        s->d_arec_p[tp] = nullptr;
+    }
     if (s->d_drows) (void)hipFree(s->d_drows);
     if (s->d_order_tot) (void)hipFree(s->d_order_tot);
     s->d_arec = nullptr;
@@ -645,10 +671,13 @@ static int setup_deal_records(rs_solver *s) {
                 const uint32_t n_chunks = uint32_t(std::min<size_t>(size_t(s->n_cus) * 2, (size_t(n) + kOrderThreads - 1) / kOrderThreads));
                 const uint32_t chunk = uint32_t(round_up((size_t(n) + n_chunks - 1) / n_chunks, kOrderThreads));
                 const uint32_t max_bins = std::max(bins[0], bins[1]);
-                s->other_bytes += pitch * 32 + size_t(2) * max_bins * sizeof(uint32_t);
-                e = hipMalloc(&s->d_arec, pitch * 32);
-                if (e == hipSuccess) e = hipMemsetAsync(s->d_arec, 0, pitch * 32, table->stream);
-                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(2) * max_bins * sizeof(uint32_t));
+                s->other_bytes += 2 * pitch * 32 + size_t(4) * max_bins * sizeof(uint32_t);
+                for (int tp = 0; tp < 2 && e == hipSuccess; ++tp) {
+                    e = hipMalloc(&s->d_arec_p[tp], pitch * 32);
+                    if (e == hipSuccess) e = hipMemsetAsync(s->d_arec_p[tp], 0, pitch * 32, table->stream);
+                }
+                s->d_arec = s->d_arec_p[0];
+                if (e == hipSuccess) e = hipMalloc((void **)&s->d_order_tot, size_t(4) * max_bins * sizeof(uint32_t));
                 if (e != hipSuccess) {
                     return hip_fail(e, "rs_solver_create: ordered deal records");
                 }
@@ -660,9 +689,9 @@ static int setup_deal_records(rs_solver *s) {
                         for (int pl = 0; pl < 2; ++pl) oj.cid[2 * r + pl] = s->deals.d_cluster[r][pl];
                     oj.leaf = leaf;
                     oj.prune = (s->params.mode & RS_UPD_PRUNE) ? s->deals.d_prune : nullptr;
-                    oj.tot = s->d_order_tot;
-                    oj.cursor = s->d_order_tot + bins[tp];
-                    oj.arec = s->d_arec;
+                    oj.tot = s->d_order_tot + size_t(2) * max_bins * tp;
+                    oj.cursor = oj.tot + bins[tp];
+                    oj.arec = s->d_arec_p[tp];
                     oj.n = n;
                     oj.n_bins = bins[tp];
                     oj.n_chunks = n_chunks;
@@ -954,7 +983,7 @@ void rs_solver_destroy(rs_solver *s) {
 
 static int copy_root(rs_solver *s, int traverser, float *d_root_util) {
     if (d_root_util && s->ordered) {   // the sweep's lanes are ranks of its order: hand the utilities out by deal id
-        RS_HIP(launch_unpermute_f32(s->plan[traverser].root_util, s->d_arec, d_root_util, s->deals.n_deals, s->table->stream), "rs_iterate: root util by deal id");
+        RS_HIP(launch_unpermute_f32(s->plan[traverser].root_util, s->d_arec_p[traverser], d_root_util, s->deals.n_deals, s->table->stream), "rs_iterate: root util by deal id");
         return RS_OK;
     }
     if (d_root_util)
@@ -980,6 +1009,9 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
     }
     if (s->deal_mode && s->comm && s->table->dtype != RS_I32)
         return fail(RS_ERR_UNSUPPORTED, "rs_iterate: data-parallel deal batches all-reduce i32 deltas; an RS_F32 deal solver runs on one GPU");
+    if (s->order_ahead && s->comm) return fail(RS_ERR_UNSUPPORTED, "rs_iterate: this solver's deal records are sorted ahead by its trainer, which runs on one GPU");
+    if (s->before_sweep)
+        if (int rc = s->before_sweep(s->before_sweep_ctx, traverser)) return rc;
     if (s->deal_mode && s->comm) {   // data-parallel deal batches: sweep, sum the deltas over the ranks, apply the union
         if (int rc = run_plan(s, traverser, 0)) return rc;
         if (int rc = rs_comm_allreduce_deltas(s->comm, s->table)) return rc;
@@ -1000,12 +1032,15 @@ int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util)
                 return fail(RS_ERR_UNSUPPORTED, "rs_iterate_phase: this solver adds the delta rows of its large rounds straight into the table during the walks, so the delta tables "
                                                 "a host would exchange between the phases are incomplete: create it with rs_kernel_forms.direct_rows = RS_FORM_OFF");
     RS_HIP(hipSetDevice(s->table->device), "hipSetDevice");
+    if (s->before_sweep && phase == 0)
+        if (int rc = s->before_sweep(s->before_sweep_ctx, traverser)) return rc;
     if (int rc = run_plan(s, traverser, phase)) return rc;
     return phase == 1 ? copy_root(s, traverser, d_root_util) : RS_OK;
 }
 
 int rs_solver_attach_comm(rs_solver *s, rs_comm *comm) {
     if (!s) return fail(RS_ERR_INVALID, "rs_solver_attach_comm: solver is NULL");
+    if (comm && s->order_ahead) return fail(RS_ERR_UNSUPPORTED, "rs_solver_attach_comm: this solver's deal records are sorted ahead by its trainer (one GPU); attach the communicator through rs_deal_trainer_attach_comm before the first batch");
     if (comm && s->deal_mode && s->rows && s->direct_rows)
         for (int p = 0; p < 2; ++p)
             for (int r = 0; r < s->n_rounds; ++r)

@@ -177,13 +177,13 @@ def test_device_deal_sampler_gives_up_where_the_reference_would_spin(table):
         ab.sample_deals(table, 3, 0, 0b11, [[(10, 11)], [(12, 13)]], 64)      # invalid board mask (options.rs:41)
 
 
-def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None, prune_threshold=None):
+def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None, prune_threshold=None, **trainer_kw):
     mask = ab.card_mask(board) if isinstance(board, str) else board
     n_actions, tree = rs.build_game_tree(options_rs)
     first = bin(mask).count("1") - 3
     card_abs = [ab.CardAbstraction.init(ranges, mask, first + r, None if bucket_files is None else bucket_files[r]) for r in range(rounds)]
     tr = rs.DealTrainer(tree, card_abs, ranges, mask, n_deals, seed=seed, discount_interval=interval, discount_cap=cap, fuse_subtrees=fuse,
-                        prune_threshold=prune_threshold)
+                        prune_threshold=prune_threshold, **trainer_kw)
     sizes = [(a.get_size(0), a.get_size(1)) for a in card_abs]
     otree = orc.OracleTree(options_orc)
     otab = orc.OracleDealTable(otree, sizes)
@@ -294,6 +294,62 @@ def test_deal_trainer_prune_schedule(streets):
         assert int(got.sum()) == 0 if (b + 1) * n - 1 <= ctx["prune_threshold"] else got.sum() > 0
     ctx["tr"].status()
     assert seen > n
+    compare_trainer_tables(ctx)
+
+
+@pytest.mark.parametrize("flow", ["one-call", "batch-by-batch", "batch-by-batch+graph", "resweep", "host-loop", "unordered"])
+def test_deal_trainer_deals_and_sorts_ahead(flow, monkeypatch):
+    """rs_deal_trainer_params.prefetch (the trainer's own choice beyond 256 K deals per batch, forced here): the NEXT batch is dealt on a second stream beside the sweeps, and
+    -- round 5 -- where the sweeps are ordered their 32-byte records are sorted there too, traverser p's as soon as sweep p has let go of its buffer; the live arrays are then
+    only filled for the accessors.  Nothing observable may move: cards, cluster ids, signs, prune flags after every call are the LIVE batch's, tables equal the oracle's.
+    "resweep": a sweep of the live batch asked of the trainer's solver directly, after train() has already sorted the records of the batch dealt ahead (the solver asks the
+    trainer before every sweep); "host-loop": rs_deal_trainer_deal / rs_iterate_phase / rs_deal_trainer_finish_batch driven from outside; "unordered": the same with sweeps
+    that sort nothing (the round-4 hand-over)."""
+    monkeypatch.setenv("RS_JIT_ORDERED", "0" if flow == "unordered" else "1")
+    monkeypatch.setenv("RS_JIT_ROWS", "1")
+    rng = np.random.Generator(np.random.PCG64(78))
+    mask = ab.card_mask("7h8hQc")
+    allh = ab.random_range(mask)
+    ranges = [allh[rng.permutation(len(allh))[:60]], allh[rng.permutation(len(allh))[:45]]]
+    files = [rng.integers(0, 37, size=1286792, dtype=np.uint32), rng.integers(0, 61, size=13960050, dtype=np.uint32), rng.integers(0, 150, size=123156254, dtype=np.uint32)]
+    ctx = load_trainer_pair(rs.three_street_options(), orc.options_three_street(), mask, ranges, 3, 1800, seed=6, interval=3000, cap=10**9, bucket_files=files,
+                            prune_threshold=4000, prefetch=True, use_graph="graph" in flow)
+    tr = ctx["tr"]
+
+    def live_batch_is(cards):
+        assert (tr.cards() == cards).all()
+        for r in range(3):
+            for p in (0, 1):
+                assert (tr.clusters(r, p) == ctx["cidx"][(r, p)]).all(), "cluster ids of round %d, player %d" % (r, p)
+        assert (tr.signs() == ctx["sign"]).all() and (tr.prune_flags() == ctx["prune"]).all()
+
+    if flow == "one-call":
+        tr.train(5)
+        for b in range(5):
+            cards = oracle_batch(ctx)
+        live_batch_is(cards)
+    elif flow == "host-loop":
+        for b in range(4):
+            tr.deal()
+            for player in (0, 1):
+                tr.iterate_phase(player, 0)
+                tr.iterate_phase(player, 1)
+            tr.finish_batch()
+            live_batch_is(oracle_batch(ctx))
+    else:
+        for b in range(4):
+            tr.train(1 if b != 2 else 2)
+            cards = oracle_batch(ctx)
+            if b == 2:
+                cards = oracle_batch(ctx)
+            live_batch_is(cards)
+            if flow == "resweep" and b in (1, 2):   # the live batch once more, through the solver (the oracle: the same deals, the next two sweep seeds)
+                for player in (0, 1):
+                    tr.iterate_phase(player, 0)
+                    tr.iterate_phase(player, 1)
+                    ctx["osol"].iterate(player)
+                live_batch_is(cards)
+    tr.status()
     compare_trainer_tables(ctx)
 
 
