@@ -341,8 +341,11 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
  * per player and round).  Several deals of a batch may address the same info set, which the reference lets race
  * (cfr.rs:414); here the sweep is BATCH-SYNCHRONOUS and deterministic: every deal reads the table as it was when the
  * sweep started, its update becomes the i32 delta (new - old) against the value it read, deltas are accumulated with
- * atomic adds (wrapping, order-independent) and applied when the sweep ends.  RS_I32 tables, RS_CHANCE_PASS (one run-out
- * per deal, cfr.rs:306-313).  Leaf buffers and d_root_util hold one float per deal, pitch = round_up(n_deals, 64);
+ * atomic adds (wrapping, order-independent) and applied when the sweep ends.  RS_CHANCE_PASS (one run-out per deal,
+ * cfr.rs:306-313).  Float tables (RS_F32, RS_F16: extensions, fuse_subtrees = 1, one GPU, no RS_UPD_PRUNE): a visit's deltas
+ * (scale*reach)*(u - util) and (scale*reach)*sigma are f32, every cell's deltas are added IN DEAL ORDER from 0.0 and then to
+ * the cell -- one rounding to the table's type per cell and sweep, and with RS_UPD_RMPLUS the traverser's regrets that do
+ * not end the sweep above 0 end it at 0.  Leaf buffers and d_root_util hold one float per deal, pitch = round_up(n_deals, 64);
  * cluster-id vectors have the same pitch (padding ignored). */
 typedef struct rs_deal_batch {
     uint32_t n_deals;

@@ -786,10 +786,11 @@ float orc_traverse_deal(const orc_deal_ctx *dc, int node_id, int player, size_t 
         orc_infoset *dinfo = &dc->delta->rows[nd->index][cluster_idx];
         float utils[ORC_MAX_ACTIONS], strategy[ORC_MAX_ACTIONS], util = 0.0f;
         const int prune = ctx->prune && (!dc->prune_deal || dc->prune_deal[deal]);   /* the `prune` argument of mccfr(), cfr.rs:219-221 */
-        if (ctx->table->dtype == ORC_T_F32) {
-            /* f32 tables (extension): every deal reads the table as of sweep start; its visit contributes dr = (scale*reach)*(u-util), ds = (scale*reach)*sigma, which
-             * are added to the cell's delta IN DEAL ORDER (this loop runs deals 0, 1, 2, ..), each delta starting the sweep at 0.0; orc_iterate_deals then adds the deltas
-             * to the table.  No prune, no RM+ (the device refuses them for f32 deal batches) */
+        if (ctx->table->dtype != ORC_T_I32) {
+            /* float tables (extension; binary32, or binary16 storage held here as floats that are exactly representable as halves): every deal reads the table as of sweep
+             * start; its visit contributes dr = (scale*reach)*(u-util), ds = (scale*reach)*sigma in f32, which are added to the cell's f32 delta IN DEAL ORDER (this loop
+             * runs deals 0, 1, 2, ..), each delta starting the sweep at 0.0; orc_iterate_deals then adds the deltas to the table -- ONE rounding to the storage type per cell
+             * and sweep, and the RM+ floor (regrets only) on that write.  No prune (float tables have none anywhere) */
             orc_get_strategy_f32(infoset->fregrets, n_actions, strategy);
             if (nd->player == player) {
                 float k;
@@ -850,13 +851,20 @@ void orc_iterate_deals(const orc_deal_ctx *dc, int player, float *root_util) {
         float u = orc_traverse_deal(dc, 0, player, d, 1.0f);
         if (root_util) root_util[d] = u;
     }
-    for (i = 0; i < dc->ctx->table->n_rows; i++)
+    for (i = 0; i < dc->ctx->table->n_rows; i++) {
+        int row_player = -1, q;   /* float tables: the write-back (and its RM+ floor) is the TRAVERSER's -- nobody else's rows took a delta in this sweep */
+        for (q = 0; q < dc->ctx->tree->n_nodes; q++)
+            if (dc->ctx->tree->nodes[q].kind == ORC_ACTION && dc->ctx->tree->nodes[q].index == i) row_player = dc->ctx->tree->nodes[q].player;
         for (j = 0; j < dc->ctx->table->row_len[i]; j++) {
             orc_infoset *is = &dc->ctx->table->rows[i][j], *di = &dc->delta->rows[i][j];
-            if (dc->ctx->table->dtype == ORC_T_F32) {
+            if (dc->ctx->table->dtype != ORC_T_I32) {
+                if (row_player != player) continue;
+                const int storage = dc->ctx->table->dtype == ORC_T_F16 ? ORC_F_F16 : ORC_F_F32;
                 for (k = 0; k < is->n_actions; k++) {
-                    is->fregrets[k] = is->fregrets[k] + di->fregrets[k];
-                    is->fstrategy_sum[k] = is->fstrategy_sum[k] + di->fstrategy_sum[k];
+                    float r = is->fregrets[k] + di->fregrets[k];
+                    if (dc->ctx->rmplus && !(r > 0.0f)) r = 0.0f;
+                    is->fregrets[k] = store_round(r, storage);
+                    is->fstrategy_sum[k] = store_round(is->fstrategy_sum[k] + di->fstrategy_sum[k], storage);
                     di->fregrets[k] = 0.0f;
                     di->fstrategy_sum[k] = 0.0f;
                 }
@@ -869,6 +877,7 @@ void orc_iterate_deals(const orc_deal_ctx *dc, int player, float *root_util) {
                 di->strategy_sum[k] = 0;
             }
         }
+    }
 }
 
 void orc_iterate_range(const orc_ctx *ctx, int player, size_t lane_lo, size_t lane_hi, float *root_util) {

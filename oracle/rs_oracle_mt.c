@@ -137,7 +137,7 @@ int orc_table_create_sizes(const orc_tree *t, const uint32_t sizes[ORC_MAX_ROUND
     out->dtype = dtype;
     out->rows = (orc_infoset **)calloc((size_t)out->n_rows, sizeof(orc_infoset *));
     out->row_len = (size_t *)calloc((size_t)out->n_rows, sizeof(size_t));
-    if (!out->rows || !out->row_len || (dtype != ORC_T_I32 && dtype != ORC_T_F32)) return -1;
+    if (!out->rows || !out->row_len || (dtype != ORC_T_I32 && dtype != ORC_T_F32 && dtype != ORC_T_F16)) return -1;
     return create_sizes_rec(t, sizes, out, 0);
 }
 

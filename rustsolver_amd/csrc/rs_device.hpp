@@ -173,6 +173,18 @@ __device__ __forceinline__ void gather_i32(const void *base, unsigned row_off, c
 #pragma unroll
     for (int j = 0; j < kVecD; j++) out[j] = p[idx[j]];
 }
+// float tables under deal sweeps (no shadow): a node's regrets from the table's own [A][pitch] rows, binary32 or binary16 in memory, f32 in registers
+template <int A, int DT>
+__device__ __forceinline__ void gather_tbl(const void *reg, unsigned tpitch, const unsigned (&idx)[kVecD], float (&r)[A][kVecD]) {
+    static_assert(DT == kDT_F32 || DT == kDT_F16, "float tables");
+#pragma unroll
+    for (int a = 0; a < A; a++)
+#pragma unroll
+        for (int j = 0; j < kVecD; j++) {
+            if constexpr (DT == kDT_F32) r[a][j] = as_global<float>((const float *)reg + (size_t)a * tpitch)[idx[j]];
+            else r[a][j] = (float)as_global<_Float16>((const _Float16 *)reg + (size_t)a * tpitch)[idx[j]];
+        }
+}
 // AoS shadow of one action node for deal sweeps: record c = [regrets 0..H) [strategy_sum 0..H)], H = 2 ints (A <= 2), 4 (A <= 4) or 8 (A <= 8), built from
 // the SoA table at the start of every sweep (k_build_shadow).  A deal then reads a node with ONE load where it can -- 8 bytes of regrets or the whole 16-byte record of a
 // two-action node -- instead of one 4-byte load per (action, array): the 64 lanes of a gather touch 64 different cache lines, every one of them a cycle of the CU's L1,

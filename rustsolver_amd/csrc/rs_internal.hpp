@@ -187,12 +187,12 @@ hipError_t launch_apply_delta_jobs(void *regrets, void *dregrets, void *ssum, vo
 // deal sweeps on f32 tables: the per-deal delta rows of one traverser node ([2A][pitch]: regret deltas, then strategy-sum deltas) are summed per cluster over the cluster's
 // deals IN DEAL ORDER (members[start[c] .. start[c + 1]) ascending) from 0.0 and the sums added to the node's table rows
 struct ApplyF32Job {
-    float *reg, *ssm;          // [A][tpitch]
+    void *reg, *ssm;           // [A][tpitch] table elements (binary32 or binary16)
     const float *rows;         // [2A][pitch]
     const uint32_t *start, *members;
     uint32_t n_actions, tpitch, n_clusters, pad_;
 };
-hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, hipStream_t stream);
+hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, int dtype, bool rmplus, hipStream_t stream);
 // i32 deal sweeps with delta rows: the walk of a round subtree stored, for every traverser node, [2A][pitch] i32 deltas at the list position of each walked deal (zero where
 // the deal did not come by).  One job = the A rows of one node and array + the key row beside them (the traverser's cluster of every position); a workgroup takes one chunk
 // of positions, sums it per cluster in an LDS tile [n_rows][n_clusters] and adds the non-zero cells to the delta table's rows -- integer adds: any order, same bits

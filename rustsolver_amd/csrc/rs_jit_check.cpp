@@ -143,6 +143,12 @@ int rs_jit_check_tree_deals(const rs_tree *tree, int mode, int opp_mode, int *n_
                     if (!(down && jf.boundary_roots.empty()) && !seen.count(jf.source)) {
                         seen[jf.source] = 1;
                     }
+                    if (f6 == 4 && lanes == 1 && int(i) == first) {   // ... and on binary16 tables (the same walks: gather_tbl converts; one kernel is enough to build the path)
+                        JitSubtree jh;
+                        jit_emit_subtree(nodes, int(i), p, has_own, leaf_buf, leaf_flags, RS_F16, mode & RS_UPD_ARITH_MASK, opp_mode == RS_OPP_SAMPLE, true, false, false, down, false, lanes,
+                                         &root, jh, knobs);
+                        if (!seen.count(jh.source)) seen[jh.source] = 1;
+                    }
                 }
                 if (lanes == 1 && sparse && !lds) {   // staged rows: the list walkers of large batches (delta-rows walk, reach-down kernel) read their records from rows staged in LDS
                     JitStage st;

@@ -1078,7 +1078,9 @@ hipError_t launch_apply_delta(void *regrets, void *dregrets, void *ssum, void *d
     return hipGetLastError();
 }
 // deal sweeps on f32 tables: one thread per (cluster, row of the node's [2A] delta rows) adds the deltas of the cluster's deals one after the other, in deal order
-__global__ __launch_bounds__(kBlock) void k_apply_f32_rows(const ApplyF32Job *__restrict__ jobs, uint32_t pitch) {
+// E = the table's element (float or _Float16): the sum is f32 whatever the storage, the cell is rounded ONCE, on this write; rmplus: a regret that does not end above 0 ends at 0
+template <typename E>
+__global__ __launch_bounds__(kBlock) void k_apply_f32_rows(const ApplyF32Job *__restrict__ jobs, uint32_t pitch, int rmplus) {
     const ApplyF32Job job = jobs[blockIdx.y];
     const uint32_t rows = 2 * job.n_actions, n = job.n_clusters * rows;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -1086,14 +1088,18 @@ __global__ __launch_bounds__(kBlock) void k_apply_f32_rows(const ApplyF32Job *__
         const float *__restrict__ row = job.rows + (size_t)x * pitch;
         float acc = 0.0f;
         for (uint32_t m = job.start[c]; m < job.start[c + 1]; ++m) acc += row[job.members[m]];
-        float *cell = (x < job.n_actions ? job.reg + (size_t)x * job.tpitch : job.ssm + (size_t)(x - job.n_actions) * job.tpitch) + c;
-        *cell = *cell + acc;
+        const bool regret = x < job.n_actions;
+        E *cell = (regret ? (E *)job.reg + (size_t)x * job.tpitch : (E *)job.ssm + (size_t)(x - job.n_actions) * job.tpitch) + c;
+        float v = (float)*cell + acc;
+        if (rmplus && regret && !(v > 0.0f)) v = 0.0f;
+        *cell = (E)v;
     }
 }
-hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, hipStream_t stream) {
+hipError_t launch_apply_f32_rows(const ApplyF32Job *d_jobs, int n_jobs, uint32_t max_clusters, uint32_t pitch, int dtype, bool rmplus, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
     dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((size_t(max_clusters) * 2 * RS_MAX_ACTIONS + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
-    hipLaunchKernelGGL(k_apply_f32_rows, grid, block, 0, stream, d_jobs, pitch);
+    if (dtype == RS_F16) hipLaunchKernelGGL((k_apply_f32_rows<_Float16>), grid, block, 0, stream, d_jobs, pitch, rmplus ? 1 : 0);
+    else hipLaunchKernelGGL((k_apply_f32_rows<float>), grid, block, 0, stream, d_jobs, pitch, rmplus ? 1 : 0);
     return hipGetLastError();
 }
 // i32 deal sweeps with delta rows (rs_kernel_forms.delta_rows): workgroup (x, y) sums positions [y * chunk, (y + 1) * chunk) of job x's rows per cluster (the JOB is the fast

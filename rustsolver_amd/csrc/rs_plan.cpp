@@ -303,8 +303,8 @@ int PlanBuilder::build() {
         if (kn.lanes != kUnset) jit_lanes = jit_lanes_below = (kn.lanes == 1 || kn.lanes == 2) ? kn.lanes : 4;
         round_mode = s->deal_mode && s->params.fuse_subtrees && nodes[first_root].kind == RS_NODE_ACTION &&
                      nodes[first_root].n_children > 0;
-        if (s->deal_mode && s->table->dtype == RS_F32 && !round_mode)
-            return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables run through the generated round subtrees only (the first node below the root must be an action node)");
+        if (s->deal_mode && s->table->dtype != RS_I32 && !round_mode)
+            return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: float tables run through the generated round subtrees only (the first node below the root must be an action node)");
         want_lists = s->deal_mode && s->params.opp_mode == RS_OPP_SAMPLE && s->table->dtype == RS_I32;   // f32 deal sweeps walk every deal (their delta rows are per deal)
         want_parts = round_mode && want_lists;
         // three streets, 4 M deals per batch: 13.49 -> 12.51 ms; 1 M: 5.98 -> 5.74; but 64 K: 2.14 -> 2.34 (latency-bound: the list adds a dependent load per entry),
@@ -520,7 +520,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
                 const bool own = an.player == p && an.n_children > 0;
                 put_ptr(js.off_dreg + 8 * k, own ? s->d_drows + plan.drow_off[size_t(an.index)] : nullptr);
                 put_ptr(js.off_dssm + 8 * k, nullptr);
-            } else if (t->dtype == RS_F32) {   // the node's per-deal delta rows [2A][pitch] (traverser nodes only)
+            } else if (t->dtype != RS_I32) {   // the node's per-deal delta rows [2A][pitch] (traverser nodes only)
                 put_ptr(js.off_dreg + 8 * k, (an.player == p && an.n_children > 0) ? plan.d_frows + plan.frow_off[size_t(an.index)] : nullptr);
                 put_ptr(js.off_dssm + 8 * k, nullptr);
             } else {
@@ -656,7 +656,7 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
 int PlanBuilder::emit() {
     const size_t n = nodes.size();
     const rs_table *t = s->table;
-    if (s->deal_mode && t->dtype == RS_F32) {   // per-deal delta rows of this traverser's nodes: [2A][deal pitch] floats each
+    if (s->deal_mode && t->dtype != RS_I32) {   // per-deal delta rows of this traverser's nodes: [2A][deal pitch] floats each
         plan.frow_off.assign(t->nodes.size(), SIZE_MAX);
         size_t floats = 0;
         for (size_t i = 0; i < t->nodes.size(); ++i) {

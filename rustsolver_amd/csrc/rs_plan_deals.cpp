@@ -416,7 +416,7 @@ int PlanBuilder::emit_row_sums() {   // delta rows: the job descriptors of the s
 
 int PlanBuilder::emit_apply() {
     const rs_table *t = s->table;
-    if (s->deal_mode && t->dtype == RS_F32) {   // the ordered apply: member lists per round of the traverser's cluster ids, then one job per traverser node
+    if (s->deal_mode && t->dtype != RS_I32) {   // the ordered apply (float tables, binary32 or binary16): member lists per round of the traverser's cluster ids, then one job per traverser node
         std::vector<ApplyF32Job> jobs;
         const uint32_t n = s->deals.n_deals;
         size_t scratch = 0;
@@ -438,8 +438,8 @@ int PlanBuilder::emit_apply() {
             const rs_node_desc &d = t->nodes[i];
             if (d.n_actions == 0 || d.player != p) continue;
             ApplyF32Job j{};
-            j.reg = static_cast<float *>(t->regrets_ptr(int(i)));
-            j.ssm = static_cast<float *>(t->ssum_ptr(int(i)));
+            j.reg = t->regrets_ptr(int(i));
+            j.ssm = t->ssum_ptr(int(i));
             j.rows = plan.d_frows + plan.frow_off[i];
             j.start = plan.d_member_start[d.round_idx];
             j.members = plan.d_members[d.round_idx];

@@ -19,7 +19,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     rs_table *t = s->table;
     if (!tree_stream) tree_stream = t->stream;
     static const int prof_kind[] = {RS_K_REACH, RS_K_REACH, RS_K_CHANCE, RS_K_UPDATE, RS_K_NODE_UTIL, RS_K_CHANCE, RS_K_TREE, RS_K_CHANCE, RS_K_DISCOUNT};
-    if (L.kind == L_APPLY && t->dtype == RS_F32) {   // every cell's deltas summed in deal order: the traverser's deals listed per cluster, round by round, then the node jobs
+    if (L.kind == L_APPLY && t->dtype != RS_I32 && s->deal_mode) {   // every cell's deltas summed in deal order: the traverser's deals listed per cluster, round by round, then the node jobs
         const int pl = &plan == &s->plan[1] ? 1 : 0;
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         hipError_t ef = hipSuccess;
@@ -31,7 +31,7 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
             ef = launch_member_lists(s->deals.d_cluster[r][pl], s->deals.n_deals, int(k), plan.d_member_scratch, plan.d_member_scratch + member_list_tiles(s->deals.n_deals) * size_t(k),
                                      plan.d_member_start[r], plan.d_members[r], t->stream);
         }
-        if (ef == hipSuccess) ef = launch_apply_f32_rows(plan.d_f32_jobs, plan.n_f32_jobs, plan.f32_max_clusters, uint32_t(s->pitch[0]), t->stream);
+        if (ef == hipSuccess) ef = launch_apply_f32_rows(plan.d_f32_jobs, plan.n_f32_jobs, plan.f32_max_clusters, uint32_t(s->pitch[0]), t->dtype, (s->params.mode & RS_UPD_RMPLUS) != 0, t->stream);
         prof_end(t);
         RS_HIP(ef, "k_apply_f32_rows");
         return RS_OK;
@@ -233,11 +233,10 @@ int rs_solver_create(rs_table *table, const rs_tree *tree, const rs_leaf_desc *l
 int rs_solver_create_deals(rs_table *table, const rs_tree *tree, const rs_deal_batch *deals, const rs_leaf_desc *leaves_p0,
                            const rs_leaf_desc *leaves_p1, const rs_solver_params *params, rs_solver **out) {
     if (!deals || deals->n_deals == 0) return fail(RS_ERR_INVALID, "rs_solver_create_deals: empty deal batch");
-    if (table && table->dtype == RS_F16)
-        return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: deal batches run on RS_I32 tables (i32 deltas, atomics) or RS_F32 tables (per-deal deltas summed in deal order)");
-    if (table && table->dtype == RS_F32) {   // the float form: dense walks, no atomics, every cell's deltas added in deal order (bit-identical to the oracle's sequential loop)
-        if (!params || !params->fuse_subtrees) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables need fuse_subtrees = 1 (the generated kernels)");
-        if (params->mode & (RS_UPD_PRUNE | RS_UPD_RMPLUS)) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_F32 tables take neither RS_UPD_PRUNE nor RS_UPD_RMPLUS");
+    if (table && table->dtype != RS_I32) {   // the float form (binary32 or binary16 tables, f32 arithmetic): dense walks, no atomics, every cell's f32 deltas added in deal order
+                                             // (bit-identical to the oracle's sequential loop), ONE rounding to the table's type and the RM+ floor on the write-back
+        if (!params || !params->fuse_subtrees) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: float tables need fuse_subtrees = 1 (the generated kernels)");
+        if (params->mode & RS_UPD_PRUNE) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: RS_UPD_PRUNE needs an RS_I32 table (cfr.rs:352 compares i32 regrets)");
         if (params->chance_mode != RS_CHANCE_PASS) return fail(RS_ERR_UNSUPPORTED, "rs_solver_create_deals: a deal has one run-out: use RS_CHANCE_PASS (cfr.rs:306-313)");
         return solver_create_impl(table, tree, deals, leaves_p0, leaves_p1, params, out);
     }
@@ -1008,7 +1007,7 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
         return copy_root(s, traverser, d_root_util);
     }
     if (s->deal_mode && s->comm && s->table->dtype != RS_I32)
-        return fail(RS_ERR_UNSUPPORTED, "rs_iterate: data-parallel deal batches all-reduce i32 deltas; an RS_F32 deal solver runs on one GPU");
+        return fail(RS_ERR_UNSUPPORTED, "rs_iterate: data-parallel deal batches all-reduce i32 deltas; a deal solver on a float table runs on one GPU");
     if (s->order_ahead && s->comm) return fail(RS_ERR_UNSUPPORTED, "rs_iterate: this solver's deal records are sorted ahead by its trainer, which runs on one GPU");
     if (s->before_sweep)
         if (int rc = s->before_sweep(s->before_sweep_ctx, traverser)) return rc;

@@ -160,13 +160,13 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     # deal batches: round subtrees (reach-down half, walk; dense / live-deal list; LDS tiles / direct atomics), sampled and full width
     # river tree: no reach-down half; 4 walks per traverser, each with 4 and 1 deals per thread, + the work-list form of the list walk with LDS tiles (20), + the ordered forms
     # (rs_kernel_forms.deal_order): the segment-summing walk over the whole batch and over a list, one deal per thread (4), + the f32-table forms (per-deal delta rows, dense
-    # walks: 4), + the delta-rows forms (rs_kernel_forms.delta_rows: the list walk stores its deltas by position, 4 and 1 deals per thread: 4), + the staged
+    # walks: 4; round 5: the one-deal-per-thread walk on a binary16 table too: 2), + the delta-rows forms (rs_kernel_forms.delta_rows: the list walk stores its deltas by position, 4 and 1 deals per thread: 4), + the staged
     # form of the list walk (round 4: the wave copies its deals' shadow rows into LDS, no gather per node: 2)
-    assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 34
+    assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) == 36
     assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64, rs.OPP_SAMPLE) > 8
     assert rs.jit_check_tree_deals(tree3, rs.UPD_WRAP_I32, rs.OPP_FULL) >= 4
     # the pruned forms (cfr.rs:379-386 per deal) of the same kernels
-    assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) == 34
+    assert rs.jit_check_tree_deals(tree, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) == 36
     assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) > 8
 
 

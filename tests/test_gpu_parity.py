@@ -1432,24 +1432,32 @@ test_deal_sweeps_with_and_without_table_shadows.workspace = {}
 
 
 @pytest.mark.parametrize("variant", ["river-sampled", "river-full", "three-street-sampled", "three-street-full", "river-sampled-4-per-thread"])
-def test_f32_deal_batches_vs_oracle(variant, monkeypatch):
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32+rmplus", "f16+rmplus"])
+def test_f32_deal_batches_vs_oracle(variant, dtype, monkeypatch):
     """rs_solver_create_deals on an RS_F32 table (north_star: "f32 regrets"): deal sweeps whose sums are float.  f32 additions do not commute, so there are no atomics: every
     deal walks its subtrees densely, a traverser visit stores its two delta vectors per deal, and after the sweep every cell's deltas are added IN DEAL ORDER from 0.0 and
-    then to the table -- exactly the oracle's sequential loop over the deals, hence bit-identical, with thousands of deals per info set.  Root utilities too."""
+    then to the table -- exactly the oracle's sequential loop over the deals, hence bit-identical, with thousands of deals per info set.  Root utilities too.
+    "f16" (round 5; BASELINE configs[4]: "fp16 regret/strategy tables with fp32 accumulators"): binary16 in memory, the same f32 deltas and f32 sums, ONE rounding per cell and
+    sweep on the write-back; "+rmplus": a regret that does not end the sweep above 0 ends it at 0."""
+    if dtype != "f32" and variant in ("river-full", "river-sampled-4-per-thread") and "rmplus" in dtype:
+        pytest.skip("RM+ on two river variants and both three-street ones")
     three, sampled = variant.startswith("three"), "sampled" in variant
+    half, rmplus = dtype.startswith("f16"), "rmplus" in dtype
     if variant.endswith("4-per-thread"):
         monkeypatch.setenv("RS_JIT_LANES", "4")
     n_deals = 2003 if three else 5001
     rng = np.random.Generator(np.random.PCG64(55))
     sizes = [(7, 9), (11, 8), (13, 17)] if three else [(13, 17)]
     n_actions, tree = rs.build_game_tree(rs.three_street_options() if three else rs.default_flop())
-    table = rs.create_infosets(n_actions, tree, sizes, [1] * len(sizes), rs.F32)
+    table = rs.create_infosets(n_actions, tree, sizes, [1] * len(sizes), rs.F16 if half else rs.F32)
     otree = orc.OracleTree(orc.options_three_street() if three else orc.options_default_river())
-    otab = orc.OracleDealTable(otree, sizes, orc.T_F32)
+    otab = orc.OracleDealTable(otree, sizes, orc.T_F16 if half else orc.T_F32)
     for nd in tree.action_nodes():
         a, n = nd.n_children, sizes[nd.round_idx][nd.player]
         R = rng.uniform(-1000, 1000, size=(a, n)).astype(np.float32)
         S = rng.uniform(0, 1000, size=(a, n)).astype(np.float32)
+        if half:
+            R, S = R.astype(np.float16).astype(np.float32), S.astype(np.float16).astype(np.float32)
         table.upload_node(nd.index, R, S)
         otab.set_node(nd.index, R, S)
     cidx = {(r, p): rng.integers(0, sizes[r][p], size=n_deals).astype(np.uint32) for r in range(len(sizes)) for p in (0, 1)}
@@ -1457,8 +1465,8 @@ def test_f32_deal_batches_vs_oracle(variant, monkeypatch):
     sbuf = rs.deal_buffer(table, n_deals, sign)
     lg = {i: (rs.LEAF_SIGN, sbuf) for i, nd in enumerate(tree.nodes) if nd.kind == rs.NODE_TERMINAL and nd.ttype != rs.TERM_UNCONTESTED}
     lo = {i: (orc.LEAF_SIGN, sign) for i in lg}
-    tr = rs.MCCFRTrainer(tree, table, lg, scale=0.25, mode=rs.UPD_CLAMP_I64, fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=5)
-    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=0.25, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=5)
+    tr = rs.MCCFRTrainer(tree, table, lg, scale=0.25, mode=rs.UPD_CLAMP_I64 | (rs.UPD_RMPLUS if rmplus else 0), fuse_subtrees=1, deals=cidx, opp_mode=rs.OPP_SAMPLE if sampled else rs.OPP_FULL, sample_seed=5)
+    osol = orc.OracleDealSolver(otree, otab, lo, cidx, n_deals, scale=0.25, mode=orc.UPD_CLAMP_I64, rmplus=rmplus, opp_mode=orc.OPP_SAMPLE if sampled else orc.OPP_FULL, base_seed=5)
     for it in range(3):
         for player in (0, 1):
             assert_bits(tr.iterate(player, want_root_util=True), osol.iterate(player), "root util it=%d p=%d" % (it, player))
