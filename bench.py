@@ -895,14 +895,17 @@ def dp_deals_leg(rs, dist, rank, n_gpus, device, steps, warmup, n=1 << 22):
     dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
     dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
     cells = tr.infosets.cells
+    exchanged = tr.exchange_bytes() / max(1, warmup + steps)   # what this rank handed to the collectives per global batch (rs_solver_exchange_bytes)
     tr.attach_comm(None)
     L.load().rs_comm_destroy(comm)
     tr.destroy()
     return {"metric": "mccfr_deal_iterations_per_sec", "value": n * n_gpus * steps / elapsed, "unit": "deal-iterations/s", "n_gpus": n_gpus,
             "rccl_ranks": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "i32",
             "workload": "MCCFRTrainer::train as coded (default_flop board, random ranges, ISOMORPHIC river, 1081 clusters), data-parallel: %d deals "
-                        "per rank and batch, 1 step = 1 global batch (both traversers), deltas all-reduced as ncclInt32" % n,
-            "parallelism": "dp%d: replicated table, 2 all-reduces of %d i32 cells per traverser sweep" % (n_gpus, cells),
+                        "per rank and batch, 1 step = 1 global batch (both traversers), the traverser's delta cells all-reduced as ncclInt32" % n,
+            "parallelism": "dp%d: replicated table of %d i32 cells per array; per traverser sweep ONE all-reduce of that traverser's packed delta cells (rounds with direct "
+                           "rows: their rows all-gathered as 12-byte items instead)" % (n_gpus, cells),
+            "exchange_bytes_per_batch_and_rank": exchanged, "exchange_bytes_per_batch_round4": 2 * 2 * 4 * cells,
             "replicas_identical": bool(cmin.item() == cmax.item())}
 
 

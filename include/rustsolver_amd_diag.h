@@ -37,6 +37,9 @@ int rs_plant_outliers_f32(rs_table *table, float *d_dst, size_t n, uint64_t seed
 /* ---- deal sweeps: how many (deal, round subtree) walks did the LAST sweep of `traverser` make?  out[r] = live-list entries summed over the round subtrees of betting
  * round r (a round whose subtrees walk the whole batch counts n_deals per subtree).  Synchronises.  The unit the deal kernels' costs are quoted per. */
 int rs_solver_walk_counts(rs_solver *solver, int traverser, uint64_t *out /* [RS_MAX_ROUNDS] */);
+/* ---- data-parallel deal sweeps: the bytes THIS rank has handed to the collectives since the solver was created (the packed delta cells of every all-reduce + every rank's
+ * items of every all-gather) and the sweeps that exchanged anything.  bench.py --gpus N --dp-deals 1 reports bytes per batch from it. */
+int rs_solver_exchange_bytes(const rs_solver *solver, uint64_t *bytes, uint64_t *sweeps);
 
 /* ---- checks of the generated (hipRTC) kernels without a GPU ---------------------------------------------------------------------- */
 /* generate + compile (no GPU needed) the tree-specialised kernels of every chance-free subtree, both traversers */

@@ -166,6 +166,7 @@ SYMBOLS = {
     "rs_solver_workspace_bytes": (C.c_size_t, [_P]),
     "rs_solver_n_launches": (C.c_int, [_P, C.c_int]),
     "rs_solver_walk_counts": (C.c_int, [_P, C.c_int, _P]),
+    "rs_solver_exchange_bytes": (C.c_int, [_P, _P, _P]),
     "rs_solver_forms": (C.c_int, [_P]),
     "rs_jit_available": (C.c_int, []),
     "rs_jit_check_tree": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -151,6 +151,29 @@ int rs_comm_allreduce_deltas(rs_comm *c, rs_table *t) {
     return RS_OK;
 }
 
+}  // extern "C" (interrupted: the solver's own collectives)
+namespace rs {
+int comm_world(const rs_comm *c) { return c ? c->n_ranks : 1; }
+int comm_rank(const rs_comm *c) { return c ? c->rank : 0; }
+// in-place wrapping sum of n ints over the ranks
+int comm_allreduce_i32(rs_comm *c, rs_table *t, void *d_buf, size_t n) {
+    Rccl *r = rccl();
+    if (!c || !t || !r) return fail(RS_ERR_COMM, "comm_allreduce_i32: no communicator / librccl.so could not be loaded");
+    if (n == 0) return RS_OK;
+    const int rc = r->AllReduce(d_buf, d_buf, n, ncclInt32_, ncclSum_, c->comm, t->stream);
+    return rc == ncclSuccess_ ? RS_OK : comm_fail(rc, "ncclAllReduce(packed deal deltas)");
+}
+// every rank's n words, gathered in rank order: d_recv [n_ranks][n]
+int comm_allgather_u32(rs_comm *c, rs_table *t, const void *d_send, void *d_recv, size_t n) {
+    Rccl *r = rccl();
+    if (!c || !t || !r) return fail(RS_ERR_COMM, "comm_allgather_u32: no communicator / librccl.so could not be loaded");
+    if (n == 0) return RS_OK;
+    const int rc = r->AllGather(d_send, d_recv, n, ncclInt32_, c->comm, t->stream);
+    return rc == ncclSuccess_ ? RS_OK : comm_fail(rc, "ncclAllGather(deal delta items)");
+}
+}  // namespace rs
+extern "C" {
+
 int rs_replicated_begin(rs_table *t, uint32_t round_mask) {
     if (!t) return fail(RS_ERR_INVALID, "rs_replicated_begin: table is NULL");
     if (t->dtype == RS_F16) return fail(RS_ERR_UNSUPPORTED, "rs_replicated_begin: RS_F16 tables are not reduced (use RS_F32 accumulators)");

@@ -213,6 +213,10 @@ struct DiscountJob {
 hipError_t launch_discount_jobs(const DiscountJob *d_jobs, int n_jobs, size_t max_vec, float d, int dtype, hipStream_t stream);
 hipError_t launch_unbuild_shadow(const ShadowJob *d_jobs, int n_jobs, uint32_t max_clusters, hipStream_t stream);
 hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream);
+// data-parallel deal batches: the rows of the direct rounds as 12-byte (job, row, cluster, delta) items for the ranks to exchange, and every rank's items applied
+hipError_t launch_rows_to_items(const RowSumJob *d_jobs, int first_job, int n_jobs, uint32_t max_entries, uint32_t *d_items, uint32_t *d_cursor, uint32_t cap, hipStream_t stream);
+hipError_t launch_apply_items(const RowSumJob *d_jobs, const uint32_t *d_items, uint32_t n, hipStream_t stream);
+hipError_t launch_pack_cells(void *dregrets, void *dssum, const ApplyJob *d_jobs, const size_t *d_pack_off, int n_jobs, size_t max_vec, void *packed, size_t total_vec, bool unpack, hipStream_t stream);
 hipError_t launch_row_sums(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, uint32_t chunk, uint32_t max_cells, hipStream_t stream);
 constexpr uint32_t kRowSumMaxCells = 16384;   // ints of one job's LDS tile (64 KiB: two workgroups per CU)
 constexpr uint32_t kRowSumChunk = 262144;     // list positions per workgroup
@@ -425,6 +429,11 @@ void solver_table_discounted(struct rs_solver *s, float d, uint64_t epoch_before
 int solver_kept_primary(struct rs_solver *s, bool on);
 constexpr uint64_t kKeptPrimaryMinTrips = 16;   // training loops shorter than this leave the table's rows the working copy (the write-back at the end would cost more than it saves)
 bool solver_is_primary(const struct rs_solver *s);
+// rs_comm.cpp: the collectives of a data-parallel deal sweep (rs_solver.cpp solver_exchange_deltas)
+int comm_world(const struct rs_comm *c);
+int comm_rank(const struct rs_comm *c);
+int comm_allreduce_i32(struct rs_comm *c, rs_table *t, void *d_buf, size_t n);
+int comm_allgather_u32(struct rs_comm *c, rs_table *t, const void *d_send, void *d_recv, size_t n);
 // ordered deal sweeps: the caller sorts the per-deal records of every batch itself, ahead of the sweep (true: accepted -- an ordered solver on one GPU that has not swept yet)
 bool solver_order_ahead(struct rs_solver *s, bool on, int (*before_sweep)(void *ctx, int traverser), void *ctx);
 int solver_order_on(struct rs_solver *s, int traverser, hipStream_t stream, const uint32_t *const cluster[RS_MAX_ROUNDS][RS_MAX_PLAYERS], const float *leaf, const uint8_t *prune);

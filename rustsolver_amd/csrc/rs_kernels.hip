@@ -1210,6 +1210,84 @@ __global__ __launch_bounds__(kBlock) void k_row_apply(const RowSumJob *__restric
         }
     }
 }
+// Data-parallel deal batches (rs_solver.cpp solver_exchange_deltas): what k_row_apply would add, written out instead as (job, row, cluster, delta) items -- 12 bytes each -- for
+// the ranks to exchange: the rows of a direct round hold a few dozen non-zero deltas per walked deal, the table behind them millions of cells per node.
+// word 0 = (job index in the plan's row jobs << 3) | row, word 1 = the traverser's cluster, word 2 = the delta.  One cursor reservation per wave; items beyond `cap` are
+// counted, not written (the host grows the buffer and asks again).
+__global__ __launch_bounds__(kBlock) void k_rows_to_items(const RowSumJob *__restrict__ jobs, uint32_t first_job, uint32_t *__restrict__ items, uint32_t *__restrict__ cursor, uint32_t cap) {
+    const RowSumJob J = jobs[first_job + blockIdx.y];
+    const uint32_t n = J.count ? *J.count : J.n_const;
+    const __attribute__((address_space(1))) uint32_t *key = (const __attribute__((address_space(1))) uint32_t *)J.key;
+    const __attribute__((address_space(1))) int *rows = (const __attribute__((address_space(1))) int *)J.rows;
+    const uint32_t lane = threadIdx.x & 63u, trips = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t trip = 0; trip < trips; ++trip) {   // every lane of a wave makes every trip: the ballots below are the whole wave's
+        const uint32_t i = (trip * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        const bool in = i < n;
+        const uint32_t k = in ? key[i] : 0u;
+        for (uint32_t r = 0; r < J.n_rows; ++r) {
+            const int d = in ? rows[(size_t)r * J.pitch + i] : 0;
+            const unsigned long long ballot = __ballot(d != 0);
+            if (!ballot) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, (uint32_t)__popcll(ballot));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (d) {
+                const uint32_t at = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (at < cap) {
+                    items[3 * (size_t)at] = ((first_job + blockIdx.y) << 3) | r;
+                    items[3 * (size_t)at + 1] = k;
+                    items[3 * (size_t)at + 2] = (uint32_t)d;
+                }
+            }
+        }
+    }
+}
+// ... and every rank's items added to this rank's table (and kept records) exactly as k_row_apply adds its own rows: integer adds, any order, same bits
+__global__ __launch_bounds__(kBlock) void k_apply_items(const RowSumJob *__restrict__ jobs, const uint32_t *__restrict__ items, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t w = items[3 * (size_t)i], k = items[3 * (size_t)i + 1];
+        const int d = (int)items[3 * (size_t)i + 2];
+        const RowSumJob *J = jobs + (w >> 3);
+        const uint32_t r = w & 7u;
+        int32_t *mirror = J->mirror;
+        const bool only_records = mirror && J->primary && *J->primary != 0;
+        if (!only_records) __hip_atomic_fetch_add(J->dst + (size_t)r * J->tpitch + k, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mirror) __hip_atomic_fetch_add(mirror + (size_t)(k * J->mstride) + r, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+hipError_t launch_rows_to_items(const RowSumJob *d_jobs, int first_job, int n_jobs, uint32_t max_entries, uint32_t *d_items, uint32_t *d_cursor, uint32_t cap, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((size_t(max_entries) + kBlock - 1) / kBlock, 1), 1024);
+    hipLaunchKernelGGL(k_rows_to_items, dim3(blocks, (unsigned)n_jobs), dim3(kBlock), 0, stream, d_jobs, (uint32_t)first_job, d_items, d_cursor, cap);
+    return hipGetLastError();
+}
+hipError_t launch_apply_items(const RowSumJob *d_jobs, const uint32_t *d_items, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_apply_items, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_jobs, d_items, n);
+    return hipGetLastError();
+}
+// the delta cells of the traverser's own nodes (the ranges table += delta runs over) packed into one contiguous buffer [2][n_vec] for the ranks' sum, and back
+__global__ __launch_bounds__(kBlock) void k_pack_cells(int32_t *__restrict__ dregrets, int32_t *__restrict__ dssum, const ApplyJob *__restrict__ jobs, const size_t *__restrict__ pack_off,
+                                                       int32_t *__restrict__ packed, size_t total_vec, int unpack) {
+    const ApplyJob job = jobs[blockIdx.y];
+    const size_t off = pack_off[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < job.n_vec; i += (size_t)gridDim.x * kBlock) {
+        const size_t v = job.first_vec + i;
+        if (unpack) {
+            ((i32x4 *)dregrets)[v] = ((const i32x4 *)packed)[off + i];
+            ((i32x4 *)dssum)[v] = ((const i32x4 *)packed)[total_vec + off + i];
+        } else {
+            ((i32x4 *)packed)[off + i] = ((const i32x4 *)dregrets)[v];
+            ((i32x4 *)packed)[total_vec + off + i] = ((const i32x4 *)dssum)[v];
+        }
+    }
+}
+hipError_t launch_pack_cells(void *dregrets, void *dssum, const ApplyJob *d_jobs, const size_t *d_pack_off, int n_jobs, size_t max_vec, void *packed, size_t total_vec, bool unpack, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((max_vec + kBlock - 1) / kBlock, 1024)), (unsigned)n_jobs), block(kBlock);
+    hipLaunchKernelGGL(k_pack_cells, grid, block, 0, stream, (int32_t *)dregrets, (int32_t *)dssum, d_jobs, d_pack_off, (int32_t *)packed, total_vec, unpack ? 1 : 0);
+    return hipGetLastError();
+}
 hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((size_t(max_entries) + kBlock - 1) / kBlock, 1), 1024);

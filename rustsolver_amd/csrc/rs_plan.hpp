@@ -91,6 +91,9 @@ struct Plan {
     uint32_t *d_member_scratch = nullptr;   // tile histograms, then totals
     int n_apply_jobs = 0;
     size_t apply_max_vec = 0;
+    bool apply_whole = false;           // the apply pass runs over the whole table (cell ranges that are no multiple of four: never with 64-lane padded pitches)
+    size_t *d_pack_off = nullptr;       // data-parallel sweeps: where every apply job's cells start in the packed buffer the ranks sum (vectors of 4 cells)
+    size_t pack_vec = 0;                // ... and its length per array
     size_t aux_bytes = 0;               // device memory of this plan beside the arena: live-deal lists and the reach rows of the round subtrees
     size_t n_count_words = 0;           // u32 words of d_counts (all counters, kCountStride apart)
     bool counts_zeroed_by_shadow = false;   // the sweep opens with a k_build_shadow launch, which zeroes d_counts too (else: a memset in front of every compaction)
@@ -193,6 +196,14 @@ struct rs_solver {
     // The records depend on the deals alone, not on the table: a caller that knows the next batch early (rs_deal_trainer deals ahead on a second stream) sorts them itself,
     // beside the sweeps (solver_order_on), and the plans' own L_ORDER launches do nothing.  Set before the first sweep (a captured graph keeps what it was captured with).
     bool order_ahead = false;
+    // data-parallel deal sweeps (a communicator attached): what the ranks exchange between sweep and apply (solver_exchange_deltas)
+    int32_t *d_packed = nullptr;        // [2][max pack_vec * 4] the traverser's delta cells of the rounds that sum through the delta tables, one ncclInt32 all-reduce
+    uint32_t *d_items = nullptr;        // [3 * item_cap] this rank's (job, row, cluster, delta) items of the rounds whose rows go straight into the table
+    uint32_t *d_items_all = nullptr;    // [world][3 * item_cap]
+    uint32_t *d_item_count = nullptr;   // [1 + world]: this rank's cursor, then every rank's count
+    uint32_t item_cap = 0;
+    uint64_t dp_bytes_total = 0, dp_sweeps = 0;
+    uint64_t dp_bytes_last = 0;         // bytes this rank handed to the collectives in its last sweep (all-reduce buffer + every rank's items)
     int (*before_sweep)(void *ctx, int traverser) = nullptr;   // ... and is asked in front of every sweep whether the records are the live batch's (rs_iterate, rs_iterate_phase 0)
     void *before_sweep_ctx = nullptr;
     // delta rows (rs_kernel_forms.delta_rows): one buffer for both traversers' sweeps (they never overlap), [2A][batch pitch] i32 per traverser node of an eligible round

@@ -469,7 +469,7 @@ int PlanBuilder::emit_apply() {
             if (d.n_actions == 0 || d.player != p) continue;
             if (rows_round_direct(s, p, d.round_idx) && s->rows) continue;   // its deltas never touch the delta tables
             const size_t nc = size_t(d.n_actions) * t->pitch[i];
-            if ((t->cell_off[i] % kVec) || (nc % kVec)) { aj.clear(); break; }   // never with 64-lane padded pitches; the whole-table form is the fallback
+            if ((t->cell_off[i] % kVec) || (nc % kVec)) { aj.clear(); plan.apply_whole = true; break; }   // never with 64-lane padded pitches; the whole-table form is the fallback
             aj.push_back(ApplyJob{t->cell_off[i] / kVec, nc / kVec});
             plan.apply_max_vec = std::max(plan.apply_max_vec, nc / kVec);
             cells += double(nc);
@@ -479,6 +479,16 @@ int PlanBuilder::emit_apply() {
             if (ea == hipSuccess) ea = hipMemcpy(plan.d_apply_jobs, aj.data(), aj.size() * sizeof(ApplyJob), hipMemcpyHostToDevice);
             if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");
             plan.n_apply_jobs = int(aj.size());
+            std::vector<size_t> off(aj.size());   // data-parallel sweeps sum these cells over the ranks, packed back to back
+            size_t at = 0;
+            for (size_t k = 0; k < aj.size(); ++k) {
+                off[k] = at;
+                at += aj[k].n_vec;
+            }
+            plan.pack_vec = at;
+            ea = hipMalloc((void **)&plan.d_pack_off, aj.size() * sizeof(size_t));
+            if (ea == hipSuccess) ea = hipMemcpy(plan.d_pack_off, off.data(), aj.size() * sizeof(size_t), hipMemcpyHostToDevice);
+            if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: apply jobs");
         }
         Launch L;
         L.kind = L_APPLY;

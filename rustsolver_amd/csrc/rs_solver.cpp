@@ -75,7 +75,9 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
     if (L.kind == L_ROWSUM) {
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         const uint32_t chunk = s->knobs.rows_chunk != kUnset && s->knobs.rows_chunk > 0 ? uint32_t(s->knobs.rows_chunk) : kRowSumChunk;
-        hipError_t er = L.n_actions ? launch_row_apply(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, tree_stream)
+        // direct rows under a communicator: the additions are written out as items for the ranks to exchange (solver_exchange_deltas applies everybody's)
+        hipError_t er = L.n_actions ? (s->comm ? launch_rows_to_items(plan.d_row_jobs, L.first_job, L.n_jobs, s->deals.n_deals, s->d_items, s->d_item_count, s->item_cap, tree_stream)
+                                               : launch_row_apply(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, tree_stream))
                                     : launch_row_sums(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, chunk, plan.row_max_cells, tree_stream);
         prof_end(t);
         RS_HIP(er, "k_row_sums");
@@ -344,6 +346,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_compact_groups) (void)hipFree(pl.d_compact_groups);
         if (pl.d_row_jobs) (void)hipFree(pl.d_row_jobs);
         if (pl.d_apply_jobs) (void)hipFree(pl.d_apply_jobs);
+        if (pl.d_pack_off) (void)hipFree(pl.d_pack_off);
         if (pl.d_frows) (void)hipFree(pl.d_frows);
         if (pl.d_f32_jobs) (void)hipFree(pl.d_f32_jobs);
         if (pl.d_member_scratch) (void)hipFree(pl.d_member_scratch);
@@ -397,6 +400,12 @@ void rs::solver_release_device(rs_solver *s) {
     if (s->d_seed_state) (void)hipFree(s->d_seed_state);
     if (s->d_exchange) (void)hipFree(s->d_exchange);
     s->d_exchange = nullptr;
+    if (s->d_packed) (void)hipFree(s->d_packed);
+    if (s->d_items) (void)hipFree(s->d_items);
+    if (s->d_items_all) (void)hipFree(s->d_items_all);
+    if (s->d_item_count) (void)hipFree(s->d_item_count);
+    s->d_packed = nullptr;
+    s->d_items = s->d_items_all = s->d_item_count = nullptr;
     s->d_arena = nullptr;
     s->d_seed_state = nullptr;
     t->solvers.erase(std::remove(t->solvers.begin(), t->solvers.end(), s), t->solvers.end());
@@ -992,6 +1001,67 @@ static int copy_root(rs_solver *s, int traverser, float *d_root_util) {
     return RS_OK;
 }
 
+// Data-parallel deal batches, between sweep and apply: every rank must end up adding the deltas of the UNION batch.
+//  * rounds that sum through the delta tables (LDS tiles, k_row_sums): the traverser's delta cells -- the ranges the apply pass runs over, nobody else's hold anything --
+//    packed back to back, ONE in-place ncclInt32 all-reduce, unpacked (round 4 reduced both whole delta arrays: twice the bytes, and every cell of the direct rounds on top);
+//  * rounds whose delta rows go straight into the table (more clusters than a summing tile holds: direct rows): the walks' rows as 12-byte (job, row, cluster, delta) items,
+//    counts and items all-gathered, every rank's items added to table and kept records (k_apply_items) -- a 2 GB lossless table exchanges what its 64 K deals touched, not
+//    itself, and keeps direct rows and kept records under a communicator.
+// Integer adds commute: N ranks x n deals = one GPU with N x n deals, bit for bit.  Two small device-to-host reads (the counts) per sweep.
+static int solver_exchange_deltas(rs_solver *s, int p) {
+    rs_table *t = s->table;
+    Plan &plan = s->plan[p];
+    const int world = comm_world(s->comm);
+    s->dp_bytes_last = 0;
+    if (plan.apply_whole || !plan.n_apply_jobs) {
+        if (plan.apply_whole) {
+            if (int rc = rs_comm_allreduce_deltas(s->comm, t)) return rc;
+            s->dp_bytes_last += uint64_t(t->n_cells) * 8;
+        }
+    } else {
+        RS_HIP(launch_pack_cells(t->d_dregrets, t->d_dssum, plan.d_apply_jobs, plan.d_pack_off, plan.n_apply_jobs, plan.apply_max_vec, s->d_packed, plan.pack_vec, false, t->stream), "k_pack_cells");
+        if (int rc = comm_allreduce_i32(s->comm, t, s->d_packed, plan.pack_vec * 8)) return rc;
+        RS_HIP(launch_pack_cells(t->d_dregrets, t->d_dssum, plan.d_apply_jobs, plan.d_pack_off, plan.n_apply_jobs, plan.apply_max_vec, s->d_packed, plan.pack_vec, true, t->stream), "k_pack_cells");
+        s->dp_bytes_last += uint64_t(plan.pack_vec) * 32;
+    }
+    if (!s->d_items) return RS_OK;   // no round of this solver adds rows straight into the table
+    bool any = false;
+    for (const Launch &L : plan.launches) any = any || (L.kind == L_ROWSUM && L.n_actions);
+    if (!any) return RS_OK;
+    std::vector<uint32_t> counts(size_t(world) + 1);
+    for (int attempt = 0;; ++attempt) {
+        if (int rc = comm_allgather_u32(s->comm, t, s->d_item_count, s->d_item_count + 1, 1)) return rc;
+        RS_HIP(hipMemcpyAsync(counts.data(), s->d_item_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream), "deal delta items: counts");
+        RS_HIP(hipStreamSynchronize(t->stream), "deal delta items: counts");
+        uint32_t most = 0;
+        for (int r = 0; r < world; ++r) most = std::max(most, counts[size_t(r) + 1]);
+        if (most <= s->item_cap) break;
+        if (attempt) return fail(RS_ERR_HIP, "deal delta items: the count changed between two passes over the same rows");
+        // some rank's rows hold more items than the buffers: every rank grows (the counts are everybody's) and writes its items again -- the rows are still there
+        (void)hipFree(s->d_items);
+        (void)hipFree(s->d_items_all);
+        s->d_items = s->d_items_all = nullptr;
+        s->other_bytes -= size_t(s->item_cap) * 12 * (size_t(world) + 1);
+        s->item_cap = uint32_t(std::min<uint64_t>(uint64_t(most) + most / 8 + 1024, 0xfffffff0ull / 3));
+        if (most > s->item_cap) return fail(RS_ERR_OOM, "deal delta items: more than 2^32 / 3 items in one sweep");
+        RS_HIP(hipMalloc((void **)&s->d_items, size_t(s->item_cap) * 12), "deal delta items");
+        RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * size_t(world)), "deal delta items");
+        s->other_bytes += size_t(s->item_cap) * 12 * (size_t(world) + 1);
+        RS_HIP(hipMemsetAsync(s->d_item_count, 0, sizeof(uint32_t), t->stream), "deal delta items");
+        for (const Launch &L : plan.launches)
+            if (L.kind == L_ROWSUM && L.n_actions)
+                RS_HIP(launch_rows_to_items(plan.d_row_jobs, L.first_job, L.n_jobs, s->deals.n_deals, s->d_items, s->d_item_count, s->item_cap, t->stream), "k_rows_to_items");
+    }
+    uint32_t most = 0;
+    for (int r = 0; r < world; ++r) most = std::max(most, counts[size_t(r) + 1]);
+    if (most == 0) return RS_OK;
+    if (int rc = comm_allgather_u32(s->comm, t, s->d_items, s->d_items_all, size_t(most) * 3)) return rc;   // every rank sends `most` items' worth: the tail beyond its count is never read
+    for (int r = 0; r < world; ++r)
+        RS_HIP(launch_apply_items(plan.d_row_jobs, s->d_items_all + size_t(r) * most * 3, counts[size_t(r) + 1], t->stream), "k_apply_items");
+    s->dp_bytes_last += uint64_t(most) * 12 * uint64_t(world) + 4 * uint64_t(world);
+    return RS_OK;
+}
+
 int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
     if (!s) return fail(RS_ERR_INVALID, "rs_iterate: solver is NULL");
     if (!s->table) return fail(RS_ERR_INVALID, "rs_iterate: the solver's table has been destroyed");
@@ -1011,9 +1081,12 @@ int rs_iterate(rs_solver *s, int traverser, float *d_root_util) {
     if (s->order_ahead && s->comm) return fail(RS_ERR_UNSUPPORTED, "rs_iterate: this solver's deal records are sorted ahead by its trainer, which runs on one GPU");
     if (s->before_sweep)
         if (int rc = s->before_sweep(s->before_sweep_ctx, traverser)) return rc;
-    if (s->deal_mode && s->comm) {   // data-parallel deal batches: sweep, sum the deltas over the ranks, apply the union
+    if (s->deal_mode && s->comm) {   // data-parallel deal batches: sweep, exchange the deltas of the ranks, apply the union
+        if (s->d_item_count) RS_HIP(hipMemsetAsync(s->d_item_count, 0, sizeof(uint32_t), s->table->stream), "deal delta items");
         if (int rc = run_plan(s, traverser, 0)) return rc;
-        if (int rc = rs_comm_allreduce_deltas(s->comm, s->table)) return rc;
+        if (int rc = solver_exchange_deltas(s, traverser)) return rc;
+        s->dp_bytes_total += s->dp_bytes_last;
+        s->dp_sweeps += 1;
         if (int rc = run_plan(s, traverser, 1)) return rc;
         return copy_root(s, traverser, d_root_util);
     }
@@ -1040,12 +1113,26 @@ int rs_iterate_phase(rs_solver *s, int traverser, int phase, float *d_root_util)
 int rs_solver_attach_comm(rs_solver *s, rs_comm *comm) {
     if (!s) return fail(RS_ERR_INVALID, "rs_solver_attach_comm: solver is NULL");
     if (comm && s->order_ahead) return fail(RS_ERR_UNSUPPORTED, "rs_solver_attach_comm: this solver's deal records are sorted ahead by its trainer (one GPU); attach the communicator through rs_deal_trainer_attach_comm before the first batch");
-    if (comm && s->deal_mode && s->rows && s->direct_rows)
+    if (comm && s->deal_mode && s->table && s->table->dtype == RS_I32) {   // the buffers of solver_exchange_deltas
+        rs_table *t = s->table;
+        RS_HIP(hipSetDevice(t->device), "hipSetDevice");
+        const size_t pack_vec = std::max(s->plan[0].pack_vec, s->plan[1].pack_vec);
+        if (pack_vec && !s->d_packed) {
+            RS_HIP(hipMalloc((void **)&s->d_packed, pack_vec * 32), "rs_solver_attach_comm: packed delta cells");
+            s->other_bytes += pack_vec * 32;
+        }
+        bool direct = false;
         for (int p = 0; p < 2; ++p)
-            for (int r = 0; r < s->n_rounds; ++r)
-                if (rows_round_direct(s, p, r))
-                    return fail(RS_ERR_UNSUPPORTED, "rs_solver_attach_comm: this solver adds the delta rows of its large rounds straight into the table; data-parallel deal batches "
-                                                    "exchange the delta tables: create it with rs_kernel_forms.direct_rows = RS_FORM_OFF");
+            for (const Launch &L : s->plan[p].launches) direct = direct || (L.kind == L_ROWSUM && L.n_actions);
+        const size_t world = size_t(comm_world(comm));
+        if (direct && !s->d_item_count) RS_HIP(hipMalloc((void **)&s->d_item_count, (world + 1) * sizeof(uint32_t) + 256), "rs_solver_attach_comm: item counts");
+        if (direct && !s->d_items) {
+            s->item_cap = uint32_t(std::min<uint64_t>(uint64_t(s->deals.n_deals) * 16 + 4096, 0xfffffff0ull / 3));   // grown when a sweep writes more (solver_exchange_deltas)
+            RS_HIP(hipMalloc((void **)&s->d_items, size_t(s->item_cap) * 12), "rs_solver_attach_comm: delta items");
+            RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * world), "rs_solver_attach_comm: delta items");
+            s->other_bytes += size_t(s->item_cap) * 12 * (world + 1);
+        }
+    }
     s->comm = comm;
     return RS_OK;
 }
@@ -1089,6 +1176,12 @@ int rs_train(rs_solver *s, uint64_t iterations, uint64_t discount_interval, uint
 
 size_t rs_solver_workspace_bytes(const rs_solver *s) { return s ? s->arena_bytes + s->plan[0].aux_bytes + s->plan[1].aux_bytes + s->other_bytes : 0; }
 
+int rs_solver_exchange_bytes(const rs_solver *s, uint64_t *bytes, uint64_t *sweeps) {
+    if (!s || !bytes || !sweeps) return fail(RS_ERR_INVALID, "rs_solver_exchange_bytes: NULL argument");
+    *bytes = s->dp_bytes_total;
+    *sweeps = s->dp_sweeps;
+    return RS_OK;
+}
 int rs_solver_forms(const rs_solver *s) { return s ? ((s->ordered ? 1 : 0) | (s->rows ? 2 : 0)) : RS_ERR_INVALID; }
 int rs_solver_walk_counts(rs_solver *s, int traverser, uint64_t *out) {
     if (!s || !s->table || !out || traverser < 0 || traverser > 1) return fail(RS_ERR_INVALID, "rs_solver_walk_counts: bad argument");

@@ -230,7 +230,6 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         rs_solver_params sp = params->solver;
         sp.chance_mode = RS_CHANCE_PASS;   // one run-out per deal: the board is dealt up front (cfr.rs:115-122, :306-313)
         sp.deal_offset = tr->rank * params->deals_per_batch;
-        if (tr->world > 1) sp.forms.direct_rows = RS_FORM_OFF;   // the ranks exchange the delta TABLES between sweep and apply: every delta has to pass through them
         if (params->prune_threshold != UINT64_MAX) sp.mode |= RS_UPD_PRUNE;   // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune
         rc = rs_solver_create_deals(tr->table, tr->tree, &batch, leaves.data(), leaves.data(), &sp, &tr->solver);
         if (rc == RS_OK && tr->deal_stream && tr->world == 1) tr->ahead = solver_order_ahead(tr->solver, true, before_sweep, tr);   // false: not an ordered solver

@@ -705,6 +705,12 @@ class DealTrainer:
     def finish_batch(self):
         L.check(L.load().rs_deal_trainer_finish_batch(self._h))
 
+    def exchange_bytes(self):
+        """bytes this rank has handed to the collectives of its data-parallel sweeps so far (rs_solver_exchange_bytes)"""
+        b, n = C.c_uint64(), C.c_uint64()
+        L.check(L.load().rs_solver_exchange_bytes(L.load().rs_deal_trainer_solver(self._h), C.byref(b), C.byref(n)))
+        return b.value
+
     def deltas(self):
         """(regret deltas, strategy_sum deltas) as int32 arrays of rs_table_cells() elements"""
         a, b = C.c_void_p(), C.c_void_p()

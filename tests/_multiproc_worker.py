@@ -69,7 +69,8 @@ elif case == "dp-deals":
     comm = C.c_void_p()
     L.check(lib.rs_comm_create(tr.infosets._h, ident, rank, world, C.byref(comm)))
     tr.attach_comm(comm)
-    tr.train(batches)                                   # deal, sweep, ncclAllReduce of both delta arrays, apply, discount ticks: all inside rs_deal_trainer_train
+    tr.train(batches)                                   # deal, sweep, the ranks' deltas exchanged (packed all-reduce + all-gathered items), apply, discount ticks: all inside rs_deal_trainer_train
+    out["exchange_bytes"] = np.array([tr.exchange_bytes()], dtype=np.uint64)
     out["cards"] = tr.cards()
     out["iterations"] = np.array([tr.iterations])
     for nd in tree.action_nodes():

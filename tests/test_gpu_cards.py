@@ -400,7 +400,9 @@ def test_data_parallel_ranks_equal_one_gpu_with_the_union_batch(world, streets, 
         files = [rng.integers(0, 23, size=1286792, dtype=np.uint32), rng.integers(0, 41, size=13960050, dtype=np.uint32), None]
         card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
     kw = dict(seed=21, discount_interval=2 * world * n - 100, discount_cap=10**9)
-    ranks = [rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, world=world, rank=r, **kw) for r in range(world)]
+    # ranks driven phase by phase from outside exchange the delta TABLES: every delta has to pass through them (rs_iterate_phase refuses a solver whose big rounds add their rows
+    # straight into the table; the library's own data-parallel path, rs_iterate under a communicator, exchanges those rows as items: tests/test_gpu_multiproc.py)
+    ranks = [rs.DealTrainer(tree, card_abs, [hands, hands], mask, n, world=world, rank=r, forms={"direct_rows": rs.FORM_OFF}, **kw) for r in range(world)]
     single = rs.DealTrainer(tree, card_abs, [hands, hands], mask, world * n, **kw)
     for batch in range(4 if streets == 1 else 2):
         for tr in ranks:

@@ -84,11 +84,15 @@ def test_sharded_sweep_in_real_processes_equals_one_gpu(world, fuse, dtype, tmp_
             assert got["S%d" % nd.index].tobytes() == np.ascontiguousarray(S[:, cols[nd.round_idx]]).tobytes(), "strategy sums of node %d on rank %d" % (nd.index, g)
 
 
-@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (5, 1, 300), (2, 3, 700), (3, 3, 60_000)])
+@pytest.mark.parametrize("world,streets,n", [(2, 1, 700), (3, 1, 700), (5, 1, 300), (2, 3, 700), (3, 3, 60_000), (2, 4, 30_000), (3, 4, 2_000)])
 def test_data_parallel_trainer_in_real_processes_equals_one_gpu_with_the_union_batch(world, streets, n, tmp_path):
-    """`world` PROCESSES x n deals on replicated tables, rs_deal_trainer_train issuing the ncclInt32 all-reduce of both delta arrays between sweep and apply itself: cards, tables and
-    iteration counts must equal ONE trainer with world * n deals per batch.  60 000 deals per rank on three streets: delta rows, ordered sweeps and the staged list walkers under
-    the collective (their summing launches belong to phase 0: the delta tables must be complete when the ranks exchange them)."""
+    """`world` PROCESSES x n deals on replicated tables, rs_deal_trainer_train exchanging the deltas between sweep and apply itself: cards, tables and iteration counts must
+    equal ONE trainer with world * n deals per batch.  60 000 deals per rank on three streets: delta rows, ordered sweeps and the staged list walkers under the collective
+    (their summing launches belong to phase 0: the delta tables must be complete when the ranks exchange them).
+    Round 5: the ranks sum the traverser's delta cells alone (packed, one ncclInt32 all-reduce), and rounds whose rows go straight into the table (the ISOMORPHIC river of the
+    three-street cases: > 16 384 clusters) exchange their rows as (job, row, cluster, delta) items, all-gathered and applied by every rank -- direct rows and kept records
+    stay on under the communicator.  streets = 4: three streets with 200 hole-card combos per player, a river round of more than 100 000 clusters, 20 batches in
+    the second case (the kept records are the working copy: the items go into them alone)."""
     if streets == 1:
         mask = ab.card_mask("4d5dAs3cKs")
         hands = ab.random_range(mask)[::3]
@@ -99,12 +103,15 @@ def test_data_parallel_trainer_in_real_processes_equals_one_gpu_with_the_union_b
         rng = np.random.Generator(np.random.PCG64(4))
         mask = ab.card_mask("2c9dKh")
         allh = ab.random_range(mask)
-        hands = allh[rng.permutation(len(allh))[:35]]
+        hands = allh[rng.permutation(len(allh))[:35 if streets == 3 else 200]]
         n_actions, tree = rs.build_game_tree(rs.three_street_options())
         files = [rng.integers(0, 23, size=1286792, dtype=np.uint32), rng.integers(0, 41, size=13960050, dtype=np.uint32), None]
         card_abs = [ab.CardAbstraction.init([hands, hands], mask, r, files[r]) for r in range(3)]
         extra = dict(file0=files[0], file1=files[1])
-    batches = 3
+        if streets == 4:
+            assert card_abs[2].get_size(0) >= 100_000, card_abs[2].get_size(0)
+    batches = 20 if (streets, n) == (4, 2_000) else 3
+    streets = min(streets, 3)
     di = 2 * world * n - 100
     np.savez(os.path.join(tmp_path, "inputs.npz"), n=n, streets=streets, batches=batches, mask=mask, hands=hands, discount_interval=di, **extra)
     single = rs.DealTrainer(tree, card_abs, [hands, hands], mask, world * n, seed=21, discount_interval=di, discount_cap=10**9)
@@ -117,6 +124,12 @@ def test_data_parallel_trainer_in_real_processes_equals_one_gpu_with_the_union_b
             want = single.infosets.download_node(nd.index)
             assert (got["R%d" % nd.index] == want[0]).all() and (got["S%d" % nd.index] == want[1]).all(), "node %d on rank %d" % (nd.index, g)
     single.status()
+    # what a rank handed to the collectives per batch, against what round 4 reduced (both whole delta arrays, twice per batch): the packed traverser cells are half of that at
+    # most, the rounds with direct rows send items instead of cells
+    per_batch = int(ranks[0]["exchange_bytes"][0]) / batches
+    whole = 2 * 2 * 4 * single.infosets.cells
+    print("data-parallel exchange: %.3f MB per batch and rank (round 4: %.3f MB)" % (per_batch / 1e6, whole / 1e6))
+    assert 0 < per_batch <= whole / 2 + 1
 
 
 @pytest.mark.parametrize("world,dtype,layout,fuse", [(2, "i32", "plain", 1), (3, "i32", "tiled64", 1), (5, "i32", "plain", 0), (2, "f32", "plain", 1), (3, "f32", "tiled64", 1)])
