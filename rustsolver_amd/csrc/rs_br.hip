@@ -583,6 +583,180 @@ __device__ __forceinline__ void br_terminal_sorted_body(const uint8_t *__restric
     }
 }
 
+// one JOB per node of the level plan (all nodes of one tree depth and kind in one launch)
+struct BrJob {
+    BrNodeRow row;                 // action nodes: the node's strategy_sum block
+    const uint32_t *cid;           // opponent node: the opponent's lane -> cluster of the node's round
+    const uint32_t *start, *order; // own node: the lanes of every info set of the node's round
+    const double *q;               // opponent node: the reach that comes in; terminal: the opponent's reach
+    double *q_out;                 // opponent node: [A][n_pad] reach of its children
+    const double *vch;             // action node: [A][n_pad] values of its children
+    double *v;                     // where the node's own value goes (a slot of its parent's vch, or the root vector)
+    uint32_t n_clusters, n_children;
+    int uncontested, pad_;
+    double value;
+};
+// The level plan's form (round 5): ONE workgroup per run-out takes every leaf of the tree in turn.  What the leaves share -- the run-out's rank order, the holders of every
+// card, where each of the traverser's hands stands in that order, its weight -- is read ONCE (25 KB per run-out and side; the one-leaf kernel above read it again at each of the
+// 1 073 leaves of the three-street tree: 45 of its 111 MB per launch), the order and the card lists into LDS, the per-hand positions into registers (at most kBrHandsPerThread
+// hands per thread); per leaf the workgroup streams the opponent's reach of its run-out in and its hands' values out.  The sums are br_terminal_sorted_body's, order and all.
+constexpr int kBrHandsPerThread = 6;   // 1 326 two-card hands at most, 256 threads
+constexpr int kBrChunkMax = 21;        // ... in 64 chunks of the rank order
+static_assert(kBrCardHolders == 3 * 17, "the card scans of k_br_terminal_sorted_loop run in three blocks of 17");
+__global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
+                                                                      uint32_t n_p, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
+                                                                      const BrJob *__restrict__ jobs, uint32_t n_jobs) {
+    extern __shared__ unsigned char br_lds[];
+    double *P = (double *)br_lds;                                // [n_o]
+    double *Pc = P + n_o;                                        // [52][51]
+    double *O = Pc + 52 * kBrCardHolders;                        // [65]
+    double *Q = O + 65;                                          // [n_o]
+    uint16_t *Lord = (uint16_t *)(Q + n_o);                      // [n_o rounded up to 4]
+    uint16_t *Lcl = Lord + ((n_o + 3u) & ~3u);                   // [52][51]
+    uint8_t *Lcc = (uint8_t *)(Lcl + 52 * kBrCardHolders);       // [52]
+    const uint32_t b = blockIdx.x;
+    const uint32_t nv = ix.nv[b];
+    const uint64_t bm = bmask[b];
+    for (uint32_t i = threadIdx.x; i < n_o; i += kBrBlock) Lord[i] = ix.ord[(size_t)b * n_o + i];
+    for (uint32_t i = threadIdx.x; i < 52u * kBrCardHolders; i += kBrBlock) Lcl[i] = ix.cl[(size_t)b * 52 * kBrCardHolders + i];
+    if (threadIdx.x < 52) Lcc[threadIdx.x] = ix.cc[(size_t)b * 52 + threadIdx.x];
+    // this thread's hands: h = threadIdx.x + k * 256
+    uint32_t hw0[kBrHandsPerThread], hw1[kBrHandsPerThread];     // hw0 = nl | nle << 16; hw1 = a0 | a1 << 8 | e0 << 16 | e1 << 24
+    uint32_t hc[kBrHandsPerThread];                              // c0 | c1 << 8 | live << 16
+    int hs[kBrHandsPerThread];
+    double hp[kBrHandsPerThread];
+#pragma unroll
+    for (int k = 0; k < kBrHandsPerThread; ++k) {
+        const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
+        hw0[k] = hw1[k] = hc[k] = 0;
+        hs[k] = -1;
+        hp[k] = 0.0;
+        if (h < n_p) {
+            const size_t lane = (size_t)b * n_p + h;
+            const bool live = !(mask_p[h] & bm);
+            hc[k] = (uint32_t)hands_p[2 * h] | (uint32_t)hands_p[2 * h + 1] << 8 | (live ? 1u << 16 : 0u);
+            if (live) {
+                hw0[k] = (uint32_t)ix.nl[lane] | (uint32_t)ix.nle[lane] << 16;
+                hw1[k] = (uint32_t)ix.kl[2 * lane] | (uint32_t)ix.kl[2 * lane + 1] << 8 | (uint32_t)ix.kle[2 * lane] << 16 | (uint32_t)ix.kle[2 * lane + 1] << 24;
+                hs[k] = ix.same[h];
+                hp[k] = pw[lane];
+            }
+        }
+    }
+    const uint32_t len = (nv + 63u) / 64u;
+    __syncthreads();
+    // What the scans below walk is the same for every leaf, so it lives in registers: wave 0's lane k owns chunk k of the rank order (at most kBrChunkMax positions), the first
+    // 52 lanes of wave 1 a card's holders each.  Per leaf every value is then fetched from LDS in one go and added up in registers, in the body's order: a chunk's running sums,
+    // the chunk offsets (one after the other over the lanes: readlane), P = offset + running sum; a card's running sums.  (The first version walked ord -> Q -> add -> store as
+    // four dependent LDS operations per step, 51 steps for a card: 11.5 us per leaf and workgroup.)
+    const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
+    const uint32_t i0 = min(nv, wl * len), cnt0 = wave == 0 ? min(nv, i0 + len) - i0 : 0u;
+    uint32_t ordr[kBrChunkMax];
+#pragma unroll
+    for (int k = 0; k < kBrChunkMax; ++k) ordr[k] = (uint32_t)k < cnt0 ? Lord[i0 + k] : 0u;
+    const uint32_t cardc = wl < 52u ? wl : 0u, cntc = (wave == 1 && wl < 52u) ? Lcc[cardc] : 0u;
+    uint32_t clr[kBrCardHolders];
+#pragma unroll
+    for (int k = 0; k < kBrCardHolders; ++k) clr[k] = (uint32_t)k < cntc ? Lcl[cardc * kBrCardHolders + k] : 0u;
+    // the opponent's reach of the NEXT leaf is fetched while this one is worked on: with two workgroups per CU nothing else hides a leaf's round trip to memory
+    double qn[kBrHandsPerThread];
+    if (blockIdx.y < n_jobs) {
+        const double *__restrict__ q0 = jobs[blockIdx.y].q + (size_t)b * n_o;
+#pragma unroll
+        for (int k = 0; k < kBrHandsPerThread; ++k) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
+            qn[k] = i < n_o ? q0[i] : 0.0;
+        }
+    }
+    for (uint32_t j = blockIdx.y; j < n_jobs; j += gridDim.y) {
+        double *__restrict__ v = jobs[j].v;
+        const int uncontested = jobs[j].uncontested;
+        const double value = jobs[j].value;
+#pragma unroll
+        for (int k = 0; k < kBrHandsPerThread; ++k) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
+            if (i < n_o) Q[i] = qn[k];
+        }
+        if (j + gridDim.y < n_jobs) {
+            const double *__restrict__ q1 = jobs[j + gridDim.y].q + (size_t)b * n_o;
+#pragma unroll
+            for (int k = 0; k < kBrHandsPerThread; ++k) {
+                const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
+                qn[k] = i < n_o ? q1[i] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double t[kBrChunkMax];
+#pragma unroll
+            for (int k = 0; k < kBrChunkMax; ++k) t[k] = Q[ordr[k]];
+            double run = 0.0;
+#pragma unroll
+            for (int k = 0; k < kBrChunkMax; ++k) {
+                if ((uint32_t)k < cnt0) run += t[k];
+                t[k] = run;                                      // the chunk's running sum up to and including position k
+            }
+            const int s_lo = __double2loint(run), s_hi = __double2hiint(run);
+            double off = 0.0, tot = 0.0;
+            for (uint32_t k = 0; k < 64; ++k) {                  // offsets: sequential over the chunks
+                const double c = __hiloint2double(__builtin_amdgcn_readlane(s_hi, (int)k), __builtin_amdgcn_readlane(s_lo, (int)k));
+                if (wl == k) off = tot;
+                tot += c;
+            }
+            if (!uncontested) {                                  // an uncontested leaf reads the totals only
+#pragma unroll
+                for (int k = 0; k < kBrChunkMax; ++k)
+                    if ((uint32_t)k < cnt0) P[i0 + k] = off + t[k];
+            }
+            if (wl == 0) O[64] = tot;
+        } else if (wave == 1 && wl < 52u) {
+            double run = 0.0;
+#pragma unroll
+            for (int k0 = 0; k0 < kBrCardHolders; k0 += 17) {
+                double t[17];
+#pragma unroll
+                for (int k = 0; k < 17; ++k) t[k] = Q[clr[k0 + k]];
+#pragma unroll
+                for (int k = 0; k < 17; ++k)
+                    if ((uint32_t)(k0 + k) < cntc) {
+                        run += t[k];
+                        Pc[cardc * kBrCardHolders + k0 + k] = run;
+                    }
+            }
+        }
+        __syncthreads();
+        const double T = O[64];
+#pragma unroll
+        for (int k = 0; k < kBrHandsPerThread; ++k) {
+            const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
+            if (h >= n_p) continue;
+            const size_t lane = (size_t)b * n_p + h;
+            if (!(hc[k] >> 16)) {
+                v[lane] = 0.0;
+                continue;
+            }
+            const uint32_t c0 = hc[k] & 0xffu, c1 = (hc[k] >> 8) & 0xffu;
+            const uint32_t n0 = Lcc[c0], n1 = Lcc[c1];
+            const double T0 = n0 ? Pc[c0 * kBrCardHolders + n0 - 1] : 0.0, T1 = n1 ? Pc[c1 * kBrCardHolders + n1 - 1] : 0.0;
+            double acc;
+            if (uncontested) {
+                acc = value * (((T - T0) - T1) + (hs[k] >= 0 ? Q[hs[k]] : 0.0));
+            } else {
+                const uint32_t nl = hw0[k] & 0xffffu, nle = hw0[k] >> 16;
+                const uint32_t a0 = hw1[k] & 0xffu, a1 = (hw1[k] >> 8) & 0xffu, e0 = (hw1[k] >> 16) & 0xffu, e1 = hw1[k] >> 24;
+                const double L = nl ? P[nl - 1] : 0.0, LE = nle ? P[nle - 1] : 0.0;
+                const double L0 = a0 ? Pc[c0 * kBrCardHolders + a0 - 1] : 0.0, L1 = a1 ? Pc[c1 * kBrCardHolders + a1 - 1] : 0.0;
+                const double E0 = e0 ? Pc[c0 * kBrCardHolders + e0 - 1] : 0.0, E1 = e1 ? Pc[c1 * kBrCardHolders + e1 - 1] : 0.0;
+                const double win = (L - L0) - L1;
+                const double lose = ((T - LE) - (T0 - E0)) - (T1 - E1);
+                acc = value * (win - lose);
+            }
+            v[lane] = hp[k] * acc;
+        }
+        __syncthreads();                                         // Q, P, Pc, O are the next leaf's
+    }
+}
+
 // the same with one WAVE per info set, for rounds whose info sets hold many lanes (a flop info set of the 1 176-combo game: 3 800 of the 2.8 M lanes -- one thread per info set
 // left three workgroups walking 3 800 dependent gathers each, 13 ms per node).  The lanes of the wave fetch 64 list entries at a time; the additions still run one after the
 // other in list order (every lane adds the 64 values in the same order, read from its neighbours' registers), so the sums keep the oracle's bits.
@@ -628,18 +802,6 @@ __device__ __forceinline__ void br_own_wave_body(const void *__restrict__ ssum, 
 
 
 // ---- the kernels: one node per launch (the depth-first walk), or one JOB per node and grid row (the level plan: all nodes of one tree depth and kind in one launch) -------------
-struct BrJob {
-    BrNodeRow row;                 // action nodes: the node's strategy_sum block
-    const uint32_t *cid;           // opponent node: the opponent's lane -> cluster of the node's round
-    const uint32_t *start, *order; // own node: the lanes of every info set of the node's round
-    const double *q;               // opponent node: the reach that comes in; terminal: the opponent's reach
-    double *q_out;                 // opponent node: [A][n_pad] reach of its children
-    const double *vch;             // action node: [A][n_pad] values of its children
-    double *v;                     // where the node's own value goes (a slot of its parent's vch, or the root vector)
-    uint32_t n_clusters, n_children;
-    int uncontested, pad_;
-    double value;
-};
 template <int DT>
 __global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n, uint32_t n_pad,
                                                            const double *__restrict__ q, double *__restrict__ q_out) {
@@ -701,7 +863,8 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_boards_jobs(const uint
     br_terminal_boards_body(mask_p, score_p, pw, n_p, mask_o, score_o, j.q, n_o, bmask, j.uncontested, j.value, j.v);
 }
 
-constexpr size_t kBrLevelPlanBytes = size_t(16) << 30;   // the level plan's workspace is kept with the object: not beyond 16 GB
+constexpr size_t kBrLevelPlanBytes = size_t(96) << 30;   // the level plan's workspace is kept with the object: not beyond 96 GB (a third of the card; 16 GB until round 5, when
+                                                         // the plan bought launches only -- since the leaf loop it halves the terminals' traffic, and full 1 176-combo ranges need 59 GB)
 
 struct BrSide {
     uint32_t n_hands = 0;
@@ -879,7 +1042,12 @@ struct BrRun {
         }
         for (size_t lo = 0; lo < leaves.size() && err == hipSuccess; lo += 16384) {   // every leaf
             const uint32_t nj = uint32_t(std::min<size_t>(16384, leaves.size() - lo));
-            if (sorted) {
+            if (sorted && me.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock && op.n_hands <= uint32_t(kBrChunkMax) * 64u && op.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock) {   // a workgroup per run-out (and slice of the leaves, when run-outs alone do not fill the card)
+                const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double) + (((size_t(op.n_hands) + 3) & ~size_t(3)) + 52 * kBrCardHolders) * sizeof(uint16_t) + 64;
+                const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(nj, 2048u / std::max<uint32_t>(NB, 1)));
+                hipLaunchKernelGGL(k_br_terminal_sorted_loop, dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
+                                   d_jobs + o_leaves + lo, nj);
+            } else if (sorted) {
                 const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double);
                 hipLaunchKernelGGL(k_br_terminal_sorted_jobs, dim3(NB, nj), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
                                    d_jobs + o_leaves + lo);
