@@ -274,10 +274,19 @@ struct Knobs {
     int no_stage = 0;               // RS_JIT_NO_STAGE: the list walkers gather their records per node instead of staging their deals' rows in LDS
     int jit_no_procs = 0;           // RS_JIT_NO_PROCS: the kernels of a plan are compiled in this process one by one (what happens anyway when the rs_jitc helper is missing)
     int br_depth_first = 0;         // RS_BR_DEPTH_FIRST: the best response walks the tree depth first (what happens anyway when the level plan's buffers do not fit)
+    int no_merge = 0;               // RS_JIT_NO_MERGE: small deal batches keep one launch per subtree shape, spread over the auxiliary streams (what larger batches get)
     int no_overlap = 0;             // RS_JIT_NO_OVERLAP: the launches of a round run one after the other on the table's stream (profiling: overlapped kernels stretch each other's durations)
     int dump = 0;                   // RS_JIT_DUMP: every generated source is written to /tmp/rs_tree_kernel_<hash>.hip
 };
 Knobs knobs_resolve(const rs_kernel_forms *forms);
+// Several generated kernels as ONE: every member's body becomes a device function in a namespace of its own (its JArgs with it), the entry point dispatches on blockIdx.y
+// ranges.  offs[k] = {src_struct, src_entry, src_body} of sources[k].  Empty string: the members' preludes differ (deals per thread), they cannot share a translation unit.
+constexpr int kMergeMax = 16;
+struct MergedArgs {                // the merged kernel's first argument, by value
+    const void *blob[kMergeMax];
+    unsigned first[kMergeMax + 1];
+};
+std::string jit_merge_sources(const std::vector<const std::string *> &sources, const std::vector<const size_t *> &offs, const std::string &entry);
 const char *rccl_library_override();   // $RS_RCCL_LIB (tests: tests/stub_rccl.c), or nullptr
 std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), else ~/.cache/rustsolver_amd
 
@@ -285,6 +294,7 @@ std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), e
 struct JitSubtree {
     std::string source;
     std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals|deals_lds}[_sampled]
+    size_t src_struct = 0, src_entry = 0, src_body = 0;   // where `struct JArgs`, the kernel's signature and its body start inside `source` (jit_merge_sources)
     int threads = 256;             // workgroup size the kernel was generated for
     bool worklist = false;         // the kernel takes a third argument (the work list of its launch, rs_kernels.hip k_worklist) and a 1-D grid
     int lanes = 4;                 // lanes (deals) per thread the kernel was generated for: n_vec = pitch / lanes

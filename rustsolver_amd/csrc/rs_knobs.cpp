@@ -34,6 +34,7 @@ const Entry kEntries[] = {
     {"RS_JIT_LDS_MAX", INT, &Knobs::lds_max, nullptr},
     {"RS_JIT_MAX_BLOCKS", INT, &Knobs::max_blocks, nullptr},
     {"RS_JIT_NO_OVERLAP", FLAG, &Knobs::no_overlap, nullptr},
+    {"RS_JIT_NO_MERGE", FLAG, &Knobs::no_merge, nullptr},
     {"RS_TABLE_TILE_LANES", LONG, nullptr, &Knobs::tile_lanes},
 };
 }  // namespace

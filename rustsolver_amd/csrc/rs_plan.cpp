@@ -453,6 +453,9 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         plan.jit.emplace_back();
         plan.jit.back().source = js.source;
         plan.jit.back().entry = js.entry;
+        plan.jit.back().src_off[0] = js.src_struct;
+        plan.jit.back().src_off[1] = js.src_entry;
+        plan.jit.back().src_off[2] = js.src_body;
         plan.jit.back().stride = js.args_size;
         plan.jit.back().threads = js.threads;
         plan.jit.back().worklist = js.worklist;

@@ -18,8 +18,11 @@ constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this siz
 // Deal batches beyond kRowsMinDeals store delta rows in their list walkers, beyond kOrderMinDeals they also walk the batch in the order of the traverser's last-round cluster
 // (rs_solver.cpp).  Three streets, 5 000-bucket files, ms per batch with LDS tiles / rows / rows + order (profiles/r04_deals.md): 1 K deals 0.55 / 0.46 / 0.48, 4 K 0.60 / 0.52 /
 // 0.53, 16 K 0.70-0.81 / 0.65 / 0.72, 32 K 0.80 / 0.77 / 0.60-0.70, 64 K - / 0.83-0.91 / 0.74-0.84 (until the end of round 4 both forms started at 48 K deals).
-constexpr uint32_t kRowsMinDeals = 1024;
-constexpr uint32_t kOrderMinDeals = 24576;
+constexpr uint32_t kRowApplyMaxDeals = 32768;   // up to here the delta rows of a round go into the delta tables by atomics (k_row_apply) instead of k_row_sums' LDS tiles (rs_solver.cpp)
+// Round 5 (merged launches, one stream; ms per batch with LDS tiles / rows / rows + order): 256 deals 0.54 / 0.22 / -, 1 K 0.49 / 0.26 / -, 4 K - / 0.34 / 0.33, 8 K - / 0.41 / 0.38,
+// 16 K - / 0.50 / 0.44: rows from 64 deals, order from 6 K.
+constexpr uint32_t kRowsMinDeals = 63;
+constexpr uint32_t kOrderMinDeals = 6144;
                                             // Round 3 (gathering walks): 4 M deals 1.13-1.19x, 256 K a wash -> 512 K.  Round 4 (staged rows, runs summed by DPP): 4 M 1.16x, 1 M 1.18x, 512 K 1.16x,
                                             // 256 K 1.10x, 128 K 1.11x, 64 K 1.24x over the tile kernels on one card (profiles/r04_deals.md)
 constexpr size_t kWorklistLdsBytes = 64;   // in front of the tiles of a work-list kernel: lds_all[0] holds the ticket (rs_jit.cpp)
@@ -46,6 +49,12 @@ struct ReachSrc {
 struct JitLaunch {
     hipFunction_t fn = nullptr;         // resolved by rs_solver_create once the whole plan is known (all kernels compiled together)
     std::string source, entry;          // the generated source and its entry point (released after the compile)
+    size_t src_off[3] = {0, 0, 0};      // JitSubtree::src_struct / src_entry / src_body of `source`
+    // Small deal batches (rs_solver.cpp merge_small_groups): the kernels of one group of independent round subtrees -- different shapes, different code -- run as ONE launch
+    // whose entry point dispatches on blockIdx.y; `members` = the launches it stands for (their blobs stay where they are), this launch holds the merged kernel alone.
+    std::vector<int> members;
+    bool absorbed = false;              // a member of a merged launch: never compiled or launched on its own
+    MergedArgs margs{};
     std::vector<unsigned char> blob;   // n_jobs * stride bytes, layout = JArgs of the generated source
     size_t stride = 0;
     int n_jobs = 0;

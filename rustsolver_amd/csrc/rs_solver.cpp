@@ -76,7 +76,10 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         prof_begin(t, RS_K_DISCOUNT, L.bytes);
         const uint32_t chunk = s->knobs.rows_chunk != kUnset && s->knobs.rows_chunk > 0 ? uint32_t(s->knobs.rows_chunk) : kRowSumChunk;
         // direct rows under a communicator: the additions are written out as items for the ranks to exchange (solver_exchange_deltas applies everybody's)
-        hipError_t er = L.n_actions ? (s->comm ? launch_rows_to_items(plan.d_row_jobs, L.first_job, L.n_jobs, s->deals.n_deals, s->d_items, s->d_item_count, s->item_cap, tree_stream)
+        // small batches: a summing job's fixed cost -- zeroing and scanning its 64 KB tile, 574 jobs for the turn of the three-street tree: 18 us whatever the batch -- exceeds
+        // one atomic per non-zero delta into the delta table (k_row_apply with the job's delta-table rows as its destination): same sums, integer adds
+        const bool few = !L.n_actions && s->deals.n_deals <= kRowApplyMaxDeals;
+        hipError_t er = few ? launch_row_apply(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, tree_stream) : L.n_actions ? (s->comm ? launch_rows_to_items(plan.d_row_jobs, L.first_job, L.n_jobs, s->deals.n_deals, s->d_items, s->d_item_count, s->item_cap, tree_stream)
                                                : launch_row_apply(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, tree_stream))
                                     : launch_row_sums(plan.d_row_jobs + L.first_job, L.n_jobs, s->deals.n_deals, chunk, plan.row_max_cells, tree_stream);
         prof_end(t);
@@ -133,6 +136,17 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
             uint32_t *d_wl = JL.d_wl;
             void *wparams[] = {&d_blob, &flags, &d_wl};
             e = hipModuleLaunchKernel(JL.fn, (unsigned)grid, 1, 1, (unsigned)JL.threads, 1, 1, (unsigned)(JL.lds_bytes + kWorklistLdsBytes), tree_stream, wparams, nullptr);
+            break;
+        }
+        if (!JL.members.empty()) {   // one launch for the kernels of a whole group (merge_small_groups)
+            // The merged kernel keeps the registers of its largest member (two workgroups per CU), and a list holds a fraction of the batch: a grid sized for the whole batch
+            // per job is 98 % workgroups that find nothing and leave, thirty-odd rounds of them (64 K deals, 73 river lists: 96 us, a quarter of the sweep).  Sized for four
+            // times the average list of a round in which every deal is walked twice; the grid-stride loop takes what is longer.
+            if (s->knobs.max_blocks == kUnset)
+                blocks = std::min<size_t>(blocks, std::max<size_t>(4, (size_t(s->deals.n_deals) * 8 / size_t(JL.n_jobs) + size_t(JL.threads) - 1) / size_t(JL.threads)));
+            MergedArgs A = JL.margs;
+            void *mparams[] = {&A, &flags};
+            e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, tree_stream, mparams, nullptr);
             break;
         }
         void *params[] = {&d_blob, &flags};
@@ -735,6 +749,90 @@ static int setup_deal_records(rs_solver *s) {
     return RS_OK;
 }
 
+// Small deal batches: a sweep is a chain of ~40 dependent launches of 10-25 us each (one wave's walk), and every hand-over between the groups of independent round subtrees --
+// six kernels of different shapes on three streams -- costs another ~10 us of cross-queue signalling (kernel trace of a 4 K-deal batch: 7 such gaps per sweep, a quarter of the
+// batch).  Below kMergeMaxDeals the kernels of a group are compiled into ONE kernel whose entry point dispatches on blockIdx.y (jit_merge_sources) and the whole sweep runs on
+// the table's stream: no fork, no join.  The members keep their argument blobs; nothing about a subtree's code changes, so neither do its bits.
+constexpr uint32_t kMergeMaxDeals = 393216;   // 256 K deals: 1.20 against 1.28 ms per batch, 512 K: 1.73 either way (three streets, 5 000-bucket files)
+static int merge_small_groups(rs_solver *s) {
+    if (!s->deal_mode || s->deals.n_deals > kMergeMaxDeals || s->knobs.no_merge) return RS_OK;
+    for (int p = 0; p < 2; ++p) {
+        Plan &plan = s->plan[p];
+        std::vector<Launch> out;
+        size_t removed_before_split = 0;
+        for (size_t i = 0; i < plan.launches.size();) {
+            size_t j = i + 1;
+            if (plan.launches[i].group > 0)
+                while (j < plan.launches.size() && plan.launches[j].group == plan.launches[i].group) ++j;
+            std::vector<size_t> trees;
+            bool ok = true;
+            for (size_t k = i; k < j; ++k) {
+                const Launch &L = plan.launches[k];
+                if (L.kind != L_TREE) continue;
+                const JitLaunch &JL = plan.jit[size_t(L.first_job)];
+                ok = ok && JL.threads == 256 && !JL.worklist && !JL.persistent && (JL.staged || JL.lds_bytes == 0) && JL.members.empty() && !JL.absorbed;
+                trees.push_back(k);
+            }
+            std::string merged;
+            if (ok && trees.size() >= 2 && trees.size() <= size_t(kMergeMax)) {
+                std::vector<const std::string *> srcs;
+                std::vector<const size_t *> offs;
+                for (size_t k : trees) {
+                    srcs.push_back(&plan.jit[size_t(plan.launches[k].first_job)].source);
+                    offs.push_back(plan.jit[size_t(plan.launches[k].first_job)].src_off);
+                }
+                merged = jit_merge_sources(srcs, offs, "rs_tree_p" + std::to_string(p) + "_deals_merged" + std::to_string(trees.size()));
+            }
+            if (merged.empty()) {   // nothing to merge (one subtree kernel, or kernels with LDS tiles): the group's launches one after the other all the same -- at these sizes a
+                                    // fork and a join cost more than two short kernels side by side save
+                for (size_t k = i; k < j; ++k) {
+                    out.push_back(plan.launches[k]);
+                    if (j - i <= 2) out.back().group = 0;   // (the tile kernels of the smallest batches, one launch per shape, stay side by side)
+                }
+                i = j;
+                continue;
+            }
+            JitLaunch M;
+            M.source = std::move(merged);
+            M.entry = "rs_tree_p" + std::to_string(p) + "_deals_merged" + std::to_string(trees.size());
+            M.threads = 256;
+            M.staged = true;   // its LDS is a staging area (or nothing): the grid of the forms without tiles
+            for (size_t k : trees) {
+                JitLaunch &JL = plan.jit[size_t(plan.launches[k].first_job)];
+                M.members.push_back(plan.launches[k].first_job);
+                M.lds_bytes = std::max(M.lds_bytes, JL.lds_bytes);
+                M.max_n_vec = std::max(M.max_n_vec, JL.max_n_vec);
+                M.n_jobs += JL.n_jobs;
+                M.bytes += JL.bytes;
+                M.seg = M.seg || JL.seg;
+                M.rows = M.rows || JL.rows;
+                JL.absorbed = true;
+            }
+            const int mi = int(plan.jit.size());
+            plan.jit.push_back(std::move(M));
+            bool placed = false;
+            for (size_t k = i; k < j; ++k) {   // the group's other launches (the summing pass of the round below) stay, in order, on the same stream; the trees become one launch
+                Launch L = plan.launches[k];
+                L.group = 0;
+                if (L.kind == L_TREE) {
+                    if (placed) {
+                        if (k < plan.split) ++removed_before_split;
+                        continue;
+                    }
+                    L.first_job = mi;
+                    L.bytes = plan.jit[size_t(mi)].bytes;
+                    placed = true;
+                }
+                out.push_back(L);
+            }
+            i = j;
+        }
+        plan.launches.swap(out);
+        plan.split -= std::min(plan.split, removed_before_split);
+    }
+    return RS_OK;
+}
+
 // Only the list-walking kernels read the packed records: a round whose subtrees all walk the whole batch (the first round; every round of a one-round game) needs none
 static int trim_packed_records(rs_solver *s) {
     hipError_t e = hipSuccess;
@@ -919,10 +1017,15 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         rs_solver_destroy(s);
         return rc;
     }
+    if ((rc = merge_small_groups(s)) != RS_OK) {
+        rs_solver_destroy(s);
+        return rc;
+    }
     {   // the generated kernels of both plans: compiled together (concurrently where no cache has them), then bound to their launches
         std::vector<JitRequest> reqs;
         for (int p = 0; p < 2; ++p)
-            for (JitLaunch &JL : s->plan[p].jit) reqs.push_back(JitRequest{&JL.source, &JL.entry, nullptr});
+            for (JitLaunch &JL : s->plan[p].jit)
+                if (!JL.absorbed) reqs.push_back(JitRequest{&JL.source, &JL.entry, nullptr});
         if (!reqs.empty() && (rc = jit_get_kernels(reqs, table->device, s->knobs.dump != 0)) != RS_OK) {
             rs_solver_destroy(s);
             return rc;
@@ -930,7 +1033,7 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
         size_t k = 0;
         for (int p = 0; p < 2; ++p)
             for (JitLaunch &JL : s->plan[p].jit) {
-                JL.fn = reqs[k++].fn;
+                if (!JL.absorbed) JL.fn = reqs[k++].fn;
                 JL.source = std::string();
             }
     }
@@ -958,12 +1061,23 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 rs_solver_destroy(s);
                 return rc;
             }
+            if (JL.blob.empty()) continue;   // a merged launch: its members hold the blobs
             if ((e = hipMalloc((void **)&JL.d_blob, JL.blob.size())) != hipSuccess ||
                 (e = hipMemcpyAsync(JL.d_blob, JL.blob.data(), JL.blob.size(), hipMemcpyHostToDevice, table->stream)) != hipSuccess) {
                 rc = hip_fail(e, "rs_solver_create: tree-kernel argument upload");
                 rs_solver_destroy(s);
                 return rc;
             }
+        }
+        for (JitLaunch &JL : pl.jit) {   // merged launches: where every member's jobs start on the grid's y axis, and its blob
+            unsigned at = 0;
+            for (size_t k = 0; k < JL.members.size(); ++k) {
+                const JitLaunch &m = pl.jit[size_t(JL.members[k])];
+                JL.margs.blob[k] = m.d_blob;
+                JL.margs.first[k] = at;
+                at += unsigned(m.n_jobs);
+            }
+            for (size_t k = JL.members.size(); k <= size_t(kMergeMax); ++k) JL.margs.first[k] = at;
         }
         if ((e = hipMemcpyAsync(pl.d_jobs, pl.jobs.data(), pl.jobs.size() * sizeof(NodeJob), hipMemcpyHostToDevice,
                                 table->stream)) != hipSuccess) {

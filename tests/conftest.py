@@ -58,7 +58,19 @@ FAN_LOOP_TESTS = {
 # (test_randomised_differential draws its own form per seed: 32 cases instead of 192, every form still met eight times)
 
 
+# Deal batches up to 128 K deals run the kernels of a group of independent round subtrees as ONE merged kernel on one stream (rs_solver.cpp merge_small_groups); larger ones
+# keep a launch per subtree shape, spread over the auxiliary streams.  Every test batch is small: these tests run both ways (RS_JIT_NO_MERGE forces the large-batch form).
+MERGE_TESTS = {
+    "test_sparse_subtree_sweeps_three_streets_many_deals", "test_ordered_deal_sweeps_vs_oracle", "test_delta_rows_deal_sweeps_vs_oracle",
+    "test_deal_trainer_three_streets_from_a_flop_with_bucket_files", "test_deal_trainer_deals_and_sorts_ahead",
+}
+
+
 def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in MERGE_TESTS:
+        if "merge_form" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("merge_form")
+        metafunc.parametrize("merge_form", ["merged", "separate"], indirect=True)
     if metafunc.function.__name__ in FAN_LOOP_TESTS:
         if "fan_loop" not in metafunc.fixturenames:
             metafunc.fixturenames.append("fan_loop")
@@ -71,6 +83,13 @@ def pytest_generate_tests(metafunc):
         if "deals_per_thread" not in metafunc.fixturenames:
             metafunc.fixturenames.append("deals_per_thread")
         metafunc.parametrize("deals_per_thread", ["auto", "2", "4"] if metafunc.function.__name__ in TWO_DEALS_PER_THREAD_TESTS else ["auto", "4"], indirect=True)
+
+
+@pytest.fixture
+def merge_form(request, monkeypatch):
+    if request.param == "separate":
+        monkeypatch.setenv("RS_JIT_NO_MERGE", "1")
+    return request.param
 
 
 @pytest.fixture
