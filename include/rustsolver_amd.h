@@ -364,8 +364,9 @@ int rs_iterate(rs_solver *solver, int traverser, float *d_root_util);
 int rs_train(rs_solver *solver, uint64_t iterations, uint64_t discount_interval, uint64_t discount_cap);
 /* For a host that writes MCCFRTrainer::train's loop itself (rs_iterate / rs_iterate_phase per batch, rs_discount at its ticks): on = 1 in front of the loop, on = 0 behind
  * it.  In between the solver's kept shadow records (rs_kernel_forms.kept_records) are the working copy, as they are inside rs_train and rs_deal_trainer_train: the table's rows
- * of those nodes are neither added to nor discounted until on = 0 writes them back, so BETWEEN the two calls nothing but this solver's sweeps and rs_discount may touch or read
- * the table (no download, strategy query, best response, checkpoint, second solver).  A solver without kept records: both calls do nothing. */
+ * of those nodes are neither added to nor discounted until on = 0 writes them back.  Any call that reads or writes table contents in between (download, upload, strategy
+ * query, best response, checkpoint, fill) writes them back itself first and ends the working-copy state -- correct, but the rest of the loop then updates table and records
+ * both; a second solver sweeping the same table in between is not covered.  A solver without kept records: both calls do nothing. */
 int rs_solver_training_loop(rs_solver *solver, int on);
 /* Deal-batch solvers: rs_iterate_phase(.., 0) = the sweep (deltas accumulated, table untouched), (.., 1) = table += delta, delta = 0;
  * between the two the ranks' delta tables are summed (rs_comm_allreduce_deltas; tests emulate ranks and add them on the host).

@@ -147,6 +147,7 @@ extern "C" {
 
 int rs_table_save(rs_table *t, const char *path) {
     if (!t || !path) return fail(RS_ERR_INVALID, "rs_table_save: NULL argument");
+    if (int rc = rs::table_settle(t)) return rc;
     FILE *f = std::fopen(path, "wb");
     if (!f) return fail(RS_ERR_INVALID, std::string("rs_table_save: cannot create ") + path);
     Fnv fnv;

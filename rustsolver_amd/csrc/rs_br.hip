@@ -281,6 +281,7 @@ int rs_calc_br(rs_table *t, const rs_tree *tree, float *out) {
     if (!t || !tree || !out) return fail(RS_ERR_INVALID, "rs_calc_br: NULL argument");
     if (tree->nodes.empty()) return fail(RS_ERR_INVALID, "rs_calc_br: empty tree");
     if (int rc = check_tree_against_table(t, tree, "rs_calc_br")) return rc;
+    if (int rc = table_settle(t)) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     const uint32_t n_nodes = uint32_t(t->nodes.size());
     std::vector<BrNodeRow> rows(n_nodes);
@@ -1378,6 +1379,7 @@ int br_execute(BrRun *prepared, int mode, double *out) {
     if (mode != RS_BR_MAX && mode != RS_BR_AVERAGE) return fail(RS_ERR_INVALID, "rs_best_response: mode is RS_BR_MAX or RS_BR_AVERAGE (| RS_BR_SORTED)");
     BrRun &run = *prepared;
     rs_table *t = run.t;
+    if (int rc = table_settle(t)) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     run.mode = mode;
     run.err = hipSuccess;

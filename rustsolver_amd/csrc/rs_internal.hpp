@@ -439,6 +439,7 @@ void solver_table_discounted(struct rs_solver *s, float d, uint64_t epoch_before
 int solver_kept_primary(struct rs_solver *s, bool on);
 constexpr uint64_t kKeptPrimaryMinTrips = 16;   // training loops shorter than this leave the table's rows the working copy (the write-back at the end would cost more than it saves)
 bool solver_is_primary(const struct rs_solver *s);
+int table_settle(rs_table *t);   // rs_table.cpp: the table's rows up to date before anything reads or writes them (a training loop's working copy written back)
 // rs_comm.cpp: the collectives of a data-parallel deal sweep (rs_solver.cpp solver_exchange_deltas)
 int comm_world(const struct rs_comm *c);
 int comm_rank(const struct rs_comm *c);

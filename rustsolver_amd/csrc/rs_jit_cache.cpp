@@ -1,6 +1,7 @@
 // rs_jit_cache.cpp -- the other half of the tree-specialised kernels (rs_jit.cpp writes their source): sources compiled for gfx950 with hipRTC -- the kernels of one plan that no
 // cache holds by a handful of helper PROCESSES side by side (rs_jitc: hipRTC serialises compiles inside a process), or in this process when the helper is not there or fails --,
 // code objects cached in the process and on disk (keyed by source + compiler version + options; a blob that does not load is thrown away and rebuilt), functions handed out per device.
+#include <dirent.h>
 #include <dlfcn.h>
 #include <spawn.h>
 #include <sys/stat.h>
@@ -182,6 +183,17 @@ static std::string helper_path() {
     p = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/rs_jitc";
     return access(p.c_str(), X_OK) == 0 ? p : std::string();
 }
+// a scratch directory made for one hand-over: whatever a helper left behind (a .tmp of a compile that was killed, a .log) goes with it
+static void remove_scratch_dir(const std::string &dir) {
+    if (DIR *d = opendir(dir.c_str())) {
+        while (const dirent *e = readdir(d)) {
+            const std::string name = e->d_name;
+            if (name != "." && name != "..") (void)unlink((dir + "/" + name).c_str());
+        }
+        closedir(d);
+    }
+    (void)rmdir(dir.c_str());
+}
 static void compile_in_processes(const std::vector<std::pair<std::string, std::string>> &jobs /* (source file, output file) */) {
     const std::string exe = helper_path();
     if (exe.empty() || jobs.empty()) return;
@@ -189,7 +201,21 @@ static void compile_in_processes(const std::vector<std::pair<std::string, std::s
     const size_t n_proc = std::min<size_t>({jobs.size(), size_t(hw), size_t(16)});
     std::vector<pid_t> pids;
     for (size_t k = 0; k < n_proc; ++k) {
-        std::vector<std::string> args{exe};
+        std::vector<std::string> args{exe};   // the compiler options and the hipRTC version this library keys its cache with travel along (rs_jitc.cpp)
+        {
+            int major = 0, minor = 0;
+            if (Rtc *r = rtc()) {
+                auto ver = (int (*)(int *, int *))dlsym(r->handle, "hiprtcVersion");
+                if (ver) (void)ver(&major, &minor);
+            }
+            args.push_back("--rtc");
+            args.push_back(std::to_string(major) + "." + std::to_string(minor));
+            for (const char *o : kRtcOpts) {
+                args.push_back("--opt");
+                args.push_back(o);
+            }
+            args.push_back("--");
+        }
         for (size_t i = k; i < jobs.size(); i += n_proc) {
             args.push_back(jobs[i].first);
             args.push_back(jobs[i].second);
@@ -311,7 +337,7 @@ int jit_get_kernels(std::vector<JitRequest> &reqs, int device, bool dump) {
                         (void)unlink(jobs[i].second.c_str());
                     }
                 }
-                if (scratch) (void)rmdir(dir.c_str());
+                if (scratch) remove_scratch_dir(dir);
             }
         }
     }
@@ -376,7 +402,7 @@ int jit_compile_many(const std::map<std::string, int> &sources, bool dump) {
                 (void)unlink(jobs[i].second.c_str());
                 (void)unlink((jobs[i].second + ".log").c_str());
             }
-            (void)rmdir(dir.c_str());
+            remove_scratch_dir(dir);
         }
     }
     for (size_t i = 0; i < todo.size(); ++i) {

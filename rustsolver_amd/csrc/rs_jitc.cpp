@@ -1,6 +1,10 @@
 // rs_jitc.cpp -- the compile helper of rs_jit_cache.cpp: a small program that compiles HIP sources for gfx950 with hipRTC and writes the code objects to files.
 //
-//     rs_jitc <source file> <output file> [<source file> <output file> ...]
+//     rs_jitc [--rtc <major.minor>] [--opt <compiler option>]... [--] <source file> <output file> [<source file> <output file> ...]
+//
+// The library hands over ITS option list (--opt, one each; part of its cache key) and the hipRTC version it keyed the cache with (--rtc): a helper that finds another hipRTC
+// through its own dlopen search refuses (exit 104) instead of filing another compiler's code under the library's key -- the sweeps are bit-exact contracts
+// (-ffp-contract=off, -fno-fast-math).  Without --opt (the CPU test calls the helper by hand) the defaults below apply.
 //
 // hipRTC serialises compiles inside one process (36 kernels of a three-street deal plan: 44 s of CPU in 49 s of wall clock, whatever the number of threads), separate processes do
 // not: the library writes the sources no cache holds to files and starts a handful of these, each with its share.  No GPU is touched (hipRTC cross-compiles), nothing of the
@@ -26,8 +30,20 @@ static bool read_text(const char *path, std::string &out) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3 || (argc - 1) % 2) {
-        fprintf(stderr, "usage: rs_jitc <source> <output> [<source> <output> ...]\n");
+    std::vector<const char *> given;
+    std::string want_rtc;
+    int first = 1;
+    while (first + 1 < argc && argv[first][0] == '-' && argv[first][1] == '-') {
+        const std::string a = argv[first];
+        if (a == "--") { ++first; break; }
+        if (a == "--opt") given.push_back(argv[first + 1]);
+        else if (a == "--rtc") want_rtc = argv[first + 1];
+        else break;
+        first += 2;
+    }
+    if (first < argc && std::string(argv[first]) == "--") ++first;
+    if (argc - first < 2 || (argc - first) % 2) {
+        fprintf(stderr, "usage: rs_jitc [--rtc <major.minor>] [--opt <option>]... [--] <source> <output> [<source> <output> ...]\n");
         return 100;
     }
     if (getenv("RS_JITC_SELFTEST_FAIL")) return 103;   // test hook (tests/test_jit_cpu.py): a helper that delivers nothing -- the library must then compile in its own process
@@ -48,10 +64,21 @@ int main(int argc, char **argv) {
     auto Code = (int (*)(hiprtcProgram, char *))dlsym(h, "hiprtcGetCode");
     auto Destroy = (int (*)(hiprtcProgram *))dlsym(h, "hiprtcDestroyProgram");
     if (!Create || !Compile || !LogSize || !Log || !CodeSize || !Code || !Destroy) return 102;
-    // the options of rs_jit_cache.cpp kRtcOpts (part of the cache key there): keep the two lists the same
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    if (!want_rtc.empty()) {   // the library's cache key names a hipRTC version: this process must have found the same one
+        auto Version = (int (*)(int *, int *))dlsym(h, "hiprtcVersion");
+        int major = 0, minor = 0;
+        if (!Version || Version(&major, &minor) != 0 || want_rtc != std::to_string(major) + "." + std::to_string(minor)) {
+            fprintf(stderr, "rs_jitc: hipRTC %d.%d here, the caller keyed its cache with %s\n", major, minor, want_rtc.c_str());
+            return 104;
+        }
+    }
+    static const char *const defaults[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};   // a call by hand (tests); the library passes its own
+    std::vector<const char *> opts_v = given;
+    if (opts_v.empty()) opts_v.assign(defaults, defaults + sizeof(defaults) / sizeof(defaults[0]));
+    const char **opts = opts_v.data();
+    const int n_opts = int(opts_v.size());
     int failed = 0;
-    for (int i = 1; i + 1 < argc; i += 2) {
+    for (int i = first; i + 1 < argc; i += 2) {
         std::string src;
         const std::string out = argv[i + 1];
         if (!read_text(argv[i], src)) {
@@ -59,7 +86,7 @@ int main(int argc, char **argv) {
             continue;
         }
         hiprtcProgram prog = nullptr;
-        bool ok = Create(&prog, src.c_str(), "rs_tree_kernel.hip", 0, nullptr, nullptr) == 0 && Compile(prog, int(sizeof(opts) / sizeof(opts[0])), opts) == 0;
+        bool ok = Create(&prog, src.c_str(), "rs_tree_kernel.hip", 0, nullptr, nullptr) == 0 && Compile(prog, n_opts, opts) == 0;
         if (ok) {
             size_t n = 0;
             CodeSize(prog, &n);

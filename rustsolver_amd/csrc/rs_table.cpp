@@ -71,6 +71,17 @@ double algo_bytes_update(const rs_table *t, int node, int n_buf_children, bool h
     return lanes * (A * 4.0 * es + 4.0 * n_buf_children + (has_reach ? 4.0 : 0.0) + (has_out ? 4.0 : 0.0));
 }
 
+// A training loop may have made a solver's kept shadow records the working copy (rs_solver.cpp solver_kept_primary): the table's rows of those nodes are stale until they are
+// written back.  Every entry point that reads or writes table contents settles that first -- rows written back, the records no longer the working copy (the loop goes on with table
+// and records both updated, as outside a loop) -- so that nothing ever reads stale rows or loses what a loop has trained.
+int table_settle(rs_table *t) {
+    if (!t) return RS_OK;
+    for (rs_solver *s : t->solvers)
+        if (solver_is_primary(s))
+            if (int rc = solver_kept_primary(s, false)) return rc;
+    return RS_OK;
+}
+
 static int check_node(const rs_table *t, int node, const char *fn) {
     if (!t) return fail(RS_ERR_INVALID, std::string(fn) + ": table is NULL");
     if (node < 0 || node >= int(t->nodes.size()))
@@ -297,6 +308,7 @@ void *rs_stream(rs_table *t) { return t ? (void *)t->stream : nullptr; }
 // ---- host <-> device ------------------------------------------------------------------------------------------
 static int board_copy(rs_table *t, int node, int board, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
+    if (int rc = table_settle(t)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     if (nd.n_actions == 0) return RS_OK;
     if (board < 0 || uint32_t(board) >= nd.n_boards) return fail(RS_ERR_OOB, std::string(fn) + ": board out of bounds");
@@ -316,6 +328,7 @@ int rs_table_download(rs_table *t, int node, int board, void *regrets, void *ssu
 }
 static int node_copy(rs_table *t, int node, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
+    if (int rc = table_settle(t)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     if (nd.n_actions == 0) return RS_OK;   // nothing to copy
     const size_t lanes = size_t(nd.n_boards) * nd.n_clusters;
@@ -336,6 +349,7 @@ int rs_table_download_node(rs_table *t, int node, void *regrets, void *ssum) {
 // get-infoset: &self.infosets[an.index][cluster_idx] (cfr.rs:375)
 static int infoset_copy(rs_table *t, int node, int board, int cluster, void *regrets, void *ssum, int dir, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
+    if (int rc = table_settle(t)) return rc;
     const rs_node_desc &nd = t->nodes[node];
     if (nd.n_actions == 0) return RS_OK;
     if (board < 0 || uint32_t(board) >= nd.n_boards || cluster < 0 || uint32_t(cluster) >= nd.n_clusters)
@@ -359,6 +373,7 @@ int rs_set_infoset(rs_table *t, int node, int board, int cluster, const void *re
 // get-infoset for a batch of lanes of one node: one gather kernel per array instead of n strided copies
 int rs_get_infosets(rs_table *t, int node, const uint32_t *lanes, size_t n, void *regrets, void *ssum) {
     if (int rc = check_node(t, node, "rs_get_infosets")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (!lanes && n) return fail(RS_ERR_INVALID, "rs_get_infosets: lanes is NULL");
     const rs_node_desc &nd = t->nodes[node];
     if (nd.n_actions == 0 || n == 0) return RS_OK;
@@ -411,6 +426,7 @@ int rs_selftest_division(rs_table *t, size_t n, uint64_t seed, uint64_t *mismatc
 
 int rs_table_checksum(rs_table *t, uint64_t *out) {
     if (!t || !out) return fail(RS_ERR_INVALID, "rs_table_checksum: NULL argument");
+    if (int rc = table_settle(t)) return rc;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     unsigned long long *d = nullptr;
     hipError_t e = hipMalloc((void **)&d, 16);
@@ -433,6 +449,7 @@ int rs_table_checksum(rs_table *t, uint64_t *out) {
 // 64-lane group that contains the lane (so the numbers come from the same code as the bulk path).
 static int single_strategy(rs_table *t, int node, int board, int cluster, float *out, bool final_, const char *fn) {
     if (int rc = check_node(t, node, fn)) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (!out) return fail(RS_ERR_INVALID, std::string(fn) + ": out is NULL");
     const rs_node_desc &nd = t->nodes[node];
     if (nd.n_actions == 0) return RS_OK;   // vec![0.0; 0]
@@ -474,6 +491,7 @@ int rs_get_final_strategy(rs_table *t, int node, int board, int cluster, float *
 int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi) {
     if (!t) return fail(RS_ERR_INVALID, "rs_table_fill_random: table is NULL");
     if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random: empty range");
+    if (int rc = table_settle(t)) return rc;
     ++t->epoch;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     RS_HIP(launch_fill_random(t->d_regrets, t->n_cells, seed, rlo, rhi, t->dtype, t->stream), "fill_random(regrets)");
@@ -484,6 +502,7 @@ int rs_table_fill_random(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, i
 int rs_table_plant_saturating(rs_table *t, uint64_t seed, uint32_t one_in) {
     if (!t || one_in == 0) return fail(RS_ERR_INVALID, "rs_table_plant_saturating: bad argument");
     if (t->dtype != RS_I32) return fail(RS_ERR_UNSUPPORTED, "rs_table_plant_saturating: i32 tables (the saturating range is the i32 range)");
+    if (int rc = table_settle(t)) return rc;
     ++t->epoch;
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
     RS_HIP(launch_plant_saturating(t->d_regrets, t->n_cells, seed, one_in, t->stream), "plant_saturating");
@@ -530,11 +549,13 @@ static int logical_sweep(rs_table *t, const uint64_t *lane_off, int op, uint64_t
 }
 int rs_table_fill_random_logical(rs_table *t, uint64_t seed, int64_t rlo, int64_t rhi, int64_t slo, int64_t shi, const uint64_t *lane_off) {
     if (rhi < rlo || shi < slo) return fail(RS_ERR_INVALID, "rs_table_fill_random_logical: empty range");
+    if (int rc = table_settle(t)) return rc;
     if (t) ++t->epoch;
     return logical_sweep(t, lane_off, 0, seed, rlo, rhi, slo, shi, nullptr, "rs_table_fill_random_logical");
 }
 int rs_table_checksum_logical(rs_table *t, const uint64_t *lane_off, uint64_t *out) {
     if (!out) return fail(RS_ERR_INVALID, "rs_table_checksum_logical: NULL argument");
+    if (int rc = table_settle(t)) return rc;
     return logical_sweep(t, lane_off, 1, 0, 0, 0, 0, 0, out, "rs_table_checksum_logical");
 }
 int rs_fill_uniform_f32(rs_table *t, float *d_dst, size_t n, uint64_t seed, float lo, float hi) {
@@ -615,6 +636,7 @@ static void base_job(const rs_table *t, int node, NodeJob &job) {
 
 int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
     if (int rc = check_node(t, node, "rs_regret_match_node")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_strategy) return fail(RS_ERR_INVALID, "rs_regret_match_node: d_strategy is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -627,6 +649,7 @@ int rs_regret_match_node(rs_table *t, int node, float *d_strategy) {
 }
 int rs_final_strategy_node(rs_table *t, int node, float *d_strategy) {
     if (int rc = check_node(t, node, "rs_final_strategy_node")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_strategy) return fail(RS_ERR_INVALID, "rs_final_strategy_node: d_strategy is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -658,6 +681,7 @@ static int check_mode(const rs_table *t, int mode, const char *fn) {
 int rs_update_node(rs_table *t, int node, const float *d_action_utils, const float *d_reach, float scale, int mode,
                    float *d_node_util) {
     if (int rc = check_node(t, node, "rs_update_node")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     ++t->epoch;
     if (!d_action_utils) return fail(RS_ERR_INVALID, "rs_update_node: d_action_utils is NULL");
@@ -679,6 +703,7 @@ int rs_update_node(rs_table *t, int node, const float *d_action_utils, const flo
 
 int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_node_util) {
     if (int rc = check_node(t, node, "rs_node_util")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_action_utils || !d_node_util) return fail(RS_ERR_INVALID, "rs_node_util: NULL argument");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");
@@ -697,6 +722,7 @@ int rs_node_util(rs_table *t, int node, const float *d_action_utils, float *d_no
 
 int rs_child_reach(rs_table *t, int node, const float *d_reach, float *d_child_reach) {
     if (int rc = check_node(t, node, "rs_child_reach")) return rc;
+    if (int rc = table_settle(t)) return rc;
     if (t->nodes[node].n_actions == 0) return RS_OK;   // a node without actions has nothing to compute
     if (!d_child_reach) return fail(RS_ERR_INVALID, "rs_child_reach: d_child_reach is NULL");
     RS_HIP(hipSetDevice(t->device), "hipSetDevice");

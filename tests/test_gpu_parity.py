@@ -1171,7 +1171,7 @@ def test_delta_rows_deal_sweeps_vs_oracle(variant, monkeypatch):
         assert (r == ro).all() and (s == so).all(), "table differs at node %d" % nd.index
 
 
-@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "host-loop", "host-loop-destroyed", "host-phases-refused", "two-solvers"])
+@pytest.mark.parametrize("variant", ["steps", "steps+graph", "steps-off", "train-loop", "train-loop-off", "host-loop", "host-loop-destroyed", "host-loop-read-inside", "host-phases-refused", "two-solvers"])
 def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
     """A round whose delta rows go straight into the table (20 000 / 17 000 river clusters: rs_kernel_forms.direct_rows) keeps its shadow records between sweeps: k_row_apply adds
     every delta to the record as well as to the table row, rs_discount sweeps the records too, and any other write to the table has them rebuilt before the next sweep
@@ -1236,6 +1236,22 @@ def test_kept_shadow_records_stay_in_step_with_the_table(variant, monkeypatch):
         tr_off.iterate_phase(0, 1)
         osol.iterate(0)
         same_tables("phases driven by hand, direct rows off")
+        return
+    if variant == "host-loop-read-inside":   # a download in the middle of the loop: the records' rows are written back first (and the loop goes on with table and records both up to date)
+        tr.training_loop(True)
+        for it in range(4):
+            for player in (0, 1):
+                tr.iterate(player)
+                osol.iterate(player)
+            if it == 1:
+                same_tables("a download inside rs_solver_training_loop")
+                nd = river[0]
+                r, s_ = table.download_node(nd.index)
+                r[:, 77] -= 4242
+                table[nd.index][77].set(r[:, 77], s_[:, 77])      # ... and a write: nothing trained so far is lost
+                otab.set_node(nd.index, r, s_)
+        tr.training_loop(False)
+        same_tables("the loop after a read and a write inside it")
         return
     if variant == "host-loop":   # rs_solver_training_loop around a loop the HOST writes: sweeps and discounts only in between, the table read after it
         tr.training_loop(True)
