@@ -743,6 +743,20 @@ def three_street_leg(rs, device, with_cpu=False, cpu_seconds=6.0):
     out["roofline_deals"] = roofline_deals("three_street_4m", out["ms_per_batch"])
     sizes = [(a_.get_size(0), a_.get_size(1)) for a_ in card_abs]
     tr.destroy()
+    # the same game at the batch sizes that decide time-to-exploitability: 64 K and 4 K deals per batch, batches 4-43 of a fresh trainer
+    for nn, key in ((1 << 16, "ms_per_batch_64k"), (1 << 12, "ms_per_batch_4k")):
+        try:
+            ts = rs.DealTrainer(tree, card_abs, [hands, hands], mask, nn, seed=7, discount_interval=0, use_graph=True, device=device)
+            ts.train(3)
+            ts.status()
+            t0 = time.perf_counter()
+            ts.train(40)
+            ts.infosets.sync()
+            out[key] = (time.perf_counter() - t0) / 40 * 1e3
+            ts.destroy()
+        except Exception as e:
+            out[key] = None
+            out[key + "_error"] = str(e)
     if with_cpu:   # the same loop on the host cores: the oracle's train-from-cards (reference layout, per-visit allocations), 8 threads
         from oracle import orc
         threads = min(8, os.cpu_count() or 1)
@@ -1010,9 +1024,19 @@ def pmc_traffic(a, kernel):
     if not files:
         return None, None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+        rec = json.load(open(files[-1]))
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("rs_device.hpp", "rs_jit.cpp", "rs_kernels.hip"):
+            h.update(open(os.path.join(ROOT, "rustsolver_amd", "csrc", f), "rb").read())
+        pmc_traffic.info = {"commit": rec.get("commit"), "kernel_source_sha16": rec.get("kernel_source_sha16"),
+                            "stale": (rec.get("kernel_source_sha16") != h.hexdigest()[:16]) if rec.get("kernel_source_sha16") else None}
+        return float(rec["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+pmc_traffic.info = {}
 
 
 def compact_line(out):
@@ -1034,7 +1058,7 @@ def compact_line(out):
     line["config"] = {k: cfg[k] for k in ("workload", "n_boards_per_gpu", "n_clusters", "regret_fill", "table_bytes_per_gpu", "launches_per_step", "parallelism",
                                           "process_group_ranks") if k in cfg}
     rf = out["roofline"]
-    line["roofline"] = {k: r3(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_canned", "launches", "avg_launch_ms",
+    line["roofline"] = {k: r3(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_canned", "traffic_commit", "traffic_stale", "launches", "avg_launch_ms",
                                                "algo_bytes_per_launch", "copy_GBps", "frac_of_copy_on_this_card") if k in rf}
     line["roofline"]["kernel"] = "rs_tree_p{0,1}_lanes" if "rs_tree" in rf.get("kernel", "") else "rs::k_update"
     cb = out.get("cpu_baseline")
@@ -1055,6 +1079,7 @@ def compact_line(out):
         "deal_trainer_Mps": (g(out, "deal_trainer", "value") or 0) / 1e6 or None, "deal_trainer_ms": g(out, "deal_trainer", "ms_per_batch"),
         "deal_trainer_valu_frac": g(out, "deal_trainer", "roofline_deals", "frac"),
         "deal_trainer_3s_Mps": (g(out, "deal_trainer_three_street", "value") or 0) / 1e6 or None, "deal_trainer_3s_ms": g(out, "deal_trainer_three_street", "ms_per_batch"), "deal_trainer_3s_ms_later": g(out, "deal_trainer_three_street", "ms_per_batch_batches_48_67"),
+        "deal_trainer_3s_64k_ms": g(out, "deal_trainer_three_street", "ms_per_batch_64k"), "deal_trainer_3s_4k_ms": g(out, "deal_trainer_three_street", "ms_per_batch_4k"),
         "deal_trainer_3s_valu_frac": g(out, "deal_trainer_three_street", "roofline_deals", "frac"),
         "solve_expl": [g(out, "solve", "exploitability_before"), g(out, "solve", "exploitability_after")], "solve_s": g(out, "solve", "seconds_training"),
         "solve_3s_expl": [x[1] for x in (g(out, "solve_three_street", "exploitability_curve") or [])] or None, "solve_3s_s": g(out, "solve_three_street", "seconds_training"),
@@ -1308,6 +1333,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_canned": traffic is not None,
+            # the canned figure's provenance: the commit its PMC passes ran at, and whether the kernel sources (rs_device.hpp, rs_jit.cpp, rs_kernels.hip) have changed since
+            "traffic_commit": pmc_traffic.info.get("commit"), "traffic_stale": pmc_traffic.info.get("stale"),
             "traffic_source": ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; NOT measured in this run" % traffic_file) if traffic_file else None,
             "launches": upd["launches"], "avg_launch_ms": upd["ms"] / max(1, upd["launches"]),
             "algo_bytes_per_launch": upd["algo_bytes"] / max(1, upd["launches"]),

@@ -24,6 +24,24 @@ src, prefix = sys.argv[1], sys.argv[2]
 FULL = 1 << 19   # the LDS deal-batch kernels run 1024 workgroups of 512 threads
 
 
+def kernel_source_sha16():
+    """what the profiled kernels were generated from: bench.py recomputes it and reports the canned traffic as stale when the sources have moved on"""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("rs_device.hpp", "rs_jit.cpp", "rs_kernels.hip"):
+        h.update(open(os.path.join(root, "rustsolver_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip()
+    except Exception:
+        return None
+
+
 def one(pattern):
     g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # gpurun MERGES runs into gpurun_out/: newest wins
     return g[-1] if g else None
@@ -97,7 +115,7 @@ if traffic:
         if n:
             per_launch = tot / n
             lines += ["", "`k_%s`: PMC HBM bytes per dispatch (dispatch-weighted) = %.4g" % (name, per_launch)]
-            json.dump({"kernel": "rs::k_" + name, "hbm_bytes_per_launch": per_launch, "dispatches": n,
+            json.dump({"kernel": "rs::k_" + name, "hbm_bytes_per_launch": per_launch, "dispatches": n, "kernel_source_sha16": kernel_source_sha16(), "commit": git_head(),
                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB x1024",
                        "workload": "bench.py default (9216 boards x 1000 clusters, clamp)"},
                       open(prefix + "_roofline_traffic_%s.json" % name, "w"), indent=1)
