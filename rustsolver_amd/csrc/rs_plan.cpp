@@ -436,10 +436,45 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
         }
         if (!all) stage.ch[0] = stage.ch[1] = 0;
     }
+    // the dense reach-down kernel of the first round of a big batch: staged too, from the row copy setup_table_shadow keeps for it (one deal per lane)
+    bool dense_down_staged = false;
+    if (s->deal_mode && down && !sparse && id == first_root && !s->down_off_p[p].empty() && !s->knobs.no_stage && s->knobs.lanes == kUnset) {
+        stage = JitStage{};
+        stage.off.assign(n, 0);
+        stage_rows_of[0] = stage_rows_of[1] = nullptr;
+        bool all = true, any = false;
+        std::vector<int> stack{id};
+        while (!stack.empty()) {
+            const int q = stack.back();
+            stack.pop_back();
+            const rs_tree_node &qn = nodes[q];
+            if (qn.kind == RS_NODE_ACTION && qn.n_children > 0) {
+                const size_t ti = size_t(qn.index);
+                const int32_t *base = s->down_off_p[p][ti] == SIZE_MAX ? nullptr : s->d_shadow + (s->down_off_p[p][ti] - s->down_rowoff_p[p][ti]);
+                if (!base || (stage_rows_of[qn.player] && stage_rows_of[qn.player] != base)) all = false;
+                else {
+                    stage.ch[qn.player] = stage.chp[qn.player] = int(s->down_stride_p[p][ti] / 4);
+                    stage.off[size_t(q)] = int(s->down_rowoff_p[p][ti]);
+                    stage_rows_of[qn.player] = base;
+                    any = true;
+                }
+            }
+            for (int k = 0; k < qn.n_children; ++k) {
+                const int c = qn.children[k];
+                const bool chance = nodes[c].kind == RS_NODE_PRIVATE_CHANCE || nodes[c].kind == RS_NODE_PUBLIC_CHANCE;
+                if (!(round_mode && chance)) stack.push_back(c);
+            }
+        }
+        dense_down_staged = all && any;
+        if (!dense_down_staged) {
+            stage = JitStage{};
+            stage_rows_of[0] = stage_rows_of[1] = nullptr;
+        }
+    }
     JitSubtree js;
     jit_emit_subtree(nodes, id, p, has_own, leaf_buf, leaf_flags, t->dtype, s->params.mode & RS_UPD_ARITH_MASK,
                      s->params.opp_mode == RS_OPP_SAMPLE, s->deal_mode, use_lds, sparse, down, (s->params.mode & RS_UPD_PRUNE) != 0,
-                     (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
+                     dense_down_staged ? 1 : (use_lds && s->knobs.lanes == kUnset) ? ((!sparse && s->deals.n_deals > kSmallDealBatch) ? 2 : 1) : ((id == first_root || nodes[id].round_idx == nodes[first_root].round_idx) ? jit_lanes : jit_lanes_below),
                      round_mode ? &fused_root : (lane_rounds ? &next_root : nullptr), js, s->knobs,
                      int(fan_root[id]), sparse && s->d_attr[nodes[id].round_idx] != nullptr, pos_rows, true, s->ordered, seg, rows, sigma_node.empty() ? nullptr : &sigma_node, s->deal_mode && handoff_root(id), &stage);
     const bool xfan = fan_root[id] == 1;

@@ -18,6 +18,7 @@ constexpr uint32_t kSiblingsMinDeals = 524288;   // deal batches beyond this siz
 // Deal batches beyond kRowsMinDeals store delta rows in their list walkers, beyond kOrderMinDeals they also walk the batch in the order of the traverser's last-round cluster
 // (rs_solver.cpp).  Three streets, 5 000-bucket files, ms per batch with LDS tiles / rows / rows + order (profiles/r04_deals.md): 1 K deals 0.55 / 0.46 / 0.48, 4 K 0.60 / 0.52 /
 // 0.53, 16 K 0.70-0.81 / 0.65 / 0.72, 32 K 0.80 / 0.77 / 0.60-0.70, 64 K - / 0.83-0.91 / 0.74-0.84 (until the end of round 4 both forms started at 48 K deals).
+constexpr uint32_t kDownRowsMinDeals = 262144;   // batches beyond this keep a row copy of the first round for their dense reach-down kernel, which stages it (one deal per lane)
 constexpr uint32_t kRowApplyMaxDeals = 32768;   // up to here the delta rows of a round go into the delta tables by atomics (k_row_apply) instead of k_row_sums' LDS tiles (rs_solver.cpp)
 // Round 5 (merged launches, one stream; ms per batch with LDS tiles / rows / rows + order): 256 deals 0.54 / 0.22 / -, 1 K 0.49 / 0.26 / -, 4 K - / 0.34 / 0.33, 8 K - / 0.41 / 0.38,
 // 16 K - / 0.50 / 0.44: rows from 64 deals, order from 6 K.
@@ -175,6 +176,11 @@ struct rs_solver {
     std::vector<uint32_t> shadow_rec_p[2];      // ints of the node's own record: 2 * half at the sweep's traverser nodes, half at the opponent's
     std::vector<uint32_t> shadow_rowoff_p[2];   // ints from the start of the row to the node's record
     uint32_t shadow_max_clusters = 0;
+    // The FIRST round's nodes a second time, as rows of narrow records (regrets / strategy only), for the dense reach-down kernel of a big batch alone (round 5): its 4 M deals
+    // read every node of the round, 28 gathers of 64 lines each per thread pair; staged like the list walkers' rows (rs_device.hpp stage_rows) the wave touches 4-8 rows per
+    // load.  The dense WALK keeps the node arrays above (its deltas go to LDS tiles: no staging area to spare, and node arrays serve it better: NOTES round 4).
+    std::vector<size_t> down_off_p[2];          // per traverser and table node (SIZE_MAX: none)
+    std::vector<uint32_t> down_stride_p[2], down_rowoff_p[2];
     // KEPT records (setup_table_shadow): the nodes of the rounds whose delta rows go straight into the table keep their records between sweeps -- wide records ({regrets,
     // strategy sums}, no strategies) at the front of d_shadow, shared by both traversers' sweeps, built when the table has moved on without them (rs_table.epoch), and taking
     // every addition k_row_apply makes to the table and every discount sweep (solver_table_discounted)

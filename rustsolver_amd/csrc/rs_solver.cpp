@@ -582,6 +582,51 @@ static int setup_table_shadow(rs_solver *s) {
                 }
                 ints += round_up(size_t(n_cl) * row, 64);
             }
+            // the first round once more, as rows for the dense reach-down kernel (rs_plan.hpp down_off_p)
+            s->down_off_p[tp].assign(table->nodes.size(), SIZE_MAX);
+            s->down_stride_p[tp].assign(table->nodes.size(), 0);
+            s->down_rowoff_p[tp].assign(table->nodes.size(), 0);
+            if (staged_rows && first_round >= 0 && s->n_rounds > 1 && (s->deals.n_deals > kDownRowsMinDeals || s->knobs.ordered == 1)) {   // (RS_JIT_ORDERED = 1: the tests' way to
+                                                                                                                                       // give a small batch the big batches' forms)
+                std::map<std::pair<int, int>, std::vector<size_t>> first;
+                for (size_t i = 0; i < table->nodes.size(); ++i) {
+                    const rs_node_desc &d = table->nodes[i];
+                    if (d.n_actions == 0 || int(d.round_idx) != first_round || tree_of[i] < 0 || s->shadow_off_p[tp][i] == SIZE_MAX || table->tiled(int(i))) continue;
+                    first[{comp_root[size_t(tree_of[i])], int(d.player)}].push_back(i);
+                }
+                for (auto &kv : first) {
+                    std::vector<size_t> &mem = kv.second;
+                    std::vector<uint32_t> acts, recs, offs;
+                    uint32_t n_cl = 0;
+                    for (size_t i : mem) {
+                        acts.push_back(table->nodes[i].n_actions);
+                        n_cl = std::max(n_cl, table->nodes[i].n_clusters);
+                    }
+                    const uint32_t row = uint32_t(round_up(size_t(shadow_row_layout(acts, false, recs, offs)), 4));   // narrow records for both roles: a reach-down kernel reads regrets (its own
+                                                                                                                        // nodes' explored[] bits) or strategies, never strategy sums
+                    if (row > uint32_t(kStageMaxChunks) * 4 || size_t(n_cl) * row >= (size_t(1) << 32)) continue;
+                    for (size_t m = 0; m < mem.size(); ++m) {
+                        const size_t i = mem[m];
+                        const rs_node_desc &d = table->nodes[i];
+                        s->down_off_p[tp][i] = ints + offs[m];
+                        s->down_stride_p[tp][i] = row;
+                        s->down_rowoff_p[tp][i] = offs[m];
+                        ShadowJob j{};
+                        j.regrets = static_cast<const int32_t *>(table->regrets_ptr(int(i)));
+                        j.ssum = static_cast<const int32_t *>(table->ssum_ptr(int(i)));
+                        j.pitch = uint32_t(table->pitch[i]);
+                        j.n_clusters = d.n_clusters;
+                        j.n_actions = d.n_actions;
+                        j.half = d.n_actions <= 2 ? 2 : (d.n_actions <= 4 ? 4 : 8);
+                        j.stride = recs[m];
+                        j.row_stride = row;
+                        j.sigma = d.player != tp ? 1u : 0u;
+                        j.dst = reinterpret_cast<int32_t *>(ints + offs[m]);
+                        jobs.push_back(j);
+                    }
+                    ints += round_up(size_t(n_cl) * row, 64);
+                }
+            }
             if (tp == 0) s->n_shadow_jobs = int(jobs.size());
         }
         s->other_bytes += std::max<size_t>(ints * 4, 256) + std::max<size_t>(jobs.size() * sizeof(ShadowJob), 256) + kept_jobs.size() * sizeof(ShadowJob);

@@ -254,9 +254,22 @@ def test_sorted_showdowns_full_ranges_from_a_flop():
     tr4 = rs.DealTrainer(tree4, abs4, [hands4, hands4], mask4, 1 << 16, seed=6, discount_interval=0)
     tr4.train(20)
     tr4.status()
+    level = {}
     for mode in (L.BR_MAX, L.BR_AVERAGE):
         pair, srt = tr4.best_response(mode), tr4.best_response(mode | L.BR_SORTED)
         assert np.allclose(srt, pair, rtol=1e-10, atol=1e-12), (mode, pair, srt)
+        level[mode] = srt
+    # the level plan's leaf loop (one workgroup per run-out takes every leaf in turn: ranges of 512 combos and more) against the depth-first walk's one-leaf kernel: the same
+    # sums in the same order, hence the same bits
+    assert tr4.br_launches() > 0
+    os.environ["RS_BR_DEPTH_FIRST"] = "1"
+    try:
+        tr4.br_release()
+        for mode in (L.BR_MAX, L.BR_AVERAGE):
+            assert tr4.best_response(mode | L.BR_SORTED).tobytes() == level[mode].tobytes()
+        assert tr4.br_launches() == -1
+    finally:
+        del os.environ["RS_BR_DEPTH_FIRST"]
     tr4.destroy()
 
 
