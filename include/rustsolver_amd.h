@@ -39,10 +39,12 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 5   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h;
+#define RS_ABI_VERSION 6   /* 2: rs_deal_batch.d_prune, rs_deal_trainer_params.prune_threshold, tiled node blocks (rs_table_tile_lanes); 3: rs_get_infosets, diagnostics split into rustsolver_amd_diag.h;
                               4: rs_kernel_forms inside rs_solver_params, rs_table_params + rs_table_create_with, rs_deal_trainer_params.prefetch, f32 deal batches;
                               5: rs_kernel_forms without `worklist` and RS_FAN_LOOP / RS_SHADOW_WIDE, with direct_rows and kept_records (same size: a zeroed struct means what it meant);
-                                 rs_hand_index_verify, rs_deal_trainer_br_bytes / _br_release / _br_launches, RS_ERR_MISMATCH */
+                                 rs_hand_index_verify, rs_deal_trainer_br_bytes / _br_release / _br_launches, RS_ERR_MISMATCH;
+                              6: rs_deal_trainer_params.table_dtype (was `reserved`: zero = RS_I32 means what it meant), float deal tables RS_F16 and RS_UPD_RMPLUS,
+                                 rs_solver_exchange_bytes (diagnostics), data-parallel sweeps keep direct rows */
 #define RS_MAX_ACTIONS 8
 #define RS_MAX_ROUNDS 3
 #define RS_MAX_SIZES 4
@@ -492,8 +494,10 @@ typedef struct rs_deal_trainer_params {
     uint64_t prune_threshold;      /* cfr.rs:190 PRUNE_THRESHOLD (10 000 000): deals numbered beyond it are traversed with prune = true when their
                                       q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  With a finite threshold the solver runs
                                       in RS_UPD_PRUNE mode with per-deal flags that stay zero (= unpruned, bit for bit) before it */
-    int32_t prefetch;              /* RS_FORM_*: deal the next batch on a second stream while the current one is swept (default: on beyond 262 144 deals per batch) */
-    int32_t reserved;              /* zero */
+    int32_t prefetch;              /* RS_FORM_*: deal the next batch on a second stream while the current one is swept (default: on from 65 536 deals per batch) */
+    int32_t table_dtype;           /* element type of the table the trainer creates: RS_I32 (0: the reference's), or -- extensions -- RS_F32 / RS_F16: float deal sweeps
+                                      (rs_solver_create_deals: f32 per-deal deltas summed in deal order, one rounding per cell and sweep); these need prune_threshold =
+                                      UINT64_MAX and world <= 1.  (The field was `reserved`, zero, until ABI 5) */
 } rs_deal_trainer_params;
 /* MCCFRTrainer::init (cfr.rs:159-184): card_abs[round_idx] for the tree's rounds (borrowed: keep them alive), ranges as above;
  * creates the zero-filled table from the abstractions' sizes (create_infosets, cfr.rs:176) on `device`. */
@@ -511,7 +515,9 @@ int rs_deal_trainer_attach_comm(rs_deal_trainer *trainer, rs_comm *comm);
  * callers that drive rs_deal_trainer_deal + rs_iterate_phase themselves call it once per batch */
 int rs_deal_trainer_finish_batch(rs_deal_trainer *trainer);
 int rs_deal_trainer_deal(rs_deal_trainer *trainer);             /* only the dealing half of a batch (cards, cluster ids, signs) */
-int rs_deal_trainer_status(rs_deal_trainer *trainer);           /* synchronises; error if a deal could not be sampled / addressed */
+/* synchronises; error if a deal could not be sampled / addressed since the last call.  A trainer that deals ahead (prefetch) has dealt the batch AFTER the last one it trained
+ * as well -- it waits in the staging buffers for the next call -- so the report covers that batch too. */
+int rs_deal_trainer_status(rs_deal_trainer *trainer);
 uint64_t rs_deal_trainer_iterations(const rs_deal_trainer *trainer);   /* t of cfr.rs:200 */
 /* calc_br at the discount ticks (cfr.rs:244-246 runs it before the sweep and prints the two numbers): enable != 0 makes every tick
  * call rs_calc_br first; rs_deal_trainer_last_br returns the latest pair and the iteration count it was taken at (RS_ERR_INVALID

@@ -77,7 +77,7 @@ class SolverParams(C.Structure):
 class DealTrainerParams(C.Structure):
     _fields_ = [("board_mask", C.c_uint64), ("deals_per_batch", C.c_uint32), ("seed", C.c_uint64), ("discount_interval", C.c_uint64),
                 ("discount_cap", C.c_uint64), ("solver", SolverParams), ("world", C.c_uint32), ("rank", C.c_uint32),
-                ("prune_threshold", C.c_uint64), ("prefetch", C.c_int32), ("reserved", C.c_int32)]
+                ("prune_threshold", C.c_uint64), ("prefetch", C.c_int32), ("table_dtype", C.c_int32)]
 
 
 class Profile(C.Structure):

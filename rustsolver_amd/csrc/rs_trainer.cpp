@@ -153,7 +153,11 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
             if (nodes[size_t(i)].kind == RS_NODE_ACTION && nodes[size_t(i)].round_idx >= n_rounds)
                 rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: the tree has more rounds than abstractions were passed");
     }
-    if (rc == RS_OK) rc = rs_create_infosets(tr->tree, n_clusters, n_boards, RS_I32, device, &tr->table);   // cfr.rs:176
+    const int dtype = params->table_dtype;
+    if (rc == RS_OK && dtype != RS_I32 && dtype != RS_F32 && dtype != RS_F16) rc = fail(RS_ERR_INVALID, "rs_deal_trainer_create: table_dtype is RS_I32, RS_F32 or RS_F16");
+    if (rc == RS_OK && dtype != RS_I32 && (params->prune_threshold != UINT64_MAX || tr->world > 1))
+        rc = fail(RS_ERR_UNSUPPORTED, "rs_deal_trainer_create: float tables (extension) take no pruning (prune_threshold = UINT64_MAX: cfr.rs:352 compares i32 regrets) and run on one GPU");
+    if (rc == RS_OK) rc = rs_create_infosets(tr->tree, n_clusters, n_boards, dtype, device, &tr->table);   // cfr.rs:176
     const size_t pitch = round_up(params->deals_per_batch, kLanePad);
     const size_t n_hands[2] = {n_hands_p0, n_hands_p1};
     const uint8_t *hands[2] = {hands_p0, hands_p1};

@@ -658,7 +658,7 @@ class DealTrainer:
 
     def __init__(self, tree, card_abs, hand_ranges, board_mask, deals_per_batch, seed=0, scale=100.0, mode=L.UPD_CLAMP_I64,
                  opp_mode=L.OPP_SAMPLE, discount_interval=MCCFRTrainer.DISCOUNT_INTERVAL, discount_cap=MCCFRTrainer.DISCOUNT_CAP,
-                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0, prune_threshold=10_000_000, forms=None, prefetch=None):
+                 use_graph=False, fuse_subtrees=None, device=0, world=1, rank=0, prune_threshold=10_000_000, forms=None, prefetch=None, dtype=L.I32):
         """prune_threshold: cfr.rs:190 PRUNE_THRESHOLD (None = never prune).  forms: rs_kernel_forms fields by name, as for MCCFRTrainer.  world / rank: data-parallel training on replicated tables (one process per GPU): this rank deals its share of every global
         batch; attach_comm() makes every rank apply the deltas of the union batch."""
         if fuse_subtrees is None:
@@ -669,6 +669,7 @@ class DealTrainer:
         p.world, p.rank = world, rank
         p.prune_threshold = 2**64 - 1 if prune_threshold is None else prune_threshold
         p.discount_interval, p.discount_cap = discount_interval, discount_cap
+        p.table_dtype = dtype   # rs_deal_trainer_params.table_dtype: RS_I32 (the reference), or RS_F32 / RS_F16 (float deal sweeps: prune_threshold=None)
         p.prefetch = L.FORM_DEFAULT if prefetch is None else (L.FORM_ON if prefetch else L.FORM_OFF)   # rs_deal_trainer_params.prefetch: deal the next batch beside this one's sweeps
         p.solver.scale, p.solver.mode, p.solver.chance_mode = scale, mode, L.CHANCE_PASS
         p.solver.use_graph, p.solver.fuse_subtrees = int(use_graph), int(bool(fuse_subtrees))

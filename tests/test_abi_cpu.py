@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "librustsolver_amd.so does not export %s" % n
     assert sorted(L.SYMBOLS) == names, set(L.SYMBOLS) ^ set(names)
-    assert lib.rs_abi_version() == 5
+    assert lib.rs_abi_version() == 6
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -177,21 +177,22 @@ def test_device_deal_sampler_gives_up_where_the_reference_would_spin(table):
         ab.sample_deals(table, 3, 0, 0b11, [[(10, 11)], [(12, 13)]], 64)      # invalid board mask (options.rs:41)
 
 
-def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None, prune_threshold=None, **trainer_kw):
+def load_trainer_pair(options_rs, options_orc, board, ranges, rounds, n_deals, seed, interval, cap, bucket_files=None, fuse=None, prune_threshold=None, odtype=None, scale=100.0,
+                      **trainer_kw):
     mask = ab.card_mask(board) if isinstance(board, str) else board
     n_actions, tree = rs.build_game_tree(options_rs)
     first = bin(mask).count("1") - 3
     card_abs = [ab.CardAbstraction.init(ranges, mask, first + r, None if bucket_files is None else bucket_files[r]) for r in range(rounds)]
     tr = rs.DealTrainer(tree, card_abs, ranges, mask, n_deals, seed=seed, discount_interval=interval, discount_cap=cap, fuse_subtrees=fuse,
-                        prune_threshold=prune_threshold, **trainer_kw)
+                        prune_threshold=prune_threshold, scale=scale, **trainer_kw)
     sizes = [(a.get_size(0), a.get_size(1)) for a in card_abs]
     otree = orc.OracleTree(options_orc)
-    otab = orc.OracleDealTable(otree, sizes)
+    otab = orc.OracleDealTable(otree, sizes) if odtype is None else orc.OracleDealTable(otree, sizes, odtype)
     cidx = {(r, p): np.zeros(n_deals, dtype=np.uint32) for r in range(rounds) for p in (0, 1)}
     sign = np.zeros(n_deals, dtype=np.float32)
     leaves = {d["id"]: (orc.LEAF_SIGN, sign) for d in otree.as_dicts() if d["kind"] == orc.TERMINAL and d["ttype"] != orc.UNCONTESTED}
     prune = np.zeros(n_deals, dtype=np.uint8)   # all zero = every deal unpruned, whatever ctx.prune says
-    osol = orc.OracleDealSolver(otree, otab, leaves, cidx, n_deals, scale=100.0, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed,
+    osol = orc.OracleDealSolver(otree, otab, leaves, cidx, n_deals, scale=scale, mode=orc.UPD_CLAMP_I64, opp_mode=orc.OPP_SAMPLE, base_seed=seed,
                                 prune=True, prune_deal=prune)
     return dict(prune=prune, prune_threshold=prune_threshold, tr=tr, tree=tree, card_abs=card_abs, mask=mask, first=first, otab=otab, osol=osol, cidx=cidx, sign=sign, ranges=ranges,
                 rounds=rounds, n_deals=n_deals, seed=seed, interval=interval, cap=cap, bucket_files=bucket_files, t=0, threshold=interval,
@@ -232,7 +233,7 @@ def compare_trainer_tables(ctx):
     for nd in ctx["tree"].action_nodes():
         r, s = ctx["tr"].infosets.download_node(nd.index)
         ro, so = ctx["otab"].get_node(nd.index)
-        assert (r == ro).all() and (s == so).all(), "table differs from the oracle at node %d" % nd.index
+        assert r.tobytes() == np.ascontiguousarray(ro).tobytes() and s.tobytes() == np.ascontiguousarray(so).tobytes(), "table differs from the oracle at node %d" % nd.index
 
 
 @pytest.mark.parametrize("fuse", [1, 0])
@@ -351,6 +352,33 @@ def test_deal_trainer_deals_and_sorts_ahead(flow, monkeypatch):
                 live_batch_is(cards)
     tr.status()
     compare_trainer_tables(ctx)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_deal_trainer_on_float_tables(dtype):
+    """rs_deal_trainer_params.table_dtype (round 5; BASELINE configs[4], "fp16 regret/strategy tables with fp32 accumulators", on the algorithm the reference runs): the whole
+    device trainer -- dealing, cluster ids, showdowns, the sampled sweeps, the reference's discount ticks -- on a binary16 (or f32) table: f32 per-deal deltas summed in deal
+    order, one rounding per cell and sweep.  Same bits as the oracle chain, batch after batch; pruning is refused."""
+    rng = np.random.Generator(np.random.PCG64(79))
+    mask = ab.card_mask("7h8hQc")
+    allh = ab.random_range(mask)
+    ranges = [allh[rng.permutation(len(allh))[:40]], allh[rng.permutation(len(allh))[:55]]]
+    files = [rng.integers(0, 37, size=1286792, dtype=np.uint32), rng.integers(0, 61, size=13960050, dtype=np.uint32), rng.integers(0, 90, size=123156254, dtype=np.uint32)]
+    dt_g, dt_o = (rs.F16, orc.T_F16) if dtype == "f16" else (rs.F32, orc.T_F32)
+    ctx = load_trainer_pair(rs.three_street_options(), orc.options_three_street(), mask, ranges, 3, 1200, seed=8, interval=2000, cap=10**9, bucket_files=files, odtype=dt_o,
+                            scale=0.5, dtype=dt_g)
+    assert ctx["tr"].infosets.download_node(0)[0].dtype == np.float32
+    for b in range(4):
+        ctx["tr"].train(1 if b else 2)
+        cards = oracle_batch(ctx)
+        if not b:
+            cards = oracle_batch(ctx)
+        assert (ctx["tr"].cards() == cards).all()
+    ctx["tr"].status()
+    compare_trainer_tables(ctx)
+    n_actions, tree = rs.build_game_tree(rs.three_street_options())
+    with pytest.raises(rs.RsError):
+        rs.DealTrainer(tree, ctx["card_abs"], ranges, mask, 64, dtype=dt_g, prune_threshold=10**7)
 
 
 @pytest.mark.parametrize("parts", [True, False])
