@@ -6,6 +6,9 @@ Pure host code (no GPU needed), so that the N > 1 path is testable with gloo on 
   * apply_summed_deltas   the arithmetic between sweep and apply of a data-parallel deal batch: table + allreduce_sum(delta), wrapping i32;
   * replicated_allreduce  the arithmetic of rs_allreduce_replicated: x = snap + allreduce_sum(x - snap),
                           wrapping i32 (order-independent) or f32.
+  * exchange_items        the other half of a data-parallel sweep's exchange (csrc/rs_solver.cpp solver_exchange_deltas): the non-zero deltas of the rounds whose rows
+                          go straight into the table travel as (cell, delta) items -- counts all-gathered, items all-gathered padded to the longest rank's, every rank's
+                          items added (wrapping i32: any order, same bits).
 """
 import numpy as np
 
@@ -44,3 +47,20 @@ def apply_summed_deltas(table, delta, all_reduce_sum):
     """table, delta: int32 arrays (delta = this rank's sweep result); all ranks end with table + sum of all deltas (wrapping)"""
     total = np.asarray(all_reduce_sum(np.ascontiguousarray(delta, dtype=np.int32)), dtype=np.int32)
     return (table.view(np.uint32) + total.view(np.uint32)).view(np.int32)
+
+
+def exchange_items(table, delta, all_gather):
+    """table, delta: int32 arrays of one shape (delta = this rank's sweep result, mostly zero); all_gather(array) -> list of every rank's array (equal shapes), rank order.
+    Returns table + the non-zero deltas of ALL ranks, moved as items the way rs_iterate moves them under a communicator, and the number of item words this rank received."""
+    flat = np.ascontiguousarray(delta, dtype=np.int32).ravel()
+    cells = np.flatnonzero(flat).astype(np.uint32)
+    counts = [int(c[0]) for c in all_gather(np.array([len(cells)], dtype=np.int64))]
+    most = max(counts)
+    mine = np.zeros((most, 2), dtype=np.uint32)                 # the tail beyond a rank's count is sent and never read
+    mine[: len(cells), 0] = cells
+    mine[: len(cells), 1] = flat[cells].view(np.uint32)
+    out = np.ascontiguousarray(table, dtype=np.int32).ravel().view(np.uint32).copy()
+    for r, items in enumerate(all_gather(mine)):
+        items = np.asarray(items, dtype=np.uint32)[: counts[r]]
+        np.add.at(out, items[:, 0].astype(np.int64), items[:, 1])   # wrapping adds
+    return out.view(np.int32).reshape(np.shape(table)), most * 2 * len(counts)

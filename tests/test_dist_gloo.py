@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from rustsolver_amd.dist import apply_summed_deltas, deal_numbers, replicated_allreduce, shard_boards
+from rustsolver_amd.dist import apply_summed_deltas, deal_numbers, exchange_items, replicated_allreduce, shard_boards
 
 WORLD = 2
 C, B_TOTAL = 6, 5
@@ -143,9 +143,10 @@ def _dp_inputs():
     return tree, init, mask, hands
 
 
-def _dp_run(tree, init, mask, hands, rank, world, all_reduce_sum):
-    """the CPU mirror of rs_deal_trainer_train with `world` ranks: deal this rank's numbers, sweep against the replicated table, sum the
-    i32 deltas over the ranks, apply"""
+def _dp_run(tree, init, mask, hands, rank, world, all_reduce_sum, all_gather=None):
+    """the CPU mirror of rs_deal_trainer_train with `world` ranks: deal this rank's numbers, sweep against the replicated table, exchange the
+    i32 deltas of the ranks -- nodes with an even index summed as whole cell ranges (the packed all-reduce), nodes with an odd index as all-gathered
+    (cell, delta) items (the rounds whose rows go straight into the table: rs_solver.cpp solver_exchange_deltas) -- and apply"""
     n = DP_N
     tb = orc.OracleDealTable(tree, DP_SIZES)
     for idx, (R, S) in init.items():
@@ -167,8 +168,11 @@ def _dp_run(tree, init, mask, hands, rank, world, all_reduce_sum):
             sol.iterate(player)                                   # sweep + local apply ...
             for idx in init:                                      # ... turned back into (table, delta), reduced, applied
                 after = tb.get_node(idx)
-                new = [apply_summed_deltas(before[idx][k], (after[k].view(np.uint32) - before[idx][k].view(np.uint32)).view(np.int32), all_reduce_sum)
-                       for k in (0, 1)]
+                deltas = [(after[k].view(np.uint32) - before[idx][k].view(np.uint32)).view(np.int32) for k in (0, 1)]
+                if all_gather is not None and idx % 2:
+                    new = [exchange_items(before[idx][k], deltas[k], all_gather)[0] for k in (0, 1)]
+                else:
+                    new = [apply_summed_deltas(before[idx][k], deltas[k], all_reduce_sum) for k in (0, 1)]
                 tb.set_node(idx, new[0], new[1])
     return {idx: tb.get_node(idx) for idx in init}
 
@@ -182,8 +186,15 @@ def _dp_worker(rank, port, q):
             t = torch.from_numpy(np.ascontiguousarray(a).copy())
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return t.numpy()
+        def allgather(a):
+            a = np.ascontiguousarray(a)
+            as_u32 = a.dtype == np.uint32                      # gloo knows no unsigned 32-bit type: the same bits as int32
+            t = torch.from_numpy((a.view(np.int32) if as_u32 else a).copy())
+            outs = [torch.empty_like(t) for _ in range(WORLD)]
+            dist.all_gather(outs, t)
+            return [o.numpy().view(np.uint32) if as_u32 else o.numpy() for o in outs]
         tree, init, mask, hands = _dp_inputs()
-        q.put((rank, _dp_run(tree, init, mask, hands, rank, WORLD, allreduce)))
+        q.put((rank, _dp_run(tree, init, mask, hands, rank, WORLD, allreduce, allgather)))
     finally:
         dist.destroy_process_group()
 
@@ -205,7 +216,7 @@ def test_world2_data_parallel_deal_batches_equal_the_union_batch():
     tree, init, mask, hands = _dp_inputs()
     DP_N *= WORLD
     try:
-        want = _dp_run(tree, init, mask, hands, 0, 1, lambda a: a)
+        want = _dp_run(tree, init, mask, hands, 0, 1, lambda a: a, lambda a: [a])
     finally:
         DP_N //= WORLD
     for r in range(WORLD):
