@@ -494,7 +494,7 @@ typedef struct rs_deal_trainer_params {
     uint64_t prune_threshold;      /* cfr.rs:190 PRUNE_THRESHOLD (10 000 000): deals numbered beyond it are traversed with prune = true when their
                                       q > 0.05 (cfr.rs:213-221, rs_deals_prune_flags); UINT64_MAX = never.  With a finite threshold the solver runs
                                       in RS_UPD_PRUNE mode with per-deal flags that stay zero (= unpruned, bit for bit) before it */
-    int32_t prefetch;              /* RS_FORM_*: deal the next batch on a second stream while the current one is swept (default: on from 65 536 deals per batch) */
+    int32_t prefetch;              /* RS_FORM_*: deal the next batch on a second stream while the current one is swept (default: on from 65 536 deals per batch for multi-round games, beyond 262 144 for one-round games) */
     int32_t table_dtype;           /* element type of the table the trainer creates: RS_I32 (0: the reference's), or -- extensions -- RS_F32 / RS_F16: float deal sweeps
                                       (rs_solver_create_deals: f32 per-deal deltas summed in deal order, one rounding per cell and sweep); these need prune_threshold =
                                       UINT64_MAX and world <= 1.  (The field was `reserved`, zero, until ABI 5) */

@@ -1,6 +1,6 @@
 // rs_knobs.cpp -- the ONE place where the library reads switches from the environment.
 //
-// A caller chooses kernel forms through the API (rs_kernel_forms in rs_solver_params, rs_table_params, rs_deal_trainer_params.prefetch).  The fifteen variables below
+// A caller chooses kernel forms through the API (rs_kernel_forms in rs_solver_params, rs_table_params, rs_deal_trainer_params.prefetch).  The sixteen variables below
 // exist for the test-suite and the profiling tools: each forces a form that the engine otherwise picks by batch or table size (so that small test inputs meet the forms big
 // inputs get), or switches a facility off that has a fallback (staged rows, helper processes, launch overlap); they are resolved once per solver / table / trainer, at its
 // creation.  Round 4 removed twenty-four more: forms measured as losers went with their code (the whole-deal-loop lane kernels, dense walks on delta rows, wide opponent

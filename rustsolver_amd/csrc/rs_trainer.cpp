@@ -183,7 +183,9 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
     // staged batch in costs more of them (four copies + the flags) than dealing in place (two kernels): no staging up to 256 K deals
     // (round 5: from 64 K deals -- a small batch's sweep now runs on ONE stream, merged launches, so the dealing stream has a hardware queue of its own, and with the records
     // sorted ahead nothing is copied on the table's stream: 64 K deals 0.58 -> 0.56 ms, 128 K 0.81 -> 0.76, 256 K 1.27 -> 1.21; 16 K and 4 K lose 0.01-0.03)
-    const bool prefetch = params->prefetch == RS_FORM_ON || (params->prefetch != RS_FORM_OFF && params->deals_per_batch >= (1u << 16));
+    // A one-round game's sweeps are not ordered: its staged batch is swapped in with copies on the table's stream (four launches against two for dealing in place), which only
+    // pays beyond 256 K deals (the river game as coded at 64 K deals: 0.10 against 0.12 s for 1 024 batches).
+    const bool prefetch = params->prefetch == RS_FORM_ON || (params->prefetch != RS_FORM_OFF && params->deals_per_batch >= (n_rounds > 1 ? (1u << 16) : (1u << 18) + 1u));
     if (rc == RS_OK && prefetch) {
         rc = rs_dmalloc(tr->table, 9 * pitch, reinterpret_cast<void **>(&tr->s_cards));
         if (rc == RS_OK) rc = rs_dmemset(tr->table, tr->s_cards, 0, 9 * pitch);
