@@ -1290,7 +1290,12 @@ hipError_t launch_pack_cells(void *dregrets, void *dssum, const ApplyJob *d_jobs
 }
 hipError_t launch_row_apply(const RowSumJob *d_jobs, int n_jobs, uint32_t max_entries, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((size_t(max_entries) + kBlock - 1) / kBlock, 1), 1024);
+    // max_entries = the batch; a job's list holds a fraction of it (about eight jobs -- a subtree's traverser nodes x two arrays -- share a list, and a round's lists hold at most
+    // about two walks per deal between them).  A grid sized for the whole batch per job was 147 K workgroups for the 574 jobs of a 64 K-deal batch, nearly all of which found
+    // nothing (146 -> 128 us per launch; the rest is the atomics themselves: ~5 M scattered read-modify-writes into 2-5 GB, which two arrays' deltas issued back to back by
+    // one thread -- one visit per 32-byte record instead of two -- did not speed up: they execute at the memory side).  Four times the average list; the loop takes the rest.
+    const size_t lists = std::max<size_t>(1, size_t(n_jobs) / 8), est = std::min<size_t>(max_entries, size_t(max_entries) * 8 / lists + kBlock);
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((est + kBlock - 1) / kBlock, 1), 1024);
     hipLaunchKernelGGL(k_row_apply, dim3(blocks, (unsigned)n_jobs), dim3(kBlock), 0, stream, d_jobs);
     return hipGetLastError();
 }

@@ -241,6 +241,12 @@ int rs_deal_trainer_create(const rs_tree *tree, rs_card_abs *const *card_abs, in
         if (params->prune_threshold != UINT64_MAX) sp.mode |= RS_UPD_PRUNE;   // cfr.rs:352, :379-386, :419-441, per deal through batch.d_prune
         rc = rs_solver_create_deals(tr->table, tr->tree, &batch, leaves.data(), leaves.data(), &sp, &tr->solver);
         if (rc == RS_OK && tr->deal_stream && tr->world == 1) tr->ahead = solver_order_ahead(tr->solver, true, before_sweep, tr);   // false: not an ordered solver
+        if (rc == RS_OK && tr->deal_stream && !tr->ahead && params->prefetch != RS_FORM_ON && params->deals_per_batch <= (1u << 18)) {
+            // dealt ahead from 64 K deals on BECAUSE the records can be sorted ahead with it; sweeps that are not ordered (more last-round clusters than the sort has bins: the
+            // lossless abstractions; a communicator) would swap every staged batch in with eight copies on the table's stream: up to 256 K deals they deal in place
+            (void)hipStreamDestroy(tr->deal_stream);
+            tr->deal_stream = nullptr;
+        }
     }
     if (rc != RS_OK) {
         rs_deal_trainer_destroy(tr);
