@@ -802,6 +802,81 @@ __device__ __forceinline__ void br_own_wave_body(const void *__restrict__ ssum, 
 }
 
 
+// ---- own nodes by groups of run-outs (level plan, RS_BR_MAX) ------------------------------------------------------------------------------------------------------
+// A lossless river abstraction puts four lanes in an info set, each in a run-out of its own (the two orders of turn and river card, the swap of the two suits the flop does
+// not hold): a thread per info set (br_own_body) fetches every 8-byte child value as a cache line of its own and moves nine times its algorithmic bytes (profiles/r05_br.md:
+// 461 GB per call at the HBM roofline).  But the info sets of such a round stay within FEW run-outs: the run-outs fall into components (run-outs that share an info set) of
+// two, four or eight run-outs there.  br_prepare packs components into groups of `cap` run-outs; a workgroup takes one group: the group's rows of a child's values come in
+// whole (9 KB of consecutive doubles per run-out) into LDS, the info sets add up from LDS in br_own_body's order (same sums, same bits) and note the action that leads; each
+// thread keeps the leader's value of the lanes it fetched and writes them out as whole rows.  Each child row is read once, the node's row written once.
+struct BrGroups {
+    const uint32_t *runouts;   // [n_groups][cap]: the group's run-outs (0xffffffff: none)
+    const uint32_t *cstart;    // [n_groups + 1]: the group's info sets, as positions in lstart
+    const uint32_t *lstart;    // [info sets + 1]: an info set's lanes in llane
+    const uint16_t *llane;     // slot * n_hands + hand, in the order of BrSide::d_order (ascending lane)
+    const uint16_t *lane_set;  // [n_groups][cap * n_hands]: the lane's info set within its group (0xffff: none -- the hand holds a card of the run-out, or no run-out in the slot)
+    uint32_t n_groups, cap, n_hands, max_sets;
+};
+constexpr int kBrGroupBlock = 1024;    // one workgroup per CU at eight run-outs of 1 176 hands (75 KB of staged values + 26 KB of sums and leaders): sixteen waves of it
+constexpr int kBrGroupPerThread = 11;  // cap * n_hands <= 11 264 values per row set (eight run-outs of 1 326 hands)
+__global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJob *__restrict__ jobs, BrGroups g, uint32_t n_pad) {
+    extern __shared__ double br_group_lds[];
+    const BrJob j = jobs[blockIdx.y];
+    const uint32_t grp = blockIdx.x, tid = threadIdx.x, GH = g.cap * g.n_hands;
+    double *stage = br_group_lds, *bestv = stage + GH;
+    uint32_t *besta = reinterpret_cast<uint32_t *>(bestv + g.max_sets);
+    uint32_t goff[kBrGroupPerThread];   // the thread's values of a row set: global lane, or none
+    uint32_t setof[kBrGroupPerThread];
+    double outv[kBrGroupPerThread], regs[kBrGroupPerThread];
+#pragma unroll
+    for (int k = 0; k < kBrGroupPerThread; k++) {
+        const uint32_t e = tid + uint32_t(k) * kBrGroupBlock;
+        goff[k] = 0xffffffffu;
+        setof[k] = 0xffffu;
+        outv[k] = 0.0;   // a lane in no info set (its hand holds a card of the run-out) is worth 0
+        if (e < GH) {
+            const uint32_t slot = e / g.n_hands, ro = g.runouts[(size_t)grp * g.cap + slot];
+            if (ro != 0xffffffffu) {
+                goff[k] = ro * g.n_hands + (e - slot * g.n_hands);
+                setof[k] = g.lane_set[(size_t)grp * GH + e];
+            }
+        }
+    }
+    const uint32_t c_lo = g.cstart[grp], c_hi = g.cstart[grp + 1];
+#pragma unroll
+    for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = goff[k] != 0xffffffffu ? j.vch[goff[k]] : 0.0;
+    for (uint32_t a = 0; a < j.n_children; a++) {
+#pragma unroll
+        for (int k = 0; k < kBrGroupPerThread; k++) {
+            const uint32_t e = tid + uint32_t(k) * kBrGroupBlock;
+            if (e < GH) stage[e] = regs[k];
+        }
+        __syncthreads();
+        if (a + 1 < j.n_children) {   // the next child's rows are on their way while this one's info sets add up
+            const double *va = j.vch + (size_t)(a + 1) * n_pad;
+#pragma unroll
+            for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = goff[k] != 0xffffffffu ? va[goff[k]] : 0.0;
+        }
+        for (uint32_t c = c_lo + tid; c < c_hi; c += kBrGroupBlock) {
+            const uint32_t lo = g.lstart[c], hi = g.lstart[c + 1];
+            double acc = 0.0;
+            for (uint32_t i = lo; i < hi; i++) acc += stage[g.llane[i]];   // list order: br_own_body's sum
+            if (a == 0 || bestv[c - c_lo] < acc) {                          // first maximum, strict < (cfr.rs:684-690)
+                bestv[c - c_lo] = acc;
+                besta[c - c_lo] = a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBrGroupPerThread; k++)
+            if (setof[k] != 0xffffu && besta[setof[k]] == a) outv[k] = stage[tid + uint32_t(k) * kBrGroupBlock];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < kBrGroupPerThread; k++)
+        if (goff[k] != 0xffffffffu) j.v[goff[k]] = outv[k];
+}
+
 // ---- the kernels: one node per launch (the depth-first walk), or one JOB per node and grid row (the level plan: all nodes of one tree depth and kind in one launch) -------------
 template <int DT>
 __global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n, uint32_t n_pad,
@@ -874,6 +949,9 @@ struct BrSide {
     uint64_t *d_mask = nullptr;    // [n_hands]
     uint32_t *d_score = nullptr;   // [n]
     uint32_t *d_cid[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_start[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_order[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
+    BrGroups groups[RS_MAX_ROUNDS] = {};   // own nodes by groups of run-outs (k_br_own_grouped_jobs), where the round's info sets stay within a few run-outs each
+    bool grouped[RS_MAX_ROUNDS] = {false, false, false};
+    size_t group_lds[RS_MAX_ROUNDS] = {0, 0, 0};
     double *d_init_q = nullptr;    // this side's lanes as the OPPONENT's initial reach (its share of the deal probability)
     double *d_pw = nullptr;        // this side's lanes as the TRAVERSER's weight
     uint8_t *d_hands = nullptr;    // [n_hands][2]
@@ -964,6 +1042,8 @@ struct BrRun {
         v_out[0] = *root_out;
         q_in[0] = op.d_init_q;
         std::vector<std::vector<BrJob>> down(size_t(max_depth) + 1), up_own(size_t(max_depth) + 1), up_wave(size_t(max_depth) + 1), up_sum(size_t(max_depth) + 1);
+        std::vector<std::vector<BrJob>> up_grp[RS_MAX_ROUNDS];   // own nodes taken by groups of run-outs, per round (the groups are the round's)
+        for (auto &v : up_grp) v.resize(size_t(max_depth) + 1);
         std::vector<BrJob> leaves;
         for (size_t id = 0; id < N; ++id) {   // parents before children: a node's q and v slot are known when it comes up
             const rs_tree_node &n = tree->nodes[id];
@@ -998,7 +1078,8 @@ struct BrRun {
                 j.start = me.d_start[r];
                 j.order = me.d_order[r];
                 j.n_clusters = me.n_clusters[r];
-                (size_t(me.n) >= size_t(me.n_clusters[r]) * 32 ? up_wave : up_own)[size_t(d)].push_back(j);   // many lanes per info set: a wave each
+                if (mode == RS_BR_MAX && me.grouped[r]) up_grp[r][size_t(d)].push_back(j);
+                else (size_t(me.n) >= size_t(me.n_clusters[r]) * 32 ? up_wave : up_own)[size_t(d)].push_back(j);   // many lanes per info set: a wave each
                 for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = q_in[id];
             } else {
                 qch[id] = at;
@@ -1019,10 +1100,11 @@ struct BrRun {
             all.insert(all.end(), v.begin(), v.end());
             return at_;
         };
-        std::vector<size_t> o_down, o_own, o_wave, o_sum;
+        std::vector<size_t> o_down, o_own, o_wave, o_sum, o_grp[RS_MAX_ROUNDS];
         for (int d = 0; d <= max_depth; ++d) {
             o_down.push_back(put(down[size_t(d)]));
             o_own.push_back(put(up_own[size_t(d)]));
+            for (int r = 0; r < RS_MAX_ROUNDS; ++r) o_grp[r].push_back(put(up_grp[r][size_t(d)]));
             o_wave.push_back(put(up_wave[size_t(d)]));
             o_sum.push_back(put(up_sum[size_t(d)]));
         }
@@ -1072,6 +1154,14 @@ struct BrRun {
                 err = hipGetLastError();
                 ++n_launches;
             }
+            for (int r = 0; r < RS_MAX_ROUNDS && err == hipSuccess; ++r)
+                if (const uint32_t nj = uint32_t(up_grp[r][size_t(d)].size())) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_br_own_grouped_jobs), hipFuncAttributeMaxDynamicSharedMemorySize, int(me.group_lds[r]));
+                    hipLaunchKernelGGL(k_br_own_grouped_jobs, dim3(me.groups[r].n_groups, nj), dim3(kBrGroupBlock), me.group_lds[r], t->stream, d_jobs + o_grp[r][size_t(d)],
+                                       me.groups[r], me.n_pad);
+                    err = hipGetLastError();
+                    ++n_launches;
+                }
             if (const uint32_t nj = uint32_t(up_own[size_t(d)].size())) {
                 uint32_t ncl = 0;
                 for (const BrJob &j : up_own[size_t(d)]) ncl = std::max(ncl, j.n_clusters);
@@ -1206,6 +1296,100 @@ namespace rs {
 // Everything of a best-response pass that depends on the GAME only (tree shape, ranges, board, cluster ids) and not on the table's contents: lane scores and masks, the lanes of
 // every info set in ascending order, the rank-order index of the showdowns, the walk's buffers.  A caller that asks again for the same game (the trainer's exploitability
 // ticks) keeps the object and pays for the walk alone.
+// The run-outs fall into components (two run-outs that hold lanes of one info set belong together); where the largest is small, components are packed into groups of
+// `cap` run-outs and the round's own nodes go to k_br_own_grouped_jobs.  Random bucket files tie every run-out to every other: one component, no groups.
+static void build_groups(BrRun &run, BrSide &s, int r, size_t NB, size_t H, const std::vector<uint32_t> &start, const std::vector<uint32_t> &order) {
+    const uint32_t NC = s.n_clusters[r];
+    if (H == 0 || H > size_t(kBrGroupPerThread) * kBrGroupBlock) return;
+    std::vector<uint32_t> parent(NB);
+    for (size_t b = 0; b < NB; ++b) parent[b] = uint32_t(b);
+    auto find = [&](uint32_t b) {
+        while (parent[b] != b) b = parent[b] = parent[parent[b]];
+        return b;
+    };
+    for (uint32_t c = 0; c < NC; ++c) {
+        const uint32_t lo = start[c], hi = start[size_t(c) + 1];
+        if (lo == hi) continue;
+        uint32_t b0 = find(uint32_t(order[lo] / H));
+        for (uint32_t i = lo + 1; i < hi; ++i) {
+            const uint32_t b = find(uint32_t(order[i] / H));
+            if (b == b0) continue;
+            if (b < b0) parent[b0] = b, b0 = b;
+            else parent[b] = b0;
+        }
+    }
+    std::vector<uint32_t> size(NB, 0);
+    uint32_t largest = 0;
+    for (size_t b = 0; b < NB; ++b) largest = std::max(largest, ++size[find(uint32_t(b))]);
+    const uint32_t cap_max = uint32_t(size_t(kBrGroupPerThread) * kBrGroupBlock / H);
+    if (largest > cap_max) return;
+    const uint32_t cap = std::min(cap_max, std::max<uint32_t>(largest, std::max<uint32_t>(1, uint32_t(5400 / H))));
+    // components in the order of their first run-out (the root: the smallest member), packed greedily
+    std::vector<uint32_t> group_of(NB, 0), slot_of(NB, 0), group_root(NB, 0xffffffffu);
+    std::vector<uint32_t> runouts;
+    uint32_t n_groups = 0, used = cap;
+    for (size_t b = 0; b < NB; ++b) {
+        const uint32_t root = find(uint32_t(b));
+        if (group_root[root] == 0xffffffffu) {   // b is the root (roots are the smallest members, and b ascends)
+            if (used + size[root] > cap) {
+                ++n_groups;
+                used = 0;
+                runouts.resize(size_t(n_groups) * cap, 0xffffffffu);
+            }
+            group_root[root] = n_groups - 1;
+            used += size[root];
+        }
+        const uint32_t g = group_root[root];
+        group_of[b] = g;
+        uint32_t slot = 0;
+        while (runouts[size_t(g) * cap + slot] != 0xffffffffu) ++slot;   // members arrive in ascending order; room was reserved when the component's root came up
+        runouts[size_t(g) * cap + slot] = uint32_t(b);
+        slot_of[b] = slot;
+    }
+    std::vector<uint32_t> cstart(size_t(n_groups) + 1, 0);
+    for (uint32_t c = 0; c < NC; ++c)
+        if (start[c] != start[size_t(c) + 1]) cstart[size_t(group_of[order[start[c]] / H]) + 1]++;
+    uint32_t max_sets = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        max_sets = std::max(max_sets, cstart[size_t(g) + 1]);
+        cstart[size_t(g) + 1] += cstart[g];
+    }
+    const size_t lds = (size_t(cap) * H + max_sets) * sizeof(double) + size_t(max_sets) * sizeof(uint32_t);
+    if (lds > size_t(150) << 10) return;
+    const uint32_t n_sets = cstart[n_groups];
+    std::vector<uint32_t> lstart(size_t(n_sets) + 1, 0), at(cstart.begin(), cstart.end() - 1), set_of(NC, 0xffffffffu);
+    for (uint32_t c = 0; c < NC; ++c)   // ascending cluster id within a group
+        if (start[c] != start[size_t(c) + 1]) {
+            const uint32_t k = at[group_of[order[start[c]] / H]]++;
+            set_of[c] = k;
+            lstart[size_t(k) + 1] = start[size_t(c) + 1] - start[c];
+        }
+    for (uint32_t k = 0; k < n_sets; ++k) lstart[size_t(k) + 1] += lstart[k];
+    std::vector<uint16_t> llane(lstart[n_sets]), lane_set(size_t(n_groups) * cap * H, uint16_t(0xffff));
+    for (uint32_t c = 0; c < NC; ++c) {
+        if (set_of[c] == 0xffffffffu) continue;
+        uint32_t o = lstart[set_of[c]];
+        const uint32_t grp = group_of[order[start[c]] / H];
+        for (uint32_t i = start[c]; i < start[size_t(c) + 1]; ++i) {
+            const uint32_t b = uint32_t(order[i] / H), local = uint32_t(slot_of[b] * H + (order[i] - b * H));
+            llane[o++] = uint16_t(local);
+            lane_set[size_t(grp) * cap * H + local] = uint16_t(set_of[c] - cstart[grp]);
+        }
+    }
+    BrGroups &g = s.groups[r];
+    g.runouts = run.upload(runouts);
+    g.cstart = run.upload(cstart);
+    g.lstart = run.upload(lstart);
+    g.llane = run.upload(llane);
+    g.lane_set = run.upload(lane_set);
+    g.n_groups = n_groups;
+    g.cap = cap;
+    g.n_hands = uint32_t(H);
+    g.max_sets = max_sets;
+    s.group_lds[r] = lds;
+    s.grouped[r] = n_groups > 0;
+}
+
 int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
                size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, bool sorted, BrRun **prepared) {
     if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !prepared) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
@@ -1317,6 +1501,7 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
             s.d_cid[r] = run.upload(cv);
             s.d_start[r] = run.upload(start);
             s.d_order[r] = run.upload(order);
+            if (size_t(s.n) < size_t(NC) * 32) build_groups(run, s, r, NB, n_hands[p], start, order);   // (rounds of many lanes per info set go a wave per info set)
         }
     }
     if (sorted)   // the node-independent half of the rank-order showdowns: once per call

@@ -216,7 +216,7 @@ struct rs_solver {
     uint32_t *d_items = nullptr;        // [3 * item_cap] this rank's (job, row, cluster, delta) items of the rounds whose rows go straight into the table
     uint32_t *d_items_all = nullptr;    // [world][3 * item_cap]
     uint32_t *d_item_count = nullptr;   // [1 + world]: this rank's cursor, then every rank's count
-    uint32_t item_cap = 0;
+    uint32_t item_cap = 0, items_world = 0;   // items_world: ranks d_items_all and d_item_count were sized for
     uint64_t dp_bytes_total = 0, dp_sweeps = 0;
     uint64_t dp_bytes_last = 0;         // bytes this rank handed to the collectives in its last sweep (all-reduce buffer + every rank's items)
     int (*before_sweep)(void *ctx, int traverser) = nullptr;   // ... and is asked in front of every sweep whether the records are the live batch's (rs_iterate, rs_iterate_phase 0)

@@ -1200,12 +1200,13 @@ static int solver_exchange_deltas(rs_solver *s, int p) {
         (void)hipFree(s->d_items);
         (void)hipFree(s->d_items_all);
         s->d_items = s->d_items_all = nullptr;
-        s->other_bytes -= size_t(s->item_cap) * 12 * (size_t(world) + 1);
+        const size_t sized = std::max<size_t>(size_t(world), s->items_world);
+        s->other_bytes -= size_t(s->item_cap) * 12 * (sized + 1);
         s->item_cap = uint32_t(std::min<uint64_t>(uint64_t(most) + most / 8 + 1024, 0xfffffff0ull / 3));
         if (most > s->item_cap) return fail(RS_ERR_OOM, "deal delta items: more than 2^32 / 3 items in one sweep");
         RS_HIP(hipMalloc((void **)&s->d_items, size_t(s->item_cap) * 12), "deal delta items");
-        RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * size_t(world)), "deal delta items");
-        s->other_bytes += size_t(s->item_cap) * 12 * (size_t(world) + 1);
+        RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * sized), "deal delta items");
+        s->other_bytes += size_t(s->item_cap) * 12 * (sized + 1);
         RS_HIP(hipMemsetAsync(s->d_item_count, 0, sizeof(uint32_t), t->stream), "deal delta items");
         for (const Launch &L : plan.launches)
             if (L.kind == L_ROWSUM && L.n_actions)
@@ -1284,12 +1285,21 @@ int rs_solver_attach_comm(rs_solver *s, rs_comm *comm) {
         for (int p = 0; p < 2; ++p)
             for (const Launch &L : s->plan[p].launches) direct = direct || (L.kind == L_ROWSUM && L.n_actions);
         const size_t world = size_t(comm_world(comm));
+        if (direct && s->items_world && world > s->items_world) {   // a communicator of more ranks than the buffers were sized for: again, bigger
+            RS_HIP(hipStreamSynchronize(t->stream), "rs_solver_attach_comm");
+            (void)hipFree(s->d_item_count);
+            (void)hipFree(s->d_items);
+            (void)hipFree(s->d_items_all);
+            s->other_bytes -= size_t(s->item_cap) * 12 * (size_t(s->items_world) + 1);
+            s->d_item_count = s->d_items = s->d_items_all = nullptr;
+        }
         if (direct && !s->d_item_count) RS_HIP(hipMalloc((void **)&s->d_item_count, (world + 1) * sizeof(uint32_t) + 256), "rs_solver_attach_comm: item counts");
+        if (direct) s->items_world = uint32_t(std::max<size_t>(world, s->items_world));
         if (direct && !s->d_items) {
             s->item_cap = uint32_t(std::min<uint64_t>(uint64_t(s->deals.n_deals) * 16 + 4096, 0xfffffff0ull / 3));   // grown when a sweep writes more (solver_exchange_deltas)
             RS_HIP(hipMalloc((void **)&s->d_items, size_t(s->item_cap) * 12), "rs_solver_attach_comm: delta items");
-            RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * world), "rs_solver_attach_comm: delta items");
-            s->other_bytes += size_t(s->item_cap) * 12 * (world + 1);
+            RS_HIP(hipMalloc((void **)&s->d_items_all, size_t(s->item_cap) * 12 * size_t(s->items_world)), "rs_solver_attach_comm: delta items");
+            s->other_bytes += size_t(s->item_cap) * 12 * (size_t(s->items_world) + 1);
         }
     }
     s->comm = comm;

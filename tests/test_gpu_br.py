@@ -168,7 +168,7 @@ def test_trainer_ticks_run_calc_br_and_exploitability_falls():
 
 # ---- best response over multi-round trees (rs_best_response_rounds; oracle: best_response.c orc_best_response_rounds) ------------------------------
 
-def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, sparse=0.15):
+def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, sparse=0.15, tied=0):
     K = 5 - len(board0)
     free = [c for c in range(52) if c not in board0]
     combos = np.array([(a, b) for i, a in enumerate(free) for b in free[i + 1:]], dtype=np.uint8)
@@ -176,6 +176,14 @@ def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, spars
     D = 52 - len(board0)
     prefixes = [1, D, D * (D - 1)][: K + 1]
     cids = [[rng.integers(0, n_clusters[r], size=(prefixes[r], len(h[p]))).astype(np.uint32) for p in (0, 1)] for r in range(K + 1)]
+    if tied:
+        # last-round info sets that stay within `tied` run-outs each (what a lossless abstraction gives: the two orders of turn and river card, suit swaps): the run-outs
+        # fall into small components and the level plan takes the round's own nodes by groups of run-outs (k_br_own_grouped_jobs)
+        ro = orc.br_runouts(board0)
+        pair = {}
+        pid = np.array([pair.setdefault(tuple(sorted(int(c) for c in row[len(board0):])), len(pair)) for row in ro], dtype=np.uint32) // (tied // 2)
+        assert len(ro) == prefixes[K] and n_clusters[K] >= (int(pid.max()) + 1) * max(n0, n1)
+        cids[K] = [(pid[:, None] * len(h[p]) + np.arange(len(h[p]), dtype=np.uint32)[None, :]).astype(np.uint32) for p in (0, 1)]
     n_actions, tree = rs.build_game_tree(rs.Options(n_board_cards=len(board0), bet_sizes=bets, raise_sizes=raises))
     sizes = [(n_clusters[r], n_clusters[r]) for r in range(K + 1)]
     table = rs.create_infosets(n_actions, tree, sizes, [1] * (K + 1))
@@ -190,10 +198,15 @@ def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, spars
     ([9, 13, 51, 4], 200, 150, ((0.5,), (1.0,)), ((), ()), [40, 300]),
     ([9, 13, 51], 24, 20, ((0.5,), (0.5,), (1.0,)), ((), (), ()), [4, 6, 8]),                # flop start, 2 352 ordered run-outs
     ([9, 13, 51, 4, 47], 90, 70, ((0.5, 1.0),), ((3.0,),), [11]),                          # the full board: one run-out, the single-round case through the same code
+    ([9, 13, 51], 24, 20, ((0.5,), (0.5,), (1.0,)), ((), (), ()), [4, 6, -2]),               # river info sets of two lanes (the two orders of turn and river card): groups of run-outs
+    ([9, 13, 51], 30, 33, ((0.5,), (0.5,), (0.5, 1.0)), ((), (), ()), [5, 7, -4]),           # ... of four lanes in four run-outs
 ])
 def test_multi_round_best_response_equals_oracle_bit_for_bit(board0, n0, n1, bets, raises, n_clusters):
     rng = np.random.Generator(np.random.PCG64(n0 * 3 + n1 + len(board0)))
-    tree, table, otab, h, cids = multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters)
+    tied = -n_clusters[-1] if n_clusters[-1] < 0 else 0
+    if tied:
+        n_clusters = n_clusters[:-1] + [1176 * 2 // tied * max(n0, n1)]
+    tree, table, otab, h, cids = multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, tied=tied)
     assert len(orc.br_runouts(board0)) == {3: 2352, 4: 48, 5: 1}[len(board0)]
     import ctypes as C
     nb = L.load().rs_br_runouts(np.array(board0, dtype=np.uint8).ctypes.data_as(C.c_void_p), len(board0), None)
@@ -245,6 +258,16 @@ def test_sorted_showdowns_full_ranges_from_a_flop():
     dt = (time.perf_counter() - t0) / 2
     assert abs(ev.sum()) < 1e-9 and (br >= ev - 1e-9).all() and br.sum() / 2 > 0
     assert dt < 30.0, "one full-range best response took %.2f s (a sanity bound only: bench.py times it, solve_3s_full_br_s)" % dt
+    # the river's own nodes went by groups of four run-outs (the lossless river abstraction: 4.3 lanes per info set, each in a run-out of its own) and the leaves through the
+    # leaf loop: the depth-first walk -- a thread per info set, a launch per leaf -- gives the same bits
+    assert tr.br_launches() > 0
+    os.environ["RS_BR_DEPTH_FIRST"] = "1"
+    try:
+        tr.br_release()
+        assert tr.best_response(L.BR_MAX | L.BR_SORTED).tobytes() == br.tobytes()
+        assert tr.br_launches() == -1
+    finally:
+        del os.environ["RS_BR_DEPTH_FIRST"]
     tr.destroy()
     # turn start, full ranges (1 128 combos, 48 run-outs): sorted against the pair loop
     mask4 = ab.card_mask("7h8hQc2d")
