@@ -596,6 +596,8 @@ struct BrJob {
     uint32_t n_clusters, n_children;
     int uncontested, pad_;
     double value;
+    const uint32_t *tord, *perm;   // own node by columns (k_br_own_cols_jobs): [kmax][n_sets] the k-th lane of the i-th info set, and which cluster that info set is
+    uint32_t n_sets, kmax;
 };
 // The level plan's form (round 5): ONE workgroup per run-out takes every leaf of the tree in turn.  What the leaves share -- the run-out's rank order, the holders of every
 // card, where each of the traverser's hands stands in that order, its weight -- is read ONCE (25 KB per run-out and side; the one-leaf kernel above read it again at each of the
@@ -877,6 +879,57 @@ __global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJ
         if (goff[k] != 0xffffffffu) j.v[goff[k]] = outv[k];
 }
 
+// ---- own nodes by columns (level plan) ---------------------------------------------------------------------------------------------------------------------------
+// A lossless turn abstraction puts ~92 lanes in an info set: one hand under one turn card, every river card (and the suit-swapped twin).  A wave per info set
+// (br_own_wave_body) reads 64 lanes of 64 run-outs per step: every 8-byte value a cache line of its own, eight times the algorithmic bytes (profiles/r05_br.md).  Here a THREAD
+// takes an info set, and the info sets are ordered by their first lane: neighbouring threads hold neighbouring hands under the same turn card, so the k-th lanes of a wave's
+// info sets lie side by side in one run-out's row (where a hand holds a river card its list is one entry ahead of its neighbours': two rows).  The lane lists come
+// transposed ([k][info set]) so that the indices load coalesced too.  The sums run down each list in order: br_own_body's, and the wave kernel's, bits.
+template <int DT>
+__global__ __launch_bounds__(kBrBlock) void k_br_own_cols_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n_pad, int mode) {
+    const BrJob j = jobs[blockIdx.y];
+    for (uint32_t i = j.start[j.n_clusters] + blockIdx.x * kBrBlock + threadIdx.x; i < j.start[j.n_clusters + 1]; i += gridDim.x * kBrBlock) j.v[j.order[i]] = 0.0;
+    const uint32_t i = blockIdx.x * kBrBlock + threadIdx.x;
+    if (i >= j.n_sets) return;
+    const uint32_t *__restrict__ col = j.tord + i;
+    const uint32_t A = j.row.n_actions;
+    if (mode == RS_BR_MAX) {
+        double s_best = 0.0;
+        uint32_t best = 0;
+        for (uint32_t a = 0; a < A; a++) {
+            const double *va = j.vch + (size_t)a * n_pad;
+            double acc = 0.0;
+            for (uint32_t k = 0; k < j.kmax; k += 8) {   // eight gathers in flight, the additions one after the other in list order
+                uint32_t idx[8];
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) idx[q] = k + q < j.kmax ? col[(size_t)(k + q) * j.n_sets] : 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < 8; q++) t[q] = idx[q] != 0xffffffffu ? va[idx[q]] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (idx[q] != 0xffffffffu) acc += t[q];
+            }
+            if (a == 0 || s_best < acc) s_best = acc, best = a;   // first maximum, strict < (cfr.rs:684-690)
+        }
+        const double *vb = j.vch + (size_t)best * n_pad;
+        for (uint32_t k = 0; k < j.kmax; k++) {
+            const uint32_t idx = col[(size_t)k * j.n_sets];
+            if (idx != 0xffffffffu) j.v[idx] = vb[idx];
+        }
+    } else {
+        float sig[RS_MAX_ACTIONS];
+        final_sigma<DT>(ssum, j.row.cell_off, j.row.pitch, A, j.perm[i], sig);
+        for (uint32_t k = 0; k < j.kmax; k++) {
+            const uint32_t h = col[(size_t)k * j.n_sets];
+            if (h == 0xffffffffu) continue;
+            double acc = 0.0;
+            for (uint32_t a = 0; a < A; a++) acc += (double)sig[a] * j.vch[(size_t)a * n_pad + h];
+            j.v[h] = acc;
+        }
+    }
+}
+
 // ---- the kernels: one node per launch (the depth-first walk), or one JOB per node and grid row (the level plan: all nodes of one tree depth and kind in one launch) -------------
 template <int DT>
 __global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restrict__ ssum, BrNodeRow row, const uint32_t *__restrict__ cid, uint32_t n, uint32_t n_pad,
@@ -951,6 +1004,8 @@ struct BrSide {
     uint32_t *d_cid[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_start[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_order[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};
     BrGroups groups[RS_MAX_ROUNDS] = {};   // own nodes by groups of run-outs (k_br_own_grouped_jobs), where the round's info sets stay within a few run-outs each
     bool grouped[RS_MAX_ROUNDS] = {false, false, false};
+    uint32_t *d_tord[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr}, *d_perm[RS_MAX_ROUNDS] = {nullptr, nullptr, nullptr};   // own nodes by columns (k_br_own_cols_jobs)
+    uint32_t n_sets[RS_MAX_ROUNDS] = {0, 0, 0}, kmax[RS_MAX_ROUNDS] = {0, 0, 0};
     size_t group_lds[RS_MAX_ROUNDS] = {0, 0, 0};
     double *d_init_q = nullptr;    // this side's lanes as the OPPONENT's initial reach (its share of the deal probability)
     double *d_pw = nullptr;        // this side's lanes as the TRAVERSER's weight
@@ -1042,6 +1097,7 @@ struct BrRun {
         v_out[0] = *root_out;
         q_in[0] = op.d_init_q;
         std::vector<std::vector<BrJob>> down(size_t(max_depth) + 1), up_own(size_t(max_depth) + 1), up_wave(size_t(max_depth) + 1), up_sum(size_t(max_depth) + 1);
+        std::vector<std::vector<BrJob>> up_cols(size_t(max_depth) + 1);   // own nodes by columns
         std::vector<std::vector<BrJob>> up_grp[RS_MAX_ROUNDS];   // own nodes taken by groups of run-outs, per round (the groups are the round's)
         for (auto &v : up_grp) v.resize(size_t(max_depth) + 1);
         std::vector<BrJob> leaves;
@@ -1079,6 +1135,13 @@ struct BrRun {
                 j.order = me.d_order[r];
                 j.n_clusters = me.n_clusters[r];
                 if (mode == RS_BR_MAX && me.grouped[r]) up_grp[r][size_t(d)].push_back(j);
+                else if (me.d_tord[r]) {
+                    j.tord = me.d_tord[r];
+                    j.perm = me.d_perm[r];
+                    j.n_sets = me.n_sets[r];
+                    j.kmax = me.kmax[r];
+                    up_cols[size_t(d)].push_back(j);
+                }
                 else (size_t(me.n) >= size_t(me.n_clusters[r]) * 32 ? up_wave : up_own)[size_t(d)].push_back(j);   // many lanes per info set: a wave each
                 for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = q_in[id];
             } else {
@@ -1100,9 +1163,10 @@ struct BrRun {
             all.insert(all.end(), v.begin(), v.end());
             return at_;
         };
-        std::vector<size_t> o_down, o_own, o_wave, o_sum, o_grp[RS_MAX_ROUNDS];
+        std::vector<size_t> o_down, o_own, o_wave, o_sum, o_cols, o_grp[RS_MAX_ROUNDS];
         for (int d = 0; d <= max_depth; ++d) {
             o_down.push_back(put(down[size_t(d)]));
+            o_cols.push_back(put(up_cols[size_t(d)]));
             o_own.push_back(put(up_own[size_t(d)]));
             for (int r = 0; r < RS_MAX_ROUNDS; ++r) o_grp[r].push_back(put(up_grp[r][size_t(d)]));
             o_wave.push_back(put(up_wave[size_t(d)]));
@@ -1151,6 +1215,15 @@ struct BrRun {
 #define RS_OWNWJ(DT_) hipLaunchKernelGGL((k_br_own_wave_jobs<DT_>), dim3(blocks, nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_wave[size_t(d)], me.n_pad, mode)
                 RS_BR_DT(t->dtype, RS_OWNWJ);
 #undef RS_OWNWJ
+                err = hipGetLastError();
+                ++n_launches;
+            }
+            if (const uint32_t nj = uint32_t(up_cols[size_t(d)].size())) {
+                uint32_t ns = 0;
+                for (const BrJob &j : up_cols[size_t(d)]) ns = std::max(ns, j.n_sets);
+#define RS_OWNC(DT_) hipLaunchKernelGGL((k_br_own_cols_jobs<DT_>), dim3(grid1(ns), nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_cols[size_t(d)], me.n_pad, mode)
+                RS_BR_DT(t->dtype, RS_OWNC);
+#undef RS_OWNC
                 err = hipGetLastError();
                 ++n_launches;
             }
@@ -1390,6 +1463,32 @@ static void build_groups(BrRun &run, BrSide &s, int r, size_t NB, size_t H, cons
     s.grouped[r] = n_groups > 0;
 }
 
+// Own nodes by columns (k_br_own_cols_jobs): the info sets ordered by their first lane, their lane lists transposed.  Taken where neighbours in that order mostly hold
+// neighbouring lanes (a lossless abstraction: the same cards under the next hand) and the lists are of a length a single thread walks (32 .. 2 048 lanes per info set).
+static void build_columns(BrRun &run, BrSide &s, int r, const std::vector<uint32_t> &start, const std::vector<uint32_t> &order) {
+    const uint32_t NC = s.n_clusters[r];
+    std::vector<uint32_t> perm;
+    uint32_t kmax = 0;
+    for (uint32_t c = 0; c < NC; ++c)
+        if (start[c] != start[size_t(c) + 1]) {
+            perm.push_back(c);
+            kmax = std::max(kmax, start[size_t(c) + 1] - start[c]);
+        }
+    if (perm.size() < 2 || kmax > 2048 || size_t(kmax) * perm.size() > (size_t(1) << 27)) return;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return order[start[a]] < order[start[b]]; });
+    size_t side_by_side = 0;
+    for (size_t i = 0; i + 1 < perm.size(); ++i) side_by_side += order[start[perm[i + 1]]] == order[start[perm[i]]] + 1;
+    if (side_by_side * 2 < perm.size()) return;
+    const size_t n_sets = perm.size();
+    std::vector<uint32_t> tord(size_t(kmax) * n_sets, 0xffffffffu);
+    for (size_t i = 0; i < n_sets; ++i)
+        for (uint32_t k = 0, lo = start[perm[i]], n = start[size_t(perm[i]) + 1] - lo; k < n; ++k) tord[size_t(k) * n_sets + i] = order[lo + k];
+    s.d_tord[r] = run.upload(tord);
+    s.d_perm[r] = run.upload(perm);
+    s.n_sets[r] = uint32_t(n_sets);
+    s.kmax[r] = kmax;
+}
+
 int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_board0, const uint8_t *hands_p0, size_t n_hands_p0, const uint8_t *hands_p1,
                size_t n_hands_p1, const uint32_t *const *cluster, int n_rounds, bool sorted, BrRun **prepared) {
     if (!t || !tree || !board0 || !hands_p0 || !hands_p1 || !cluster || !prepared) return fail(RS_ERR_INVALID, "rs_best_response: NULL argument");
@@ -1501,7 +1600,8 @@ int br_prepare(rs_table *t, const rs_tree *tree, const uint8_t *board0, int n_bo
             s.d_cid[r] = run.upload(cv);
             s.d_start[r] = run.upload(start);
             s.d_order[r] = run.upload(order);
-            if (size_t(s.n) < size_t(NC) * 32) build_groups(run, s, r, NB, n_hands[p], start, order);   // (rounds of many lanes per info set go a wave per info set)
+            if (size_t(s.n) < size_t(NC) * 32) build_groups(run, s, r, NB, n_hands[p], start, order);
+            else build_columns(run, s, r, start, order);   // (what neither takes goes a thread per info set, or a wave where the info sets hold many lanes)
         }
     }
     if (sorted)   // the node-independent half of the rank-order showdowns: once per call

@@ -184,6 +184,9 @@ def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, spars
         pid = np.array([pair.setdefault(tuple(sorted(int(c) for c in row[len(board0):])), len(pair)) for row in ro], dtype=np.uint32) // (tied // 2)
         assert len(ro) == prefixes[K] and n_clusters[K] >= (int(pid.max()) + 1) * max(n0, n1)
         cids[K] = [(pid[:, None] * len(h[p]) + np.arange(len(h[p]), dtype=np.uint32)[None, :]).astype(np.uint32) for p in (0, 1)]
+        if K == 2:   # and turn info sets of one hand under one turn card (47 or 48 lanes, the first ones side by side): own nodes by columns (k_br_own_cols_jobs)
+            assert n_clusters[1] >= D * max(n0, n1)
+            cids[1] = [(np.arange(D, dtype=np.uint32)[:, None] * len(h[p]) + np.arange(len(h[p]), dtype=np.uint32)[None, :]).astype(np.uint32) for p in (0, 1)]
     n_actions, tree = rs.build_game_tree(rs.Options(n_board_cards=len(board0), bet_sizes=bets, raise_sizes=raises))
     sizes = [(n_clusters[r], n_clusters[r]) for r in range(K + 1)]
     table = rs.create_infosets(n_actions, tree, sizes, [1] * (K + 1))
@@ -205,7 +208,7 @@ def test_multi_round_best_response_equals_oracle_bit_for_bit(board0, n0, n1, bet
     rng = np.random.Generator(np.random.PCG64(n0 * 3 + n1 + len(board0)))
     tied = -n_clusters[-1] if n_clusters[-1] < 0 else 0
     if tied:
-        n_clusters = n_clusters[:-1] + [1176 * 2 // tied * max(n0, n1)]
+        n_clusters = [n_clusters[0], 49 * max(n0, n1), 1176 * 2 // tied * max(n0, n1)]
     tree, table, otab, h, cids = multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, tied=tied)
     assert len(orc.br_runouts(board0)) == {3: 2352, 4: 48, 5: 1}[len(board0)]
     import ctypes as C
