@@ -10,6 +10,7 @@
 //    ranges of a single-round game on a full board -- the configuration the reference ships (options::default_flop()).  Reach and
 //    value vectors live on the device as f64; every sum runs in a fixed order, so the CPU oracle reproduces the result bit for bit.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <memory>
@@ -817,6 +818,7 @@ struct BrGroups {
     const uint32_t *lstart;    // [info sets + 1]: an info set's lanes in llane
     const uint16_t *llane;     // slot * n_hands + hand, in the order of BrSide::d_order (ascending lane)
     const uint16_t *lane_set;  // [n_groups][cap * n_hands]: the lane's info set within its group (0xffff: none -- the hand holds a card of the run-out, or no run-out in the slot)
+    const uint32_t *set_cluster;   // [info sets]: the cluster id (k_br_opp_reach_grouped_jobs looks the strategy-sum rows up once per info set)
     uint32_t n_groups, cap, n_hands, max_sets;
 };
 constexpr int kBrGroupBlock = 1024;    // one workgroup per CU at eight run-outs of 1 176 hands (75 KB of staged values + 26 KB of sums and leaders): sixteen waves of it
@@ -879,6 +881,34 @@ __global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJ
         if (goff[k] != 0xffffffffu) j.v[goff[k]] = outv[k];
 }
 
+// The opponent's reach through the same groups: sigma_bar of an info set is computed ONCE (a lane-parallel kernel gathers the strategy-sum rows for each of its 4.3 lanes)
+// into LDS; the group's lanes then stream through: q in, A products out, whole rows.  Lanes in no info set take cluster 0's strategy, as br_opp_reach_body has it (their
+// reach is never looked at: the leaves skip hands that hold a card of the run-out).
+template <int DT>
+__global__ __launch_bounds__(kBrGroupBlock) void k_br_opp_reach_grouped_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, BrGroups g, uint32_t n_pad) {
+    extern __shared__ double br_group_lds[];
+    float *sg = reinterpret_cast<float *>(br_group_lds);   // [A][max_sets + 1]
+    const BrJob j = jobs[blockIdx.y];
+    const uint32_t grp = blockIdx.x, tid = threadIdx.x, GH = g.cap * g.n_hands, A = j.row.n_actions, pitch = g.max_sets + 1;
+    const uint32_t c_lo = g.cstart[grp], n_sets = g.cstart[grp + 1] - c_lo;
+    for (uint32_t k = tid; k <= n_sets; k += kBrGroupBlock) {
+        float sig[RS_MAX_ACTIONS];
+        final_sigma<DT>(ssum, j.row.cell_off, j.row.pitch, A, k < n_sets ? g.set_cluster[c_lo + k] : 0u, sig);
+        const uint32_t at = k < n_sets ? k : g.max_sets;
+        for (uint32_t a = 0; a < A; a++) sg[a * pitch + at] = sig[a];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t e = tid; e < GH; e += kBrGroupBlock) {
+        const uint32_t slot = e / g.n_hands, ro = g.runouts[(size_t)grp * g.cap + slot];
+        if (ro == 0xffffffffu) continue;
+        const uint32_t h = ro * g.n_hands + (e - slot * g.n_hands), set = g.lane_set[(size_t)grp * GH + e];
+        const uint32_t at = set != 0xffffu ? set : g.max_sets;
+        const double qh = j.q[h];
+        for (uint32_t a = 0; a < A; a++) j.q_out[(size_t)a * n_pad + h] = qh * (double)sg[a * pitch + at];
+    }
+}
+
 // ---- own nodes by columns (level plan) ---------------------------------------------------------------------------------------------------------------------------
 // A lossless turn abstraction puts ~92 lanes in an info set: one hand under one turn card, every river card (and the suit-swapped twin).  A wave per info set
 // (br_own_wave_body) reads 64 lanes of 64 run-outs per step: every 8-byte value a cache line of its own, eight times the algorithmic bytes (profiles/r05_br.md).  Here a THREAD
@@ -936,10 +966,21 @@ __global__ __launch_bounds__(kBrBlock) void k_br_opp_reach(const void *__restric
                                                            const double *__restrict__ q, double *__restrict__ q_out) {
     br_opp_reach_body<DT>(ssum, row, cid, n, n_pad, q, q_out);
 }
+// (level plan) The strategy-sum rows are gathered by cluster id, and a lossless abstraction numbers its clusters hand by hand: workgroups go round the eight XCDs in turn, so
+// workgroup x takes hands of slice x % 8 only (every run-out of them) -- an XCD's L2 then sees an eighth (with the suit-swapped twins: a quarter) of the node's rows instead of
+// all of them (the river's 7.7 MB per node against 4 MB of L2: 250 MB fetched per node, profiles/r05_br.md).  gridDim.x = 8 * ceil(run-outs * ceil(n_hands / 8) / kBrBlock).
 template <int DT>
-__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n, uint32_t n_pad) {
+__global__ __launch_bounds__(kBrBlock) void k_br_opp_reach_jobs(const void *__restrict__ ssum, const BrJob *__restrict__ jobs, uint32_t n, uint32_t n_pad, uint32_t n_hands) {
     const BrJob j = jobs[blockIdx.y];
-    br_opp_reach_body<DT>(ssum, j.row, j.cid, n, n_pad, j.q, j.q_out);
+    const uint32_t xcd = blockIdx.x & 7u, w = blockIdx.x >> 3, per = (n_hands + 7u) / 8u, lo = xcd * per;
+    if (lo >= n_hands) return;
+    const uint32_t hs = min(per, n_hands - lo), idx = w * kBrBlock + threadIdx.x, b = idx / hs;
+    const uint32_t h = b * n_hands + lo + (idx - b * hs);
+    if (h >= n || b >= n / n_hands) return;
+    float sig[RS_MAX_ACTIONS];
+    final_sigma<DT>(ssum, j.row.cell_off, j.row.pitch, j.row.n_actions, j.cid[h], sig);
+    const double qh = j.q[h];
+    for (uint32_t a = 0; a < j.row.n_actions; a++) j.q_out[(size_t)a * n_pad + h] = qh * (double)sig[a];
 }
 __global__ __launch_bounds__(kBrBlock) void k_br_sum(const double *__restrict__ vch, uint32_t n_actions, uint32_t n, uint32_t n_pad, double *__restrict__ v) {
     br_sum_body(vch, n_actions, n, n_pad, v);
@@ -1098,8 +1139,9 @@ struct BrRun {
         q_in[0] = op.d_init_q;
         std::vector<std::vector<BrJob>> down(size_t(max_depth) + 1), up_own(size_t(max_depth) + 1), up_wave(size_t(max_depth) + 1), up_sum(size_t(max_depth) + 1);
         std::vector<std::vector<BrJob>> up_cols(size_t(max_depth) + 1);   // own nodes by columns
-        std::vector<std::vector<BrJob>> up_grp[RS_MAX_ROUNDS];   // own nodes taken by groups of run-outs, per round (the groups are the round's)
+        std::vector<std::vector<BrJob>> up_grp[RS_MAX_ROUNDS], down_grp[RS_MAX_ROUNDS];   // own / opponent nodes taken by groups of run-outs, per round (the groups are the round's)
         for (auto &v : up_grp) v.resize(size_t(max_depth) + 1);
+        for (auto &v : down_grp) v.resize(size_t(max_depth) + 1);
         std::vector<BrJob> leaves;
         for (size_t id = 0; id < N; ++id) {   // parents before children: a node's q and v slot are known when it comes up
             const rs_tree_node &n = tree->nodes[id];
@@ -1150,7 +1192,7 @@ struct BrRun {
                 j.cid = op.d_cid[r];
                 j.q = q_in[id];
                 j.q_out = qch[id];
-                down[size_t(d)].push_back(j);
+                (op.grouped[r] ? down_grp[r] : down)[size_t(d)].push_back(j);
                 up_sum[size_t(d)].push_back(j);
                 for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = qch[id] + size_t(a) * op.n_pad;
             }
@@ -1163,12 +1205,13 @@ struct BrRun {
             all.insert(all.end(), v.begin(), v.end());
             return at_;
         };
-        std::vector<size_t> o_down, o_own, o_wave, o_sum, o_cols, o_grp[RS_MAX_ROUNDS];
+        std::vector<size_t> o_down, o_own, o_wave, o_sum, o_cols, o_grp[RS_MAX_ROUNDS], o_dgrp[RS_MAX_ROUNDS];
         for (int d = 0; d <= max_depth; ++d) {
             o_down.push_back(put(down[size_t(d)]));
             o_cols.push_back(put(up_cols[size_t(d)]));
             o_own.push_back(put(up_own[size_t(d)]));
             for (int r = 0; r < RS_MAX_ROUNDS; ++r) o_grp[r].push_back(put(up_grp[r][size_t(d)]));
+            for (int r = 0; r < RS_MAX_ROUNDS; ++r) o_dgrp[r].push_back(put(down_grp[r][size_t(d)]));
             o_wave.push_back(put(up_wave[size_t(d)]));
             o_sum.push_back(put(up_sum[size_t(d)]));
         }
@@ -1179,9 +1222,24 @@ struct BrRun {
         if (err == hipSuccess) err = hipStreamSynchronize(t->stream);   // `all` is a local
         n_launches = 0;
         for (int d = 0; d <= max_depth && err == hipSuccess; ++d) {   // reach, level by level
+            for (int r = 0; r < RS_MAX_ROUNDS && err == hipSuccess; ++r)
+                if (const uint32_t nj = uint32_t(down_grp[r][size_t(d)].size())) {
+                    uint32_t amax = 0;
+                    for (const BrJob &j : down_grp[r][size_t(d)]) amax = std::max(amax, j.row.n_actions);
+                    const size_t lds = size_t(amax) * (size_t(op.groups[r].max_sets) + 1) * sizeof(float);
+#define RS_OPPG(DT_)                                                                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_br_opp_reach_grouped_jobs<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                    \
+    hipLaunchKernelGGL((k_br_opp_reach_grouped_jobs<DT_>), dim3(op.groups[r].n_groups, nj), dim3(kBrGroupBlock), lds, t->stream, t->d_ssum, d_jobs + o_dgrp[r][size_t(d)], \
+                       op.groups[r], op.n_pad)
+                    RS_BR_DT(t->dtype, RS_OPPG);
+#undef RS_OPPG
+                    err = hipGetLastError();
+                    ++n_launches;
+                }
             const uint32_t nj = uint32_t(down[size_t(d)].size());
             if (!nj) continue;
-#define RS_OPPJ(DT_) hipLaunchKernelGGL((k_br_opp_reach_jobs<DT_>), dim3(grid1(op.n), nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_down[size_t(d)], op.n, op.n_pad)
+            const uint32_t sliced = 8u * grid1(NB * ((op.n_hands + 7u) / 8u));
+#define RS_OPPJ(DT_) hipLaunchKernelGGL((k_br_opp_reach_jobs<DT_>), dim3(sliced, nj), dim3(kBrBlock), 0, t->stream, t->d_ssum, d_jobs + o_down[size_t(d)], op.n, op.n_pad, op.n_hands)
             RS_BR_DT(t->dtype, RS_OPPJ);
 #undef RS_OPPJ
             err = hipGetLastError();
@@ -1192,7 +1250,20 @@ struct BrRun {
             // (small ranges keep a workgroup per (run-out, leaf): the loop's scans are unrolled for 1 326 hands whatever the range holds -- 200 combos: 0.047 against 0.059 s per call)
             if (sorted && op.n_hands >= 512 && me.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock && op.n_hands <= uint32_t(kBrChunkMax) * 64u && op.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock) {   // a workgroup per run-out (and slice of the leaves, when run-outs alone do not fill the card)
                 const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double) + (((size_t(op.n_hands) + 3) & ~size_t(3)) + 52 * kBrCardHolders) * sizeof(uint16_t) + 64;
-                const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(nj, 2048u / std::max<uint32_t>(NB, 1)));
+                // slices of the leaves: enough workgroups to fill the card, and a count that leaves the last round of workgroups (two per CU: 217 registers) nearly full --
+                // 2 352 run-outs on 512 slots are 4.6 rounds (the fifth 59 % full), five slices 22.97
+                uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(nj, 2048u / std::max<uint32_t>(NB, 1)));
+                {
+                    int cus = 256;
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || cus < 1) cus = 256;
+                    const double slots = 2.0 * cus;
+                    double best = 0.0;
+                    for (uint32_t sl = slices; sl <= std::min<uint32_t>(nj, slices + 7); ++sl) {
+                        const double rounds = double(NB) * sl / slots, eff = rounds / std::ceil(rounds);
+                        if (eff > best + 0.02) best = eff, slices = sl;
+                        if (eff >= 0.95) break;
+                    }
+                }
                 hipLaunchKernelGGL(k_br_terminal_sorted_loop, dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
                                    d_jobs + o_leaves + lo, nj);
             } else if (sorted) {
@@ -1455,6 +1526,12 @@ static void build_groups(BrRun &run, BrSide &s, int r, size_t NB, size_t H, cons
     g.lstart = run.upload(lstart);
     g.llane = run.upload(llane);
     g.lane_set = run.upload(lane_set);
+    {
+        std::vector<uint32_t> set_cluster(n_sets, 0);
+        for (uint32_t c = 0; c < NC; ++c)
+            if (set_of[c] != 0xffffffffu) set_cluster[set_of[c]] = c;
+        g.set_cluster = run.upload(set_cluster);
+    }
     g.n_groups = n_groups;
     g.cap = cap;
     g.n_hands = uint32_t(H);
