@@ -141,9 +141,15 @@ int run_launch(rs_solver *s, const Plan &plan, const Launch &L, hipStream_t tree
         if (!JL.members.empty()) {   // one launch for the kernels of a whole group (merge_small_groups)
             // The merged kernel keeps the registers of its largest member (two workgroups per CU), and a list holds a fraction of the batch: a grid sized for the whole batch
             // per job is 98 % workgroups that find nothing and leave, thirty-odd rounds of them (64 K deals, 73 river lists: 96 us, a quarter of the sweep).  Sized for four
-            // times the average list of a round in which every deal is walked twice; the grid-stride loop takes what is longer.
-            if (s->knobs.max_blocks == kUnset)
-                blocks = std::min<size_t>(blocks, std::max<size_t>(4, (size_t(s->deals.n_deals) * 8 / size_t(JL.n_jobs) + size_t(JL.threads) - 1) / size_t(JL.threads)));
+            // times the average list of a round in which every deal is walked twice; the grid-stride loop takes what is longer.  The lists are uneven (the check-through
+            // lines hold most of the deals): between 4 K and 96 K deals the long ones then make several trips one after the other in a sweep that is a chain of latencies --
+            // sixteen times the average there (8 K deals 0.38 -> 0.36 ms per batch, 16 K 0.45 -> 0.40, 32 K 0.47 -> 0.44, 64 K 0.58 -> 0.53; 4 K 0.31 -> 0.34 and 128 K and beyond 0-6 %
+            // slower: left at four).
+            // (A flat grid -- every workgroup finds its (job, trip) from a prefix of the counts -- balances exactly and costs each workgroup the prefix: no better.)
+            if (s->knobs.max_blocks == kUnset) {
+                const size_t mult = (s->deals.n_deals > 4096 && s->deals.n_deals <= 98304) ? 32 : 8;
+                blocks = std::min<size_t>(blocks, std::max<size_t>(4, (size_t(s->deals.n_deals) * mult / size_t(JL.n_jobs) + size_t(JL.threads) - 1) / size_t(JL.threads)));
+            }
             MergedArgs A = JL.margs;
             void *mparams[] = {&A, &flags};
             e = hipModuleLaunchKernel(JL.fn, (unsigned)blocks, (unsigned)JL.n_jobs, 1, (unsigned)JL.threads, 1, 1, (unsigned)JL.lds_bytes, tree_stream, mparams, nullptr);
