@@ -168,7 +168,7 @@ def test_trainer_ticks_run_calc_br_and_exploitability_falls():
 
 # ---- best response over multi-round trees (rs_best_response_rounds; oracle: best_response.c orc_best_response_rounds) ------------------------------
 
-def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, sparse=0.15, tied=0):
+def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, sparse=0.15, tied=0, dtype=L.I32):
     K = 5 - len(board0)
     free = [c for c in range(52) if c not in board0]
     combos = np.array([(a, b) for i, a in enumerate(free) for b in free[i + 1:]], dtype=np.uint8)
@@ -189,10 +189,10 @@ def multi_round_device_game(rng, board0, n0, n1, bets, raises, n_clusters, spars
             cids[1] = [(np.arange(D, dtype=np.uint32)[:, None] * len(h[p]) + np.arange(len(h[p]), dtype=np.uint32)[None, :]).astype(np.uint32) for p in (0, 1)]
     n_actions, tree = rs.build_game_tree(rs.Options(n_board_cards=len(board0), bet_sizes=bets, raise_sizes=raises))
     sizes = [(n_clusters[r], n_clusters[r]) for r in range(K + 1)]
-    table = rs.create_infosets(n_actions, tree, sizes, [1] * (K + 1))
+    table = rs.create_infosets(n_actions, tree, sizes, [1] * (K + 1), dtype=dtype)
     ot = orc.OracleTree(orc.make_options(n_board_cards=len(board0), bet_sizes=bets, raise_sizes=raises))
-    otab = orc.OracleDealTable(ot, sizes)
-    fill_both(table, otab, tree, rng, sparse)
+    otab = orc.OracleDealTable(ot, sizes, dtype={L.I32: orc.T_I32, L.F32: orc.T_F32, L.F16: orc.T_F16}[dtype])
+    fill_both(table, otab, tree, rng, sparse, dtype)
     return tree, table, otab, h, cids
 
 
@@ -239,6 +239,20 @@ def test_multi_round_best_response_equals_oracle_bit_for_bit(board0, n0, n1, bet
             assert dfs.view(np.uint64).tolist() == want.view(np.uint64).tolist(), (mode, dfs, want)
     finally:
         del os.environ["RS_BR_DEPTH_FIRST"]
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_multi_round_best_response_on_float_tables(dtype):
+    """the level plan's kernels read the strategy sums through the table's type: binary32 and binary16 tables, river info sets of four lanes in four run-outs (own nodes and
+    the opponent's reach by groups of run-outs), turn info sets by columns -- bit for bit the oracle's on its table of the same type"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    board0, n0, n1 = [9, 13, 51], 26, 31
+    n_clusters = [5, 49 * 31, 1176 * 2 // 4 * 31]
+    tree, table, otab, h, cids = multi_round_device_game(rng, board0, n0, n1, ((0.5,), (0.5,), (1.0,)), ((), (), ()), n_clusters, tied=4, dtype=dtype)
+    for mode in (L.BR_MAX | L.BR_SORTED, L.BR_AVERAGE | L.BR_SORTED, L.BR_MAX):
+        got = table.best_response_rounds(tree, board0, h[0], h[1], cids, mode)
+        want = otab.best_response_rounds(board0, h[0], h[1], cids, mode)
+        assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist(), (dtype, mode, got, want)
 
 
 def test_sorted_showdowns_full_ranges_from_a_flop():
