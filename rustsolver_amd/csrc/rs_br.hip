@@ -929,7 +929,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_own_cols_jobs(const void *__res
         for (uint32_t a = 0; a < A; a++) {
             const double *va = j.vch + (size_t)a * n_pad;
             double acc = 0.0;
-            for (uint32_t k = 0; k < j.kmax; k += 8) {   // eight gathers in flight, the additions one after the other in list order
+            for (uint32_t k = 0; k < j.kmax; k += 8) {   // eight gathers in flight (sixteen: no faster), the additions one after the other in list order
                 uint32_t idx[8];
                 double t[8];
 #pragma unroll
@@ -943,9 +943,16 @@ __global__ __launch_bounds__(kBrBlock) void k_br_own_cols_jobs(const void *__res
             if (a == 0 || s_best < acc) s_best = acc, best = a;   // first maximum, strict < (cfr.rs:684-690)
         }
         const double *vb = j.vch + (size_t)best * n_pad;
-        for (uint32_t k = 0; k < j.kmax; k++) {
-            const uint32_t idx = col[(size_t)k * j.n_sets];
-            if (idx != 0xffffffffu) j.v[idx] = vb[idx];
+        for (uint32_t k = 0; k < j.kmax; k += 8) {   // the winner's values: eight lanes' indices, then their values, then the stores
+            uint32_t idx[8];
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) idx[q] = k + q < j.kmax ? col[(size_t)(k + q) * j.n_sets] : 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 8; q++) t[q] = idx[q] != 0xffffffffu ? vb[idx[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (idx[q] != 0xffffffffu) j.v[idx[q]] = t[q];
         }
     } else {
         float sig[RS_MAX_ACTIONS];
