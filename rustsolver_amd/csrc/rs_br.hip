@@ -597,6 +597,8 @@ struct BrJob {
     uint32_t n_clusters, n_children;
     int uncontested, pad_;
     double value;
+    const double *sum_src[RS_MAX_ACTIONS];   // own node by groups: child a is an opponent's node whose value is the sum of ITS children's rows (sum_n[a] of them, n_pad apart,
+    uint32_t sum_n[RS_MAX_ACTIONS];          // from sum_src[a]) -- added up while the rows are staged instead of written by k_br_sum_jobs and read again; 0: child a's row is vch + a * n_pad
     const uint32_t *tord, *perm;   // own node by columns (k_br_own_cols_jobs): [kmax][n_sets] the k-th lane of the i-th info set, and which cluster that info set is
     uint32_t n_sets, kmax;
 };
@@ -847,8 +849,26 @@ __global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJ
         }
     }
     const uint32_t c_lo = g.cstart[grp], c_hi = g.cstart[grp + 1];
+    // child a's values of this thread's lanes: the child's row, or -- the child an opponent's node -- the sum of its children's rows in action order (br_sum_body's additions)
+    const BrJob *__restrict__ jp = jobs + blockIdx.y;   // (sum_src / sum_n are indexed by the action: read where they lie, not from the by-value copy)
+    auto fetch = [&](uint32_t a) {
+        const uint32_t ns = jp->sum_n[a];
+        if (ns == 0) {
+            const double *va = j.vch + (size_t)a * n_pad;
 #pragma unroll
-    for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = goff[k] != 0xffffffffu ? j.vch[goff[k]] : 0.0;
+            for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = goff[k] != 0xffffffffu ? va[goff[k]] : 0.0;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = 0.0;
+        const double *src = jp->sum_src[a];
+        for (uint32_t c = 0; c < ns; c++) {
+            const double *vc = src + (size_t)c * n_pad;
+#pragma unroll
+            for (int k = 0; k < kBrGroupPerThread; k++) regs[k] += goff[k] != 0xffffffffu ? vc[goff[k]] : 0.0;
+        }
+    };
+    fetch(0);
     for (uint32_t a = 0; a < j.n_children; a++) {
 #pragma unroll
         for (int k = 0; k < kBrGroupPerThread; k++) {
@@ -856,11 +876,7 @@ __global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJ
             if (e < GH) stage[e] = regs[k];
         }
         __syncthreads();
-        if (a + 1 < j.n_children) {   // the next child's rows are on their way while this one's info sets add up
-            const double *va = j.vch + (size_t)(a + 1) * n_pad;
-#pragma unroll
-            for (int k = 0; k < kBrGroupPerThread; k++) regs[k] = goff[k] != 0xffffffffu ? va[goff[k]] : 0.0;
-        }
+        if (a + 1 < j.n_children) fetch(a + 1);   // the next child's rows are on their way while this one's info sets add up
         for (uint32_t c = c_lo + tid; c < c_hi; c += kBrGroupBlock) {
             const uint32_t lo = g.lstart[c], hi = g.lstart[c + 1];
             double acc = 0.0;
@@ -1145,6 +1161,7 @@ struct BrRun {
         v_out[0] = *root_out;
         q_in[0] = op.d_init_q;
         std::vector<std::vector<BrJob>> down(size_t(max_depth) + 1), up_own(size_t(max_depth) + 1), up_wave(size_t(max_depth) + 1), up_sum(size_t(max_depth) + 1);
+        std::vector<std::pair<int, int>> grp_at(N, {-1, -1});   // an own node taken by groups: (round, index in up_grp[round][depth])
         std::vector<std::vector<BrJob>> up_cols(size_t(max_depth) + 1);   // own nodes by columns
         std::vector<std::vector<BrJob>> up_grp[RS_MAX_ROUNDS], down_grp[RS_MAX_ROUNDS];   // own / opponent nodes taken by groups of run-outs, per round (the groups are the round's)
         for (auto &v : up_grp) v.resize(size_t(max_depth) + 1);
@@ -1183,7 +1200,10 @@ struct BrRun {
                 j.start = me.d_start[r];
                 j.order = me.d_order[r];
                 j.n_clusters = me.n_clusters[r];
-                if (mode == RS_BR_MAX && me.grouped[r]) up_grp[r][size_t(d)].push_back(j);
+                if (mode == RS_BR_MAX && me.grouped[r]) {
+                    grp_at[id] = {r, int(up_grp[r][size_t(d)].size())};
+                    up_grp[r][size_t(d)].push_back(j);
+                }
                 else if (me.d_tord[r]) {
                     j.tord = me.d_tord[r];
                     j.perm = me.d_perm[r];
@@ -1200,7 +1220,20 @@ struct BrRun {
                 j.q = q_in[id];
                 j.q_out = qch[id];
                 (op.grouped[r] ? down_grp[r] : down)[size_t(d)].push_back(j);
-                up_sum[size_t(d)].push_back(j);
+                // its value is the sum of its children's; where the parent is an own node taken by groups, that kernel adds the rows up as it stages them
+                const int par = n.parent;
+                bool taken = false;
+                if (par >= 0 && grp_at[size_t(par)].first >= 0) {
+                    const rs_tree_node &pn = tree->nodes[size_t(par)];
+                    BrJob &pj = up_grp[grp_at[size_t(par)].first][size_t(depth_of[size_t(par)])][size_t(grp_at[size_t(par)].second)];
+                    for (int a = 0; a < pn.n_children && !taken; ++a)
+                        if (pn.children[a] == int(id)) {
+                            pj.sum_src[a] = vch[id];
+                            pj.sum_n[a] = uint32_t(n.n_children);
+                            taken = true;
+                        }
+                }
+                if (!taken) up_sum[size_t(d)].push_back(j);
                 for (int a = 0; a < n.n_children; ++a) q_in[size_t(n.children[a])] = qch[id] + size_t(a) * op.n_pad;
             }
             for (int a = 0; a < n.n_children; ++a) v_out[size_t(n.children[a])] = vch[id] + size_t(a) * me.n_pad;
