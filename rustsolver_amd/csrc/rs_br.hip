@@ -905,7 +905,11 @@ __global__ __launch_bounds__(kBrGroupBlock) void k_br_opp_reach_grouped_jobs(con
     extern __shared__ double br_group_lds[];
     float *sg = reinterpret_cast<float *>(br_group_lds);   // [A][max_sets + 1]
     const BrJob j = jobs[blockIdx.y];
-    const uint32_t grp = blockIdx.x, tid = threadIdx.x, GH = g.cap * g.n_hands, A = j.row.n_actions, pitch = g.max_sets + 1;
+    // workgroups go round the eight XCDs in turn: XCD x takes the groups [x n/8, (x+1) n/8) in order, so that neighbouring groups -- whose info sets are neighbours in the
+    // strategy-sum rows (br_prepare packs the components in the order of their cluster ids) -- meet in one L2 at about the same time
+    const uint32_t per_xcd = (g.n_groups + 7u) / 8u, grp = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (grp >= g.n_groups || (blockIdx.x >> 3) >= per_xcd) return;
+    const uint32_t tid = threadIdx.x, GH = g.cap * g.n_hands, A = j.row.n_actions, pitch = g.max_sets + 1;
     const uint32_t c_lo = g.cstart[grp], n_sets = g.cstart[grp + 1] - c_lo;
     for (uint32_t k = tid; k <= n_sets; k += kBrGroupBlock) {
         float sig[RS_MAX_ACTIONS];
@@ -1269,7 +1273,7 @@ struct BrRun {
                     const size_t lds = size_t(amax) * (size_t(op.groups[r].max_sets) + 1) * sizeof(float);
 #define RS_OPPG(DT_)                                                                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_br_opp_reach_grouped_jobs<DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                    \
-    hipLaunchKernelGGL((k_br_opp_reach_grouped_jobs<DT_>), dim3(op.groups[r].n_groups, nj), dim3(kBrGroupBlock), lds, t->stream, t->d_ssum, d_jobs + o_dgrp[r][size_t(d)], \
+    hipLaunchKernelGGL((k_br_opp_reach_grouped_jobs<DT_>), dim3(8u * ((op.groups[r].n_groups + 7u) / 8u), nj), dim3(kBrGroupBlock), lds, t->stream, t->d_ssum, d_jobs + o_dgrp[r][size_t(d)], \
                        op.groups[r], op.n_pad)
                     RS_BR_DT(t->dtype, RS_OPPG);
 #undef RS_OPPG
@@ -1508,25 +1512,37 @@ static void build_groups(BrRun &run, BrSide &s, int r, size_t NB, size_t H, cons
     const uint32_t cap_max = uint32_t(size_t(kBrGroupPerThread) * kBrGroupBlock / H);
     if (largest > cap_max) return;
     const uint32_t cap = std::min(cap_max, std::max<uint32_t>(largest, std::max<uint32_t>(1, uint32_t(5400 / H))));
-    // components in the order of their first run-out (the root: the smallest member), packed greedily
+    // components in the order of their smallest cluster id, packed greedily: neighbours in that order hold neighbouring info sets -- the same 64-byte lines of the
+    // strategy-sum rows (a lossless abstraction numbers its clusters hand by hand, then by the larger and the smaller of the two cards to come) -- and the reach kernel hands
+    // neighbouring groups to one XCD
+    std::vector<uint32_t> comp_order;
+    {
+        std::vector<char> seen(NB, 0);
+        for (uint32_t c = 0; c < NC; ++c) {
+            if (start[c] == start[size_t(c) + 1]) continue;
+            const uint32_t root = find(uint32_t(order[start[c]] / H));
+            if (!seen[root]) seen[root] = 1, comp_order.push_back(root);
+        }
+        for (size_t b = 0; b < NB; ++b)   // run-outs without a single info set (no hand fits): on their own, last
+            if (find(uint32_t(b)) == b && !seen[b]) comp_order.push_back(uint32_t(b));
+    }
     std::vector<uint32_t> group_of(NB, 0), slot_of(NB, 0), group_root(NB, 0xffffffffu);
     std::vector<uint32_t> runouts;
     uint32_t n_groups = 0, used = cap;
-    for (size_t b = 0; b < NB; ++b) {
-        const uint32_t root = find(uint32_t(b));
-        if (group_root[root] == 0xffffffffu) {   // b is the root (roots are the smallest members, and b ascends)
-            if (used + size[root] > cap) {
-                ++n_groups;
-                used = 0;
-                runouts.resize(size_t(n_groups) * cap, 0xffffffffu);
-            }
-            group_root[root] = n_groups - 1;
-            used += size[root];
+    for (uint32_t root : comp_order) {
+        if (used + size[root] > cap) {
+            ++n_groups;
+            used = 0;
+            runouts.resize(size_t(n_groups) * cap, 0xffffffffu);
         }
-        const uint32_t g = group_root[root];
+        group_root[root] = n_groups - 1;
+        used += size[root];
+    }
+    for (size_t b = 0; b < NB; ++b) {   // members take their group's slots in ascending order
+        const uint32_t g = group_root[find(uint32_t(b))];
         group_of[b] = g;
         uint32_t slot = 0;
-        while (runouts[size_t(g) * cap + slot] != 0xffffffffu) ++slot;   // members arrive in ascending order; room was reserved when the component's root came up
+        while (runouts[size_t(g) * cap + slot] != 0xffffffffu) ++slot;
         runouts[size_t(g) * cap + slot] = uint32_t(b);
         slot_of[b] = slot;
     }
