@@ -608,7 +608,10 @@ struct BrJob {
 // hands per thread); per leaf the workgroup streams the opponent's reach of its run-out in and its hands' values out.  The sums are br_terminal_sorted_body's, order and all.
 constexpr int kBrHandsPerThread = 6;   // 1 326 two-card hands at most, 256 threads
 constexpr int kBrChunkMax = 21;        // ... in 64 chunks of the rank order
+// (the kernel is compiled for four range sizes -- <HPT, CHUNK> = <1, 4> up to 256 combos, <2, 8> up to 512, <4, 16> up to 1 024, <6, 21> beyond: its scans are unrolled to those
+// bounds, and at <6, 21> a 200-combo range paid for 1 326 -- until then small ranges kept a workgroup per (run-out, leaf), 2.5 M workgroups per traverser)
 static_assert(kBrCardHolders == 3 * 17, "the card scans of k_br_terminal_sorted_loop run in three blocks of 17");
+template <int HPT, int CHUNK>
 __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
                                                                       uint32_t n_p, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
                                                                       const BrJob *__restrict__ jobs, uint32_t n_jobs) {
@@ -627,12 +630,12 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
     for (uint32_t i = threadIdx.x; i < 52u * kBrCardHolders; i += kBrBlock) Lcl[i] = ix.cl[(size_t)b * 52 * kBrCardHolders + i];
     if (threadIdx.x < 52) Lcc[threadIdx.x] = ix.cc[(size_t)b * 52 + threadIdx.x];
     // this thread's hands: h = threadIdx.x + k * 256
-    uint32_t hw0[kBrHandsPerThread], hw1[kBrHandsPerThread];     // hw0 = nl | nle << 16; hw1 = a0 | a1 << 8 | e0 << 16 | e1 << 24
-    uint32_t hc[kBrHandsPerThread];                              // c0 | c1 << 8 | live << 16
-    int hs[kBrHandsPerThread];
-    double hp[kBrHandsPerThread];
+    uint32_t hw0[HPT], hw1[HPT];     // hw0 = nl | nle << 16; hw1 = a0 | a1 << 8 | e0 << 16 | e1 << 24
+    uint32_t hc[HPT];                              // c0 | c1 << 8 | live << 16
+    int hs[HPT];
+    double hp[HPT];
 #pragma unroll
-    for (int k = 0; k < kBrHandsPerThread; ++k) {
+    for (int k = 0; k < HPT; ++k) {
         const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
         hw0[k] = hw1[k] = hc[k] = 0;
         hs[k] = -1;
@@ -651,25 +654,27 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
     }
     const uint32_t len = (nv + 63u) / 64u;
     __syncthreads();
-    // What the scans below walk is the same for every leaf, so it lives in registers: wave 0's lane k owns chunk k of the rank order (at most kBrChunkMax positions), the first
+    // What the scans below walk is the same for every leaf, so it lives in registers: wave 0's lane k owns chunk k of the rank order (at most CHUNK positions), the first
     // 52 lanes of wave 1 a card's holders each.  Per leaf every value is then fetched from LDS in one go and added up in registers, in the body's order: a chunk's running sums,
     // the chunk offsets (one after the other over the lanes: readlane), P = offset + running sum; a card's running sums.  (The first version walked ord -> Q -> add -> store as
     // four dependent LDS operations per step, 51 steps for a card: 11.5 us per leaf and workgroup.)
     const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
     const uint32_t i0 = min(nv, wl * len), cnt0 = wave == 0 ? min(nv, i0 + len) - i0 : 0u;
-    uint32_t ordr[kBrChunkMax];
+    uint32_t ordr[CHUNK];
 #pragma unroll
-    for (int k = 0; k < kBrChunkMax; ++k) ordr[k] = (uint32_t)k < cnt0 ? Lord[i0 + k] : 0u;
+    for (int k = 0; k < CHUNK; ++k) ordr[k] = (uint32_t)k < cnt0 ? Lord[i0 + k] : 0u;
     const uint32_t cardc = wl < 52u ? wl : 0u, cntc = (wave == 1 && wl < 52u) ? Lcc[cardc] : 0u;
     uint32_t clr[kBrCardHolders];
 #pragma unroll
     for (int k = 0; k < kBrCardHolders; ++k) clr[k] = (uint32_t)k < cntc ? Lcl[cardc * kBrCardHolders + k] : 0u;
+    uint32_t most_holders = 0;   // of any card in this run-out: a small range's card scans end after the first block of 17
+    for (uint32_t c = 0; c < 52u; ++c) most_holders = max(most_holders, (uint32_t)Lcc[c]);
     // the opponent's reach of the NEXT leaf is fetched while this one is worked on: with two workgroups per CU nothing else hides a leaf's round trip to memory
-    double qn[kBrHandsPerThread];
+    double qn[HPT];
     if (blockIdx.y < n_jobs) {
         const double *__restrict__ q0 = jobs[blockIdx.y].q + (size_t)b * n_o;
 #pragma unroll
-        for (int k = 0; k < kBrHandsPerThread; ++k) {
+        for (int k = 0; k < HPT; ++k) {
             const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
             qn[k] = i < n_o ? q0[i] : 0.0;
         }
@@ -679,26 +684,26 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
         const int uncontested = jobs[j].uncontested;
         const double value = jobs[j].value;
 #pragma unroll
-        for (int k = 0; k < kBrHandsPerThread; ++k) {
+        for (int k = 0; k < HPT; ++k) {
             const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
             if (i < n_o) Q[i] = qn[k];
         }
         if (j + gridDim.y < n_jobs) {
             const double *__restrict__ q1 = jobs[j + gridDim.y].q + (size_t)b * n_o;
 #pragma unroll
-            for (int k = 0; k < kBrHandsPerThread; ++k) {
+            for (int k = 0; k < HPT; ++k) {
                 const uint32_t i = threadIdx.x + (uint32_t)k * kBrBlock;
                 qn[k] = i < n_o ? q1[i] : 0.0;
             }
         }
         __syncthreads();
         if (wave == 0) {
-            double t[kBrChunkMax];
+            double t[CHUNK];
 #pragma unroll
-            for (int k = 0; k < kBrChunkMax; ++k) t[k] = Q[ordr[k]];
+            for (int k = 0; k < CHUNK; ++k) t[k] = Q[ordr[k]];
             double run = 0.0;
 #pragma unroll
-            for (int k = 0; k < kBrChunkMax; ++k) {
+            for (int k = 0; k < CHUNK; ++k) {
                 if ((uint32_t)k < cnt0) run += t[k];
                 t[k] = run;                                      // the chunk's running sum up to and including position k
             }
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
             }
             if (!uncontested) {                                  // an uncontested leaf reads the totals only
 #pragma unroll
-                for (int k = 0; k < kBrChunkMax; ++k)
+                for (int k = 0; k < CHUNK; ++k)
                     if ((uint32_t)k < cnt0) P[i0 + k] = off + t[k];
             }
             if (wl == 0) O[64] = tot;
@@ -719,6 +724,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
             double run = 0.0;
 #pragma unroll
             for (int k0 = 0; k0 < kBrCardHolders; k0 += 17) {
+                if ((uint32_t)k0 >= most_holders) break;
                 double t[17];
 #pragma unroll
                 for (int k = 0; k < 17; ++k) t[k] = Q[clr[k0 + k]];
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
         __syncthreads();
         const double T = O[64];
 #pragma unroll
-        for (int k = 0; k < kBrHandsPerThread; ++k) {
+        for (int k = 0; k < HPT; ++k) {
             const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
             if (h >= n_p) continue;
             const size_t lane = (size_t)b * n_p + h;
@@ -1292,15 +1298,17 @@ struct BrRun {
         for (size_t lo = 0; lo < leaves.size() && err == hipSuccess; lo += 16384) {   // every leaf
             const uint32_t nj = uint32_t(std::min<size_t>(16384, leaves.size() - lo));
             // (small ranges keep a workgroup per (run-out, leaf): the loop's scans are unrolled for 1 326 hands whatever the range holds -- 200 combos: 0.047 against 0.059 s per call)
-            if (sorted && op.n_hands >= 512 && me.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock && op.n_hands <= uint32_t(kBrChunkMax) * 64u && op.n_hands <= uint32_t(kBrHandsPerThread) * kBrBlock) {   // a workgroup per run-out (and slice of the leaves, when run-outs alone do not fill the card)
+            const uint32_t most_hands = std::max(me.n_hands, op.n_hands);
+            if (sorted && most_hands <= uint32_t(kBrHandsPerThread) * kBrBlock && op.n_hands <= uint32_t(kBrChunkMax) * 64u) {   // a workgroup per run-out (and slice of the leaves, when run-outs alone do not fill the card)
                 const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double) + (((size_t(op.n_hands) + 3) & ~size_t(3)) + 52 * kBrCardHolders) * sizeof(uint16_t) + 64;
-                // slices of the leaves: enough workgroups to fill the card, and a count that leaves the last round of workgroups (two per CU: 217 registers) nearly full --
-                // 2 352 run-outs on 512 slots are 4.6 rounds (the fifth 59 % full), five slices 22.97
+                // slices of the leaves: enough workgroups to fill the card, and a count that leaves the last round of workgroups (two per CU at full ranges: 217 registers;
+                // about four for the small-range forms) nearly full -- 2 352 run-outs on 512 slots are 4.6 rounds (the fifth 59 % full), three slices 13.8
+                const int form = most_hands <= 256 ? 0 : (most_hands <= 512 ? 1 : (most_hands <= 1024 ? 2 : 3));
                 uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(nj, 2048u / std::max<uint32_t>(NB, 1)));
                 {
                     int cus = 256;
                     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || cus < 1) cus = 256;
-                    const double slots = 2.0 * cus;
+                    const double slots = (form == 3 ? 2.0 : 4.0) * cus;
                     double best = 0.0;
                     for (uint32_t sl = slices; sl <= std::min<uint32_t>(nj, slices + 7); ++sl) {
                         const double rounds = double(NB) * sl / slots, eff = rounds / std::ceil(rounds);
@@ -1308,8 +1316,14 @@ struct BrRun {
                         if (eff >= 0.95) break;
                     }
                 }
-                hipLaunchKernelGGL(k_br_terminal_sorted_loop, dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
-                                   d_jobs + o_leaves + lo, nj);
+#define RS_LEAF_LOOP(HPT_, CHUNK_)                                                                                                                                     \
+    hipLaunchKernelGGL((k_br_terminal_sorted_loop<HPT_, CHUNK_>), dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, \
+                       d_bmask, me.index, d_jobs + o_leaves + lo, nj)
+                if (form == 0) RS_LEAF_LOOP(1, 4);
+                else if (form == 1) RS_LEAF_LOOP(2, 8);
+                else if (form == 2) RS_LEAF_LOOP(4, 16);
+                else RS_LEAF_LOOP(kBrHandsPerThread, kBrChunkMax);
+#undef RS_LEAF_LOOP
             } else if (sorted) {
                 const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double);
                 hipLaunchKernelGGL(k_br_terminal_sorted_jobs, dim3(NB, nj), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, d_bmask, me.index,
