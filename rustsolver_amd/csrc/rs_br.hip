@@ -611,7 +611,7 @@ constexpr int kBrChunkMax = 21;        // ... in 64 chunks of the rank order
 // (the kernel is compiled for four range sizes -- <HPT, CHUNK> = <1, 4> up to 256 combos, <2, 8> up to 512, <4, 16> up to 1 024, <6, 21> beyond: its scans are unrolled to those
 // bounds, and at <6, 21> a 200-combo range paid for 1 326 -- until then small ranges kept a workgroup per (run-out, leaf), 2.5 M workgroups per traverser)
 static_assert(kBrCardHolders == 3 * 17, "the card scans of k_br_terminal_sorted_loop run in three blocks of 17");
-template <int HPT, int CHUNK>
+template <int HPT, int CHUNK, bool REG_IDX>
 __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint8_t *__restrict__ hands_p, const uint64_t *__restrict__ mask_p, const double *__restrict__ pw,
                                                                       uint32_t n_p, uint32_t n_o, const uint64_t *__restrict__ bmask, BrIndex ix,
                                                                       const BrJob *__restrict__ jobs, uint32_t n_jobs) {
@@ -631,14 +631,12 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
     if (threadIdx.x < 52) Lcc[threadIdx.x] = ix.cc[(size_t)b * 52 + threadIdx.x];
     // this thread's hands: h = threadIdx.x + k * 256
     uint32_t hw0[HPT], hw1[HPT];     // hw0 = nl | nle << 16; hw1 = a0 | a1 << 8 | e0 << 16 | e1 << 24
-    uint32_t hc[HPT];                              // c0 | c1 << 8 | live << 16
-    int hs[HPT];
+    uint32_t hc[HPT];                              // c0 | c1 << 8 | live << 16 | (the opponent's hand of the same two cards + 1, or 0) << 17
     double hp[HPT];
 #pragma unroll
     for (int k = 0; k < HPT; ++k) {
         const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
         hw0[k] = hw1[k] = hc[k] = 0;
-        hs[k] = -1;
         hp[k] = 0.0;
         if (h < n_p) {
             const size_t lane = (size_t)b * n_p + h;
@@ -647,7 +645,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
             if (live) {
                 hw0[k] = (uint32_t)ix.nl[lane] | (uint32_t)ix.nle[lane] << 16;
                 hw1[k] = (uint32_t)ix.kl[2 * lane] | (uint32_t)ix.kl[2 * lane + 1] << 8 | (uint32_t)ix.kle[2 * lane] << 16 | (uint32_t)ix.kle[2 * lane + 1] << 24;
-                hs[k] = ix.same[h];
+                hc[k] |= (uint32_t)(ix.same[h] + 1) << 17;
                 hp[k] = pw[lane];
             }
         }
@@ -660,13 +658,16 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
     // four dependent LDS operations per step, 51 steps for a card: 11.5 us per leaf and workgroup.)
     const uint32_t wave = threadIdx.x >> 6, wl = threadIdx.x & 63u;
     const uint32_t i0 = min(nv, wl * len), cnt0 = wave == 0 ? min(nv, i0 + len) - i0 : 0u;
-    uint32_t ordr[CHUNK];
-#pragma unroll
-    for (int k = 0; k < CHUNK; ++k) ordr[k] = (uint32_t)k < cnt0 ? Lord[i0 + k] : 0u;
     const uint32_t cardc = wl < 52u ? wl : 0u, cntc = (wave == 1 && wl < 52u) ? Lcc[cardc] : 0u;
-    uint32_t clr[kBrCardHolders];
+    // REG_IDX (full ranges): the positions the scans read live in registers -- 72 of them, two workgroups per CU; from LDS at every leaf the kernel fits three workgroups
+    // per CU at 168 registers and is slower (0.099 against 0.096 s per call).  The small-range forms (64-126 registers) read them from LDS: 200 combos 0.029 -> 0.026 s.
+    uint32_t ordr[REG_IDX ? CHUNK : 1], clr[REG_IDX ? kBrCardHolders : 1];
+    if (REG_IDX) {
 #pragma unroll
-    for (int k = 0; k < kBrCardHolders; ++k) clr[k] = (uint32_t)k < cntc ? Lcl[cardc * kBrCardHolders + k] : 0u;
+        for (int k = 0; k < (REG_IDX ? CHUNK : 1); ++k) ordr[k] = (uint32_t)k < cnt0 ? Lord[i0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < (REG_IDX ? kBrCardHolders : 1); ++k) clr[k] = (uint32_t)k < cntc ? Lcl[cardc * kBrCardHolders + k] : 0u;
+    }
     uint32_t most_holders = 0;   // of any card in this run-out: a small range's card scans end after the first block of 17
     for (uint32_t c = 0; c < 52u; ++c) most_holders = max(most_holders, (uint32_t)Lcc[c]);
     // the opponent's reach of the NEXT leaf is fetched while this one is worked on: with two workgroups per CU nothing else hides a leaf's round trip to memory
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
         if (wave == 0) {
             double t[CHUNK];
 #pragma unroll
-            for (int k = 0; k < CHUNK; ++k) t[k] = Q[ordr[k]];
+            for (int k = 0; k < CHUNK; ++k) t[k] = Q[REG_IDX ? ordr[REG_IDX ? k : 0] : ((uint32_t)k < cnt0 ? Lord[i0 + k] : 0u)];
             double run = 0.0;
 #pragma unroll
             for (int k = 0; k < CHUNK; ++k) {
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
                 if ((uint32_t)k0 >= most_holders) break;
                 double t[17];
 #pragma unroll
-                for (int k = 0; k < 17; ++k) t[k] = Q[clr[k0 + k]];
+                for (int k = 0; k < 17; ++k) t[k] = Q[REG_IDX ? clr[REG_IDX ? k0 + k : 0] : ((uint32_t)(k0 + k) < cntc ? Lcl[cardc * kBrCardHolders + k0 + k] : 0u)];
 #pragma unroll
                 for (int k = 0; k < 17; ++k)
                     if ((uint32_t)(k0 + k) < cntc) {
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
             const uint32_t h = threadIdx.x + (uint32_t)k * kBrBlock;
             if (h >= n_p) continue;
             const size_t lane = (size_t)b * n_p + h;
-            if (!(hc[k] >> 16)) {
+            if (!((hc[k] >> 16) & 1u)) {
                 v[lane] = 0.0;
                 continue;
             }
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(kBrBlock) void k_br_terminal_sorted_loop(const uint
             const double T0 = n0 ? Pc[c0 * kBrCardHolders + n0 - 1] : 0.0, T1 = n1 ? Pc[c1 * kBrCardHolders + n1 - 1] : 0.0;
             double acc;
             if (uncontested) {
-                acc = value * (((T - T0) - T1) + (hs[k] >= 0 ? Q[hs[k]] : 0.0));
+                acc = value * (((T - T0) - T1) + ((hc[k] >> 17) ? Q[(hc[k] >> 17) - 1u] : 0.0));
             } else {
                 const uint32_t nl = hw0[k] & 0xffffu, nle = hw0[k] >> 16;
                 const uint32_t a0 = hw1[k] & 0xffu, a1 = (hw1[k] >> 8) & 0xffu, e0 = (hw1[k] >> 16) & 0xffu, e1 = hw1[k] >> 24;
@@ -1301,8 +1302,8 @@ struct BrRun {
             const uint32_t most_hands = std::max(me.n_hands, op.n_hands);
             if (sorted && most_hands <= uint32_t(kBrHandsPerThread) * kBrBlock && op.n_hands <= uint32_t(kBrChunkMax) * 64u) {   // a workgroup per run-out (and slice of the leaves, when run-outs alone do not fill the card)
                 const size_t lds = (size_t(op.n_hands) * 2 + 52 * kBrCardHolders + 65) * sizeof(double) + (((size_t(op.n_hands) + 3) & ~size_t(3)) + 52 * kBrCardHolders) * sizeof(uint16_t) + 64;
-                // slices of the leaves: enough workgroups to fill the card, and a count that leaves the last round of workgroups (two per CU at full ranges: 217 registers;
-                // about four for the small-range forms) nearly full -- 2 352 run-outs on 512 slots are 4.6 rounds (the fifth 59 % full), three slices 13.8
+                // slices of the leaves: enough workgroups to fill the card, and a count that leaves the last round of workgroups (two per CU at full ranges: 220 registers;
+                // four and more for the small-range forms) nearly full -- 2 352 run-outs on 512 slots are 4.6 rounds (the fifth 59 % full), three slices 13.8
                 const int form = most_hands <= 256 ? 0 : (most_hands <= 512 ? 1 : (most_hands <= 1024 ? 2 : 3));
                 uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(nj, 2048u / std::max<uint32_t>(NB, 1)));
                 {
@@ -1317,7 +1318,7 @@ struct BrRun {
                     }
                 }
 #define RS_LEAF_LOOP(HPT_, CHUNK_)                                                                                                                                     \
-    hipLaunchKernelGGL((k_br_terminal_sorted_loop<HPT_, CHUNK_>), dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, \
+    hipLaunchKernelGGL((k_br_terminal_sorted_loop<HPT_, CHUNK_, (HPT_ == kBrHandsPerThread)>), dim3(NB, slices), dim3(kBrBlock), lds, t->stream, me.d_hands, me.d_mask, me.d_pw, me.n_hands, op.n_hands, \
                        d_bmask, me.index, d_jobs + o_leaves + lo, nj)
                 if (form == 0) RS_LEAF_LOOP(1, 4);
                 else if (form == 1) RS_LEAF_LOOP(2, 8);
