@@ -282,9 +282,13 @@ Knobs knobs_resolve(const rs_kernel_forms *forms);
 // Several generated kernels as ONE: every member's body becomes a device function in a namespace of its own (its JArgs with it), the entry point dispatches on blockIdx.y
 // ranges.  offs[k] = {src_struct, src_entry, src_body} of sources[k].  Empty string: the members' preludes differ (deals per thread), they cannot share a translation unit.
 constexpr int kMergeMax = 16;
+constexpr int kMergeCountJobs = 640;   // jobs whose list counters the merged kernel finds through its arguments (2.5 KB of the 4 KB a kernel may take)
 struct MergedArgs {                // the merged kernel's first argument, by value
     const void *blob[kMergeMax];
     unsigned first[kMergeMax + 1];
+    unsigned per_block;            // deals a workgroup takes per trip (256 threads x deals per thread)
+    const unsigned *counts;        // the plan's list counters, or nullptr: no early exit
+    unsigned cidx[kMergeCountJobs];   // per job (grid row): its counter's index in `counts`, 0xffffffff = the job walks the whole batch
 };
 std::string jit_merge_sources(const std::vector<const std::string *> &sources, const std::vector<const size_t *> &offs, const std::string &entry);
 const char *rccl_library_override();   // $RS_RCCL_LIB (tests: tests/stub_rccl.c), or nullptr

@@ -1129,6 +1129,25 @@ static int solver_create_impl(rs_table *table, const rs_tree *tree, const rs_dea
                 at += unsigned(m.n_jobs);
             }
             for (size_t k = JL.members.size(); k <= size_t(kMergeMax); ++k) JL.margs.first[k] = at;
+            if (!JL.members.empty() && at <= unsigned(kMergeCountJobs) && pl.d_counts) {   // where every job's list counter lies (the merged kernel's early exit)
+                unsigned row = 0;
+                uint32_t per_block = 0;
+                bool same = true;
+                for (int mk : JL.members) {
+                    const JitLaunch &m = pl.jit[size_t(mk)];
+                    same = same && (per_block == 0 || per_block == m.deals_per_trip);
+                    per_block = m.deals_per_trip;
+                    for (int j = 0; j < m.n_jobs; ++j, ++row) {
+                        const uint32_t *cnt = nullptr;
+                        std::memcpy(&cnt, m.blob.data() + size_t(j) * m.stride + m.off_count, sizeof(cnt));
+                        JL.margs.cidx[row] = (cnt && cnt >= pl.d_counts) ? uint32_t(cnt - pl.d_counts) : 0xffffffffu;
+                    }
+                }
+                if (same && per_block) {
+                    JL.margs.per_block = per_block;
+                    JL.margs.counts = pl.d_counts;
+                }
+            }
         }
         if ((e = hipMemcpyAsync(pl.d_jobs, pl.jobs.data(), pl.jobs.size() * sizeof(NodeJob), hipMemcpyHostToDevice,
                                 table->stream)) != hipSuccess) {

@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/$1"; mkdir -p "$OUT"
 export RS_JIT_CACHE="$OUT/jitcache"
 cd /tmp && export TMPDIR=/tmp
-N=${N:-4194304} GRAPH=0 BATCHES=3 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$R/tools/time_three_street.py" > "$OUT/trace.log" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
+N=${N:-4194304} GRAPH=${GRAPH:-0} BATCHES=3 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$R/tools/time_three_street.py" > "$OUT/trace.log" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
 T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 python3 - "$T" <<'PY' | tee "$OUT/timeline.txt"
 import csv, sys, re
