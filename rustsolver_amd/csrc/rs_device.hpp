@@ -255,9 +255,17 @@ template <int A>
 __device__ __forceinline__ void hand_pick(const float (&g)[A][kVecD], const int (&a)[kVecD], float (&out)[kVecD]) {
 #pragma unroll
     for (int j = 0; j < kVecD; j++) {
-        float x = g[0][j];
+        // the values go through an opaque move first: the compiler otherwise turns the chain of selects over g[k][j] into ONE load at a computed address, which pins g in
+        // private memory -- 40-64 bytes of scratch per lane in every reach-down kernel, a store and a dependent load through memory at each handed-over node
+        float v[A];
 #pragma unroll
-        for (int k = 1; k < A; k++) x = (a[j] == k) ? g[k][j] : x;
+        for (int k = 0; k < A; k++) {
+            v[k] = g[k][j];
+            asm volatile("" : "+v"(v[k]));
+        }
+        float x = v[0];
+#pragma unroll
+        for (int k = 1; k < A; k++) x = (a[j] == k) ? v[k] : x;
         out[j] = x;
     }
 }
