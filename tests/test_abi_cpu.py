@@ -170,6 +170,33 @@ def test_tree_specialised_kernels_compile_without_a_gpu():
     assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) > 8
 
 
+def test_generated_deal_kernels_use_no_scratch(monkeypatch):
+    """round 5 found 40-64 bytes of private memory per lane in every reach-down kernel (a chain of selects over a small array, compiled into one load at a computed address: a
+    store and a dependent load through memory at each handed-over node; 5 % of a 4 M-deal batch, 6 % of a 64 K one).  The generated sources of a two-round tree's sampled,
+    pruned deal kernels -- dumped by the compile check, compiled here with hipcc as hipRTC compiles them -- must report `ScratchSize [bytes/lane]: 0`."""
+    import glob, os, shutil, subprocess, time
+    from rustsolver_amd import _lib as L2
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not L2.load().rs_jit_available() or not os.path.exists(hipcc):
+        pytest.skip("libhiprtc.so or hipcc not present")
+    monkeypatch.setenv("RS_JIT_DUMP", "1")
+    t0 = time.time() - 1.0
+    _, tree3 = rs.build_game_tree(rs.Options(n_board_cards=4, bet_sizes=((0.5,), (1.0,)), raise_sizes=((3.0,), (3.0,))))
+    assert rs.jit_check_tree_deals(tree3, rs.UPD_CLAMP_I64 | rs.UPD_PRUNE, rs.OPP_SAMPLE) > 8
+    fresh = [f for f in glob.glob("/tmp/rs_tree_kernel_*.hip") if os.path.getmtime(f) >= t0]
+    import re
+    down = sorted(f for f in fresh if "_deals_down_sampled" in open(f).read() and re.search(r"hand_pick<\d+>\(", open(f).read()))
+    assert down, "the compile check dumped no reach-down kernel that hands its draws over"
+    picked = down[:3] + sorted(f for f in fresh if f not in down)[:2]   # three reach-down kernels that hand their draws over (the ones that had it) and two others
+    procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-include", "hip/hip_runtime.h", "-c", f, "-o", os.devnull,
+                               "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for f in picked]
+    for f, pr in zip(picked, procs):
+        out = pr.communicate()[0]
+        assert pr.returncode == 0, out[-2000:]
+        sizes = [l.split("ScratchSize [bytes/lane]:")[1].split()[0] for l in out.splitlines() if "ScratchSize [bytes/lane]:" in l]
+        assert sizes and all(x == "0" for x in sizes), (f, sizes)
+
+
 # ---- card-abstraction plumbing (card_abstraction.rs; SURVEY N2) --------------------------------------------------
 
 def test_cluster_file_roundtrip_and_format(tmp_path):
