@@ -122,6 +122,10 @@ struct CompactJob {
     uint32_t pos_rows, key_stride;   // key_stride: words between two deals' keys (1: a plain id vector; 8: the 32-byte records of an ordered sweep)
     float *rlist;         // [n_parts][list_stride] or nullptr
     uint32_t *plist;      // [n_parts][list_stride] or nullptr: where the parent subtree will read this deal's utility (its list position; the deal id below an unlisted parent)
+    // Liveness by mask: the parent's reach-down kernel wrote ONE word per entry with a bit per next-round root it hands a reach to (and the reach rows of those alone): the
+    // scan reads 4 bytes per entry instead of a float per (entry, sibling), most of them NaN.  nullptr: liveness = the reach is not NaN.
+    const uint32_t *mask;
+    uint32_t bit, pad_;
 };
 // best response over run-outs (rs_br.hip): what depends on the game only is prepared once, the walk runs against the table as it stands
 struct BrRun;
@@ -298,6 +302,7 @@ std::string jit_cache_dir();   // $RS_JIT_CACHE (empty string: no disk cache), e
 struct JitSubtree {
     std::string source;
     std::string entry;             // kernel name: rs_tree_p{traverser}_{lanes|deals|deals_lds}[_sampled]
+    size_t off_bmask = 0, off_bbit = 0;   // deals: the reach-down kernel's liveness mask row and the bit of every next-round root (JArgs.bmask, JArgs.bbit[])
     size_t src_struct = 0, src_entry = 0, src_body = 0;   // where `struct JArgs`, the kernel's signature and its body start inside `source` (jit_merge_sources)
     int threads = 256;             // workgroup size the kernel was generated for
     bool worklist = false;         // the kernel takes a third argument (the work list of its launch, rs_kernels.hip k_worklist) and a 1-D grid

@@ -460,8 +460,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
         for (uint32_t i = 0; i < kCompactPerThread; ++i) {   // sub-round i covers entries base + i*256 .. +255: coalesced reads
             const uint32_t e = base + i * kBlock + threadIdx.x;
             deal[i] = e < n ? (src ? src[e] : e) : 0u;
-            rv[i] = (e < n && reach) ? reach[(src && job->pos_rows) ? (size_t)sq * job->src_list_stride + e : (size_t)deal[i]] : 0.0f;
-            live[i] = e < n && rv[i] == rv[i];
+            const size_t ri = (src && job->pos_rows) ? (size_t)sq * job->src_list_stride + e : (size_t)deal[i];
+            if (job->mask) {   // liveness from the parent's mask word; the reach of the live ones alone
+                live[i] = e < n && ((job->mask[ri] >> job->bit) & 1u);
+                rv[i] = (live[i] && reach) ? reach[ri] : 0.0f;
+            } else {
+                rv[i] = (e < n && reach) ? reach[ri] : 0.0f;
+                live[i] = e < n && rv[i] == rv[i];
+            }
             part[i] = (live[i] && key) ? min(key[(size_t)deal[i] * job->key_stride] / part_size, n_parts - 1u) : 0u;
             rank[i] = 0;
         }
@@ -931,20 +937,27 @@ __global__ __launch_bounds__(kBlock) void k_compact_siblings(const CompactJob *_
     const uint32_t n = src ? J[0].src_count[0] : J[0].n_lanes;
     const bool by_pos = src && J[0].pos_rows;
     for (uint32_t base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {
-        uint32_t deal[kCompactPerThread];
+        uint32_t deal[kCompactPerThread], mw[kCompactPerThread];
         unsigned long long live_bits = 0;   // bit q * kCompactPerThread + i: entry i of this thread is live below sibling q
+        const uint32_t *__restrict__ mask = J[0].mask;   // (siblings share their parent: one mask row, a bit each)
 #pragma unroll
         for (uint32_t i = 0; i < kCompactPerThread; ++i) {
             const uint32_t e = base + i * kBlock + threadIdx.x;
             deal[i] = e < n ? (src ? src[e] : e) : 0u;
+            mw[i] = (mask && e < n) ? mask[by_pos ? (size_t)e : (size_t)deal[i]] : 0u;
         }
         for (uint32_t q = 0; q < nc; ++q) {
             const float *__restrict__ reach = J[q].reach;
+            const uint32_t bit = J[q].bit;
 #pragma unroll
             for (uint32_t i = 0; i < kCompactPerThread; ++i) {
                 const uint32_t e = base + i * kBlock + threadIdx.x;
-                const float rv = e < n ? reach[by_pos ? (size_t)e : (size_t)deal[i]] : __builtin_nanf("");
-                const bool live = rv == rv;
+                bool live;
+                if (mask) live = (mw[i] >> bit) & 1u;
+                else {
+                    const float rv = e < n ? reach[by_pos ? (size_t)e : (size_t)deal[i]] : __builtin_nanf("");
+                    live = rv == rv;
+                }
                 const unsigned long long ballot = __ballot(live);
                 if (live) live_bits |= 1ull << (q * kCompactPerThread + i);
                 if (lane_in_wave == 0) wave_count[q][i][wave] = (uint32_t)__popcll(ballot);

@@ -581,7 +581,10 @@ int PlanBuilder::add_jit_job(int id, bool down, const std::vector<int> &sparse_s
             put_ptr(js.off_butil + 8 * k, uptr(b) + ((pos_rows && sparse) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
             // position-indexed rows: this job's segment of the row starts where its list does
             put_ptr(js.off_breach + 8 * k, nan_ptr(b) + ((pos_rows && sparse && down) ? size_t(part) * s->pitch[lane_round[id]] : size_t(0)));
+            put_u32(js.off_bbit + 4 * k, (down && size_t(b) < mask_bit_of_root.size() && mask_bit_of_root[size_t(b)] >= 0) ? uint32_t(mask_bit_of_root[size_t(b)]) : 0u);
         }
+        // the reach-down kernel of a root whose next-round roots are compacted by mask writes the mask row (and the reach of live entries alone)
+        put_ptr(js.off_bmask, (down && size_t(id) < mask_of_root.size()) ? mask_of_root[size_t(id)] : nullptr);
         if (sparse) {   // the subtree walks only its live deals
             const CompactJob &cj = plan.compact_jobs[size_t(sparse_slot[id])];
             put_ptr(js.off_list, cj.list + size_t(part) * cj.list_stride);

@@ -116,6 +116,7 @@ struct Plan {
     rs::CompactGroup *d_compact_groups = nullptr;
     int dense_roots[RS_MAX_ROUNDS] = {0, 0, 0};   // round subtrees that walk the whole batch, per round
     uint32_t compact_max_lanes = 0;
+    uint32_t *d_bmask = nullptr;        // liveness masks of the round subtrees' reach-down kernels (CompactJob.mask), one row per parent root
     float *d_reach_nan = nullptr;       // round subtrees: reach buffers of every root but the first, all NaN at the start of a sweep
     size_t reach_nan_bytes = 0;
     size_t split = 0;                   // sharded sweeps: launches [0, split) = phase 0, [split, end) = phase 1

@@ -41,6 +41,8 @@ struct PlanBuilder {
     int lds_limit = 64 * 1024;               // what the device gives ONE workgroup (MI355X: 160 KiB)
     bool want_lists = false, want_parts = false;
     std::vector<int> parent_root_;           // round subtrees: the root of the round subtree above a root
+    std::vector<uint32_t *> mask_of_root;    // per round root whose reach-down kernel writes a liveness mask for its next-round roots (CompactJob.mask): its mask row
+    std::vector<int> mask_bit_of_root;       // per next-round root: its bit in the parent's mask words, -1 = none
     bool scan_parent = false;                // the compaction of a root's live deals scans its parent's lists, not the whole batch
     bool pos_rows = false;                   // scan_parent only: the reach rows between a listed root's reach-down kernel and its children's compaction are indexed by the root's
                                              // LIST POSITION (written and read coalesced) and the compaction stores every live deal's reach beside its list entry

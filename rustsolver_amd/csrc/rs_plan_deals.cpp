@@ -214,6 +214,48 @@ int PlanBuilder::emit_deal_lists() {
                     plan.compact_jobs[k].rlist = plan.d_rlists + (plan.compact_jobs[k].list - plan.d_lists);
                     plan.compact_jobs[k].plist = plan.d_plists + (plan.compact_jobs[k].list - plan.d_lists);
                 }
+        // Liveness masks.  Where the sibling scan compacts a parent's next-round roots (big batches), the parent's reach-down kernel writes one mask word per entry -- a bit
+        // per root it hands a reach to -- and the reach rows of those roots alone; the scan then reads 4 bytes per entry instead of a float per (entry, root), nine in ten
+        // of them NaN (a sampled opponent sends a deal down one branch), and the kernel stops writing them.
+        mask_of_root.assign(nodes.size(), nullptr);
+        mask_bit_of_root.assign(nodes.size(), -1);
+        const bool siblings_on = s->knobs.no_siblings == kUnset ? s->deals.n_deals > kSiblingsMinDeals : s->knobs.no_siblings == 0;
+        if (scan_parent && siblings_on && !parent_root_.empty()) {
+            std::map<int, std::vector<size_t>> children;   // parent root -> its listed next-round roots (positions in ids)
+            for (size_t k = 0; k < n_sparse; ++k) {
+                const int par = parent_root_[size_t(ids[k])];
+                if (par >= 0) children[par].push_back(k);
+            }
+            size_t words = 0;
+            std::vector<std::pair<int, size_t>> rows;   // (parent, offset)
+            for (auto &kv : children) {
+                const int par = kv.first;
+                bool ok = kv.second.size() <= 32 && kv.second.size() == bnd[size_t(par)].size();   // every next-round root of the parent is listed, and has a bit
+                const bool par_listed = sparse_slot[size_t(par)] >= 0;
+                if (par_listed) ok = ok && plan.compact_jobs[size_t(sparse_slot[size_t(par)])].n_parts == 1 && pos_rows;
+                for (size_t k : kv.second) {
+                    const CompactJob &cj = plan.compact_jobs[k];
+                    ok = ok && cj.n_parts == 1 && !cj.key && cj.reach && (cj.src_list ? (cj.src_parts == 1 && cj.pos_rows) : !par_listed);
+                }
+                if (!ok) continue;
+                rows.emplace_back(par, words);
+                words += (par_listed ? size_t(plan.compact_jobs[size_t(sparse_slot[size_t(par)])].list_stride) : s->pitch[lane_round[size_t(par)]]) + kRowStagger;
+            }
+            if (words) {
+                if (hipMalloc((void **)&plan.d_bmask, words * sizeof(uint32_t)) != hipSuccess) return fail(RS_ERR_OOM, "rs_solver_create: liveness masks of the round subtrees");
+                if (hipMemsetAsync(plan.d_bmask, 0, words * sizeof(uint32_t), t->stream) != hipSuccess) return fail(RS_ERR_HIP, "rs_solver_create: liveness masks of the round subtrees");
+                plan.aux_bytes += words * sizeof(uint32_t);
+                for (auto &pr : rows) {
+                    mask_of_root[size_t(pr.first)] = plan.d_bmask + pr.second;
+                    int bit = 0;
+                    for (size_t k : children[pr.first]) {
+                        plan.compact_jobs[k].mask = plan.d_bmask + pr.second;
+                        plan.compact_jobs[k].bit = uint32_t(bit);
+                        mask_bit_of_root[size_t(ids[k])] = bit++;
+                    }
+                }
+            }
+        }
         ea = hipMemcpy(plan.d_compact_jobs, plan.compact_jobs.data(), n_sparse * sizeof(CompactJob), hipMemcpyHostToDevice);
         if (ea != hipSuccess) return hip_fail(ea, "rs_solver_create: live-deal lists");
         return RS_OK;
@@ -238,7 +280,7 @@ int PlanBuilder::emit_deal_lists() {
                 const CompactJob &a = plan.compact_jobs[size_t(k)];
                 int e = k + 1;
                 while (e < first + count && e - k < 16 && plan.compact_jobs[size_t(e)].src_list == a.src_list && plan.compact_jobs[size_t(e)].src_count == a.src_count &&
-                       plan.compact_jobs[size_t(e)].n_lanes == a.n_lanes && plan.compact_jobs[size_t(e)].pos_rows == a.pos_rows)
+                       plan.compact_jobs[size_t(e)].n_lanes == a.n_lanes && plan.compact_jobs[size_t(e)].pos_rows == a.pos_rows && plan.compact_jobs[size_t(e)].mask == a.mask)
                     ++e;
                 plan.compact_groups.push_back(CompactGroup{uint32_t(k), uint32_t(e - k)});
                 k = e;

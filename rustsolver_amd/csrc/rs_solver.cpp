@@ -358,6 +358,7 @@ void rs::solver_release_device(rs_solver *s) {
         if (pl.d_jobs) (void)hipFree(pl.d_jobs);
         if (pl.d_chance_jobs) (void)hipFree(pl.d_chance_jobs);
         if (pl.d_reach_nan) (void)hipFree(pl.d_reach_nan);
+        if (pl.d_bmask) (void)hipFree(pl.d_bmask);
         if (pl.d_lists) (void)hipFree(pl.d_lists);
         if (pl.d_rlists) (void)hipFree(pl.d_rlists);
         if (pl.d_plists) (void)hipFree(pl.d_plists);
