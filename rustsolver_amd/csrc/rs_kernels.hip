@@ -481,19 +481,21 @@ __global__ __launch_bounds__(kBlock) void k_compact_live(const CompactJob *__res
             }
         }
         __syncthreads();
-        if (threadIdx.x < n_parts) {   // ONE reservation per workgroup and part, issued by different threads
+        if (threadIdx.x < n_parts) {   // ONE reservation per workgroup and part, issued by different threads; the part's counts become their exclusive prefix in source order
             uint32_t total = 0;
             for (uint32_t i = 0; i < kCompactPerThread; ++i)
-                for (int w = 0; w < kBlock / 64; ++w) total += wave_count[i][w][threadIdx.x];
+                for (int w = 0; w < kBlock / 64; ++w) {
+                    const uint32_t c = wave_count[i][w][threadIdx.x];
+                    wave_count[i][w][threadIdx.x] = total;
+                    total += c;
+                }
             part_base[threadIdx.x] = total ? atomicAdd(job->count + (size_t)threadIdx.x * job->count_stride, total) : 0u;
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t i = 0; i < kCompactPerThread; ++i)
             if (live[i]) {   // slots follow the SOURCE order inside the tile (sub-round, wave, lane): an ordered sweep's lists stay in runs of equal last-round cluster
-                uint32_t slot = part_base[part[i]] + rank[i];
-                for (uint32_t i2 = 0; i2 <= i; ++i2)
-                    for (uint32_t w = 0; w < (i2 < i ? (uint32_t)(kBlock / 64) : wave); ++w) slot += wave_count[i2][w][part[i]];
+                const uint32_t slot = part_base[part[i]] + wave_count[i][wave][part[i]] + rank[i];
                 job->list[(size_t)part[i] * job->list_stride + slot] = deal[i];
                 if (job->rlist) job->rlist[(size_t)part[i] * job->list_stride + slot] = rv[i];
                 if (job->plist) job->plist[(size_t)part[i] * job->list_stride + slot] = (src && job->pos_rows) ? sq * job->src_list_stride + (base + i * kBlock + threadIdx.x) : deal[i];
@@ -964,10 +966,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_siblings(const CompactJob *_
             }
         }
         __syncthreads();
-        if (threadIdx.x < nc) {
+        if (threadIdx.x < nc) {   // the sibling's counts become their exclusive prefix in source order (sub-round, wave): a live entry then finds its slot with one read
             uint32_t total = 0;
             for (uint32_t i = 0; i < kCompactPerThread; ++i)
-                for (int w = 0; w < kBlock / 64; ++w) total += wave_count[threadIdx.x][i][w];
+                for (int w = 0; w < kBlock / 64; ++w) {
+                    const uint32_t c = wave_count[threadIdx.x][i][w];
+                    wave_count[threadIdx.x][i][w] = total;
+                    total += c;
+                }
             slot_base[threadIdx.x] = total ? atomicAdd(J[threadIdx.x].count, total) : 0u;
         }
         __syncthreads();
@@ -978,9 +984,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_siblings(const CompactJob *_
                 const bool live = (live_bits >> (q * kCompactPerThread + i)) & 1ull;
                 const unsigned long long ballot = __ballot(live);
                 if (!live) continue;
-                uint32_t slot = slot_base[q] + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
-                for (uint32_t i2 = 0; i2 <= i; ++i2)
-                    for (uint32_t w = 0; w < (i2 < i ? (uint32_t)(kBlock / 64) : wave); ++w) slot += wave_count[q][i2][w];
+                const uint32_t slot = slot_base[q] + wave_count[q][i][wave] + (uint32_t)__popcll(ballot & ((1ull << lane_in_wave) - 1ull));
                 const uint32_t e = base + i * kBlock + threadIdx.x;
                 job.list[slot] = deal[i];
                 if (job.rlist) job.rlist[slot] = job.reach[by_pos ? (size_t)e : (size_t)deal[i]];
