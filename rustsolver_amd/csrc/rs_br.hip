@@ -830,6 +830,7 @@ struct BrGroups {
     const uint32_t *set_cluster;   // [info sets]: the cluster id (k_br_opp_reach_grouped_jobs looks the strategy-sum rows up once per info set)
     uint32_t n_groups, cap, n_hands, max_sets;
 };
+constexpr uint32_t kBrGroupLanes = 5400;   // lanes a group is packed up to (cap = kBrGroupLanes / n_hands run-outs, at least the largest component): four run-outs of 1 176-1 326 hands
 constexpr int kBrGroupBlock = 1024;    // one workgroup per CU at eight run-outs of 1 176 hands (75 KB of staged values + 26 KB of sums and leaders): sixteen waves of it
 constexpr int kBrGroupPerThread = 11;  // cap * n_hands <= 11 264 values per row set (eight run-outs of 1 326 hands)
 __global__ __launch_bounds__(kBrGroupBlock) void k_br_own_grouped_jobs(const BrJob *__restrict__ jobs, BrGroups g, uint32_t n_pad) {
@@ -1526,7 +1527,7 @@ static void build_groups(BrRun &run, BrSide &s, int r, size_t NB, size_t H, cons
     for (size_t b = 0; b < NB; ++b) largest = std::max(largest, ++size[find(uint32_t(b))]);
     const uint32_t cap_max = uint32_t(size_t(kBrGroupPerThread) * kBrGroupBlock / H);
     if (largest > cap_max) return;
-    const uint32_t cap = std::min(cap_max, std::max<uint32_t>(largest, std::max<uint32_t>(1, uint32_t(5400 / H))));
+    const uint32_t cap = std::min(cap_max, std::max<uint32_t>(largest, std::max<uint32_t>(1, uint32_t(kBrGroupLanes / H))));
     // components in the order of their smallest cluster id, packed greedily: neighbours in that order hold neighbouring info sets -- the same 64-byte lines of the
     // strategy-sum rows (a lossless abstraction numbers its clusters hand by hand, then by the larger and the smaller of the two cards to come) -- and the reach kernel hands
     // neighbouring groups to one XCD
